@@ -1,0 +1,103 @@
+/*
+ * segdistill_hip.h -- C ABI of libsegdistill_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the dense distillation-loss hot path of
+ * wzpscott/SegDistill.  The reference is 100 % Python and has no FFI of its
+ * own; every entry point below replaces a run of ATen calls made by the
+ * reference's Python (file:line cited per function, relative to the reference
+ * root).  The Python binding a maintainer adds is a ctypes stub, shown in
+ * INTEGRATION.md and implemented in segdistill_amd/_lib.py.
+ *
+ * Contract:
+ *  - plain C types only; device pointers are raw addresses owned by the caller
+ *    (torch tensors in practice); the library allocates nothing persistent and
+ *    keeps no global state;
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*;
+ *    NULL = the default stream) and never synchronises the host;
+ *  - return value: 0 = ok, <0 = argument error (SD_E_*), >0 = a hipError_t;
+ *    nothing throws across the boundary.  sd_error_string() names a code.
+ *
+ * Tensor layout: contiguous NCHW.  `dtype` selects the storage type of the
+ * activation operands (SD_F32 | SD_BF16); all arithmetic and all statistics
+ * are fp32 (finalisation in fp64).
+ *
+ * Row geometry of the channel-group criteria ("CGD"; g = group_size):
+ *   G = ceil(C/g) groups per image, rows = B*G, row (b,j) = channel slots
+ *   j*g .. j*g+g-1 of image b, all H*W pixels.  Slot c' < C holds channel
+ *   perm[c'] (or c' when perm == NULL); slots >= C are the reference's -1e9
+ *   padding (losses.py:55-58) and are treated as virtual (-inf): they are never
+ *   materialised, read or written.
+ */
+#ifndef SEGDISTILL_HIP_H
+#define SEGDISTILL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SD_ABI_VERSION 1
+
+enum { SD_F32 = 0, SD_BF16 = 1 };
+
+enum {
+    SD_OK = 0,
+    SD_E_NULL = -1,      /* required pointer is NULL */
+    SD_E_SHAPE = -2,     /* non-positive or overflowing dimension */
+    SD_E_DTYPE = -3,     /* unknown dtype code */
+    SD_E_WORKSPACE = -4, /* workspace too small / misaligned */
+    SD_E_ALIGN = -5,     /* operand pointer not aligned to its element size */
+    SD_E_UNSUPPORTED = -6
+};
+
+int sd_abi_version(void);
+const char *sd_error_string(int code);
+
+/* Tunables (process-wide, for benchmarking only; defaults are the shipped values).
+ * key: "cgd_chunk_iters" (vector iterations per thread per workgroup, fwd+bwd). */
+int sd_set_tunable(const char *key, int value);
+int sd_get_tunable(const char *key);
+
+/* ---------------------------------------------------------------------------
+ * CGD / CD criterion, operands ALREADY at softmax resolution ("R1").
+ * Replaces losses.py:105-112 (transform pad+view, div tau, log_softmax, softmax,
+ * KLDivLoss(sum), normalise, *alpha) and, with `perm`, the gather+copy of
+ * losses.py:39-41.  Forward reads S and T once (2*N*e bytes).
+ *
+ *   loss      = loss_scale * sum_rows KL_r           (loss_scale = alpha/rows)
+ *   row_lse2  [rows][2] : base-2 log-partition of S/tau and T/tau per row
+ *                         (consumed by the backward)
+ *   row_kl    [rows]    : KL_r in nats (diagnostic; also the parity surface)
+ *
+ * workspace: sd_cgd_kl_workspace_bytes() bytes, 16-byte aligned, contents
+ * undefined on entry and exit.
+ */
+size_t sd_cgd_kl_workspace_bytes(int B, int C, int H, int W, int g);
+
+int sd_cgd_kl_fwd(const void *S, const void *T, int dtype,
+                  int B, int C, int H, int W, int g,
+                  float inv_tau, float loss_scale,
+                  const int32_t *perm /* [C] device, or NULL */,
+                  float *row_lse2, float *row_kl, float *loss /* [1] */,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* Backward of the above w.r.t. S (the teacher gets no gradient; losses.py runs
+ * the teacher under no_grad, SD_structure.py:65-67):
+ *   dS_i = upstream * coef * (softmax(S/tau)_i - softmax(T/tau)_i),
+ *   coef = alpha/(rows*tau);  `upstream` is a 1-element DEVICE float (the
+ *   autograd grad_output) or NULL for 1.  Reads S,T, writes dS (3*N*e bytes).
+ * Replaces the autograd chain of losses.py:108-112
+ * (_log_softmax_backward_data, kl_div backward, div backward).
+ */
+int sd_cgd_kl_bwd(const void *S, const void *T, int dtype,
+                  int B, int C, int H, int W, int g,
+                  float inv_tau, float coef,
+                  const int32_t *perm, const float *row_lse2,
+                  const float *upstream, void *dS, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGDISTILL_HIP_H */

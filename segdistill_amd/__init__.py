@@ -1,0 +1,7 @@
+"""segdistill_amd -- MI355X-native knowledge-distillation train step for semantic
+segmentation (the teacher->student KD hot path of wzpscott/SegDistill).
+
+The dense distillation criteria run as hand-written HIP kernels for gfx950 behind a C ABI
+(include/segdistill_hip.h, segdistill_amd/csrc); the networks run on PyTorch-ROCm.
+"""
+__version__ = '0.1.0'

@@ -1,0 +1,74 @@
+"""ctypes binding of libsegdistill_hip.so (the C ABI declared in include/segdistill_hip.h).
+
+The library is the product: if it is missing or fails to load, every op raises.
+There is no CPU / eager fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libsegdistill_hip.so')
+
+SD_F32, SD_BF16 = 0, 1
+ABI_VERSION = 1
+
+_lib = None
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/segdistill_hip.h declares
+SIGNATURES = {
+    'sd_abi_version': (_i, []),
+    'sd_error_string': (C.c_char_p, [_i]),
+    'sd_set_tunable': (_i, [C.c_char_p, _i]),
+    'sd_get_tunable': (_i, [C.c_char_p]),
+    'sd_cgd_kl_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'sd_cgd_kl_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'sd_cgd_kl_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+}
+
+
+class SegDistillLibError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise SegDistillLibError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'(or `make -C segdistill_amd/csrc`). The distillation losses have no non-HIP implementation.')
+    try:
+        h = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise SegDistillLibError(f'cannot load {LIB_PATH}: {e}') from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(h, name)
+        except AttributeError as e:
+            raise SegDistillLibError(f'{LIB_PATH} does not export {name}') from e
+        fn.restype, fn.argtypes = res, args
+    v = h.sd_abi_version()
+    if v != ABI_VERSION:
+        raise SegDistillLibError(f'ABI version mismatch: library {v}, binding {ABI_VERSION}')
+    _lib = h
+    return h
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = lib().sd_error_string(code).decode()
+        raise RuntimeError(f'{what} failed: {msg} (code {code})')
+
+
+def set_tunable(key: str, value: int):
+    check(lib().sd_set_tunable(key.encode(), int(value)), f'sd_set_tunable({key})')
+
+
+def get_tunable(key: str) -> int:
+    return lib().sd_get_tunable(key.encode())

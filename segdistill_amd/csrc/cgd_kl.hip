@@ -1,0 +1,426 @@
+// cgd_kl.hip -- Channel-Group-Distillation KL criterion for gfx950 (MI355X), regime R1
+// (operands already at softmax resolution).
+//
+// What the reference computes with ~14 ATen passes (losses.py:105-112: pad/view, div tau,
+// log_softmax, softmax, KLDivLoss(sum) and their autograd) is done here in one streaming
+// read for the forward and one read+write pass for the backward.
+//
+// A softmax row is g planes of H*W pixels (2.1 M elements at g=8, 512x512): far beyond LDS,
+// and there are only B*ceil(C/g) rows (152 at the headline config), so parallelism comes
+// from INSIDE rows.  Each 256-thread workgroup owns one chunk of one channel plane and
+// keeps an online (max, partition-sum) pair for S and for T plus the cross term
+//     a = sum_i 2^{(t_i - m_t) c2} (t_i - s_i),   c2 = log2(e)/tau,
+// per lane, rescaling once per 16 elements; lanes are combined with wave64 shuffles, waves
+// through LDS, and the per-chunk partials by a tiny second kernel in fp64:
+//     KL_r = (a/tau)/Z_t - lse_t + lse_s.
+// HBM-bound by design: 8 B/element forward, 12 B/element backward (fp32).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sd_common.h"
+
+namespace sd {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kUnroll = 4;          // independent 16-byte loads per operand in flight per lane
+constexpr float kNegBig = -1.0e30f; // finite stand-in for -inf in running maxima
+
+struct RowPart {  // one partial of a row: raw-unit maxima, base-2-scaled sums
+    float ms, zs, mt, zt, a;
+};
+
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- 16-byte vector access for the two storage types ------------------------------------
+template <typename T> struct VecIO;
+template <> struct VecIO<float> {
+    static constexpr int N = 4;
+    typedef float raw_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void load(const float *p, float (&o)[4]) {
+        raw_t v = __builtin_nontemporal_load(reinterpret_cast<const raw_t *>(p));
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    static __device__ __forceinline__ void store(float *p, const float (&o)[4]) {
+        raw_t v = {o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<raw_t *>(p) = v;
+    }
+    static __device__ __forceinline__ float load1(const float *p) { return *p; }
+    static __device__ __forceinline__ void store1(float *p, float v) { *p = v; }
+};
+template <> struct VecIO<bf16_t> {
+    static constexpr int N = 8;
+    typedef unsigned int raw_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void load(const bf16_t *p, float (&o)[8]) {
+        raw_t v = __builtin_nontemporal_load(reinterpret_cast<const raw_t *>(p));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = __uint_as_float(v[i] << 16);
+            o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t *p, const float (&o)[8]) {
+        raw_t v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (unsigned)f32_to_bf16(o[2 * i]) | ((unsigned)f32_to_bf16(o[2 * i + 1]) << 16);
+        *reinterpret_cast<raw_t *>(p) = v;
+    }
+    static __device__ __forceinline__ float load1(const bf16_t *p) { return __uint_as_float((unsigned)p->bits << 16); }
+    static __device__ __forceinline__ void store1(bf16_t *p, float v) { p->bits = f32_to_bf16(v); }
+};
+
+// Fold n elements (raw s, raw t) into the lane's running state.
+template <int N>
+__device__ __forceinline__ void fold(RowPart &st, const float (&s)[N], const float (&t)[N], float c2) {
+    float mxs = s[0], mxt = t[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) { mxs = fmaxf(mxs, s[i]); mxt = fmaxf(mxt, t[i]); }
+    const float nms = fmaxf(st.ms, mxs), nmt = fmaxf(st.mt, mxt);
+    const float rs = ex2((st.ms - nms) * c2), rt = ex2((st.mt - nmt) * c2);
+    const float os = -nms * c2, ot = -nmt * c2;
+    float zs = st.zs * rs, zt = st.zt * rt, a = st.a * rt;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        zs += ex2(fmaf(s[i], c2, os));
+        const float e = ex2(fmaf(t[i], c2, ot));
+        zt += e;
+        a = fmaf(e, t[i] - s[i], a);
+    }
+    st.ms = nms; st.zs = zs; st.mt = nmt; st.zt = zt; st.a = a;
+}
+
+__device__ __forceinline__ void merge(RowPart &p, const RowPart &q, float c2) {
+    const float ms = fmaxf(p.ms, q.ms), mt = fmaxf(p.mt, q.mt);
+    const float ps = ex2((p.ms - ms) * c2), qs = ex2((q.ms - ms) * c2);
+    const float pt = ex2((p.mt - mt) * c2), qt = ex2((q.mt - mt) * c2);
+    p.zs = p.zs * ps + q.zs * qs;
+    p.zt = p.zt * pt + q.zt * qt;
+    p.a = p.a * pt + q.a * qt;
+    p.ms = ms; p.mt = mt;
+}
+
+// Combine the 256 lane states of a workgroup; result valid in thread 0.
+__device__ __forceinline__ RowPart block_combine(RowPart st, float c2) {
+    __shared__ RowPart wave_part[kThreads / 64];
+    const float ms = wave_max(st.ms), mt = wave_max(st.mt);
+    const float rs = ex2((st.ms - ms) * c2), rt = ex2((st.mt - mt) * c2);
+    RowPart w;
+    w.ms = ms; w.mt = mt;
+    w.zs = wave_sum(st.zs * rs);
+    w.zt = wave_sum(st.zt * rt);
+    w.a = wave_sum(st.a * rt);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) wave_part[wid] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 1; i < kThreads / 64; ++i) merge(w, wave_part[i], c2);
+    }
+    return w;
+}
+
+// ---- forward, streaming pass ----------------------------------------------------------------
+// grid.x = B*C*nchunk; workgroup k of plane slot (b,c') covers elements
+// [k*chunk, min((k+1)*chunk, HW)) of channel perm[c'] and writes partial[(b*C+c')*nchunk+k].
+template <typename T, bool VECTOR>
+__global__ __launch_bounds__(kThreads) void cgd_fwd_partials(const T *__restrict__ S, const T *__restrict__ Tt,
+                                                              const int32_t *__restrict__ perm, RowPart *__restrict__ part,
+                                                              int C, int HW, int nchunk, int iters, float c2) {
+    constexpr int N = VECTOR ? VecIO<T>::N : 1;
+    const int wg = blockIdx.x;
+    const int k = wg % nchunk;
+    const int slot = wg / nchunk;  // b*C + c'
+    const int b = slot / C, cs = slot - b * C;
+    const int ch = perm ? perm[cs] : cs;
+    const size_t base = ((size_t)b * C + ch) * (size_t)HW;
+    const T *ps = S + base, *pt = Tt + base;
+    const int chunk = kThreads * N * kUnroll * iters;
+    const int lo = k * chunk;
+    const int hi = min(lo + chunk, HW);
+
+    RowPart st = {kNegBig, 0.f, kNegBig, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+        const int e0 = lo + (it * kUnroll * kThreads + threadIdx.x) * N;
+        if (e0 + (kUnroll - 1) * kThreads * N + N <= hi) {  // all kUnroll vectors in range
+            float s[kUnroll * N], t[kUnroll * N];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int e = e0 + u * kThreads * N;
+                if constexpr (VECTOR) {
+                    VecIO<T>::load(ps + e, *reinterpret_cast<float(*)[N]>(&s[u * N]));
+                    VecIO<T>::load(pt + e, *reinterpret_cast<float(*)[N]>(&t[u * N]));
+                } else {
+                    s[u] = VecIO<T>::load1(ps + e);
+                    t[u] = VecIO<T>::load1(pt + e);
+                }
+            }
+            fold<kUnroll * N>(st, s, t, c2);
+        } else {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int e = e0 + u * kThreads * N;
+                if (e < hi) {  // HW % N == 0 in the vector build, so a vector is all-in or all-out
+                    float s[N], t[N];
+                    if constexpr (VECTOR) {
+                        VecIO<T>::load(ps + e, s);
+                        VecIO<T>::load(pt + e, t);
+                    } else {
+                        s[0] = VecIO<T>::load1(ps + e);
+                        t[0] = VecIO<T>::load1(pt + e);
+                    }
+                    fold<N>(st, s, t, c2);
+                }
+            }
+        }
+    }
+    const RowPart w = block_combine(st, c2);
+    if (threadIdx.x == 0) part[wg] = w;
+}
+
+// ---- forward, per-row finalisation (fp64) ---------------------------------------------------
+// One wave per row; row (b,j) owns partials [(b*C + j*g)*nchunk, (b*C + min(C,(j+1)*g))*nchunk).
+__global__ __launch_bounds__(kThreads) void cgd_fwd_rows(const RowPart *__restrict__ part, float *__restrict__ row_lse2,
+                                                          float *__restrict__ row_kl, int rows, int C, int g, int G,
+                                                          int nchunk, float c2, float inv_tau) {
+    const int row = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (row >= rows) return;  // whole wave exits together
+    const int lane = threadIdx.x & 63;
+    const int b = row / G, j = row - b * G;
+    const int c_lo = j * g, c_hi = min(C, c_lo + g);
+    const RowPart *p = part + ((size_t)b * C + c_lo) * nchunk;
+    const int n = (c_hi - c_lo) * nchunk;
+    float ms = kNegBig, mt = kNegBig;
+    for (int i = lane; i < n; i += 64) { ms = fmaxf(ms, p[i].ms); mt = fmaxf(mt, p[i].mt); }
+    ms = wave_max(ms); mt = wave_max(mt);
+    double zs = 0, zt = 0, a = 0;
+    for (int i = lane; i < n; i += 64) {
+        const RowPart q = p[i];
+        const double fs = exp2((double)(q.ms - ms) * (double)c2), ft = exp2((double)(q.mt - mt) * (double)c2);
+        zs += (double)q.zs * fs;
+        zt += (double)q.zt * ft;
+        a += (double)q.a * ft;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        zs += __shfl_xor(zs, o, 64);
+        zt += __shfl_xor(zt, o, 64);
+        a += __shfl_xor(a, o, 64);
+    }
+    if (lane == 0) {
+        const double l2s = (double)ms * c2 + log2(zs), l2t = (double)mt * c2 + log2(zt);
+        const double ln2 = 0.69314718055994530942;
+        row_lse2[2 * row] = (float)l2s;
+        row_lse2[2 * row + 1] = (float)l2t;
+        row_kl[row] = (float)(a * (double)inv_tau / zt + (l2s - l2t) * ln2);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void cgd_fwd_loss(const float *__restrict__ row_kl, float *__restrict__ loss, int rows,
+                                                          float loss_scale) {
+    __shared__ double acc[kThreads / 64];
+    double v = 0;
+    for (int i = threadIdx.x; i < rows; i += kThreads) v += (double)row_kl[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) acc[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0;
+        for (int i = 0; i < kThreads / 64; ++i) tot += acc[i];
+        loss[0] = (float)(tot * (double)loss_scale);
+    }
+}
+
+// ---- backward -------------------------------------------------------------------------------
+// dS_i = k (2^{s_i c2 - lse2_s} - 2^{t_i c2 - lse2_t}),  k = coef * upstream.
+template <typename T, bool VECTOR>
+__global__ __launch_bounds__(kThreads) void cgd_bwd(const T *__restrict__ S, const T *__restrict__ Tt, const int32_t *__restrict__ perm,
+                                                     const float *__restrict__ row_lse2, const float *__restrict__ upstream,
+                                                     T *__restrict__ dS, int C, int HW, int g, int G, int nchunk, int iters,
+                                                     float c2, float coef) {
+    constexpr int N = VECTOR ? VecIO<T>::N : 1;
+    const int wg = blockIdx.x;
+    const int k = wg % nchunk;
+    const int slot = wg / nchunk;
+    const int b = slot / C, cs = slot - b * C;
+    const int ch = perm ? perm[cs] : cs;
+    const int row = b * G + cs / g;
+    const float ls = row_lse2[2 * row], lt = row_lse2[2 * row + 1];
+    const float kk = upstream ? coef * upstream[0] : coef;
+    const size_t base = ((size_t)b * C + ch) * (size_t)HW;
+    const T *ps = S + base, *pt = Tt + base;
+    T *pd = dS + base;
+    const int chunk = kThreads * N * kUnroll * iters;
+    const int lo = k * chunk;
+    const int hi = min(lo + chunk, HW);
+    for (int it = 0; it < iters; ++it) {
+        const int e0 = lo + (it * kUnroll * kThreads + threadIdx.x) * N;
+        float s[kUnroll][N], t[kUnroll][N];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int e = e0 + u * kThreads * N;
+            if (e < hi) {
+                if constexpr (VECTOR) {
+                    VecIO<T>::load(ps + e, s[u]);
+                    VecIO<T>::load(pt + e, t[u]);
+                } else {
+                    s[u][0] = VecIO<T>::load1(ps + e);
+                    t[u][0] = VecIO<T>::load1(pt + e);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int e = e0 + u * kThreads * N;
+            if (e < hi) {
+                float d[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) d[i] = kk * (ex2(fmaf(s[u][i], c2, -ls)) - ex2(fmaf(t[u][i], c2, -lt)));
+                if constexpr (VECTOR) VecIO<T>::store(pd + e, d);
+                else VecIO<T>::store1(pd + e, d[0]);
+            }
+        }
+    }
+}
+
+int g_chunk_iters = 8;  // tunable "cgd_chunk_iters"
+
+struct Geo {
+    int N, iters, chunk, nchunk, G, rows;
+    bool vec;
+};
+
+template <typename T>
+Geo geometry(const void *S, const void *Tt, const void *dS, int C, int H, int W, int g, int B) {
+    Geo q;
+    const long HW = (long)H * W;
+    const int VN = VecIO<T>::N;
+    auto al = [](const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    q.vec = (HW % VN == 0) && al(S) && al(Tt) && al(dS);
+    q.N = q.vec ? VN : 1;
+    int iters = g_chunk_iters;
+    const long per_iter = (long)kThreads * q.N * kUnroll;
+    const long need = (HW + per_iter - 1) / per_iter;
+    if (iters > need) iters = (int)need;
+    if (iters < 1) iters = 1;
+    q.iters = iters;
+    q.chunk = (int)(per_iter * iters);
+    q.nchunk = (int)((HW + q.chunk - 1) / q.chunk);
+    q.G = (C + g - 1) / g;
+    q.rows = B * q.G;
+    return q;
+}
+
+int check_common(const void *S, const void *Tt, int dtype, int B, int C, int H, int W, int g) {
+    if (!S || !Tt) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || g <= 0) return SD_E_SHAPE;
+    if ((long)H * W > 0x3fffffffL) return SD_E_SHAPE;               // in-plane offsets are int32
+    const size_t es = dtype == SD_F32 ? 4 : 2;
+    if ((reinterpret_cast<uintptr_t>(S) | reinterpret_cast<uintptr_t>(Tt)) & (es - 1)) return SD_E_ALIGN;
+    return SD_OK;
+}
+
+template <typename T>
+int fwd_impl(const void *S, const void *Tt, int B, int C, int H, int W, int g, float inv_tau, float loss_scale,
+             const int32_t *perm, float *row_lse2, float *row_kl, float *loss, void *ws, size_t ws_bytes, hipStream_t st) {
+    const Geo q = geometry<T>(S, Tt, nullptr, C, H, W, g, B);
+    const long nwg = (long)B * C * q.nchunk;
+    if (nwg > 0x7fffffffL) return SD_E_SHAPE;
+    if (ws_bytes < (size_t)nwg * sizeof(RowPart) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
+    const float c2 = inv_tau * 1.44269504088896340736f;
+    RowPart *part = static_cast<RowPart *>(ws);
+    const int HW = H * W;
+    if (q.vec)
+        hipLaunchKernelGGL((cgd_fwd_partials<T, true>), dim3((unsigned)nwg), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, perm, part,
+                           C, HW, q.nchunk, q.iters, c2);
+    else
+        hipLaunchKernelGGL((cgd_fwd_partials<T, false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, perm,
+                           part, C, HW, q.nchunk, q.iters, c2);
+    const int rows_per_wg = kThreads / 64;
+    hipLaunchKernelGGL(cgd_fwd_rows, dim3((q.rows + rows_per_wg - 1) / rows_per_wg), dim3(kThreads), 0, st, part, row_lse2, row_kl,
+                       q.rows, C, g, q.G, q.nchunk, c2, inv_tau);
+    hipLaunchKernelGGL(cgd_fwd_loss, dim3(1), dim3(kThreads), 0, st, row_kl, loss, q.rows, loss_scale);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int bwd_impl(const void *S, const void *Tt, int B, int C, int H, int W, int g, float inv_tau, float coef, const int32_t *perm,
+             const float *row_lse2, const float *upstream, void *dS, hipStream_t st) {
+    const Geo q = geometry<T>(S, Tt, dS, C, H, W, g, B);
+    const long nwg = (long)B * C * q.nchunk;
+    if (nwg > 0x7fffffffL) return SD_E_SHAPE;
+    const float c2 = inv_tau * 1.44269504088896340736f;
+    const int HW = H * W;
+    if (q.vec)
+        hipLaunchKernelGGL((cgd_bwd<T, true>), dim3((unsigned)nwg), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, perm, row_lse2,
+                           upstream, (T *)dS, C, HW, g, q.G, q.nchunk, q.iters, c2, coef);
+    else
+        hipLaunchKernelGGL((cgd_bwd<T, false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, perm, row_lse2,
+                           upstream, (T *)dS, C, HW, g, q.G, q.nchunk, q.iters, c2, coef);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int cgd_set_chunk_iters(int v) {
+    if (v < 1 || v > 4096) return SD_E_SHAPE;
+    g_chunk_iters = v;
+    return SD_OK;
+}
+int cgd_get_chunk_iters() { return g_chunk_iters; }
+
+}  // namespace sd
+
+extern "C" {
+
+size_t sd_cgd_kl_workspace_bytes(int B, int C, int H, int W, int g) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || g <= 0) return 0;
+    // Upper bound over both dtypes and the scalar fallback: the smallest chunk is one
+    // iteration of the scalar build.
+    const long HW = (long)H * W;
+    const long min_chunk = (long)sd::kThreads * sd::kUnroll;  // N = 1, iters = 1
+    long iters = sd::g_chunk_iters;
+    const long need = (HW + min_chunk - 1) / min_chunk;
+    if (iters > need) iters = need;
+    const long chunk = min_chunk * iters;
+    const long nchunk = (HW + chunk - 1) / chunk;
+    return (size_t)B * C * nchunk * sizeof(sd::RowPart) + 16;
+}
+
+int sd_cgd_kl_fwd(const void *S, const void *T, int dtype, int B, int C, int H, int W, int g, float inv_tau, float loss_scale,
+                  const int32_t *perm, float *row_lse2, float *row_kl, float *loss, void *workspace, size_t workspace_bytes,
+                  void *stream) {
+    int rc = sd::check_common(S, T, dtype, B, C, H, W, g);
+    if (rc) return rc;
+    if (!row_lse2 || !row_kl || !loss || !workspace) return SD_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32)
+        return sd::fwd_impl<float>(S, T, B, C, H, W, g, inv_tau, loss_scale, perm, row_lse2, row_kl, loss, workspace, workspace_bytes, st);
+    return sd::fwd_impl<sd::bf16_t>(S, T, B, C, H, W, g, inv_tau, loss_scale, perm, row_lse2, row_kl, loss, workspace, workspace_bytes,
+                                    st);
+}
+
+int sd_cgd_kl_bwd(const void *S, const void *T, int dtype, int B, int C, int H, int W, int g, float inv_tau, float coef,
+                  const int32_t *perm, const float *row_lse2, const float *upstream, void *dS, void *stream) {
+    int rc = sd::check_common(S, T, dtype, B, C, H, W, g);
+    if (rc) return rc;
+    if (!row_lse2 || !dS) return SD_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32) return sd::bwd_impl<float>(S, T, B, C, H, W, g, inv_tau, coef, perm, row_lse2, upstream, dS, st);
+    return sd::bwd_impl<sd::bf16_t>(S, T, B, C, H, W, g, inv_tau, coef, perm, row_lse2, upstream, dS, st);
+}
+
+}  // extern "C"

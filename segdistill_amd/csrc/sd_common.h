@@ -1,0 +1,24 @@
+// sd_common.h -- shared device helpers for libsegdistill_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/segdistill_hip.h"
+
+namespace sd {
+
+struct bf16_t {
+    uint16_t bits;
+};
+
+// Round-to-nearest-even f32 -> bf16.  A plain cast through __bf16 lowers to
+// v_cvt_pk_bf16_f32 on gfx950, which keeps NaNs NaN (MI355X_MICROARCH.md, Correctness boundaries).
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    __bf16 h = static_cast<__bf16>(f);
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+int cgd_set_chunk_iters(int v);
+int cgd_get_chunk_iters();
+
+}  // namespace sd

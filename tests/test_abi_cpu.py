@@ -1,0 +1,62 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every
+symbol include/segdistill_hip.h declares (no compute calls without a GPU)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    return True
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'segdistill_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(sd_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_symbols_exported(built):
+    from segdistill_amd import _lib
+    h = _lib.lib()
+    names = _declared_symbols()
+    assert 'sd_cgd_kl_fwd' in names and 'sd_cgd_kl_bwd' in names
+    for n in names:
+        assert hasattr(h, n), f'{n} declared in the header but not exported'
+        assert n in _lib.SIGNATURES, f'{n} has no ctypes signature in _lib.SIGNATURES'
+    assert sorted(_lib.SIGNATURES) == names
+    assert h.sd_abi_version() == _lib.ABI_VERSION
+    assert h.sd_error_string(-4) == b'workspace too small or misaligned'
+
+
+def test_workspace_sizing_and_tunables(built):
+    from segdistill_amd import _lib
+    h = _lib.lib()
+    assert h.sd_cgd_kl_workspace_bytes(8, 150, 512, 512, 8) >= 8 * 150 * 20
+    assert h.sd_cgd_kl_workspace_bytes(0, 150, 512, 512, 8) == 0
+    old = _lib.get_tunable('cgd_chunk_iters')
+    _lib.set_tunable('cgd_chunk_iters', 4)
+    assert _lib.get_tunable('cgd_chunk_iters') == 4
+    _lib.set_tunable('cgd_chunk_iters', old)
+    with pytest.raises(RuntimeError):
+        _lib.set_tunable('no_such_key', 1)
+
+
+def test_ops_refuse_cpu_tensors(built):
+    import torch
+    from segdistill_amd import ops
+    with pytest.raises(RuntimeError, match='GPU only'):
+        ops.cgd_kl(torch.zeros(1, 2, 4, 4), torch.zeros(1, 2, 4, 4), group_size=2, tau=1.0, alpha=1.0)
+
+
+def test_missing_library_fails_loudly(built, monkeypatch):
+    from segdistill_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libsegdistill_hip.so')
+    with pytest.raises(_lib.SegDistillLibError):
+        _lib.lib()
