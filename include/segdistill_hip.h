@@ -56,7 +56,9 @@ int sd_abi_version(void);
 const char *sd_error_string(int code);
 
 /* Tunables (process-wide, for benchmarking only; defaults are the shipped values).
- * key: "cgd_chunk_iters" (vector iterations per thread per workgroup, fwd+bwd). */
+ * keys: "cgd_fwd_chunk_iters" / "cgd_bwd_chunk_iters" (rounds of 4 x 16-byte loads per
+ *       operand per lane per workgroup), "cgd_bwd_nt_store" (0|1),
+ *       "cgd_up_band_rows" (tap rows per workgroup of the fused-upsample kernels). */
 int sd_set_tunable(const char *key, int value);
 int sd_get_tunable(const char *key);
 
@@ -95,6 +97,49 @@ int sd_cgd_kl_bwd(const void *S, const void *T, int dtype,
                   int B, int C, int H, int W, int g,
                   float inv_tau, float coef,
                   const int32_t *perm, const float *row_lse2,
+                  const float *upstream, void *dS, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * CGD / CD criterion with the bilinear up-sampling fused in ("R2").
+ * s,t are the TAPPED tensors [B,C,h,w]; the softmax runs at (H,W) = (F*h, F*w),
+ * F in {2,4,8}, align_corners=False.  Replaces losses.py:101-102 (two
+ * F.interpolate calls, each materialising a [B,C,H,W] tensor) PLUS losses.py:105-112,
+ * and in the backward additionally upsample_bilinear2d_backward.  Nothing of size
+ * B*C*H*W is ever written to memory.  Same row geometry, outputs and statistics as
+ * sd_cgd_kl_fwd/bwd; `ds` is the gradient w.r.t. the tap s ([B,C,h,w]).
+ * sd_cgd_kl_up_supported() tells whether a shape pair has a fused kernel (otherwise the
+ * caller resizes with ATen and uses the R1 entry points).
+ */
+int sd_cgd_kl_up_supported(int h, int w, int H, int W);
+size_t sd_cgd_kl_up_workspace_bytes(int B, int C, int h, int w, int H, int W, int g);
+
+int sd_cgd_kl_up_fwd(const void *s, const void *t, int dtype,
+                     int B, int C, int h, int w, int H, int W, int g,
+                     float inv_tau, float loss_scale, const int32_t *perm,
+                     float *row_lse2, float *row_kl, float *loss,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+int sd_cgd_kl_up_bwd(const void *s, const void *t, int dtype,
+                     int B, int C, int h, int w, int H, int W, int g,
+                     float inv_tau, float coef, const int32_t *perm,
+                     const float *row_lse2, const float *upstream,
+                     void *ds, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * Pixel-wise criterion (PDLoss; KL term of ATLoss / IFVDLoss): rows = (b, pixel),
+ * softmax over the C channels, loss_scale = alpha/(B*H*W), coef = alpha/(B*H*W*tau).
+ * Replaces losses.py:47-49 (permute+reshape copy) and :108-112 for loss_type='pixel',
+ * and ATLoss/IFVDLoss's log_softmax/softmax/KLDivLoss over dim=1 (losses.py:191-195,
+ * :218-220).  pix_lse2: [2][B*H*W] base-2 log-partitions (student plane, teacher plane).
+ */
+size_t sd_pix_kl_workspace_bytes(int B, int C, int H, int W);
+
+int sd_pix_kl_fwd(const void *S, const void *T, int dtype, int B, int C, int H, int W,
+                  float inv_tau, float loss_scale, float *pix_lse2, float *loss,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+int sd_pix_kl_bwd(const void *S, const void *T, int dtype, int B, int C, int H, int W,
+                  float inv_tau, float coef, const float *pix_lse2,
                   const float *upstream, void *dS, void *stream);
 
 #ifdef __cplusplus

@@ -27,3 +27,47 @@ def probe_vector(shape):
     """Fixed direction used to compress a gradient into one number: <grad, probe>."""
     n = int(np.prod(shape))
     return np.cos(0.37 * np.arange(n, dtype=np.float64) + 0.1).reshape(shape)
+
+
+def fill_state_dict_(module):
+    """Overwrite every parameter / float buffer of a torch module with closed-form values that
+    depend only on the tensor's NAME and shape, so that two implementations with identical
+    state-dict keys (the reference's and ours) hold identical weights without storing them."""
+    import zlib
+
+    import torch
+    sd = module.state_dict()
+    with torch.no_grad():
+        for name, t in sd.items():
+            if not torch.is_floating_point(t):
+                continue
+            n = t.numel()
+            phase = (zlib.crc32(name.encode()) % 10007) / 10007.0 * 6.283185307179586
+            base = torch.sin(torch.arange(n, dtype=torch.float64) * 0.6180339887 + phase)
+            if name.endswith('running_var'):
+                v = 1.0 + 0.2 * base * base
+            elif name.endswith('running_mean'):
+                v = 0.1 * base
+            elif t.dim() <= 1 and name.endswith('weight'):
+                v = 1.0 + 0.1 * base
+            elif t.dim() <= 1:
+                v = 0.05 * base
+            elif 'relative_position_bias_table' in name or 'absolute_pos_embed' in name:
+                v = 0.2 * base
+            else:
+                fan_in = n // t.shape[0]
+                v = base * (1.5 / max(fan_in, 1) ** 0.5)
+            t.copy_(v.reshape(t.shape).to(t.dtype))
+    return module
+
+
+def wavy_image(shape=(2, 3, 64, 64)):
+    """Synthetic normalised image batch (float32) and a label map with some 255 (ignore) pixels."""
+    n = int(np.prod(shape))
+    i = np.arange(n, dtype=np.float64)
+    img = (np.sin(i * 0.01931 + 0.5 * np.cos(i * 0.000371)) + 0.3 * np.cos(i * 0.7713)).reshape(shape).astype(np.float32)
+    b, _, h, w = shape
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing='ij')
+    lab = np.stack([((yy // 7 + 2 * (xx // 5) + 3 * k) % 150) for k in range(b)]).astype(np.int64)
+    lab[:, ::9, ::4] = 255
+    return img, lab[:, None]

@@ -5,3 +5,9 @@ The dense distillation criteria run as hand-written HIP kernels for gfx950 behin
 (include/segdistill_hip.h, segdistill_amd/csrc); the networks run on PyTorch-ROCm.
 """
 __version__ = '0.1.0'
+
+
+def register_all():
+    """Import every module that registers a class (backbones, heads, losses, segmentors,
+    distillation criteria) so that configs can be built by name."""
+    from . import backbones, decode_heads, distillation, losses, segmentors  # noqa: F401

@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch first: PyTorch-ROCm bundles its own libamdhip64.so.7; loading it before our library
+# makes the dynamic linker bind libsegdistill_hip.so to that SAME runtime (one HIP runtime
+# per process -- two would give "no ROCm-capable device" on the second one's first launch).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libsegdistill_hip.so')
 
@@ -27,6 +32,13 @@ SIGNATURES = {
     'sd_cgd_kl_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'sd_cgd_kl_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'sd_cgd_kl_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'sd_cgd_kl_up_supported': (_i, [_i, _i, _i, _i]),
+    'sd_cgd_kl_up_workspace_bytes': (_sz, [_i] * 7),
+    'sd_cgd_kl_up_fwd': (_i, [_vp, _vp, _i] + [_i] * 7 + [_f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'sd_cgd_kl_up_bwd': (_i, [_vp, _vp, _i] + [_i] * 7 + [_f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'sd_pix_kl_workspace_bytes': (_sz, [_i] * 4),
+    'sd_pix_kl_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    'sd_pix_kl_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
 }
 
 

@@ -1,0 +1,212 @@
+"""Mix Transformer (SegFormer MiT-B0..B5) encoder on PyTorch-ROCm.
+
+Behavioural counterpart of the reference's mmseg/models/backbones/mix_transformer.py
+(MixVisionTransformer :221-373, Attention :63-133, Mlp :20-55, OverlapPatchEmbed :178-218,
+variants mit_b0..b5 :392-441).  Attribute names (patch_embedN.proj/norm, blockN.i.norm1/attn.
+{q,kv,sr,norm,proj}/norm2/mlp.{fc1,dwconv.dwconv,fc2}, normN) are the reference's, so its
+checkpoints load key-for-key and the distillation taps (``backbone.block1.0.attn.ATTN`` ...)
+resolve identically.  The pass-through ``Tap`` children (ATTN/Q/K/V/FEA) exist only to be
+hooked by name, as in the reference (:57-61).
+
+MI355X notes: the attention core goes through ``F.scaled_dot_product_attention`` unless the
+pre-softmax scores are tapped (a hook on ``ATTN``) or attention dropout is active, in which
+case the explicit softmax(QK^T*scale)V form is used so the tapped tensor exists.
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..builder import BACKBONES
+from ..layers import DropPath, trunc_normal_
+
+
+def _mit_init(m):
+    """reference mix_transformer.py:33-46 (same rule in every sub-module)."""
+    if isinstance(m, nn.Linear):
+        trunc_normal_(m.weight, std=.02)
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.ones_(m.weight)
+        nn.init.zeros_(m.bias)
+    elif isinstance(m, nn.Conv2d):
+        fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
+        m.weight.data.normal_(0, math.sqrt(2.0 / fan_out))
+        if m.bias is not None:
+            m.bias.data.zero_()
+
+
+class Tap(nn.Identity):
+    """Identity whose only purpose is to be addressable by a dotted module name."""
+
+
+class _DepthwiseConv(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
+
+    def forward(self, tokens, hw):
+        b, n, c = tokens.shape
+        y = self.dwconv(tokens.transpose(1, 2).reshape(b, c, *hw))
+        return y.flatten(2).transpose(1, 2)
+
+
+class MixFFN(nn.Module):
+    def __init__(self, dim, hidden, drop=0.):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.dwconv = _DepthwiseConv(hidden)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden, dim)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x, hw):
+        x = self.drop(self.act(self.dwconv(self.fc1(x), hw)))
+        return self.drop(self.fc2(x))
+
+
+class SRAttention(nn.Module):
+    """Multi-head attention whose keys/values come from a spatially reduced map (sr_ratio)."""
+
+    def __init__(self, dim, num_heads, qkv_bias, qk_scale, attn_drop, proj_drop, sr_ratio):
+        super().__init__()
+        if dim % num_heads:
+            raise ValueError(f'dim {dim} should be divided by num_heads {num_heads}.')
+        self.dim, self.num_heads = dim, num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.kv = nn.Linear(dim, 2 * dim, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.ATTN, self.Q, self.K, self.V = Tap(), Tap(), Tap(), Tap()
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.sr_ratio = sr_ratio
+        if sr_ratio > 1:
+            self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
+            self.norm = nn.LayerNorm(dim)
+
+    def forward(self, x, hw):
+        b, n, c = x.shape
+        h, d = self.num_heads, c // self.num_heads
+        q = self.Q(self.q(x).reshape(b, n, h, d).transpose(1, 2))
+        src = x
+        if self.sr_ratio > 1:
+            src = self.sr(x.transpose(1, 2).reshape(b, c, *hw)).flatten(2).transpose(1, 2)
+            src = self.norm(src)
+        kv = self.kv(src).reshape(b, -1, 2, h, d).permute(2, 0, 3, 1, 4)
+        k, v = self.K(kv[0]), self.V(kv[1])
+        explicit = bool(self.ATTN._forward_hooks) or (self.training and self.attn_drop.p > 0)
+        if explicit:
+            scores = self.ATTN((q @ k.transpose(-2, -1)) * self.scale)
+            out = self.attn_drop(scores.softmax(dim=-1)) @ v
+        else:
+            out = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
+        out = out.transpose(1, 2).reshape(b, n, c)
+        return self.proj_drop(self.proj(out))
+
+
+class EncoderBlock(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio, qkv_bias, qk_scale, drop, attn_drop, drop_path, norm_layer, sr_ratio):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = SRAttention(dim, num_heads, qkv_bias, qk_scale, attn_drop, drop, sr_ratio)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = MixFFN(dim, int(dim * mlp_ratio), drop)
+        self.FEA = Tap()
+
+    def forward(self, x, hw):
+        x = x + self.drop_path(self.attn(self.norm1(x), hw))
+        x = x + self.drop_path(self.mlp(self.norm2(x), hw))
+        return self.FEA(x)
+
+
+class OverlapPatchEmbed(nn.Module):
+    def __init__(self, patch_size, stride, in_chans, embed_dim):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride, padding=patch_size // 2)
+        self.norm = nn.LayerNorm(embed_dim)
+
+    def forward(self, x):
+        x = self.proj(x)
+        hw = tuple(x.shape[2:])
+        return self.norm(x.flatten(2).transpose(1, 2)), hw
+
+
+class MixVisionTransformer(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dims=(64, 128, 256, 512),
+                 num_heads=(1, 2, 4, 8), mlp_ratios=(4, 4, 4, 4), qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., norm_layer=nn.LayerNorm, depths=(3, 4, 6, 3), sr_ratios=(8, 4, 2, 1)):
+        super().__init__()
+        self.num_classes = num_classes
+        self.depths = tuple(depths)
+        self.embed_dims = tuple(embed_dims)
+        chans = (in_chans,) + tuple(embed_dims)
+        rates = torch.linspace(0, drop_path_rate, sum(depths)).tolist()
+        cursor = 0
+        for s in range(4):
+            setattr(self, f'patch_embed{s + 1}', OverlapPatchEmbed(7 if s == 0 else 3, 4 if s == 0 else 2, chans[s], chans[s + 1]))
+        for s in range(4):
+            blocks = nn.ModuleList(
+                EncoderBlock(embed_dims[s], num_heads[s], mlp_ratios[s], qkv_bias, qk_scale, drop_rate, attn_drop_rate,
+                             rates[cursor + i], norm_layer, sr_ratios[s]) for i in range(depths[s]))
+            cursor += depths[s]
+            setattr(self, f'block{s + 1}', blocks)
+            setattr(self, f'norm{s + 1}', norm_layer(embed_dims[s]))
+        self.apply(_mit_init)
+
+    def init_weights(self, pretrained=None):
+        if isinstance(pretrained, str):
+            from ..checkpoint import load_checkpoint
+            load_checkpoint(self, pretrained, strict=False)
+
+    def reset_drop_path(self, drop_path_rate):
+        rates = torch.linspace(0, drop_path_rate, sum(self.depths)).tolist()
+        cursor = 0
+        for s in range(4):
+            for i, blk in enumerate(getattr(self, f'block{s + 1}')):
+                if isinstance(blk.drop_path, DropPath):
+                    blk.drop_path.drop_prob = rates[cursor + i]
+            cursor += self.depths[s]
+
+    def forward_features(self, x):
+        feats = []
+        for s in range(1, 5):
+            x, hw = getattr(self, f'patch_embed{s}')(x)
+            for blk in getattr(self, f'block{s}'):
+                x = blk(x, hw)
+            x = getattr(self, f'norm{s}')(x)
+            x = x.reshape(x.shape[0], hw[0], hw[1], -1).permute(0, 3, 1, 2).contiguous()
+            feats.append(x)
+        return feats
+
+    def forward(self, x):
+        return self.forward_features(x)
+
+
+_VARIANTS = {  # embed_dims, depths  (reference mix_transformer.py:392-441)
+    'mit_b0': ((32, 64, 160, 256), (2, 2, 2, 2)),
+    'mit_b1': ((64, 128, 320, 512), (2, 2, 2, 2)),
+    'mit_b2': ((64, 128, 320, 512), (3, 4, 6, 3)),
+    'mit_b3': ((64, 128, 320, 512), (3, 4, 18, 3)),
+    'mit_b4': ((64, 128, 320, 512), (3, 8, 27, 3)),
+    'mit_b5': ((64, 128, 320, 512), (3, 6, 40, 3)),
+}
+
+
+def _make_variant(name, dims, depths):
+    def __init__(self, **kwargs):  # extra config keys such as style='pytorch' are accepted and ignored, as in the reference
+        MixVisionTransformer.__init__(self, patch_size=4, embed_dims=dims, num_heads=(1, 2, 5, 8), mlp_ratios=(4, 4, 4, 4),
+                                      qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), depths=depths,
+                                      sr_ratios=(8, 4, 2, 1), drop_rate=0.0, drop_path_rate=0.1)
+    cls = type(name, (MixVisionTransformer,), {'__init__': __init__, '__doc__': f'SegFormer {name} encoder.'})
+    return BACKBONES.register_module()(cls)
+
+
+for _n, (_d, _p) in _VARIANTS.items():
+    globals()[_n] = _make_variant(_n, _d, _p)

@@ -25,14 +25,16 @@ const char *sd_error_string(int code) {
 
 int sd_set_tunable(const char *key, int value) {
     if (!key) return SD_E_NULL;
-    if (!strcmp(key, "cgd_chunk_iters")) return sd::cgd_set_chunk_iters(value);
-    return SD_E_UNSUPPORTED;
+    int rc = sd::cgd_tunable(key, 1, value);
+    if (rc == SD_E_UNSUPPORTED) rc = sd::cgd_up_tunable(key, 1, value);
+    return rc;
 }
 
 int sd_get_tunable(const char *key) {
     if (!key) return SD_E_NULL;
-    if (!strcmp(key, "cgd_chunk_iters")) return sd::cgd_get_chunk_iters();
-    return SD_E_UNSUPPORTED;
+    int rc = sd::cgd_tunable(key, 0, 0);
+    if (rc == SD_E_UNSUPPORTED) rc = sd::cgd_up_tunable(key, 0, 0);
+    return rc;
 }
 
 }  // extern "C"

@@ -16,120 +16,13 @@
 // HBM-bound by design: 8 B/element forward, 12 B/element backward (fp32).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
-#include "sd_common.h"
+#include "cgd_device.h"
 
 namespace sd {
 
 namespace {
-
-constexpr int kThreads = 256;
-constexpr int kUnroll = 4;          // independent 16-byte loads per operand in flight per lane
-constexpr float kNegBig = -1.0e30f; // finite stand-in for -inf in running maxima
-
-struct RowPart {  // one partial of a row: raw-unit maxima, base-2-scaled sums
-    float ms, zs, mt, zt, a;
-};
-
-__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// ---- 16-byte vector access for the two storage types ------------------------------------
-template <typename T> struct VecIO;
-template <> struct VecIO<float> {
-    static constexpr int N = 4;
-    typedef float raw_t __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ void load(const float *p, float (&o)[4]) {
-        raw_t v = __builtin_nontemporal_load(reinterpret_cast<const raw_t *>(p));
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-    }
-    static __device__ __forceinline__ void store(float *p, const float (&o)[4]) {
-        raw_t v = {o[0], o[1], o[2], o[3]};
-        *reinterpret_cast<raw_t *>(p) = v;
-    }
-    static __device__ __forceinline__ float load1(const float *p) { return *p; }
-    static __device__ __forceinline__ void store1(float *p, float v) { *p = v; }
-};
-template <> struct VecIO<bf16_t> {
-    static constexpr int N = 8;
-    typedef unsigned int raw_t __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ void load(const bf16_t *p, float (&o)[8]) {
-        raw_t v = __builtin_nontemporal_load(reinterpret_cast<const raw_t *>(p));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            o[2 * i] = __uint_as_float(v[i] << 16);
-            o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
-        }
-    }
-    static __device__ __forceinline__ void store(bf16_t *p, const float (&o)[8]) {
-        raw_t v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (unsigned)f32_to_bf16(o[2 * i]) | ((unsigned)f32_to_bf16(o[2 * i + 1]) << 16);
-        *reinterpret_cast<raw_t *>(p) = v;
-    }
-    static __device__ __forceinline__ float load1(const bf16_t *p) { return __uint_as_float((unsigned)p->bits << 16); }
-    static __device__ __forceinline__ void store1(bf16_t *p, float v) { p->bits = f32_to_bf16(v); }
-};
-
-// Fold n elements (raw s, raw t) into the lane's running state.
-template <int N>
-__device__ __forceinline__ void fold(RowPart &st, const float (&s)[N], const float (&t)[N], float c2) {
-    float mxs = s[0], mxt = t[0];
-#pragma unroll
-    for (int i = 1; i < N; ++i) { mxs = fmaxf(mxs, s[i]); mxt = fmaxf(mxt, t[i]); }
-    const float nms = fmaxf(st.ms, mxs), nmt = fmaxf(st.mt, mxt);
-    const float rs = ex2((st.ms - nms) * c2), rt = ex2((st.mt - nmt) * c2);
-    const float os = -nms * c2, ot = -nmt * c2;
-    float zs = st.zs * rs, zt = st.zt * rt, a = st.a * rt;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        zs += ex2(fmaf(s[i], c2, os));
-        const float e = ex2(fmaf(t[i], c2, ot));
-        zt += e;
-        a = fmaf(e, t[i] - s[i], a);
-    }
-    st.ms = nms; st.zs = zs; st.mt = nmt; st.zt = zt; st.a = a;
-}
-
-__device__ __forceinline__ void merge(RowPart &p, const RowPart &q, float c2) {
-    const float ms = fmaxf(p.ms, q.ms), mt = fmaxf(p.mt, q.mt);
-    const float ps = ex2((p.ms - ms) * c2), qs = ex2((q.ms - ms) * c2);
-    const float pt = ex2((p.mt - mt) * c2), qt = ex2((q.mt - mt) * c2);
-    p.zs = p.zs * ps + q.zs * qs;
-    p.zt = p.zt * pt + q.zt * qt;
-    p.a = p.a * pt + q.a * qt;
-    p.ms = ms; p.mt = mt;
-}
-
-// Combine the 256 lane states of a workgroup; result valid in thread 0.
-__device__ __forceinline__ RowPart block_combine(RowPart st, float c2) {
-    __shared__ RowPart wave_part[kThreads / 64];
-    const float ms = wave_max(st.ms), mt = wave_max(st.mt);
-    const float rs = ex2((st.ms - ms) * c2), rt = ex2((st.mt - mt) * c2);
-    RowPart w;
-    w.ms = ms; w.mt = mt;
-    w.zs = wave_sum(st.zs * rs);
-    w.zt = wave_sum(st.zt * rt);
-    w.a = wave_sum(st.a * rt);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0) wave_part[wid] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 1; i < kThreads / 64; ++i) merge(w, wave_part[i], c2);
-    }
-    return w;
-}
 
 // ---- forward, streaming pass ----------------------------------------------------------------
 // grid.x = B*C*nchunk; workgroup k of plane slot (b,c') covers elements
@@ -245,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void cgd_fwd_loss(const float *__restrict
 
 // ---- backward -------------------------------------------------------------------------------
 // dS_i = k (2^{s_i c2 - lse2_s} - 2^{t_i c2 - lse2_t}),  k = coef * upstream.
-template <typename T, bool VECTOR>
+template <typename T, bool VECTOR, bool NT>
 __global__ __launch_bounds__(kThreads) void cgd_bwd(const T *__restrict__ S, const T *__restrict__ Tt, const int32_t *__restrict__ perm,
                                                      const float *__restrict__ row_lse2, const float *__restrict__ upstream,
                                                      T *__restrict__ dS, int C, int HW, int g, int G, int nchunk, int iters,
@@ -288,14 +181,16 @@ __global__ __launch_bounds__(kThreads) void cgd_bwd(const T *__restrict__ S, con
                 float d[N];
 #pragma unroll
                 for (int i = 0; i < N; ++i) d[i] = kk * (ex2(fmaf(s[u][i], c2, -ls)) - ex2(fmaf(t[u][i], c2, -lt)));
-                if constexpr (VECTOR) VecIO<T>::store(pd + e, d);
+                if constexpr (VECTOR) VecIO<T>::template store<NT>(pd + e, d);
                 else VecIO<T>::store1(pd + e, d[0]);
             }
         }
     }
 }
 
-int g_chunk_iters = 8;  // tunable "cgd_chunk_iters"
+int g_fwd_iters = 4;   // tunable "cgd_fwd_chunk_iters": 4096 float4 per operand per workgroup
+int g_bwd_iters = 1;   // tunable "cgd_bwd_chunk_iters"
+int g_bwd_nt = 1;      // tunable "cgd_bwd_nt_store": dS is consumed by a later kernel, never re-read here
 
 struct Geo {
     int N, iters, chunk, nchunk, G, rows;
@@ -303,14 +198,14 @@ struct Geo {
 };
 
 template <typename T>
-Geo geometry(const void *S, const void *Tt, const void *dS, int C, int H, int W, int g, int B) {
+Geo geometry(const void *S, const void *Tt, const void *dS, int C, int H, int W, int g, int B, int want_iters) {
     Geo q;
     const long HW = (long)H * W;
     const int VN = VecIO<T>::N;
     auto al = [](const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     q.vec = (HW % VN == 0) && al(S) && al(Tt) && al(dS);
     q.N = q.vec ? VN : 1;
-    int iters = g_chunk_iters;
+    int iters = want_iters;
     const long per_iter = (long)kThreads * q.N * kUnroll;
     const long need = (HW + per_iter - 1) / per_iter;
     if (iters > need) iters = (int)need;
@@ -336,7 +231,7 @@ int check_common(const void *S, const void *Tt, int dtype, int B, int C, int H, 
 template <typename T>
 int fwd_impl(const void *S, const void *Tt, int B, int C, int H, int W, int g, float inv_tau, float loss_scale,
              const int32_t *perm, float *row_lse2, float *row_kl, float *loss, void *ws, size_t ws_bytes, hipStream_t st) {
-    const Geo q = geometry<T>(S, Tt, nullptr, C, H, W, g, B);
+    const Geo q = geometry<T>(S, Tt, nullptr, C, H, W, g, B, g_fwd_iters);
     const long nwg = (long)B * C * q.nchunk;
     if (nwg > 0x7fffffffL) return SD_E_SHAPE;
     if (ws_bytes < (size_t)nwg * sizeof(RowPart) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
@@ -349,38 +244,53 @@ int fwd_impl(const void *S, const void *Tt, int B, int C, int H, int W, int g, f
     else
         hipLaunchKernelGGL((cgd_fwd_partials<T, false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, perm,
                            part, C, HW, q.nchunk, q.iters, c2);
-    const int rows_per_wg = kThreads / 64;
-    hipLaunchKernelGGL(cgd_fwd_rows, dim3((q.rows + rows_per_wg - 1) / rows_per_wg), dim3(kThreads), 0, st, part, row_lse2, row_kl,
-                       q.rows, C, g, q.G, q.nchunk, c2, inv_tau);
-    hipLaunchKernelGGL(cgd_fwd_loss, dim3(1), dim3(kThreads), 0, st, row_kl, loss, q.rows, loss_scale);
+    launch_row_finalize(part, row_lse2, row_kl, loss, B, C, g, q.nchunk, c2, inv_tau, loss_scale, st);
     return (int)hipGetLastError();
 }
 
 template <typename T>
 int bwd_impl(const void *S, const void *Tt, int B, int C, int H, int W, int g, float inv_tau, float coef, const int32_t *perm,
              const float *row_lse2, const float *upstream, void *dS, hipStream_t st) {
-    const Geo q = geometry<T>(S, Tt, dS, C, H, W, g, B);
+    const Geo q = geometry<T>(S, Tt, dS, C, H, W, g, B, g_bwd_iters);
     const long nwg = (long)B * C * q.nchunk;
     if (nwg > 0x7fffffffL) return SD_E_SHAPE;
     const float c2 = inv_tau * 1.44269504088896340736f;
     const int HW = H * W;
-    if (q.vec)
-        hipLaunchKernelGGL((cgd_bwd<T, true>), dim3((unsigned)nwg), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, perm, row_lse2,
-                           upstream, (T *)dS, C, HW, g, q.G, q.nchunk, q.iters, c2, coef);
+    if (q.vec && g_bwd_nt)
+        hipLaunchKernelGGL((cgd_bwd<T, true, true>), dim3((unsigned)nwg), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, perm,
+                           row_lse2, upstream, (T *)dS, C, HW, g, q.G, q.nchunk, q.iters, c2, coef);
+    else if (q.vec)
+        hipLaunchKernelGGL((cgd_bwd<T, true, false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, perm,
+                           row_lse2, upstream, (T *)dS, C, HW, g, q.G, q.nchunk, q.iters, c2, coef);
     else
-        hipLaunchKernelGGL((cgd_bwd<T, false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, perm, row_lse2,
-                           upstream, (T *)dS, C, HW, g, q.G, q.nchunk, q.iters, c2, coef);
+        hipLaunchKernelGGL((cgd_bwd<T, false, false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, perm,
+                           row_lse2, upstream, (T *)dS, C, HW, g, q.G, q.nchunk, q.iters, c2, coef);
     return (int)hipGetLastError();
 }
 
 }  // namespace
 
-int cgd_set_chunk_iters(int v) {
-    if (v < 1 || v > 4096) return SD_E_SHAPE;
-    g_chunk_iters = v;
+void launch_row_finalize(const RowPart *part, float *row_lse2, float *row_kl, float *loss, int B, int C, int g, int nchunk,
+                         float c2, float inv_tau, float loss_scale, hipStream_t st) {
+    const int G = (C + g - 1) / g, rows = B * G;
+    const int rows_per_wg = kThreads / 64;
+    hipLaunchKernelGGL(cgd_fwd_rows, dim3((rows + rows_per_wg - 1) / rows_per_wg), dim3(kThreads), 0, st, part, row_lse2, row_kl, rows,
+                       C, g, G, nchunk, c2, inv_tau);
+    hipLaunchKernelGGL(cgd_fwd_loss, dim3(1), dim3(kThreads), 0, st, row_kl, loss, rows, loss_scale);
+}
+
+int cgd_tunable(const char *key, int set, int v) {
+    int *p = nullptr;
+    int lo = 1, hi = 4096;
+    if (!strcmp(key, "cgd_fwd_chunk_iters")) p = &g_fwd_iters;
+    else if (!strcmp(key, "cgd_bwd_chunk_iters")) p = &g_bwd_iters;
+    else if (!strcmp(key, "cgd_bwd_nt_store")) { p = &g_bwd_nt; lo = 0; hi = 1; }
+    if (!p) return SD_E_UNSUPPORTED;
+    if (!set) return *p;
+    if (v < lo || v > hi) return SD_E_SHAPE;
+    *p = v;
     return SD_OK;
 }
-int cgd_get_chunk_iters() { return g_chunk_iters; }
 
 }  // namespace sd
 
@@ -392,7 +302,7 @@ size_t sd_cgd_kl_workspace_bytes(int B, int C, int H, int W, int g) {
     // iteration of the scalar build.
     const long HW = (long)H * W;
     const long min_chunk = (long)sd::kThreads * sd::kUnroll;  // N = 1, iters = 1
-    long iters = sd::g_chunk_iters;
+    long iters = sd::g_fwd_iters;
     const long need = (HW + min_chunk - 1) / min_chunk;
     if (iters > need) iters = need;
     const long chunk = min_chunk * iters;

@@ -18,7 +18,8 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     return __builtin_bit_cast(uint16_t, h);
 }
 
-int cgd_set_chunk_iters(int v);
-int cgd_get_chunk_iters();
+// returns the value (set == 0) or SD_OK / an SD_E_* code (set != 0); SD_E_UNSUPPORTED if the key is not ours
+int cgd_tunable(const char *key, int set, int v);
+int cgd_up_tunable(const char *key, int set, int v);
 
 }  // namespace sd

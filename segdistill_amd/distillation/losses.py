@@ -1,0 +1,211 @@
+"""Distillation criteria with the reference's names, constructor kwargs and call signature
+(``criterion(x_student, x_teacher, gt_semantic_seg, n_iter) -> 0-dim tensor``), computed by
+the HIP kernels of libsegdistill_hip.so.
+
+Interface counterpart of reference mmseg/models/distillation/losses.py: KLDLoss :9-113,
+PDLoss :115-128, CDLoss :130-143, CGDLoss :145-158, CGDLossWS :160-173, ATLoss :175-197,
+IFVDLoss :199-238.  Host-side decisions (alpha schedule :61-92, whether this is a shuffle
+iteration :38) are taken here; everything per-pixel runs on the GPU:
+
+* 'channel' rows (CD / CGD): ``ops.cgd_kl`` -- grouped-channel online softmax + KL, the -1e9 pad
+  of :55-58 is virtual, the channel shuffle of :39-41 is a permutation table read by the
+  kernel (no gather copies);
+* 'pixel' rows (PD): ``ops.pix_kl``.
+
+There is no eager / CPU implementation in this module: on a CPU tensor the ops raise.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..builder import DISTILL_LOSSES
+
+
+def _bilinear(x, size):
+    return F.interpolate(x, size=tuple(int(v) for v in size), mode='bilinear', align_corners=False)
+
+
+@DISTILL_LOSSES.register_module()
+class KLDLoss(nn.Module):
+    def __init__(self, alpha=1, tau=1, resize_config=None, shuffle_config=None, transform_config=None, warmup_config=None,
+                 earlydecay_config=None):
+        super().__init__()
+        self.alpha_0 = alpha
+        self.alpha = alpha
+        self.tau = tau
+        self.resize_config = resize_config
+        self.shuffle_config = shuffle_config
+        self.transform_config = transform_config
+        self.warmup_config = warmup_config
+        self.earlydecay_config = earlydecay_config
+        self.fuse_resize = True   # use the fused-upsample kernels when the resize is bilinear/align_corners=False
+        self.last_perm = None     # permutation used by the most recent shuffle iteration (for tests / logging)
+
+    # ---- host-side schedule: same state machine as reference losses.py:61-92 -------------------
+    def warmup(self, n_iter):
+        cfg = self.warmup_config
+        total = cfg['warmup_iters']
+        if n_iter > total:
+            return
+        if n_iter == total:
+            self.alpha = self.alpha_0
+        elif cfg['mode'] == 'linear':
+            self.alpha = self.alpha_0 * (n_iter / total)
+        elif cfg['mode'] == 'exp':
+            self.alpha = self.alpha_0 ** (n_iter / total)
+        elif cfg['mode'] == 'jump':
+            self.alpha = 0
+
+    def earlydecay(self, n_iter):
+        cfg = self.earlydecay_config
+        start, end = cfg['earlydecay_start'], cfg['earlydecay_end']
+        if n_iter < start:
+            return
+        if start < n_iter < end:
+            left = (end - n_iter) / (end - start)
+            if cfg['mode'] == 'linear':
+                self.alpha = self.alpha_0 * left
+            elif cfg['mode'] == 'exp':
+                self.alpha = 0.001 * self.alpha_0 ** left
+            elif cfg['mode'] == 'jump':
+                self.alpha = 0
+        elif n_iter >= end:
+            self.alpha = 0
+
+    def _draw_perm(self, channels, n_iter, device):
+        """reference :38-41 draws torch.randperm(C) from the CPU global RNG on every rank
+        independently; ranks are made to agree by broadcasting rank 0's draw."""
+        if not self.shuffle_config or n_iter % self.shuffle_config['interval'] != 0:
+            return None
+        perm = torch.randperm(channels)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            p = perm.to(device)
+            dist.broadcast(p, src=0)
+            perm = p.cpu()
+        self.last_perm = perm
+        return perm.to(device=device, dtype=torch.int32)
+
+    def forward(self, x_student, x_teacher, gt, n_iter):
+        if self.warmup_config:
+            self.warmup(n_iter)
+        if self.earlydecay_config:
+            self.earlydecay(n_iter)
+        out_size = None
+        if self.resize_config:
+            out_size = tuple(int(v) for v in gt.shape[2:])
+            bilinear = self.resize_config['mode'] == 'bilinear' and not self.resize_config['align_corners']
+            if not (bilinear and self.fuse_resize and ops.can_fuse_resize(x_student, x_teacher, out_size, self.transform_config)):
+                mode, ac = self.resize_config['mode'], self.resize_config['align_corners']
+                x_student = F.interpolate(x_student, size=out_size, mode=mode, align_corners=ac)
+                x_teacher = F.interpolate(x_teacher, size=out_size, mode=mode, align_corners=ac)
+                out_size = None
+        perm = self._draw_perm(x_student.shape[1], n_iter, x_student.device) if self.shuffle_config else None
+        kind = self.transform_config['loss_type'] if self.transform_config else None
+        if kind == 'channel':
+            g = self.transform_config['group_size']
+            if out_size is not None:
+                return ops.cgd_kl_up(x_student, x_teacher, out_size, group_size=g, tau=self.tau, alpha=self.alpha, perm=perm)
+            return ops.cgd_kl(x_student, x_teacher, group_size=g, tau=self.tau, alpha=self.alpha, perm=perm)
+        if kind == 'pixel':
+            if out_size is not None:
+                x_student, x_teacher = _bilinear(x_student, out_size), _bilinear(x_teacher, out_size)
+            return ops.pix_kl(x_student, x_teacher, tau=self.tau, alpha=self.alpha)
+        if kind is None:
+            # reference :108-111 on an untransformed 4-D tensor: softmax over the LAST axis,
+            # rows = B*C*H.  Same kernel, seen as B*C*H single-plane rows of W elements.
+            if out_size is not None:
+                x_student, x_teacher = _bilinear(x_student, out_size), _bilinear(x_teacher, out_size)
+            if perm is not None:
+                idx = perm.long()
+                x_student, x_teacher = x_student[:, idx].contiguous(), x_teacher[:, idx].contiguous()
+            w = x_student.shape[-1]
+            s2 = x_student.reshape(1, -1, 1, w)
+            t2 = x_teacher.reshape(1, -1, 1, w)
+            return ops.cgd_kl(s2, t2, group_size=1, tau=self.tau, alpha=self.alpha)
+        raise ValueError(f'unknown loss_type {kind!r}')
+
+
+_BILINEAR = {'mode': 'bilinear', 'align_corners': False}
+
+
+@DISTILL_LOSSES.register_module()
+class PDLoss(KLDLoss):
+    """Pixel-wise distillation: softmax over classes at every pixel (reference :115-128)."""
+
+    def __init__(self):
+        super().__init__(alpha=1, tau=1, resize_config=dict(_BILINEAR), transform_config={'loss_type': 'pixel'})
+
+
+@DISTILL_LOSSES.register_module()
+class CDLoss(KLDLoss):
+    """Channel-wise distillation: softmax over the H*W pixels of every channel (reference :130-143)."""
+
+    def __init__(self):
+        super().__init__(alpha=1, tau=1, resize_config=dict(_BILINEAR), transform_config={'loss_type': 'channel', 'group_size': 1})
+
+
+@DISTILL_LOSSES.register_module()
+class CGDLoss(KLDLoss):
+    """Channel Group Distillation (reference :145-158): softmax over group_size channels x H*W,
+    channel shuffle every 1000 iterations."""
+
+    def __init__(self, group_size=10, alpha=3, tau=2):
+        super().__init__(alpha=alpha, tau=tau, resize_config=dict(_BILINEAR), shuffle_config={'interval': 1000},
+                         transform_config={'loss_type': 'channel', 'group_size': group_size})
+
+
+@DISTILL_LOSSES.register_module()
+class CGDLossWS(KLDLoss):
+    """CGD with linear warm-up (2000 it) and linear early decay 110k -> 120k (reference :160-173)."""
+
+    def __init__(self):
+        super().__init__(alpha=3, tau=2, resize_config=dict(_BILINEAR), shuffle_config={'interval': 1000},
+                         transform_config={'loss_type': 'channel', 'group_size': 10},
+                         warmup_config={'mode': 'linear', 'warmup_iters': 2000},
+                         earlydecay_config={'mode': 'linear', 'earlydecay_start': 110000, 'earlydecay_end': 120000})
+
+
+@DISTILL_LOSSES.register_module()
+class ATLoss(nn.Module):
+    """Attention transfer + pixel KL (reference :175-197): MSE between channel-mean maps plus
+    the class-softmax KL (tau=1, alpha=1) of the un-resized logits."""
+
+    def forward(self, x_student, x_teacher, gt, step):
+        at = F.mse_loss(x_student.mean(dim=1), x_teacher.mean(dim=1))
+        return at + ops.pix_kl(x_student, x_teacher, tau=1.0, alpha=1.0)
+
+
+@DISTILL_LOSSES.register_module()
+class IFVDLoss(nn.Module):
+    """Intra-class feature variation distillation (reference :199-238): cosine similarity of
+    every pixel to its class centre, matched between student and teacher (x10 MSE), plus the
+    class-softmax KL.  The reference's 150-pass mask loop (:226-230) is one segmented mean
+    (index_add over class ids) here."""
+
+    @staticmethod
+    def _centres(feat, label, n_cls):
+        b, c, h, w = feat.shape
+        lab = label.reshape(b, h * w)
+        valid = (lab >= 0) & (lab < n_cls) & (lab == lab.floor())
+        idx = torch.where(valid, lab, torch.zeros_like(lab)).long()
+        flat = feat.reshape(b, c, h * w)
+        one = valid.to(feat.dtype)
+        sums = feat.new_zeros(b, c, n_cls).scatter_add_(2, idx.unsqueeze(1).expand(b, c, h * w), flat * one.unsqueeze(1))
+        cnt = feat.new_zeros(b, n_cls).scatter_add_(1, idx, one)
+        mean = sums / (cnt.unsqueeze(1) + 1e-6)
+        centre = torch.gather(mean, 2, idx.unsqueeze(1).expand(b, c, h * w))
+        centre = torch.where(valid.unsqueeze(1), centre, flat)  # pixels of no class keep their own feature
+        return centre.reshape(b, c, h, w)
+
+    def forward(self, preds_S, preds_T, target, step):
+        feat_T = _bilinear(preds_T, preds_S.shape[2:])
+        n_cls = feat_T.shape[1]
+        pd = ops.pix_kl(preds_S, feat_T, tau=1.0, alpha=1.0)
+        lab = F.interpolate(target.float(), size=preds_S.shape[2:], mode='nearest')
+        sim_s = F.cosine_similarity(preds_S, self._centres(preds_S, lab, n_cls), dim=1)
+        sim_t = F.cosine_similarity(feat_T, self._centres(feat_T, lab, n_cls), dim=1)
+        return 10 * F.mse_loss(sim_s, sim_t) + pd

@@ -1,0 +1,156 @@
+"""Building blocks the reference takes from mmcv-full 1.2.2 / timm 0.3.2 (neither is
+vendored in the reference nor installed here), restated with the same child-module names
+so that reference checkpoints' state-dict keys line up:
+
+* ``ConvModule``        conv -> norm -> act; children ``conv``, ``bn``/``gn``, ``activate``;
+                        conv bias defaults to ``norm_cfg is None``; kaiming-normal
+                        (fan_out, relu) conv init, norm weight 1 / bias 0.
+* ``build_norm_layer``  returns ``(abbr+postfix, layer)`` with abbr bn/gn/ln.
+* ``DropPath``          per-sample stochastic depth.
+* ``resize``            F.interpolate wrapper (reference mmseg/ops/wrappers.py:8-29).
+"""
+from __future__ import annotations
+
+import warnings
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _want_sync_bn():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and torch.cuda.is_available()
+
+
+def build_norm_layer(cfg, num_features, postfix=''):
+    """``cfg``: dict(type='BN'|'SyncBN'|'GN'|'LN', requires_grad=True, eps=..., ...).
+
+    'SyncBN' builds torch.nn.SyncBatchNorm when a multi-rank GPU process group exists and
+    plain BatchNorm2d otherwise (identical math on one rank, identical state-dict keys).
+    """
+    if not isinstance(cfg, dict) or 'type' not in cfg:
+        raise KeyError('the norm cfg must be a dict containing the key "type"')
+    opts = dict(cfg)
+    kind = opts.pop('type')
+    trainable = opts.pop('requires_grad', True)
+    opts.setdefault('eps', 1e-5)
+    if kind in ('BN', 'BN2d'):
+        abbr, layer = 'bn', nn.BatchNorm2d(num_features, **opts)
+    elif kind == 'SyncBN':
+        abbr = 'bn'
+        layer = nn.SyncBatchNorm(num_features, **opts) if _want_sync_bn() else nn.BatchNorm2d(num_features, **opts)
+    elif kind == 'GN':
+        abbr, layer = 'gn', nn.GroupNorm(num_channels=num_features, **opts)
+    elif kind == 'LN':
+        abbr, layer = 'ln', nn.LayerNorm(num_features, **opts)
+    else:
+        raise KeyError(f'Unrecognized norm type {kind}')
+    for p in layer.parameters():
+        p.requires_grad = trainable
+    return f'{abbr}{postfix}', layer
+
+
+def build_conv_layer(cfg, *args, **kwargs):
+    kind = 'Conv2d' if cfg is None else cfg.get('type', 'Conv2d')
+    if kind not in ('Conv2d', 'Conv'):
+        raise KeyError(f'Unrecognized conv type {kind} (DCN and friends are outside the KD path)')
+    return nn.Conv2d(*args, **kwargs)
+
+
+def kaiming_init(m, mode='fan_out', nonlinearity='relu', bias=0.):
+    if getattr(m, 'weight', None) is not None:
+        nn.init.kaiming_normal_(m.weight, a=0, mode=mode, nonlinearity=nonlinearity)
+    if getattr(m, 'bias', None) is not None:
+        nn.init.constant_(m.bias, bias)
+
+
+def constant_init(m, val, bias=0.):
+    if getattr(m, 'weight', None) is not None:
+        nn.init.constant_(m.weight, val)
+    if getattr(m, 'bias', None) is not None:
+        nn.init.constant_(m.bias, bias)
+
+
+def normal_init(m, mean=0., std=1., bias=0.):
+    if getattr(m, 'weight', None) is not None:
+        nn.init.normal_(m.weight, mean, std)
+    if getattr(m, 'bias', None) is not None:
+        nn.init.constant_(m.bias, bias)
+
+
+class ConvModule(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias='auto',
+                 conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'), inplace=True):
+        super().__init__()
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        use_bias = (not self.with_norm) if bias == 'auto' else bool(bias)
+        self.conv = build_conv_layer(conv_cfg, in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                     dilation=dilation, groups=groups, bias=use_bias)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm_name = None
+        if self.with_norm:
+            self.norm_name, norm = build_norm_layer(norm_cfg, out_channels)
+            self.add_module(self.norm_name, norm)
+        if self.with_activation:
+            if act_cfg.get('type') != 'ReLU':
+                raise KeyError(f'activation {act_cfg} is not used on the KD path')
+            self.activate = nn.ReLU(inplace=inplace)
+        kaiming_init(self.conv)
+        if self.with_norm:
+            constant_init(self.norm, 1, bias=0)
+
+    @property
+    def norm(self):
+        return getattr(self, self.norm_name) if self.norm_name else None
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.with_norm:
+            x = self.norm(x)
+        if self.with_activation:
+            x = self.activate(x)
+        return x
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample: train -> x/(1-p) * Bernoulli(1-p); eval -> identity."""
+
+    def __init__(self, drop_prob=0.):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if not self.training or self.drop_prob == 0.:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        return x.div(keep) * mask
+
+    def extra_repr(self):
+        return f'p={self.drop_prob}'
+
+
+def trunc_normal_(t, mean=0., std=1., a=-2., b=2.):
+    return nn.init.trunc_normal_(t, mean=mean, std=std, a=a, b=b)
+
+
+def to_2tuple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+def resize(input, size=None, scale_factor=None, mode='nearest', align_corners=None, warning=True):
+    if warning and size is not None and align_corners:
+        ih, iw = (int(v) for v in input.shape[2:])
+        oh, ow = (int(v) for v in size)
+        if (oh > ih or ow > iw) and min(oh, ow, ih, iw) > 1 and (oh - 1) % (ih - 1) and (ow - 1) % (iw - 1):
+            warnings.warn(f'align_corners={align_corners}: sizes {(ih, iw)} -> {(oh, ow)} are not of the form x+1 -> nx+1')
+    if isinstance(size, torch.Size):
+        size = tuple(int(v) for v in size)
+    return F.interpolate(input, size, scale_factor, mode, align_corners)
+
+
+def add_prefix(d, prefix):
+    """reference mmseg/core/utils/misc.py:1 -- names the decode./aux. loss keys."""
+    return {f'{prefix}.{k}': v for k, v in d.items()}

@@ -75,3 +75,120 @@ def cgd_kl(S, T, *, group_size, tau, alpha, perm=None, return_rows=False):
     """Channel-group KL on operands already at softmax resolution (R1).  HIP only."""
     loss, rows = _CGDKLFunction.apply(S, T, group_size, tau, alpha, perm)
     return (loss, rows) if return_rows else loss
+
+
+# ------------------------------------------------------------------------------------------------
+def can_fuse_resize(x_student, x_teacher, out_size, transform_config=None) -> bool:
+    """True when the fused-upsample CGD kernels cover this case (same tap shapes, integer factor
+    2/4/8 on both axes, 'channel' rows)."""
+    if transform_config is None or transform_config.get('loss_type') != 'channel':
+        return False
+    if x_student.dim() != 4 or x_student.shape != x_teacher.shape or x_student.dtype != x_teacher.dtype:
+        return False
+    if x_student.dtype not in _DT or not x_student.is_cuda:
+        return False
+    h, w = x_student.shape[2:]
+    return bool(_lib.lib().sd_cgd_kl_up_supported(int(h), int(w), int(out_size[0]), int(out_size[1])))
+
+
+class _CGDKLUpFunction(torch.autograd.Function):
+    """CGD/CD criterion on TAP tensors with the bilinear resize to `out_size` fused in (R2)."""
+
+    @staticmethod
+    def forward(ctx, s, t, out_size, group_size, tau, alpha, perm):
+        _require_gpu(s, t)
+        if s.shape != t.shape or s.dim() != 4:
+            raise ValueError(f'expected equal 4-D shapes, got {tuple(s.shape)} and {tuple(t.shape)}')
+        if s.dtype != t.dtype or s.dtype not in _DT:
+            raise TypeError(f'unsupported dtypes {s.dtype}/{t.dtype}')
+        s, t = s.contiguous(), t.contiguous()
+        B, Cc, h, w = s.shape
+        H, W = int(out_size[0]), int(out_size[1])
+        g = int(group_size)
+        rows = B * (-(-Cc // g))
+        L = _lib.lib()
+        if perm is not None:
+            perm = perm.to(device=s.device, dtype=torch.int32).contiguous()
+            if perm.numel() != Cc:
+                raise ValueError('perm must have C entries')
+        ws_bytes = L.sd_cgd_kl_up_workspace_bytes(B, Cc, h, w, H, W, g)
+        if ws_bytes == 0:
+            raise RuntimeError(f'no fused-upsample kernel for {h}x{w} -> {H}x{W}')
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=s.device)
+        row_lse2 = torch.empty(rows, 2, dtype=torch.float32, device=s.device)
+        row_kl = torch.empty(rows, dtype=torch.float32, device=s.device)
+        loss = torch.empty((), dtype=torch.float32, device=s.device)
+        rc = L.sd_cgd_kl_up_fwd(s.data_ptr(), t.data_ptr(), _DT[s.dtype], B, Cc, h, w, H, W, g, 1.0 / float(tau),
+                                float(alpha) / rows, _ptr(perm), row_lse2.data_ptr(), row_kl.data_ptr(), loss.data_ptr(),
+                                ws.data_ptr(), ws_bytes, _stream_ptr())
+        _lib.check(rc, 'sd_cgd_kl_up_fwd')
+        ctx.save_for_backward(s, t, row_lse2, perm if perm is not None else torch.empty(0, device=s.device))
+        ctx.meta = (H, W, g, float(tau), float(alpha), rows, perm is not None)
+        ctx.mark_non_differentiable(row_kl)
+        return loss, row_kl
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_rows):
+        s, t, row_lse2, perm = ctx.saved_tensors
+        H, W, g, tau, alpha, rows, has_perm = ctx.meta
+        B, Cc, h, w = s.shape
+        ds = torch.empty_like(s)
+        up = grad_loss.to(torch.float32).contiguous()
+        rc = _lib.lib().sd_cgd_kl_up_bwd(s.data_ptr(), t.data_ptr(), _DT[s.dtype], B, Cc, h, w, H, W, g, 1.0 / tau,
+                                         alpha / (rows * tau), perm.data_ptr() if has_perm else None, row_lse2.data_ptr(),
+                                         up.data_ptr(), ds.data_ptr(), _stream_ptr())
+        _lib.check(rc, 'sd_cgd_kl_up_bwd')
+        return ds, None, None, None, None, None, None
+
+
+def cgd_kl_up(s, t, out_size, *, group_size, tau, alpha, perm=None, return_rows=False):
+    loss, rows = _CGDKLUpFunction.apply(s, t, tuple(out_size), group_size, tau, alpha, perm)
+    return (loss, rows) if return_rows else loss
+
+
+class _PixKLFunction(torch.autograd.Function):
+    """loss = alpha/(B*H*W) * sum_pixels KL(softmax_C(T/tau) || softmax_C(S/tau))."""
+
+    @staticmethod
+    def forward(ctx, S, T, tau, alpha):
+        _require_gpu(S, T)
+        if S.shape != T.shape or S.dim() != 4:
+            raise ValueError(f'expected equal 4-D shapes, got {tuple(S.shape)} and {tuple(T.shape)}')
+        if S.dtype != T.dtype or S.dtype not in _DT:
+            raise TypeError(f'unsupported dtypes {S.dtype}/{T.dtype}')
+        S, T = S.contiguous(), T.contiguous()
+        B, Cc, H, W = S.shape
+        rows = B * H * W
+        L = _lib.lib()
+        ws_bytes = L.sd_pix_kl_workspace_bytes(B, Cc, H, W)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=S.device)
+        lse2 = torch.empty(2, rows, dtype=torch.float32, device=S.device)
+        loss = torch.empty((), dtype=torch.float32, device=S.device)
+        rc = L.sd_pix_kl_fwd(S.data_ptr(), T.data_ptr(), _DT[S.dtype], B, Cc, H, W, 1.0 / float(tau), float(alpha) / rows,
+                             lse2.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr())
+        _lib.check(rc, 'sd_pix_kl_fwd')
+        ctx.save_for_backward(S, T, lse2)
+        ctx.meta = (float(tau), float(alpha), rows)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        S, T, lse2 = ctx.saved_tensors
+        tau, alpha, rows = ctx.meta
+        B, Cc, H, W = S.shape
+        dS = torch.empty_like(S)
+        up = grad_loss.to(torch.float32).contiguous()
+        rc = _lib.lib().sd_pix_kl_bwd(S.data_ptr(), T.data_ptr(), _DT[S.dtype], B, Cc, H, W, 1.0 / tau, alpha / (rows * tau),
+                                      lse2.data_ptr(), up.data_ptr(), dS.data_ptr(), _stream_ptr())
+        _lib.check(rc, 'sd_pix_kl_bwd')
+        return dS, None, None, None
+
+
+def pix_kl(S, T, *, tau, alpha):
+    return _PixKLFunction.apply(S, T, tau, alpha)
+
+
+def align1x1(x, weight, bias=None):
+    """Y[b,:,p] = W[Ct,Cs] . X[b,:,p] + bias  (MFMA GEMM kernel; see csrc/align1x1.hip)."""
+    from .align import align1x1 as _impl
+    return _impl(x, weight, bias)

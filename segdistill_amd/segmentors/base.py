@@ -1,0 +1,85 @@
+"""Segmentor base: ``forward`` dispatch, ``train_step`` runner contract and loss parsing.
+
+Counterpart of reference mmseg/models/segmentors/base.py (forward :113-126, train_step
+:128-162, _parse_losses :174-209).  The runner contract is unchanged:
+``train_step(data_batch, optimizer) -> {'loss': tensor, 'log_vars': {str: float}, 'num_samples': int}``.
+
+MI355X difference: the reference all-reduces and ``.item()``s every log variable separately
+(4-6 NCCL calls + 4-6 host syncs per step, :204-207).  Here all log scalars are stacked into
+ONE tensor, reduced with ONE RCCL all-reduce and copied to the host with ONE sync; with
+``defer_log_sync`` the host copy is skipped entirely except on logging iterations.
+"""
+from __future__ import annotations
+
+from abc import ABCMeta, abstractmethod
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def parse_losses(losses, want_host_values=True):
+    """-> (loss tensor, OrderedDict name -> float | 0-dim tensor).
+
+    mean of every entry; ``loss`` = sum of the entries whose key contains 'loss'
+    (so acc_seg is excluded and the KD keys are included)."""
+    log_vars = OrderedDict()
+    for name, value in losses.items():
+        if isinstance(value, torch.Tensor):
+            log_vars[name] = value.mean()
+        elif isinstance(value, list):
+            log_vars[name] = sum(v.mean() for v in value)
+        else:
+            raise TypeError(f'{name} is not a tensor or list of tensors')
+    loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+    log_vars['loss'] = loss
+    names = list(log_vars)
+    packed = torch.stack([log_vars[n].detach().float().reshape(()) for n in names])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        packed = packed / dist.get_world_size()
+        dist.all_reduce(packed)
+    if want_host_values:
+        host = packed.tolist()  # the single device->host sync of the step
+        out = OrderedDict(zip(names, host))
+    else:
+        out = OrderedDict((n, packed[i]) for i, n in enumerate(names))
+    return loss, out
+
+
+class BaseSegmentor(nn.Module, metaclass=ABCMeta):
+    def __init__(self):
+        super().__init__()
+        self.fp16_enabled = False
+        self.defer_log_sync = False  # True: log_vars hold 0-dim device tensors, no host sync in train_step
+
+    with_neck = property(lambda self: getattr(self, 'neck', None) is not None)
+    with_auxiliary_head = property(lambda self: getattr(self, 'auxiliary_head', None) is not None)
+    with_decode_head = property(lambda self: getattr(self, 'decode_head', None) is not None)
+
+    @abstractmethod
+    def forward_train(self, img, img_metas, **kwargs):
+        ...
+
+    def init_weights(self, pretrained=None):
+        pass
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        raise NotImplementedError('test-time inference (slide / aug) is outside the KD train-step path')
+
+    def forward(self, img, img_metas=None, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def _parse_losses(self, losses):
+        return parse_losses(losses, want_host_values=not self.defer_log_sync)
+
+    def train_step(self, data_batch, optimizer=None, **kwargs):
+        losses = self(**data_batch)
+        loss, log_vars = self._parse_losses(losses)
+        img = data_batch['img']
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(getattr(img, 'data', img)))
+
+    def val_step(self, data_batch, **kwargs):
+        return self(**data_batch, **kwargs)

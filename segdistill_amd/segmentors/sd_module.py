@@ -1,0 +1,121 @@
+"""The distillation segmentor registered as ``SDModule``: student + frozen teacher +
+feature taps + distillation losses.
+
+Interface counterpart of reference mmseg/models/segmentors/SD_structure.py (SDModule :18-223:
+__init__ :20-55, forward_train :61-90, _parse_losses :110-144).  Constructor signature, the
+``distillation=[{student_layer, teacher_layer, loss_name, loss_config}]`` surface, the
+``cnt``-before-use step counter and the returned loss keys are the reference's.
+
+Deliberate differences:
+ * Q1  the teacher STAYS in eval mode (``train()`` does not flip it); ``teacher_train_mode=True``
+       reproduces the reference's accidental behaviour;
+ * Q9  the teacher runs backbone + head only -- its own CE loss / accuracy at 512^2 is not computed;
+ * Q11 missing checkpoint files raise unless ``segdistill_amd.checkpoint`` is told otherwise by the
+       harness (synthetic-weights mode for offline benchmarking);
+ * logging all-reduce is one packed collective (see segmentors/base.py).
+"""
+from __future__ import annotations
+
+import copy
+import os
+import warnings
+
+import torch
+
+from .. import builder
+from ..builder import SEGMENTORS
+from ..distillation.opts import DistillationLoss, Extractor
+from ..layers import resize
+from .base import BaseSegmentor
+
+SYNTHETIC_WEIGHTS_OK = False  # set True by the benchmark harness: absent checkpoints -> keep random init
+
+
+def _load_or_synth(module, path, strict, what):
+    from ..checkpoint import load_checkpoint
+    if path and os.path.isfile(path):
+        return load_checkpoint(module, path, strict=strict)
+    if SYNTHETIC_WEIGHTS_OK or os.environ.get('SEGDISTILL_SYNTHETIC_WEIGHTS') == '1':
+        warnings.warn(f'{what} checkpoint {path!r} not found: keeping random initialisation (synthetic-weights mode)')
+        return None
+    raise FileNotFoundError(f'{what} checkpoint {path!r} not found (set SEGDISTILL_SYNTHETIC_WEIGHTS=1 to train from random init)')
+
+
+def _strip_missing_pretrained(cfg):
+    """A student/teacher cfg may name a ``pretrained`` backbone file that is not present offline."""
+    p = cfg.get('pretrained')
+    if p and not os.path.isfile(p):
+        if SYNTHETIC_WEIGHTS_OK or os.environ.get('SEGDISTILL_SYNTHETIC_WEIGHTS') == '1':
+            warnings.warn(f'pretrained weights {p!r} not found: random initialisation (synthetic-weights mode)')
+            cfg['pretrained'] = None
+    return cfg
+
+
+@SEGMENTORS.register_module()
+class SDModule(BaseSegmentor):
+    def __init__(self, cfg_s, cfg_t, train_cfg, test_cfg, distillation, s_pretrain=None, t_pretrain=None,
+                 teacher_train_mode=False):
+        super().__init__()
+        cfg_s, cfg_t = copy.deepcopy(dict(cfg_s)), copy.deepcopy(dict(cfg_t))
+        distillation = [dict(d) for d in distillation]
+        self.cfg_s, self.cfg_t, self.distillation = cfg_s, cfg_t, distillation
+        self.student = builder.build_segmentor(_strip_missing_pretrained(cfg_s), train_cfg=train_cfg, test_cfg=test_cfg)
+        if s_pretrain:
+            _load_or_synth(self.student, s_pretrain, True, 'student')
+        cfg_t['pretrained'] = None
+        self.teacher = builder.build_segmentor(cfg_t, train_cfg=train_cfg, test_cfg=test_cfg)
+        _load_or_synth(self.teacher, t_pretrain, False, 'teacher')
+        self.teacher.eval()
+        self.teacher_train_mode = teacher_train_mode
+        for p in self.teacher.parameters():
+            p.requires_grad = False
+        self.log_grad = bool(distillation) and 'log_grad' in distillation[0]
+        self.extractor = Extractor(self.student, self.teacher, distillation)
+        self.distillation_loss = DistillationLoss(distillation)
+        self._teacher_needs_aux = any(str(n).startswith('auxiliary_head') for n in self.extractor.hooked['teacher'])
+        self.align_corners = False
+        self.test_cfg = test_cfg
+        self.test_mode = 'whole'
+        self.cnt = 0
+
+    def train(self, mode=True):
+        super().train(mode)
+        if not self.teacher_train_mode:
+            self.teacher.eval()
+        return self
+
+    def my_resume(self, iter):
+        self.cnt = iter
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        return sd
+
+    def forward_train(self, img, img_metas=None, gt_semantic_seg=None):
+        self.cnt += 1
+        loss_dict = self.student(img, img_metas, return_loss=True, gt_semantic_seg=gt_semantic_seg)
+        if self.distillation:
+            with torch.no_grad():
+                if self.teacher_train_mode:
+                    self.teacher(img, img_metas, return_loss=True, gt_semantic_seg=gt_semantic_seg)  # reference behaviour
+                else:
+                    self.teacher.forward_features_only(img, run_aux=self._teacher_needs_aux)
+            kd = self.distillation_loss(self.extractor.student_features, self.extractor.teacher_features, gt_semantic_seg,
+                                        self.cnt, self.student, self.teacher)
+            loss_dict.update(kd)
+            self.extractor.clear()
+        return loss_dict
+
+    # ---- inference delegates to the student (reference :146-223) ---------------------------------
+    def encode_decode(self, img, img_metas=None):
+        return self.student.encode_decode(img, img_metas)
+
+    def whole_inference(self, img, img_meta=None, rescale=False):
+        logit = self.student.encode_decode(img, img_meta)
+        if rescale and img_meta:
+            logit = resize(logit, size=img_meta[0]['ori_shape'][:2], mode='bilinear', align_corners=self.align_corners, warning=False)
+        return logit
+
+    def forward_test(self, imgs, img_metas=None, **kwargs):
+        img = imgs[0] if isinstance(imgs, (list, tuple)) else imgs
+        return self.whole_inference(img, img_metas, rescale=False)

@@ -39,10 +39,10 @@ def test_workspace_sizing_and_tunables(built):
     h = _lib.lib()
     assert h.sd_cgd_kl_workspace_bytes(8, 150, 512, 512, 8) >= 8 * 150 * 20
     assert h.sd_cgd_kl_workspace_bytes(0, 150, 512, 512, 8) == 0
-    old = _lib.get_tunable('cgd_chunk_iters')
-    _lib.set_tunable('cgd_chunk_iters', 4)
-    assert _lib.get_tunable('cgd_chunk_iters') == 4
-    _lib.set_tunable('cgd_chunk_iters', old)
+    old = _lib.get_tunable('cgd_fwd_chunk_iters')
+    _lib.set_tunable('cgd_fwd_chunk_iters', 4)
+    assert _lib.get_tunable('cgd_fwd_chunk_iters') == 4
+    _lib.set_tunable('cgd_fwd_chunk_iters', old)
     with pytest.raises(RuntimeError):
         _lib.set_tunable('no_such_key', 1)
 

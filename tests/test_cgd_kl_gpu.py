@@ -78,15 +78,18 @@ def test_r1_chunk_tunable_invariance():
     from segdistill_amd import _lib
     S, T = wavy_pair((1, 6, 128, 128))
     ref = kd_ref.rowwise_kld(S, T, alpha=3, tau=4, group_size=4)
-    old = _lib.get_tunable('cgd_chunk_iters')
+    keys = ('cgd_fwd_chunk_iters', 'cgd_bwd_chunk_iters', 'cgd_bwd_nt_store')
+    old = [_lib.get_tunable(k) for k in keys]
     try:
-        for it in (1, 2, 3, 16):
-            _lib.set_tunable('cgd_chunk_iters', it)
+        for fi, bi, nt in ((1, 1, 0), (2, 3, 1), (3, 2, 0), (16, 16, 1)):
+            for k, v in zip(keys, (fi, bi, nt)):
+                _lib.set_tunable(k, v)
             loss, _, grad = _run_hip(S, T, 4, 4.0, 3.0)
             assert loss == pytest.approx(ref['loss'], rel=LOSS_RTOL)
             assert _rel_l2(grad, ref['grad_S']) < GRAD_RL2
     finally:
-        _lib.set_tunable('cgd_chunk_iters', old)
+        for k, v in zip(keys, old):
+            _lib.set_tunable(k, v)
 
 
 def test_r1_spiky_rows_force_rescale():
@@ -150,3 +153,111 @@ def test_arg_errors_are_reported():
     with pytest.raises(RuntimeError):
         from segdistill_amd import ops
         ops.cgd_kl(torch.zeros(1, 2, 4, 4), torch.zeros(1, 2, 4, 4), group_size=2, tau=1, alpha=1)
+
+
+# ------------------------------------------------------------------ R2: fused bilinear up-sampling
+UP_CASES = [
+    # (B, C, h, w, F, g, tau, alpha)
+    (2, 6, 4, 4, 2, 4, 4.0, 3.0),
+    (2, 22, 16, 16, 4, 8, 4.0, 3.0),
+    (2, 22, 16, 16, 4, 1, 1.0, 1.0),
+    (1, 22, 16, 16, 4, 22, 2.0, 3.0),
+    (1, 7, 8, 8, 8, 3, 2.0, 2.0),
+    (1, 5, 20, 12, 4, 2, 3.0, 1.0),      # w not a multiple of 64, h != w, several bands
+    (1, 3, 40, 70, 2, 2, 2.0, 1.0),      # two waves per workgroup, partial second wave
+    (1, 4, 33, 128, 4, 4, 4.0, 3.0),     # band tail (33 = 2*16 + 1)
+    (1, 2, 64, 64, 8, 1, 1.0, 1.0),      # PSPNet-style x8
+    (2, 150, 32, 32, 4, 8, 4.0, 3.0),
+]
+
+
+def _run_hip_up(s_np, t_np, F, g, tau, alpha, perm=None, dtype=torch.float32, upstream=1.0):
+    from segdistill_amd import ops
+    dev = _dev()
+    s = torch.tensor(s_np, dtype=dtype, device=dev, requires_grad=True)
+    t = torch.tensor(t_np, dtype=dtype, device=dev)
+    p = None if perm is None else torch.tensor(np.asarray(perm), dtype=torch.int32, device=dev)
+    H, W = s.shape[2] * F, s.shape[3] * F
+    assert ops.can_fuse_resize(s, t, (H, W), {'loss_type': 'channel', 'group_size': g})
+    loss, rows = ops.cgd_kl_up(s, t, (H, W), group_size=g, tau=tau, alpha=alpha, perm=p, return_rows=True)
+    (loss * upstream).backward()
+    return float(loss), rows.cpu().numpy(), s.grad.float().cpu().numpy()
+
+
+@pytest.mark.parametrize('case', UP_CASES)
+def test_r2_matches_oracle_fp32(case):
+    B, C, h, w, F, g, tau, alpha = case
+    s, t = wavy_pair((B, C, h, w))
+    ref = kd_ref.full_kld(s, t, out_size=(h * F, w * F), alpha=alpha, tau=tau, group_size=g)
+    loss, rows, grad = _run_hip_up(s, t, F, g, tau, alpha)
+    assert loss == pytest.approx(ref['loss'], rel=LOSS_RTOL)
+    np.testing.assert_allclose(rows, ref['row_kl'], rtol=1e-4, atol=1e-6)
+    assert _rel_l2(grad, ref['grad_s']) < GRAD_RL2
+
+
+def test_r2_band_rows_invariance_and_perm():
+    from segdistill_amd import _lib
+    s, t = wavy_pair((2, 10, 24, 24))
+    perm = np.random.RandomState(5).permutation(10)
+    ref = kd_ref.full_kld(s, t, out_size=(96, 96), alpha=3, tau=4, group_size=4, perm=perm)
+    old = _lib.get_tunable('cgd_up_band_rows')
+    try:
+        for r in (1, 5, 16, 64):
+            _lib.set_tunable('cgd_up_band_rows', r)
+            loss, _, grad = _run_hip_up(s, t, 4, 4, 4.0, 3.0, perm=perm, upstream=0.5)
+            assert loss == pytest.approx(ref['loss'], rel=LOSS_RTOL)
+            assert _rel_l2(grad, 0.5 * ref['grad_s']) < GRAD_RL2
+    finally:
+        _lib.set_tunable('cgd_up_band_rows', old)
+
+
+def test_r2_bf16_storage():
+    s, t = wavy_pair((2, 22, 16, 16))
+    sb = torch.tensor(s).bfloat16().float().numpy()
+    tb = torch.tensor(t).bfloat16().float().numpy()
+    ref = kd_ref.full_kld(sb, tb, out_size=(64, 64), alpha=3, tau=4, group_size=8)
+    loss, rows, grad = _run_hip_up(sb, tb, 4, 8, 4.0, 3.0, dtype=torch.bfloat16)
+    assert loss == pytest.approx(ref['loss'], rel=LOSS_RTOL)
+    assert _rel_l2(grad, ref['grad_s']) < 4e-3
+
+
+def test_r2_golden_reference_outputs(golden):
+    """Reference outputs straight from losses.py (golden G2/G3/G4), no ATen resize involved."""
+    s0, t0 = golden['G2/inputs/s'], golden['G2/inputs/t']
+    for key in ['G2/g8_a3_t4', 'G2/g10_a3_t2', 'G2/g1_a1_t1', 'G2/g22_a3_t2', 'G2/g7_a2_t3', 'G2/g11_a1.5_t0.5', 'G2/g32_a1_t2']:
+        g, a, tau = golden[key + '/cfg']
+        loss, _, grad = _run_hip_up(s0, t0, 4, int(g), float(tau), float(a))
+        assert loss == pytest.approx(float(golden[key + '/loss']), rel=LOSS_RTOL), key
+        assert _rel_l2(grad, golden[key + '/grad']) < GRAD_RL2, key
+    for seed in (0, 7):
+        key = f'G3/seed{seed}'
+        loss, _, grad = _run_hip_up(s0, t0, 4, 8, 4.0, 3.0, perm=golden[key + '/perm'])
+        assert loss == pytest.approx(float(golden[key + '/loss']), rel=LOSS_RTOL), key
+        assert _rel_l2(grad, golden[key + '/grad']) < GRAD_RL2, key
+    from oracle.inputs import probe_vector
+    for key in [k[:-7] for k in golden.files if k.startswith('G4/') and k.endswith('/loss64')]:
+        shp = tuple(int(v) for v in golden[key + '/shape'])
+        hw = tuple(int(v) for v in golden[key + '/hw'])
+        g, a, tau = golden[key + '/cfg']
+        s, t = wavy_pair(shp)
+        loss, _, grad = _run_hip_up(s, t, hw[0] // shp[2], int(g), float(tau), float(a))
+        assert loss == pytest.approx(float(golden[key + '/loss64']), rel=1e-4), key   # north-star bar is 1e-3
+        assert (grad.astype(np.float64) * probe_vector(shp)).sum() == pytest.approx(float(golden[key + '/grad_probe']), rel=2e-3, abs=1e-7), key
+        assert np.sqrt((grad.astype(np.float64) ** 2).sum()) == pytest.approx(float(golden[key + '/grad_l2']), rel=1e-4), key
+
+
+# ------------------------------------------------------------------ pixel-wise criterion
+PIX_CASES = [(2, 6, 8, 8, 1.0, 1.0), (2, 150, 16, 16, 1.0, 1.0), (1, 19, 13, 7, 2.0, 3.0), (1, 150, 64, 64, 4.0, 2.0), (3, 5, 32, 20, 0.5, 1.0)]
+
+
+@pytest.mark.parametrize('case', PIX_CASES)
+def test_pix_kl_matches_oracle(case):
+    from segdistill_amd import ops
+    B, C, H, W, tau, alpha = case
+    S, T = wavy_pair((B, C, H, W))
+    ref = kd_ref.rowwise_kld(S, T, alpha=alpha, tau=tau, loss_type='pixel')
+    s = torch.tensor(S, device=_dev(), requires_grad=True)
+    loss = ops.pix_kl(s, torch.tensor(T, device=_dev()), tau=tau, alpha=alpha)
+    loss.backward()
+    assert float(loss) == pytest.approx(ref['loss'], rel=LOSS_RTOL)
+    assert _rel_l2(s.grad.cpu().numpy(), ref['grad_S']) < GRAD_RL2
