@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- KD train_step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full KD training iteration on one synthetic batch per rank:
+student fwd + frozen-teacher fwd + distillation loss (HIP kernels) + supervised CE + backward +
+flat-buffer gradient all-reduce (RCCL) + fused AdamW step + LR update.  Workload at N=1: BASELINE
+config 2 (Segformer-B0 <- B2, CGD group 8, T 4, bs 8, 512x512, 150 classes), fp32 as the reference.
+
+Rank 0 prints ONE JSON line with, besides the contract fields:
+  roofline      the HBM-bound CGD kernels (R1 fwd+bwd) at the config-2 operand shape, timed with HIP
+                events in this same process: achieved = 5*N*4 bytes / (t_fwd + t_bwd);
+  cpu_baseline  the whole KD step on host cores (networks on torch-CPU, criteria from oracle/), B=2,
+                a bounded sample (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def build_model(cfg, device):
+    import segdistill_amd
+    from segdistill_amd.builder import build_segmentor
+    from segdistill_amd.segmentors import sd_module
+    segdistill_amd.register_all()
+    sd_module.SYNTHETIC_WEIGHTS_OK = True  # no checkpoints offline: random-init weights of the named architectures
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = build_segmentor(cfg.model.to_dict() if hasattr(cfg.model, 'to_dict') else dict(cfg.model))
+    return model.to(device)
+
+
+def timed_steps(trainer, data, steps, world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.step(data.next())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    return time.perf_counter() - t0
+
+
+def roofline_leg(device, B, C=150, HW=512, g=8, tau=4.0, reps=20):
+    """R1 CGD kernels on operands of the config-2 softmax shape, HIP events on torch's current stream
+    (the stream the C ABI launches on)."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator(device=device).manual_seed(1234)
+    S = 2 * torch.randn(B, C, HW, HW, device=device, generator=gen)
+    T = 2 * torch.randn(B, C, HW, HW, device=device, generator=gen)
+    rows = B * (-(-C // g))
+    row_lse2 = torch.empty(rows, 2, device=device)
+    row_kl = torch.empty(rows, device=device)
+    loss = torch.empty((), device=device)
+    dS = torch.empty_like(S)
+    wsb = L.sd_cgd_kl_workspace_bytes(B, C, HW, HW, g)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fwd():
+        rc = L.sd_cgd_kl_fwd(S.data_ptr(), T.data_ptr(), 0, B, C, HW, HW, g, 1 / tau, 3.0 / rows, None, row_lse2.data_ptr(),
+                             row_kl.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, st)
+        assert rc == 0, rc
+
+    def bwd():
+        rc = L.sd_cgd_kl_bwd(S.data_ptr(), T.data_ptr(), 0, B, C, HW, HW, g, 1 / tau, 3.0 / (rows * tau), None, row_lse2.data_ptr(),
+                             None, dS.data_ptr(), st)
+        assert rc == 0, rc
+
+    def avg_ms(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    tf, tb = avg_ms(fwd), avg_ms(bwd)
+    N = S.numel()
+    achieved = 5 * N * 4 / ((tf + tb) * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_r01.json')
+    if os.path.isfile(tpath):
+        try:
+            traffic = json.load(open(tpath)).get('cgd_kl_r1_fwd_bwd_bytes')
+        except Exception:
+            traffic = None
+    del S, T, dS
+    return {
+        'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+        'traffic': traffic,
+        'kernel': 'cgd_fwd_partials + cgd_bwd (R1, operands at softmax resolution)',
+        'operand_shape': [B, C, HW, HW], 'algorithmic_bytes': 5 * N * 4,
+        'fwd_ms': round(tf, 4), 'bwd_ms': round(tb, 4),
+        'fwd_GBps': round(2 * N * 4 / (tf * 1e-3) / 1e9, 1), 'bwd_GBps': round(3 * N * 4 / (tb * 1e-3) / 1e9, 1),
+    }
+
+
+def fused_leg(device, B, C=150, hw=128, F=4, g=8, tau=4.0, reps=20):
+    """R2 (fused-upsample) kernels at the config-2 tap shape: effective GB/s by the R1 definition."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator(device=device).manual_seed(1234)
+    s = 2 * torch.randn(B, C, hw, hw, device=device, generator=gen)
+    t = 2 * torch.randn(B, C, hw, hw, device=device, generator=gen)
+    H = hw * F
+    rows = B * (-(-C // g))
+    row_lse2 = torch.empty(rows, 2, device=device)
+    row_kl = torch.empty(rows, device=device)
+    loss = torch.empty((), device=device)
+    ds = torch.empty_like(s)
+    wsb = L.sd_cgd_kl_up_workspace_bytes(B, C, hw, hw, H, H, g)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fwd():
+        rc = L.sd_cgd_kl_up_fwd(s.data_ptr(), t.data_ptr(), 0, B, C, hw, hw, H, H, g, 1 / tau, 3.0 / rows, None, row_lse2.data_ptr(),
+                                row_kl.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, st)
+        assert rc == 0, rc
+
+    def bwd():
+        rc = L.sd_cgd_kl_up_bwd(s.data_ptr(), t.data_ptr(), 0, B, C, hw, hw, H, H, g, 1 / tau, 3.0 / (rows * tau), None,
+                                row_lse2.data_ptr(), None, ds.data_ptr(), st)
+        assert rc == 0, rc
+
+    out = {}
+    for name, fn in (('fwd_ms', fwd), ('bwd_ms', bwd)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = round(e0.elapsed_time(e1) / reps, 4)
+    N = B * C * H * H
+    out['effective_GBps_r1_definition'] = round(5 * N * 4 / ((out['fwd_ms'] + out['bwd_ms']) * 1e-3) / 1e9, 1)
+    out['tap_bytes'] = 5 * s.numel() * 4
+    return out
+
+
+def cpu_baseline_leg(cfg, batch=2, timed=2):
+    """Whole KD step on host cores: networks on torch-CPU, criteria = oracle eager restatement."""
+    from oracle.eager_modules import swap_in_eager_criteria
+    from segdistill_amd.engine import KDTrainer, SyntheticADE
+    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    model = build_model(cfg, torch.device('cpu'))
+    swap_in_eager_criteria(model)
+    trainer = KDTrainer(model, cfg.optimizer.to_dict() if hasattr(cfg.optimizer, 'to_dict') else dict(cfg.optimizer),
+                        dict(cfg.lr_config), world=1)
+    data = SyntheticADE(batch, device='cpu', pool=1)
+    trainer.step(data.next())  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        trainer.step(data.next())
+    dt = time.perf_counter() - t0
+    return {'value': round(batch * timed / dt, 4), 'unit': 'imgs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{timed} KD train steps (after 1 warm-up) of the same config at batch {batch} on host cores: '
+                      f'networks on torch-CPU fp32, criteria from oracle/ (eager restatement of losses.py:95-113)',
+            's_per_step': round(dt / timed, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default=os.path.join(ROOT, 'configs', 'kd', 'cfg2_segformer_b2_b0_cgd.py'))
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: config data.samples_per_gpu)')
+    ap.add_argument('--kd-path', choices=['fused', 'r1'], default='fused',
+                    help="fused: bilinear resize fused into the CGD kernels (R2); r1: ATen resize + streaming kernels")
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from segdistill_amd.config import Config
+    from segdistill_amd.engine import KDTrainer, SyntheticADE, init_distributed
+    rank, local, world = init_distributed()
+    if world != args.gpus and rank == 0:
+        print(f'[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    torch.backends.cudnn.benchmark = True
+
+    cfg = Config.fromfile(args.config)
+    B = args.batch or int(cfg.data.samples_per_gpu)
+    torch.manual_seed(0)
+    model = build_model(cfg, device)
+    if args.kd_path == 'r1':
+        for c in model.distillation_loss.criteria:
+            if hasattr(c, 'fuse_resize'):
+                c.fuse_resize = False
+    opt_cfg = cfg.optimizer.to_dict() if hasattr(cfg.optimizer, 'to_dict') else dict(cfg.optimizer)
+    trainer = KDTrainer(model, opt_cfg, dict(cfg.lr_config), max_iters=int(cfg.runner.max_iters), world=world)
+    data = SyntheticADE(B, size=tuple(cfg.get('crop_size', (512, 512))), num_classes=int(cfg.get('num_classes', 150)), seed=0,
+                        rank=rank, device=device)
+    for _ in range(args.warmup):
+        trainer.step(data.next())
+    dt = timed_steps(trainer, data, args.steps, world)
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    logs = trainer.log_values()
+
+    if rank == 0:
+        line = {
+            'metric': 'imgs/sec/node KD train_step, Segformer-B2->B0 512x512', 'value': round(world * B * args.steps / dt, 3),
+            'unit': 'imgs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: Segformer-B0 student + B2 teacher, CGD group=8 T=4 alpha=3, 512x512, 150 classes'
+                       if 'cfg2' in os.path.basename(args.config) else os.path.basename(args.config),
+                       'config_file': os.path.relpath(args.config, ROOT), 'per_gpu_batch': B, 'global_batch': B * world,
+                       'parallelism': f'dp{world}', 'kd_path': args.kd_path, 'weights': 'random-init (no checkpoints offline)',
+                       'grad_allreduce_bytes': trainer.reducer.nbytes},
+            'final_log_vars': {k: round(v, 5) for k, v in logs.items()},
+        }
+        if not args.no_roofline:
+            torch.cuda.empty_cache()
+            line['roofline'] = roofline_leg(device, B)
+            line['roofline']['fused_r2'] = fused_leg(device, B)
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline_leg(cfg)
+        print(json.dumps(line))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

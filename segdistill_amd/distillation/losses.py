@@ -96,12 +96,18 @@ class KLDLoss(nn.Module):
             self.earlydecay(n_iter)
         out_size = None
         if self.resize_config:
-            out_size = tuple(int(v) for v in gt.shape[2:])
-            bilinear = self.resize_config['mode'] == 'bilinear' and not self.resize_config['align_corners']
-            if not (bilinear and self.fuse_resize and ops.can_fuse_resize(x_student, x_teacher, out_size, self.transform_config)):
-                mode, ac = self.resize_config['mode'], self.resize_config['align_corners']
-                x_student = F.interpolate(x_student, size=out_size, mode=mode, align_corners=ac)
-                x_teacher = F.interpolate(x_teacher, size=out_size, mode=mode, align_corners=ac)
+            # reference :101-102 resizes BOTH tensors to the label size; 'target': 'teacher' (an extension used
+            # by feature-level configs) resizes to the teacher tap's size instead.
+            ref = x_teacher if self.resize_config.get('target', 'gt') == 'teacher' else gt
+            out_size = tuple(int(v) for v in ref.shape[2:])
+            mode, ac = self.resize_config['mode'], self.resize_config['align_corners']
+            fusable = mode == 'bilinear' and not ac and self.fuse_resize and \
+                ops.can_fuse_resize(x_student, x_teacher, out_size, self.transform_config)
+            if not fusable:
+                if tuple(x_student.shape[2:]) != out_size:
+                    x_student = F.interpolate(x_student, size=out_size, mode=mode, align_corners=ac)
+                if tuple(x_teacher.shape[2:]) != out_size:
+                    x_teacher = F.interpolate(x_teacher, size=out_size, mode=mode, align_corners=ac)
                 out_size = None
         perm = self._draw_perm(x_student.shape[1], n_iter, x_student.device) if self.shuffle_config else None
         kind = self.transform_config['loss_type'] if self.transform_config else None
