@@ -165,15 +165,35 @@ def fused_leg(device, B, C=150, hw=128, F=4, g=8, tau=4.0, reps=20):
     return out
 
 
-def cpu_baseline_leg(cfg, batch=2, timed=2):
-    """Whole KD step on host cores: networks on torch-CPU, criteria = oracle eager restatement."""
-    from oracle.eager_modules import swap_in_eager_criteria
-    from segdistill_amd.engine import KDTrainer, SyntheticADE
-    threads = os.cpu_count() or 1
+def _usable_cores():
+    """Host cores this process may really use: min(affinity mask, cgroup cpu quota)."""
+    n = os.cpu_count() or 1
     try:
-        threads = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
+def cpu_baseline_leg(cfg, batch=2, budget_s=25.0, max_threads=32):
+    """Whole KD step on host cores: networks on torch-CPU, criteria = oracle eager restatement.
+    Bounded: one warm-up step, then timed steps until ~budget_s of CPU work is spent (at least 1)."""
+    from oracle.eager_modules import swap_in_eager_criteria
+    from segdistill_amd.engine import KDTrainer, SyntheticADE
+    threads = max(1, min(_usable_cores(), max_threads))  # torch-CPU stops scaling (and thrashes) far below 256 threads
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     model = build_model(cfg, torch.device('cpu'))
@@ -181,13 +201,16 @@ def cpu_baseline_leg(cfg, batch=2, timed=2):
     trainer = KDTrainer(model, cfg.optimizer.to_dict() if hasattr(cfg.optimizer, 'to_dict') else dict(cfg.optimizer),
                         dict(cfg.lr_config), world=1)
     data = SyntheticADE(batch, device='cpu', pool=1)
+    t0 = time.perf_counter()
     trainer.step(data.next())  # warm-up
+    warm = time.perf_counter() - t0
+    timed = max(1, min(5, int(budget_s / max(warm, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(timed):
         trainer.step(data.next())
     dt = time.perf_counter() - t0
-    return {'value': round(batch * timed / dt, 4), 'unit': 'imgs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{timed} KD train steps (after 1 warm-up) of the same config at batch {batch} on host cores: '
+    return {'value': round(batch * timed / dt, 4), 'unit': 'imgs/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{timed} KD train step(s) (after 1 warm-up of {warm:.1f} s) of the same config at batch {batch} on host cores: '
                       f'networks on torch-CPU fp32, criteria from oracle/ (eager restatement of losses.py:95-113)',
             's_per_step': round(dt / timed, 3)}
 
@@ -203,6 +226,7 @@ def main():
                     help="fused: bilinear resize fused into the CGD kernels (R2); r1: ATen resize + streaming kernels")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-threads', type=int, default=32)
     args = ap.parse_args()
 
     from segdistill_amd.config import Config
@@ -253,7 +277,7 @@ def main():
             line['roofline'] = roofline_leg(device, B)
             line['roofline']['fused_r2'] = fused_leg(device, B)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline_leg(cfg)
+            line['cpu_baseline'] = cpu_baseline_leg(cfg, max_threads=args.cpu_threads)
         print(json.dumps(line))
         sys.stdout.flush()
     if world > 1:
