@@ -142,6 +142,30 @@ int sd_pix_kl_bwd(const void *S, const void *T, int dtype, int B, int C, int H, 
                   float inv_tau, float coef, const float *pix_lse2,
                   const float *upstream, void *dS, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * 1x1 feature-alignment projection of the student feature: the
+ * `channel_nums=(Cs,Ct)` option documented at opts.py:25-27 of the reference (its live code
+ * never builds the nn.Conv2d(Cs, Ct, 1) it describes; the commented generation did, at
+ * losses.py:258,332-333).  Dense GEMMs on the matrix cores (v_mfma_f32_32x32x2_f32, exact
+ * fp32; bf16 storage is widened on load, fp32 accumulation).  W [Ct][Cs] and bias [Ct] are
+ * fp32 master parameters; X, Y, dY, dX are [B,C,h,w] in `dtype`.
+ *   fwd        Y  = W . X + bias
+ *   bwd_data   dX = W^T . dY
+ *   bwd_weight dW = sum_b dY_b . X_b^T (deterministic split-K: partial slabs in `workspace`,
+ *              then one combine pass), dbias = sum_{b,p} dY   (dbias may be NULL)
+ */
+size_t sd_align1x1_workspace_bytes(int B, int Cs, int Ct, int h, int w);
+
+int sd_align1x1_fwd(const void *X, const float *W, const float *bias /* or NULL */, void *Y, int dtype,
+                    int B, int Cs, int Ct, int h, int w, void *stream);
+
+int sd_align1x1_bwd_data(const void *dY, const float *W, void *dX, int dtype,
+                         int B, int Cs, int Ct, int h, int w, void *stream);
+
+int sd_align1x1_bwd_weight(const void *dY, const void *X, float *dW, float *dbias, int dtype,
+                           int B, int Cs, int Ct, int h, int w,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

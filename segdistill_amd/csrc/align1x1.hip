@@ -1,0 +1,234 @@
+// align1x1.hip -- the trainable 1x1 feature-alignment projection of the student feature
+// (documented at reference opts.py:25-27, commented-out at losses.py:258,332-333)
+// as dense GEMMs on the gfx950 matrix cores.
+//
+//   forward   Y_b [Ct x P] = W [Ct x Cs] . X_b [Cs x P] + bias          (P = h*w pixels, NCHW)
+//   bwd-data  dX_b [Cs x P] = W^T [Cs x Ct] . dY_b [Ct x P]
+//   bwd-wgt   dW [Ct x Cs]  = sum_b dY_b [Ct x P] . X_b^T [P x Cs]       (split over (b, pixel chunks))
+//   bwd-bias  db [Ct]       = sum_{b,p} dY_b[:, p]
+//
+// One kernel template serves all three products: C[M x N] = A[M x K] . B[K x N] with either
+// operand given K-major ([K][X], X contiguous) or X-major ([X][K], K contiguous).  fp32 operands use
+// v_mfma_f32_32x32x2_f32 (exact f32, bit-equal to an fmaf chain; 157 TFLOP/s dense peak); bf16
+// STORAGE is widened to f32 on the way into LDS (same instruction, fp32 accumulation).
+//
+// Tiling for wave64: 256 threads = 4 waves in a 2x2 arrangement, each wave owns a 64x64 output
+// tile = 2x2 MFMA 32x32 accumulators (64 acc registers); workgroup tile 128x128, K step 16.  Both
+// operand tiles live K-major in LDS ([16][128+4] floats) so the per-lane operand reads
+// (lane&31 -> row/col, lane>>5 -> k) are conflict-free ds_read_b32.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cgd_device.h"
+
+namespace sd {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, PITCH = BM + 4;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename T> __device__ __forceinline__ float ld1(const T *p);
+template <> __device__ __forceinline__ float ld1<float>(const float *p) { return *p; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t *p) { return __uint_as_float((unsigned)p->bits << 16); }
+template <typename T> __device__ __forceinline__ void st1(T *p, float v);
+template <> __device__ __forceinline__ void st1<float>(float *p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t *p, float v) { p->bits = f32_to_bf16(v); }
+
+// Stage a [BK x 128] K-major tile into LDS from a source that is either K-major (src[k*ld + x]) or
+// X-major (src[x*ld + k]).  Out-of-range elements are zero.  256 threads, 2048 elements -> 8 each.
+template <typename T, bool KMAJOR>
+__device__ __forceinline__ void stage(float (*dst)[PITCH], const T *__restrict__ src, long ld, int x0, int xmax, int k0, int kmax) {
+    const int t = threadIdx.x;
+    if constexpr (KMAJOR) {
+        // thread -> (k = t/16, 8 consecutive x starting at (t%16)*8): coalesced along x
+        const int k = t >> 4, xb = (t & 15) * 8;
+        const bool kin = (k0 + k) < kmax;
+        const T *row = src + (long)(k0 + k) * ld + x0 + xb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[k][xb + i] = (kin && x0 + xb + i < xmax) ? ld1<T>(row + i) : 0.f;
+    } else {
+        // thread -> (x = t/2, 8 consecutive k starting at (t%2)*8): each lane reads 32 contiguous bytes of its row
+        const int x = t >> 1, kb = (t & 1) * 8;
+        const bool xin = (x0 + x) < xmax;
+        const T *row = src + (long)(x0 + x) * ld + k0 + kb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[kb + i][x] = (xin && k0 + kb + i < kmax) ? ld1<T>(row + i) : 0.f;
+    }
+}
+
+// C_z[M x N] (+)= A_z . B_z over k in [k_begin, k_end);  z = blockIdx.z = batch*nsplit + split.
+template <typename TA, typename TB, typename TC, bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_mfma_f32(const TA *__restrict__ A, const TB *__restrict__ B, TC *__restrict__ C,
+                                                      const float *__restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
+                                                      long strideA, long strideB, long strideC, int nsplit, int klen) {
+    __shared__ float As[BK][PITCH];
+    __shared__ float Bs[BK][PITCH];
+    const int z = blockIdx.z, batch = z / nsplit, split = z - batch * nsplit;
+    const int k_begin = split * klen, k_end = min(K, k_begin + klen);
+    A += (long)batch * strideA;
+    B += (long)batch * strideB;
+    C += (long)z * strideC;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int r = lane & 31, kh = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        stage<TA, A_KMAJOR>(As, A, lda, m0, M, k0, k_end);
+        stage<TB, B_KMAJOR>(Bs, B, ldb, n0, N, k0, k_end);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = As[kk + kh][wm + r], a1 = As[kk + kh][wm + 32 + r];
+            const float b0 = Bs[kk + kh][wn + r], b1 = Bs[kk + kh][wn + 32 + r];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout of the 32x32 accumulator: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (m < M && n < N) {
+                    float v = acc[i][j][e];
+                    if (bias) v += bias[m];
+                    st1<TC>(C + (long)m * ldc + n, v);
+                }
+            }
+        }
+}
+
+// out[i] = sum_z slabs[z][i]  (deterministic split-K combine), i < n
+template <typename TC>
+__global__ __launch_bounds__(256) void slab_reduce(const float *__restrict__ slabs, TC *__restrict__ out, long n, int nz) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int z = 0; z < nz; ++z) acc += slabs[(long)z * n + i];
+    st1<TC>(out + i, acc);
+}
+
+// db[c] = sum over (b, p) of dY[b][c][p]; one workgroup per channel
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad(const T *__restrict__ dY, float *__restrict__ db, int B, int C, long P) {
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const T *row = dY + ((long)b * C + c) * P;
+        for (long p = threadIdx.x; p < P; p += 256) acc += ld1<T>(row + p);
+    }
+    __shared__ float part[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) db[c] = part[0] + part[1] + part[2] + part[3];
+}
+
+int wgrad_splits(int B, long P) {
+    // aim for >= 512 workgroups in flight: tiles(M,N) are few (e.g. 4), so split the pixel axis
+    int per_img = (int)((P + 2047) / 2048);
+    if (per_img < 1) per_img = 1;
+    while ((long)B * per_img < 128 && P / per_img > 256) per_img *= 2;
+    return per_img;
+}
+
+template <typename T>
+int align_fwd(const void *X, const void *W, const float *bias, void *Y, int B, int Cs, int Ct, long P, hipStream_t st) {
+    dim3 grid((unsigned)((P + BN - 1) / BN), (Ct + BM - 1) / BM, B);
+    hipLaunchKernelGGL((gemm_mfma_f32<float, T, T, false, true>), grid, dim3(256), 0, st, (const float *)W, (const T *)X, (T *)Y, bias, Ct,
+                       (int)P, Cs, (long)Cs, P, P, 0L, (long)Cs * P, (long)Ct * P, 1, Cs);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int align_bwd_data(const void *dY, const void *W, void *dX, int B, int Cs, int Ct, long P, hipStream_t st) {
+    // A = W^T given as W [K=Ct][M=Cs] -> K-major
+    dim3 grid((unsigned)((P + BN - 1) / BN), (Cs + BM - 1) / BM, B);
+    hipLaunchKernelGGL((gemm_mfma_f32<float, T, T, true, true>), grid, dim3(256), 0, st, (const float *)W, (const T *)dY, (T *)dX, nullptr,
+                       Cs, (int)P, Ct, (long)Cs, P, P, 0L, (long)Ct * P, (long)Cs * P, 1, Ct);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int align_bwd_weight(const void *dY, const void *X, float *dW, float *db, void *ws, size_t ws_bytes, int B, int Cs, int Ct, long P,
+                     hipStream_t st) {
+    const int nsplit = wgrad_splits(B, P);
+    const int klen = (int)(((P + nsplit - 1) / nsplit + BK - 1) / BK * BK);
+    const int nz = B * nsplit;
+    const long slab = (long)Ct * Cs;
+    if (ws_bytes < (size_t)nz * slab * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
+    float *slabs = static_cast<float *>(ws);
+    // A = dY_b [M=Ct][K=P] (X-major), B = X_b^T given as X_b [N=Cs][K=P] (X-major); C = slab z
+    dim3 grid((Cs + BN - 1) / BN, (Ct + BM - 1) / BM, nz);
+    hipLaunchKernelGGL((gemm_mfma_f32<T, T, float, false, false>), grid, dim3(256), 0, st, (const T *)dY, (const T *)X, slabs, nullptr, Ct,
+                       Cs, (int)P, P, P, (long)Cs, (long)Ct * P, (long)Cs * P, slab, nsplit, klen);
+    hipLaunchKernelGGL((slab_reduce<float>), dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, slabs, dW, slab, nz);
+    if (db) hipLaunchKernelGGL((bias_grad<T>), dim3(Ct), dim3(256), 0, st, (const T *)dY, db, B, Ct, P);
+    return (int)hipGetLastError();
+}
+
+int check_align(const void *a, const void *b, const void *c, int dtype, int B, int Cs, int Ct, int h, int w) {
+    if (!a || !b || !c) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (B <= 0 || Cs <= 0 || Ct <= 0 || h <= 0 || w <= 0 || B > 65535) return SD_E_SHAPE;
+    return SD_OK;
+}
+
+}  // namespace
+}  // namespace sd
+
+extern "C" {
+
+size_t sd_align1x1_workspace_bytes(int B, int Cs, int Ct, int h, int w) {
+    if (B <= 0 || Cs <= 0 || Ct <= 0 || h <= 0 || w <= 0) return 0;
+    const long P = (long)h * w;
+    return (size_t)B * sd::wgrad_splits(B, P) * Ct * Cs * sizeof(float) + 16;
+}
+
+int sd_align1x1_fwd(const void *X, const float *W, const float *bias, void *Y, int dtype, int B, int Cs, int Ct, int h, int w, void *stream) {
+    int rc = sd::check_align(X, W, Y, dtype, B, Cs, Ct, h, w);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long P = (long)h * w;
+    if (dtype == SD_F32) return sd::align_fwd<float>(X, W, bias, Y, B, Cs, Ct, P, st);
+    return sd::align_fwd<sd::bf16_t>(X, W, bias, Y, B, Cs, Ct, P, st);
+}
+
+int sd_align1x1_bwd_data(const void *dY, const float *W, void *dX, int dtype, int B, int Cs, int Ct, int h, int w, void *stream) {
+    int rc = sd::check_align(dY, W, dX, dtype, B, Cs, Ct, h, w);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long P = (long)h * w;
+    if (dtype == SD_F32) return sd::align_bwd_data<float>(dY, W, dX, B, Cs, Ct, P, st);
+    return sd::align_bwd_data<sd::bf16_t>(dY, W, dX, B, Cs, Ct, P, st);
+}
+
+int sd_align1x1_bwd_weight(const void *dY, const void *X, float *dW, float *dbias, int dtype, int B, int Cs, int Ct, int h, int w,
+                           void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = sd::check_align(dY, X, dW, dtype, B, Cs, Ct, h, w);
+    if (rc) return rc;
+    if (!workspace) return SD_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long P = (long)h * w;
+    if (dtype == SD_F32) return sd::align_bwd_weight<float>(dY, X, dW, dbias, workspace, workspace_bytes, B, Cs, Ct, P, st);
+    return sd::align_bwd_weight<sd::bf16_t>(dY, X, dW, dbias, workspace, workspace_bytes, B, Cs, Ct, P, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,220 @@
+"""Host-side logic on the CPU: registry / config semantics, criterion schedules, loss naming,
+the flat-buffer DP reducer under gloo (world_size 2) and the full engine step with the eager
+oracle criteria swapped in."""
+import os
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_and_build_from_cfg():
+    from segdistill_amd.registry import Registry, build_from_cfg
+    reg = Registry('thing')
+
+    @reg.register_module()
+    class Foo:
+        def __init__(self, a, b=2, train_cfg=None):
+            self.a, self.b, self.train_cfg = a, b, train_cfg
+
+    obj = build_from_cfg(dict(type='Foo', a=1), reg, default_args=dict(b=5, train_cfg='x'))
+    assert (obj.a, obj.b, obj.train_cfg) == (1, 5, 'x')
+    obj = build_from_cfg(dict(type='Foo', a=1, b=7), reg, default_args=dict(b=5))
+    assert obj.b == 7  # the config wins over default_args
+    with pytest.raises(KeyError):
+        build_from_cfg(dict(type='Nope'), reg)
+    with pytest.raises(KeyError):
+        reg.register_module()(Foo)  # duplicate
+
+
+def test_config_base_delete_and_options(tmp_path):
+    from segdistill_amd.config import Config
+    (tmp_path / 'base.py').write_text("optimizer = dict(type='SGD', lr=0.01, momentum=0.9)\nmodel = dict(type='A', head=dict(c=1, d=2))\nx = 1\n")
+    (tmp_path / 'child.py').write_text(textwrap.dedent('''
+        _base_ = ['./base.py']
+        t = '3'
+        picked = eval(f"dict(n={t})")
+        optimizer = dict(_delete_=True, type='AdamW', lr=6e-5)
+        model = dict(head=dict(c=10))
+    '''))
+    cfg = Config.fromfile(str(tmp_path / 'child.py'))
+    assert cfg.optimizer == {'type': 'AdamW', 'lr': 6e-5}          # replaced, not merged
+    assert cfg.model.head == {'c': 10, 'd': 2} and cfg.model.type == 'A'  # deep merge, child wins
+    assert cfg.picked.n == 3 and cfg.x == 1
+    cfg.merge_from_dict({'model.head.d': 5, 'data.samples_per_gpu': 8})
+    assert cfg.model.head.d == 5 and cfg.data.samples_per_gpu == 8
+
+
+@pytest.mark.reference
+def test_reference_kd_configs_load_unchanged():
+    ref = '/root/reference/local_configs'
+    if not os.path.isdir(ref):
+        pytest.skip('reference tree not present')
+    import segdistill_amd
+    from segdistill_amd.builder import DISTILL_LOSSES
+    from segdistill_amd.config import Config
+    segdistill_amd.register_all()
+    n = 0
+    for sub in ('exp_tab5', 'Teacher_Student_Size', 'Group_Size', 'Weight_Temperature'):
+        for f in sorted(os.listdir(os.path.join(ref, sub))):
+            if not f.endswith('.py'):
+                continue
+            cfg = Config.fromfile(os.path.join(ref, sub, f))
+            if cfg.model.type != 'SDModule':
+                continue
+            for d in cfg.model.distillation:
+                assert d['loss_name'] in DISTILL_LOSSES, (f, d['loss_name'])
+            assert cfg.optimizer.type == 'AdamW' and 'custom_keys' in cfg.optimizer.paramwise_cfg
+            n += 1
+    assert n >= 20
+
+
+def test_criterion_schedules_match_golden(golden):
+    """KLDLoss.warmup/earlydecay state machine vs the alpha trace recorded from the reference."""
+    import segdistill_amd
+    from segdistill_amd.distillation import CGDLossWS, KLDLoss
+    c = CGDLossWS()
+    for it, alpha in zip(golden['G1/cgdws_trace/iters'], golden['G1/cgdws_trace/alpha']):
+        c.warmup(int(it))
+        c.earlydecay(int(it))
+        assert c.alpha == pytest.approx(float(alpha), abs=1e-15), it
+    for wm in ('linear', 'exp', 'jump'):
+        for dm in ('linear', 'exp', 'jump'):
+            c = KLDLoss(alpha=2.5, tau=2, warmup_config={'mode': wm, 'warmup_iters': 10},
+                        earlydecay_config={'mode': dm, 'earlydecay_start': 20, 'earlydecay_end': 30})
+            key = f'G1/sched_{wm}_{dm}'
+            for it, alpha in zip(golden[key + '/iters'], golden[key + '/alpha']):
+                c.warmup(int(it))
+                c.earlydecay(int(it))
+                assert c.alpha == pytest.approx(float(alpha), abs=1e-15), (wm, dm, it)
+
+
+def test_preset_fields_match_reference_defaults():
+    from segdistill_amd.distillation import CDLoss, CGDLoss, CGDLossWS, PDLoss
+    c = CGDLoss()
+    assert (c.alpha_0, c.tau, c.transform_config['group_size'], c.shuffle_config['interval']) == (3, 2, 10, 1000)
+    c = CGDLoss(group_size=8, alpha=3, tau=4)
+    assert c.transform_config == {'loss_type': 'channel', 'group_size': 8} and c.tau == 4
+    assert CDLoss().transform_config == {'loss_type': 'channel', 'group_size': 1} and CDLoss().shuffle_config is None
+    assert PDLoss().transform_config == {'loss_type': 'pixel'}
+    w = CGDLossWS()
+    assert w.warmup_config == {'mode': 'linear', 'warmup_iters': 2000}
+    assert w.earlydecay_config == {'mode': 'linear', 'earlydecay_start': 110000, 'earlydecay_end': 120000}
+
+
+def _tiny_sd_cfg():
+    norm = dict(type='SyncBN', requires_grad=True)
+    def seg(v, ch, e):
+        return dict(type='EncoderDecoder', pretrained=None, backbone=dict(type=f'mit_{v}', style='pytorch'),
+                    decode_head=dict(type='SegFormerHead', in_channels=ch, in_index=[0, 1, 2, 3], feature_strides=[4, 8, 16, 32], channels=128,
+                                     dropout_ratio=0.1, num_classes=150, norm_cfg=norm, align_corners=False, decoder_params=dict(embed_dim=e),
+                                     loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)))
+    return dict(type='SDModule', cfg_s=seg('b0', [32, 64, 160, 256], 256), cfg_t=seg('b0', [32, 64, 160, 256], 256),
+                distillation=[dict(student_layer='decode_head.linear_pred', teacher_layer='decode_head.linear_pred', loss_name='CGDLoss',
+                                   loss_config={'group_size': 8, 'alpha': 3, 'tau': 4}),
+                              dict(student_layer='decode_head.linear_pred', teacher_layer='decode_head.linear_pred', loss_name='CDLoss',
+                                   loss_config={})],
+                t_pretrain=None, train_cfg=dict(), test_cfg=dict(mode='whole'))
+
+
+def test_sdmodule_contract_and_engine_step_cpu():
+    import segdistill_amd
+    from oracle.eager_modules import swap_in_eager_criteria
+    from segdistill_amd.builder import build_segmentor
+    from segdistill_amd.engine import KDTrainer, SyntheticADE
+    from segdistill_amd.segmentors import sd_module
+    segdistill_amd.register_all()
+    with pytest.raises(FileNotFoundError):
+        build_segmentor(_tiny_sd_cfg())  # the teacher checkpoint is mandatory unless synthetic-weights mode is on
+    sd_module.SYNTHETIC_WEIGHTS_OK = True
+    try:
+        torch.manual_seed(0)
+        model = build_segmentor(_tiny_sd_cfg())
+    finally:
+        sd_module.SYNTHETIC_WEIGHTS_OK = False
+    assert not any(p.requires_grad for p in model.teacher.parameters())
+    model.train()
+    assert model.student.training and not model.teacher.training  # Q1: the teacher stays in eval
+    # the product criteria are HIP-only: on CPU tensors they must raise, not fall back
+    data = SyntheticADE(1, size=(64, 64), device='cpu', pool=1)
+    with pytest.raises(RuntimeError, match='GPU only'):
+        model.train_step(data.next(), None)
+    model.cnt = 0
+    swap_in_eager_criteria(model)
+    opt = dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01,
+               paramwise_cfg=dict(custom_keys={'pos_block': dict(decay_mult=0.), 'norm': dict(decay_mult=0.), 'head': dict(lr_mult=10.)}))
+    tr = KDTrainer(model, opt, dict(policy='poly', warmup='linear', warmup_iters=1500, warmup_ratio=1e-6, power=1.0, min_lr=0.0, by_epoch=False))
+    before = model.student.decode_head.linear_pred.weight.detach().clone()
+    out = tr.step(data.next())
+    assert set(out) == {'loss', 'log_vars', 'num_samples'} and out['num_samples'] == 1
+    keys = list(out['log_vars'])
+    assert keys[:2] == ['decode.loss_seg', 'decode.acc_seg'] and keys[-1] == 'loss'
+    kd = [k for k in keys if k.startswith('loss_decode_head.linear_pred<->decode_head.linear_pred_')]
+    assert len(kd) == 2 and kd[1].endswith('#1')  # Q3: colliding names are kept apart
+    vals = tr.log_values()
+    assert vals['loss'] == pytest.approx(sum(v for k, v in vals.items() if 'loss' in k and k != 'loss'), rel=1e-5)
+    assert model.cnt == 1
+    assert not torch.equal(before, model.student.decode_head.linear_pred.weight)  # the step moved the student
+    assert model.student.decode_head.conv_seg.weight.requires_grad is False      # Q12: the dead parameter is frozen
+    lrs = sorted({g['initial_lr'] for g in tr.optimizer.param_groups})
+    assert lrs == pytest.approx([6e-5, 6e-4])
+    # poly + linear warm-up at it=0: lr * (1 - (1 - 0) * (1 - 1e-6)) = lr * 1e-6
+    assert tr.sched.lr_at(6e-5, 0) == pytest.approx(6e-5 * 1e-6, rel=1e-6)
+    assert tr.sched.lr_at(6e-5, 1500) == pytest.approx(6e-5 * (1 - 1500 / 160000), rel=1e-9)
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    from segdistill_amd.engine import DataParallelReducer, init_distributed
+    from segdistill_amd.segmentors.base import parse_losses
+    init_distributed(backend='gloo')
+    torch.manual_seed(100 + rank)  # different init per rank: broadcast must fix it
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    red = DataParallelReducer(net.parameters(), world=world)
+    red.broadcast_parameters(net)
+    full = torch.arange(4 * 6, dtype=torch.float32).reshape(4, 6) / 10.0
+    x = full[rank * 2:(rank + 1) * 2]  # batch shard
+    red.zero_grad()
+    loss = net(x).pow(2).mean()
+    loss.backward()
+    red.all_reduce()
+    _, logs = parse_losses({'loss_a': loss, 'acc': loss.detach() * 2})
+    q.put((rank, red.flat.clone(), [p.detach().clone() for p in net.parameters()], logs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_buffer_dp_matches_single_process_gloo():
+    world, port = 2, 29741
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, p0, l0), (_, g1, p1, l1) = res
+    assert torch.equal(g0, g1)                       # every rank holds the same averaged gradient
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)                     # parameters were broadcast from rank 0
+    # single-process oracle: same parameters, the concatenated batch
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    with torch.no_grad():
+        for p, v in zip(net.parameters(), p0):
+            p.copy_(v)
+    full = torch.arange(4 * 6, dtype=torch.float32).reshape(4, 6) / 10.0
+    loss = net(full).pow(2).mean()
+    loss.backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    assert torch.allclose(g0, flat, rtol=1e-5, atol=1e-7)   # mean of shard losses == loss of the whole batch (equal shards)
+    assert l0['loss'] == pytest.approx(float(loss), rel=1e-5) and l0 == l1
+    assert l0['acc'] == pytest.approx(2 * float(loss), rel=1e-5)
