@@ -29,7 +29,7 @@ def probe_vector(shape):
     return np.cos(0.37 * np.arange(n, dtype=np.float64) + 0.1).reshape(shape)
 
 
-def fill_state_dict_(module):
+def fill_state_dict_(module, salt=0):
     """Overwrite every parameter / float buffer of a torch module with closed-form values that
     depend only on the tensor's NAME and shape, so that two implementations with identical
     state-dict keys (the reference's and ours) hold identical weights without storing them."""
@@ -42,7 +42,7 @@ def fill_state_dict_(module):
             if not torch.is_floating_point(t):
                 continue
             n = t.numel()
-            phase = (zlib.crc32(name.encode()) % 10007) / 10007.0 * 6.283185307179586
+            phase = (zlib.crc32(name.encode()) % 10007) / 10007.0 * 6.283185307179586 + 0.7391 * salt
             base = torch.sin(torch.arange(n, dtype=torch.float64) * 0.6180339887 + phase)
             if name.endswith('running_var'):
                 v = 1.0 + 0.2 * base * base
