@@ -166,6 +166,26 @@ int sd_align1x1_bwd_weight(const void *dY, const void *X, float *dW, float *dbia
                            int B, int Cs, int Ct, int h, int w,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Depth-wise 3x3 convolution (stride 1, zero pad 1) on TOKEN-MAJOR activations [B, H*W, C]: the
+ * DWConv inside every MiT Mix-FFN (mix_transformer.py:376-387: transpose to NCHW ->
+ * nn.Conv2d(dim, dim, 3, 1, 1, groups=dim) -> flatten/transpose back; called from Mlp.forward :48-55).
+ * Replaces those two transposes plus the grouped conv and its two backward convs.  Weights are passed
+ * tap-major [9][C] fp32 (k = 3*ky + kx; the binding transposes Conv2d's [C,1,3,3]); C % 4 == 0
+ * (fp32) / C % 8 == 0 (bf16), 16-byte aligned pointers.
+ */
+size_t sd_dwconv3x3_workspace_bytes(int dtype, int B, int H, int W, int C);
+
+int sd_dwconv3x3_fwd(const void *x, const float *w_tap_major, const float *bias /* or NULL */, void *y,
+                     int dtype, int B, int H, int W, int C, void *stream);
+
+int sd_dwconv3x3_bwd_data(const void *dy, const float *w_tap_major, void *dx,
+                          int dtype, int B, int H, int W, int C, void *stream);
+
+int sd_dwconv3x3_bwd_weight(const void *x, const void *dy, float *dw_tap_major, float *dbias /* or NULL */,
+                            int dtype, int B, int H, int W, int C,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,8 +51,13 @@ class _DepthwiseConv(nn.Module):
         self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
 
     def forward(self, tokens, hw):
+        from .. import dwconv as hip_dw
+        conv = self.dwconv
+        if hip_dw.supported(tokens, conv.weight) and not torch.is_autocast_enabled():
+            # MI355X path: token-major depth-wise kernels, no NCHW round trip (csrc/dwconv.hip)
+            return hip_dw.dwconv3x3_tokens(tokens, conv.weight, conv.bias, hw[0], hw[1])
         b, n, c = tokens.shape
-        y = self.dwconv(tokens.transpose(1, 2).reshape(b, c, *hw))
+        y = conv(tokens.transpose(1, 2).reshape(b, c, *hw))
         return y.flatten(2).transpose(1, 2)
 
 

@@ -1,0 +1,344 @@
+// dwconv.hip -- depth-wise 3x3 convolution (stride 1, zero pad 1) on TOKEN-MAJOR activations
+// [B, H*W, C] (= NHWC), forward / backward-data / backward-weight(+bias), gfx950.
+//
+// Why it exists: the Mix-FFN of every MiT block is Linear -> DWConv3x3 -> GELU -> Linear
+// (reference mmseg/models/backbones/mix_transformer.py:20-55, DWConv :376-387).  The reference
+// transposes the tokens to NCHW, calls a grouped cuDNN conv and transposes back.  On ROCm that
+// grouped conv lands on generic MIOpen/CK kernels: the round-1 rocprof of the KD step shows
+// 15.1 ms/step (22 %) in the depth-wise WEIGHT gradient alone and 8.2 ms in the forward
+// (profiles/r01_train_step_kernels_baseline.txt), for an op whose roofline is one read and one
+// write of the hidden tensor.  Depth-wise conv is HBM-bound byte work, not a GEMM: in the
+// token-major layout the channel axis is contiguous, so a lane owns one 16-byte channel vector
+// and consecutive lanes consecutive channels (fully coalesced), no transposes at all.
+//
+//   fwd      y[b,p,c]  = bias[c] + sum_k w[k][c] * x[b, p+off(k), c]          k = 3*ky+kx
+//   bwd-data dx        = same kernel on dy with the taps mirrored (k -> 8-k), no bias
+//   bwd-wgt  dw[k][c]  = sum_{b,p} dy[b,p,c] * x[b,p+off(k),c] ;  db[c] = sum dy
+//            (per-workgroup partials in a workspace, then a deterministic second pass; no float atomics)
+// Weights are passed TAP-MAJOR [9][C] fp32 (the binding transposes nn.Conv2d's [C,1,3,3], 36 B/channel).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cgd_device.h"
+
+namespace sd {
+
+namespace {
+
+constexpr int kStrip = 4;  // output pixels per thread along the row
+
+template <typename T> struct CV;  // channel vector of 16 bytes
+template <> struct CV<float> {
+    static constexpr int N = 4;
+    typedef float raw_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void load(const float *p, float (&o)[4]) {
+        raw_t v = *reinterpret_cast<const raw_t *>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    static __device__ __forceinline__ void store(float *p, const float (&o)[4]) {
+        raw_t v = {o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<raw_t *>(p) = v;
+    }
+};
+template <> struct CV<bf16_t> {
+    static constexpr int N = 8;
+    typedef unsigned int raw_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void load(const bf16_t *p, float (&o)[8]) {
+        raw_t v = *reinterpret_cast<const raw_t *>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = __uint_as_float(v[i] << 16);
+            o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t *p, const float (&o)[8]) {
+        raw_t v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (unsigned)f32_to_bf16(o[2 * i]) | ((unsigned)f32_to_bf16(o[2 * i + 1]) << 16);
+        *reinterpret_cast<raw_t *>(p) = v;
+    }
+};
+
+template <int N>
+__device__ __forceinline__ void load_w(const float *__restrict__ w, int C, int c, int k, float (&o)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)k * C + c + i);
+        o[i] = v.x; o[i + 1] = v.y; o[i + 2] = v.z; o[i + 3] = v.w;
+    }
+}
+
+// grid: (ceil(strips_per_row * (C/N) / 256), B*H).  A thread produces kStrip consecutive pixels of one row
+// for one channel vector; per input row it loads the kStrip+2 columns once (1.5 loads per tap-row-pixel).
+template <typename T, bool FLIP, bool BIAS>
+__global__ __launch_bounds__(256) void dw3x3_fwd(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                  T *__restrict__ y, int H, int W, int C) {
+    constexpr int N = CV<T>::N;
+    const int cv = C / N;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int spr = (W + kStrip - 1) / kStrip;
+    if (t >= spr * cv) return;
+    const int c = (t % cv) * N;
+    const int x0 = (t / cv) * kStrip;
+    const int row = blockIdx.y;  // b*H + yy
+    const int yy = row % H;
+    const size_t img = (size_t)(row - yy) * W;  // pixel index of (b, 0, 0)
+
+    float acc[kStrip][N];
+#pragma unroll
+    for (int p = 0; p < kStrip; ++p)
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[p][i] = 0.f;
+    if constexpr (BIAS) {
+        float bv[N];
+#pragma unroll
+        for (int i = 0; i < N; i += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(bias + c + i);
+            bv[i] = v.x; bv[i + 1] = v.y; bv[i + 2] = v.z; bv[i + 3] = v.w;
+        }
+#pragma unroll
+        for (int p = 0; p < kStrip; ++p)
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[p][i] = bv[i];
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = yy + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+        float col[kStrip + 2][N];
+#pragma unroll
+        for (int j = 0; j < kStrip + 2; ++j) {
+            const int ix = x0 + j - 1;
+            if (ix >= 0 && ix < W) CV<T>::load(x + (img + (size_t)iy * W + ix) * C + c, col[j]);
+            else {
+#pragma unroll
+                for (int i = 0; i < N; ++i) col[j][i] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            float wv[N];
+            const int k = FLIP ? 8 - (3 * ky + kx) : 3 * ky + kx;
+            load_w<N>(w, C, c, k, wv);
+#pragma unroll
+            for (int p = 0; p < kStrip; ++p)
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc[p][i] = fmaf(wv[i], col[p + kx][i], acc[p][i]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < kStrip; ++p)
+        if (x0 + p < W) CV<T>::store(y + (img + (size_t)yy * W + x0 + p) * C + c, acc[p]);
+}
+
+// Weight / bias gradient partials.  A "segment" is up to SEG consecutive pixels of one image row.
+// grid: (ceil(C/N / LX), ceil(B*H*nseg / RY)); block = LX x RY threads, LX lanes along the channel vectors and
+// RY segments; each thread walks its segment with a sliding 3x3 window (loads for column ix+2 are issued one
+// iteration ahead of their use: 4 vector loads + 9 vector FMAs per pixel) and the RY threads of a channel
+// vector are combined through LDS.  part layout: [gridDim.y][10][C]  (k = 0..8 taps, k = 9 bias).
+template <typename T>
+__global__ __launch_bounds__(256) void dw3x3_wgrad_partials(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part,
+                                                             int nsegs, int nseg, int SEG, int H, int W, int C, int LX, int RY) {
+    constexpr int N = CV<T>::N;
+    extern __shared__ float red[];  // [RY][10][LX*N]
+    const int lx = threadIdx.x % LX, ry = threadIdx.x / LX;
+    const int c = (blockIdx.x * LX + lx) * N;
+    const int sid = blockIdx.y * RY + ry;
+    const bool live = (c < C) && (sid < nsegs);
+    float acc[10][N];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[k][i] = 0.f;
+    if (live) {
+        const int row = sid / nseg;
+        const int xa = (sid - row * nseg) * SEG, xb = min(W, xa + SEG);
+        const int yy = row % H;
+        const long img = (long)(row - yy) * W;
+        const bool up = yy > 0, dn = yy + 1 < H;
+        const T *r1 = x + ((img + (long)yy * W) * C + c);
+        const T *r0 = r1 - (long)W * C;   // only dereferenced when `up`
+        const T *r2 = r1 + (long)W * C;   // only dereferenced when `dn`
+        const T *g = dy + ((img + (long)yy * W) * C + c);
+        float win[3][3][N], nxt[3][N], gv[N], gn[N];
+        auto load_col = [&](int ix, float (&d)[3][N]) {
+            const bool in = ix >= 0 && ix < W;
+            if (in && up) CV<T>::load(r0 + (long)ix * C, d[0]);
+            else {
+#pragma unroll
+                for (int i = 0; i < N; ++i) d[0][i] = 0.f;
+            }
+            if (in) CV<T>::load(r1 + (long)ix * C, d[1]);
+            else {
+#pragma unroll
+                for (int i = 0; i < N; ++i) d[1][i] = 0.f;
+            }
+            if (in && dn) CV<T>::load(r2 + (long)ix * C, d[2]);
+            else {
+#pragma unroll
+                for (int i = 0; i < N; ++i) d[2][i] = 0.f;
+            }
+        };
+        float c0[3][N], c1[3][N];
+        load_col(xa - 1, c0);
+        load_col(xa, c1);
+        load_col(xa + 1, nxt);
+        CV<T>::load(g + (long)xa * C, gn);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int i = 0; i < N; ++i) { win[r][1][i] = c0[r][i]; win[r][2][i] = c1[r][i]; }
+        for (int ix = xa; ix < xb; ++ix) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int i = 0; i < N; ++i) { win[r][0][i] = win[r][1][i]; win[r][1][i] = win[r][2][i]; win[r][2][i] = nxt[r][i]; }
+#pragma unroll
+            for (int i = 0; i < N; ++i) gv[i] = gn[i];
+            load_col(ix + 2, nxt);                                  // consumed next iteration
+            if (ix + 1 < xb) CV<T>::load(g + (long)(ix + 1) * C, gn);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int i = 0; i < N; ++i) acc[3 * r + j][i] = fmaf(gv[i], win[r][j][i], acc[3 * r + j][i]);
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[9][i] += gv[i];
+        }
+    }
+    const int LC = LX * N;
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int i = 0; i < N; ++i) red[(ry * 10 + k) * LC + lx * N + i] = acc[k][i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 10 * LC; e += 256) {  // element e = k*LC + col, summed over the RY slices
+        float s = 0.f;
+        for (int r = 0; r < RY; ++r) s += red[r * 10 * LC + e];
+        const int k = e / LC, col = e - k * LC;
+        const int cc = blockIdx.x * LC + col;
+        if (cc < C) part[((size_t)blockIdx.y * 10 + k) * C + cc] = s;
+    }
+}
+
+// out[k][c] = sum_p part[p][k][c].  grid: ceil(10*C / 64); block 256 = 4 partial-groups x 64 outputs.
+__global__ __launch_bounds__(256) void dw3x3_wgrad_reduce(const float *__restrict__ part, float *__restrict__ dw, float *__restrict__ db,
+                                                           int nparts, int C) {
+    __shared__ float red[4][64];
+    const int o = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int grp = threadIdx.x >> 6;
+    float s = 0.f;
+    if (o < 10 * C)
+        for (int p = grp; p < nparts; p += 4) s += part[(size_t)p * 10 * C + o];
+    red[grp][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (grp == 0 && o < 10 * C) {
+        const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (o < 9 * C) dw[o] = v;
+        else if (db) db[o - 9 * C] = v;
+    }
+}
+
+constexpr int kSeg = 32;  // pixels per wgrad segment
+
+struct WgGeo {
+    int LX, RY, gx, gy, nseg, nsegs;
+    size_t lds;
+};
+template <typename T> WgGeo wgrad_geo(int B, int H, int W, int C) {
+    WgGeo q;
+    const int cv = C / CV<T>::N;
+    q.LX = cv < 64 ? (cv < 1 ? 1 : cv) : 64;
+    while (256 % q.LX) --q.LX;                // LX must divide the block
+    q.RY = 256 / q.LX;
+    q.gx = (cv + q.LX - 1) / q.LX;
+    q.nseg = (W + kSeg - 1) / kSeg;
+    q.nsegs = B * H * q.nseg;
+    q.gy = (q.nsegs + q.RY - 1) / q.RY;
+    q.lds = (size_t)q.RY * 10 * q.LX * CV<T>::N * sizeof(float);
+    return q;
+}
+
+int check_dw(const void *a, const void *b, int dtype, int B, int H, int W, int C) {
+    if (!a || !b) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (long)B * H > 0x7fffffffL) return SD_E_SHAPE;
+    if (C % (dtype == SD_F32 ? 4 : 8)) return SD_E_UNSUPPORTED;  // 16-byte channel vectors
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return SD_E_ALIGN;
+    return SD_OK;
+}
+
+template <typename T>
+int fwd_launch(const void *x, const float *w, const float *bias, void *y, int B, int H, int W, int C, bool flip, hipStream_t st) {
+    const int cv = C / CV<T>::N;
+    const int spr = (W + kStrip - 1) / kStrip;
+    dim3 grid((spr * cv + 255) / 256, B * H);
+    if (flip) hipLaunchKernelGGL((dw3x3_fwd<T, true, false>), grid, dim3(256), 0, st, (const T *)x, w, nullptr, (T *)y, H, W, C);
+    else if (bias) hipLaunchKernelGGL((dw3x3_fwd<T, false, true>), grid, dim3(256), 0, st, (const T *)x, w, bias, (T *)y, H, W, C);
+    else hipLaunchKernelGGL((dw3x3_fwd<T, false, false>), grid, dim3(256), 0, st, (const T *)x, w, nullptr, (T *)y, H, W, C);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int wgrad_launch(const void *x, const void *dy, float *dw, float *db, void *ws, size_t ws_bytes, int B, int H, int W, int C, hipStream_t st) {
+    const WgGeo q = wgrad_geo<T>(B, H, W, C);
+    if (ws_bytes < (size_t)q.gy * 10 * C * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
+    if (q.gy > 65535) return SD_E_SHAPE;
+    float *part = static_cast<float *>(ws);
+    if (q.lds > 64 * 1024) {  // bf16: 80 KB of the CU's 160 KB LDS
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dw3x3_wgrad_partials<T>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return (int)e;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((dw3x3_wgrad_partials<T>), dim3(q.gx, q.gy), dim3(256), q.lds, st, (const T *)x, (const T *)dy, part, q.nsegs,
+                       q.nseg, kSeg, H, W, C, q.LX, q.RY);
+    hipLaunchKernelGGL(dw3x3_wgrad_reduce, dim3((10 * C + 63) / 64), dim3(256), 0, st, part, dw, db, q.gy, C);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+}  // namespace sd
+
+extern "C" {
+
+size_t sd_dwconv3x3_workspace_bytes(int dtype, int B, int H, int W, int C) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    const int gy = dtype == SD_F32 ? sd::wgrad_geo<float>(B, H, W, C).gy : sd::wgrad_geo<sd::bf16_t>(B, H, W, C).gy;
+    return (size_t)gy * 10 * C * sizeof(float) + 16;
+}
+
+int sd_dwconv3x3_fwd(const void *x, const float *w_tap_major, const float *bias, void *y, int dtype, int B, int H, int W, int C,
+                     void *stream) {
+    int rc = sd::check_dw(x, y, dtype, B, H, W, C);
+    if (rc) return rc;
+    if (!w_tap_major) return SD_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32) return sd::fwd_launch<float>(x, w_tap_major, bias, y, B, H, W, C, false, st);
+    return sd::fwd_launch<sd::bf16_t>(x, w_tap_major, bias, y, B, H, W, C, false, st);
+}
+
+int sd_dwconv3x3_bwd_data(const void *dy, const float *w_tap_major, void *dx, int dtype, int B, int H, int W, int C, void *stream) {
+    int rc = sd::check_dw(dy, dx, dtype, B, H, W, C);
+    if (rc) return rc;
+    if (!w_tap_major) return SD_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32) return sd::fwd_launch<float>(dy, w_tap_major, nullptr, dx, B, H, W, C, true, st);
+    return sd::fwd_launch<sd::bf16_t>(dy, w_tap_major, nullptr, dx, B, H, W, C, true, st);
+}
+
+int sd_dwconv3x3_bwd_weight(const void *x, const void *dy, float *dw_tap_major, float *dbias, int dtype, int B, int H, int W, int C,
+                            void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = sd::check_dw(x, dy, dtype, B, H, W, C);
+    if (rc) return rc;
+    if (!dw_tap_major || !workspace) return SD_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32) return sd::wgrad_launch<float>(x, dy, dw_tap_major, dbias, workspace, workspace_bytes, B, H, W, C, st);
+    return sd::wgrad_launch<sd::bf16_t>(x, dy, dw_tap_major, dbias, workspace, workspace_bytes, B, H, W, C, st);
+}
+
+}  // extern "C"

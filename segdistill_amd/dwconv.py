@@ -1,0 +1,62 @@
+"""autograd binding of the token-major depth-wise 3x3 kernels (csrc/dwconv.hip)."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .ops import _DT, _stream_ptr
+
+
+class _DWConv3x3Tokens(torch.autograd.Function):
+    """tokens [B, H*W, C] -> [B, H*W, C]; weight is nn.Conv2d(C, C, 3, 1, 1, groups=C).weight ([C,1,3,3]), bias [C]."""
+
+    @staticmethod
+    def forward(ctx, tokens, weight, bias, H, W):
+        x = tokens.contiguous()
+        B, N, C = x.shape
+        assert N == H * W
+        w_t = weight.detach().reshape(C, 9).t().contiguous().float()  # tap-major [9][C]
+        b = None if bias is None else bias.detach().contiguous().float()
+        y = torch.empty_like(x)
+        rc = _lib.lib().sd_dwconv3x3_fwd(x.data_ptr(), w_t.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), _DT[x.dtype], B, H,
+                                         W, C, _stream_ptr())
+        _lib.check(rc, 'sd_dwconv3x3_fwd')
+        ctx.save_for_backward(x, w_t)
+        ctx.geom = (H, W, bias is not None, weight.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_t = ctx.saved_tensors
+        H, W, has_bias, wdtype = ctx.geom
+        B, N, C = x.shape
+        dy = dy.contiguous()
+        L = _lib.lib()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(L.sd_dwconv3x3_bwd_data(dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(), _DT[x.dtype], B, H, W, C, _stream_ptr()),
+                       'sd_dwconv3x3_bwd_data')
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dw_t = torch.empty(9, C, dtype=torch.float32, device=x.device)
+            dbv = torch.empty(C, dtype=torch.float32, device=x.device) if has_bias else None
+            wsb = L.sd_dwconv3x3_workspace_bytes(_DT[x.dtype], B, H, W, C)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+            _lib.check(L.sd_dwconv3x3_bwd_weight(x.data_ptr(), dy.data_ptr(), dw_t.data_ptr(), None if dbv is None else dbv.data_ptr(),
+                                                 _DT[x.dtype], B, H, W, C, ws.data_ptr(), wsb, _stream_ptr()), 'sd_dwconv3x3_bwd_weight')
+            dw = dw_t.t().reshape(C, 1, 3, 3).to(wdtype)
+            db = None if dbv is None else dbv.to(wdtype)
+        return dx, dw, db, None, None
+
+
+def supported(tokens, weight):
+    if not tokens.is_cuda or tokens.dtype not in _DT or tokens.dim() != 3:
+        return False
+    C = tokens.shape[-1]
+    if weight.shape != (C, 1, 3, 3):
+        return False
+    return C % (4 if tokens.dtype == torch.float32 else 8) == 0
+
+
+def dwconv3x3_tokens(tokens, weight, bias, H, W):
+    return _DWConv3x3Tokens.apply(tokens, weight, bias, H, W)
