@@ -186,6 +186,26 @@ int sd_dwconv3x3_bwd_weight(const void *x, const void *dy, float *dw_tap_major, 
                             int dtype, int B, int H, int W, int C,
                             void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Supervised cross-entropy of the student with the bilinear up-sampling of the logits fused in
+ * (SURVEY.md 8f rank 1).  Replaces decode_head.py:217-237 (resize to label size -> F.cross_entropy
+ * (reduction='none', ignore_index) of cross_entropy_loss.py:9-32 -> accuracy of accuracy.py:4-49)
+ * and the corresponding autograd chain.  logits [B,C,h,w] in `dtype`; label [B,H,W] int32;
+ * (H,W) = (F*h, F*w), F in {2,4,8}.
+ *   fwd: loss_pix [B,H,W] (0 on ignored pixels), pix_lse2 [B,H,W] (base-2 log-partition, for bwd),
+ *        *correct = number of pixels whose arg-max class equals the label (top-1 hits).
+ *   bwd: dlogits = g * (softmax - onehot) pulled back through the interpolation; g is either a
+ *        [B,H,W] map (upstream_is_map=1) or one device float (0), both scaled by `gscale`.
+ */
+int sd_ce_up_supported(int h, int w, int H, int W);
+
+int sd_ce_up_fwd(const void *logits, const int32_t *label, float *loss_pix, float *pix_lse2, int *correct,
+                 int dtype, int B, int C, int h, int w, int H, int W, int ignore_index, void *stream);
+
+int sd_ce_up_bwd(const void *logits, const int32_t *label, const float *pix_lse2,
+                 const float *upstream, int upstream_is_map, float gscale, void *dlogits,
+                 int dtype, int B, int C, int h, int w, int H, int W, int ignore_index, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

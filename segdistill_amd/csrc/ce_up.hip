@@ -1,0 +1,269 @@
+// ce_up.hip -- supervised segmentation loss of the student with the bilinear up-sampling of the
+// logits fused in, gfx950.
+//
+// Reference chain (mmseg/models/decode_heads/decode_head.py:217-237 -> losses/cross_entropy_loss.py:9-32,
+// losses/accuracy.py:4-49): resize the [B,C,h,w] logits to label size (a [B,150,512,512] = 1.26 GB
+// tensor at the headline config), log_softmax over C, NLL with ignore_index, reduction, plus a top-1
+// argmax for the accuracy log variable; the backward re-reads / re-writes the same 1.26 GB three
+// more times.  The round-1 rocprof of the KD step attributes ~8 ms/step to that chain.
+//
+//   forward : per output pixel an online softmax over the C channels of on-the-fly interpolated
+//             logits; writes the per-pixel loss, its base-2 log-partition (for the backward) and counts
+//             top-1 hits.  Nothing of size B*C*H*W is written.
+//   backward: structured like cgd_up_bwd (one workgroup per channel plane and band of tap rows):
+//             dlogit = g * (softmax - onehot) in registers, transposed interpolation vertically in
+//             registers and horizontally through an LDS row; the per-pixel maps (lse, label, upstream)
+//             are re-read per channel but stay L2-resident because consecutive workgroups handle the
+//             SAME pixels for consecutive channels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cgd_device.h"
+#include "up_device.h"
+
+namespace sd {
+
+namespace {
+
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLn2 = 0.69314718055994530942f;
+
+// grid: (nband, B); block: round64(w) threads; thread kx owns output columns F*kx .. F*kx+F-1.
+template <typename T, int F, int QB, int MAXT>
+__global__ __launch_bounds__(MAXT) void ce_up_fwd(const T *__restrict__ s, const int32_t *__restrict__ label, float *__restrict__ loss_pix,
+                          float *__restrict__ lse2_out, int *__restrict__ correct, int C, int h, int w, int R, int nband,
+                          int ignore_index) {
+    const int b = blockIdx.y, k = blockIdx.x;
+    const int kx = threadIdx.x;
+    const bool active = kx < w;
+    const int kxc = min(kx, w - 1);
+    const int H = F * h, W = F * w;
+    const int j0 = k * R;
+    const int j1 = (k == nband - 1) ? h + 1 : min(h, j0 + R);
+    const size_t plane = (size_t)h * w;
+    const T *sb = s + (size_t)b * C * plane;
+    const int32_t *lb = label + (size_t)b * H * W;
+    int hits = 0;
+    for (int j = j0; j < j1; ++j) {
+        const int rp = max(j - 1, 0), rc = min(j, h - 1);
+#pragma unroll 1
+        for (int qb = 0; qb < F; qb += QB) {
+            const int Y0 = F * j - F / 2 + qb;  // first output row of this block of QB rows
+            if (Y0 + QB <= 0 || Y0 >= H) continue;
+            int lab[QB][F];
+            float m[QB][F], z[QB][F], xl[QB][F], best[QB][F];
+            int bi[QB][F];
+#pragma unroll
+            for (int q = 0; q < QB; ++q)
+#pragma unroll
+                for (int rx = 0; rx < F; ++rx) {
+                    const int Y = Y0 + q;
+                    lab[q][rx] = (active && Y >= 0 && Y < H) ? lb[(size_t)Y * W + F * kx + rx] : ignore_index;
+                    m[q][rx] = kNegBig; z[q][rx] = 0.f; xl[q][rx] = 0.f; best[q][rx] = kNegBig; bi[q][rx] = -1;
+                }
+            for (int c = 0; c < C; ++c) {
+                const T *pc = sb + (size_t)c * plane;
+                float sp[F], sc[F];
+                hrow<T, F>(pc + (size_t)rp * w, kxc, w, sp);
+                hrow<T, F>(pc + (size_t)rc * w, kxc, w, sc);
+#pragma unroll
+                for (int q = 0; q < QB; ++q) {
+                    const float lam = (qb + q + 0.5f) / F;
+#pragma unroll
+                    for (int rx = 0; rx < F; ++rx) {
+                        const float v = fmaf(lam, sc[rx] - sp[rx], sp[rx]);
+                        const float d = v - m[q][rx];
+                        const float e = ex2(-fabsf(d) * kLog2e);
+                        z[q][rx] = d > 0.f ? fmaf(z[q][rx], e, 1.f) : z[q][rx] + e;
+                        m[q][rx] = fmaxf(m[q][rx], v);
+                        if (c == lab[q][rx]) xl[q][rx] = v;
+                        if (v > best[q][rx]) { best[q][rx] = v; bi[q][rx] = c; }
+                    }
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int q = 0; q < QB; ++q) {
+                    const int Y = Y0 + q;
+                    if (Y < 0 || Y >= H) continue;
+#pragma unroll
+                    for (int rx = 0; rx < F; ++rx) {
+                        const float l2 = __builtin_amdgcn_logf(z[q][rx]);  // v_log_f32 = log2
+                        const size_t o = (size_t)b * H * W + (size_t)Y * W + F * kx + rx;
+                        const bool valid = lab[q][rx] != ignore_index;
+                        loss_pix[o] = valid ? (m[q][rx] + l2 * kLn2 - xl[q][rx]) : 0.f;
+                        lse2_out[o] = fmaf(m[q][rx], kLog2e, l2);
+                        hits += (bi[q][rx] == lab[q][rx]) ? 1 : 0;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o, 64);
+    if ((threadIdx.x & 63) == 0 && hits) atomicAdd(correct, hits);
+}
+
+// grid.x = B*nband*C with the channel fastest; block: round64(w) threads; dynamic LDS 2*F*blockDim floats.
+template <typename T, int F, bool GMAP>
+__global__ void ce_up_bwd(const T *__restrict__ s, const int32_t *__restrict__ label, const float *__restrict__ lse2,
+                          const float *__restrict__ upstream, float gscale, T *__restrict__ ds, int C, int h, int w, int R, int nband,
+                          int ignore_index) {
+    extern __shared__ float rowbuf[];
+    const int wg = blockIdx.x;
+    const int c = wg % C;
+    const int k = (wg / C) % nband;
+    const int b = wg / (C * nband);
+    const int kx = threadIdx.x;
+    const bool active = kx < w;
+    const int kxc = min(kx, w - 1);
+    const int H = F * h, W = F * w;
+    const size_t plane = (size_t)h * w;
+    const T *pc = s + ((size_t)b * C + c) * plane;
+    T *pd = ds + ((size_t)b * C + c) * plane;
+    const size_t pix0 = (size_t)b * H * W;
+    const float guni = GMAP ? 0.f : gscale * upstream[0];
+    const int y0 = k * R, y1 = min(h, y0 + R);
+    const int bufstride = F * blockDim.x;
+
+    float sp[F], sc[F], accA[F], accB[F];
+#pragma unroll
+    for (int rx = 0; rx < F; ++rx) accA[rx] = 0.f;
+    hrow<T, F>(pc + (size_t)max(y0 - 1, 0) * w, kxc, w, sp);
+    int parity = 0;
+    for (int j = y0; j <= y1; ++j) {
+        hrow<T, F>(pc + (size_t)min(j, h - 1) * w, kxc, w, sc);
+        float dv[F];
+#pragma unroll
+        for (int rx = 0; rx < F; ++rx) { dv[rx] = sc[rx] - sp[rx]; accB[rx] = 0.f; }
+        const bool top = (j == 0), bot = (j == h);
+#pragma unroll
+        for (int q = 0; q < F; ++q) {
+            if ((top && q < F / 2) || (bot && q >= F / 2)) continue;
+            const float lam = (q + 0.5f) / F;
+            const float wa = top ? 0.f : (bot ? 1.f : 1.f - lam);
+            const float wb = top ? 1.f : (bot ? 0.f : lam);
+            const size_t o = pix0 + (size_t)(F * j - F / 2 + q) * W + F * kxc;
+#pragma unroll
+            for (int rx = 0; rx < F; ++rx) {
+                const int lab = label[o + rx];
+                const float gp = GMAP ? gscale * upstream[o + rx] : guni;
+                const float p = ex2(fmaf(fmaf(lam, dv[rx], sp[rx]), kLog2e, -lse2[o + rx]));
+                const float D = (lab == ignore_index) ? 0.f : gp * (p - (lab == c ? 1.f : 0.f));
+                accA[rx] = fmaf(wa, D, accA[rx]);
+                accB[rx] = fmaf(wb, D, accB[rx]);
+            }
+        }
+        if (j > y0) {
+            float *buf = rowbuf + parity * bufstride;
+#pragma unroll
+            for (int rx = 0; rx < F; ++rx) buf[F * kx + rx] = accA[rx];
+            __syncthreads();
+            if (active) {
+                float sum = 0.f;
+#pragma unroll
+                for (int q = 0; q < F; ++q) {
+                    const float lam = (q + 0.5f) / F;
+                    const int xl = F * kx - F / 2 + q;
+                    const int xr = F * kx + F / 2 + q;
+                    if (xl >= 0) sum = fmaf(kx == 0 ? 1.f : lam, buf[xl], sum);
+                    if (xr < W) sum = fmaf(kx == w - 1 ? 1.f : 1.f - lam, buf[xr], sum);
+                }
+                VecIO<T>::store1(pd + (size_t)(j - 1) * w + kx, sum);
+            }
+            parity ^= 1;
+        }
+#pragma unroll
+        for (int rx = 0; rx < F; ++rx) { accA[rx] = accB[rx]; sp[rx] = sc[rx]; }
+    }
+}
+
+int ce_factor(int h, int w, int H, int W) {
+    if (h <= 0 || w <= 0 || H % h || W % w) return 0;
+    const int f = H / h;
+    if (W / w != f || (f != 2 && f != 4 && f != 8)) return 0;
+    if (w > 1024 || (long)f * ((w + 63) / 64 * 64) > 8192) return 0;
+    return f;
+}
+
+constexpr int kCeBand = 8;  // tap rows per workgroup
+
+}  // namespace
+}  // namespace sd
+
+extern "C" {
+
+int sd_ce_up_supported(int h, int w, int H, int W) { return sd::ce_factor(h, w, H, W) ? 1 : 0; }
+
+int sd_ce_up_fwd(const void *logits, const int32_t *label, float *loss_pix, float *pix_lse2, int *correct, int dtype, int B, int C, int h,
+                 int w, int H, int W, int ignore_index, void *stream) {
+    if (!logits || !label || !loss_pix || !pix_lse2 || !correct) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (B <= 0 || C <= 0 || B > 65535) return SD_E_SHAPE;
+    const int F = sd::ce_factor(h, w, H, W);
+    if (!F) return SD_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the forward keeps no state across gaps (the channel loop is innermost), so one gap per workgroup maximises parallelism
+    const int R = 1, nband = h, threads = (w + 63) / 64 * 64;
+    hipError_t e = hipMemsetAsync(correct, 0, sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid(nband, B);
+    // wide register budget (16 pixels of softmax state per lane) needs <= 256-thread workgroups; wider taps use
+    // half the pixels per pass
+#define SD_CE_FWD(TT, FF, QQ, QQW)                                                                                                   \
+    do {                                                                                                                             \
+        if (threads <= 256)                                                                                                          \
+            hipLaunchKernelGGL((sd::ce_up_fwd<TT, FF, QQ, 256>), grid, dim3(threads), 0, st, (const TT *)logits, label, loss_pix, pix_lse2, \
+                               correct, C, h, w, R, nband, ignore_index);                                                            \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((sd::ce_up_fwd<TT, FF, QQW, 1024>), grid, dim3(threads), 0, st, (const TT *)logits, label, loss_pix, pix_lse2, \
+                               correct, C, h, w, R, nband, ignore_index);                                                            \
+    } while (0)
+    if (dtype == SD_F32) {
+        if (F == 2) SD_CE_FWD(float, 2, 2, 2);
+        else if (F == 4) SD_CE_FWD(float, 4, 4, 2);
+        else SD_CE_FWD(float, 8, 2, 1);
+    } else {
+        if (F == 2) SD_CE_FWD(sd::bf16_t, 2, 2, 2);
+        else if (F == 4) SD_CE_FWD(sd::bf16_t, 4, 4, 2);
+        else SD_CE_FWD(sd::bf16_t, 8, 2, 1);
+    }
+#undef SD_CE_FWD
+    return (int)hipGetLastError();
+}
+
+int sd_ce_up_bwd(const void *logits, const int32_t *label, const float *pix_lse2, const float *upstream, int upstream_is_map, float gscale,
+                 void *dlogits, int dtype, int B, int C, int h, int w, int H, int W, int ignore_index, void *stream) {
+    if (!logits || !label || !pix_lse2 || !upstream || !dlogits) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (B <= 0 || C <= 0) return SD_E_SHAPE;
+    const int F = sd::ce_factor(h, w, H, W);
+    if (!F) return SD_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int R = sd::kCeBand < h ? sd::kCeBand : h, nband = (h + R - 1) / R, threads = (w + 63) / 64 * 64;
+    const long nwg = (long)B * nband * C;
+    if (nwg > 0x7fffffffL) return SD_E_SHAPE;
+    const size_t lds = 2ull * F * threads * sizeof(float);
+#define SD_CE_BWD(TT, FF)                                                                                                            \
+    do {                                                                                                                             \
+        if (upstream_is_map)                                                                                                         \
+            hipLaunchKernelGGL((sd::ce_up_bwd<TT, FF, true>), dim3((unsigned)nwg), dim3(threads), lds, st, (const TT *)logits, label, pix_lse2, \
+                               upstream, gscale, (TT *)dlogits, C, h, w, R, nband, ignore_index);                                    \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((sd::ce_up_bwd<TT, FF, false>), dim3((unsigned)nwg), dim3(threads), lds, st, (const TT *)logits, label, pix_lse2, \
+                               upstream, gscale, (TT *)dlogits, C, h, w, R, nband, ignore_index);                                    \
+    } while (0)
+    if (dtype == SD_F32) {
+        if (F == 2) SD_CE_BWD(float, 2);
+        else if (F == 4) SD_CE_BWD(float, 4);
+        else SD_CE_BWD(float, 8);
+    } else {
+        if (F == 2) SD_CE_BWD(sd::bf16_t, 2);
+        else if (F == 4) SD_CE_BWD(sd::bf16_t, 4);
+        else SD_CE_BWD(sd::bf16_t, 8);
+    }
+#undef SD_CE_BWD
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -21,24 +21,11 @@
 #include <string.h>
 
 #include "cgd_device.h"
+#include "up_device.h"
 
 namespace sd {
 
 namespace {
-
-// Horizontal interpolation of one tap row at this thread's F output columns.
-template <typename T, int F>
-__device__ __forceinline__ void hrow(const T *__restrict__ row, int kx, int w, float (&o)[F]) {
-    const float a = VecIO<T>::load1(row + max(kx - 1, 0));
-    const float b = VecIO<T>::load1(row + kx);
-    const float c = VecIO<T>::load1(row + min(kx + 1, w - 1));
-    const float dl = b - a, dr = c - b;
-#pragma unroll
-    for (int rx = 0; rx < F; ++rx) {
-        if (rx < F / 2) o[rx] = fmaf((rx + F / 2 + 0.5f) / F, dl, a);
-        else o[rx] = fmaf((rx - F / 2 + 0.5f) / F, dr, b);
-    }
-}
 
 __device__ __forceinline__ RowPart block_combine_dyn(RowPart st, float c2) {
     __shared__ RowPart wave_part[16];

@@ -80,7 +80,30 @@ class BaseDecodeHead(nn.Module, metaclass=ABCMeta):
             feat = self.dropout(feat)
         return self.conv_seg(feat)
 
+    def _fused_losses(self, seg_logit, seg_label):
+        """MI355X path (csrc/ce_up.hip): bilinear resize + softmax CE + top-1 accuracy in one pass over the
+        low-resolution logits; the [B,C,H,W] up-sampled tensor is never materialised.  Used when it computes
+        exactly what the generic path below computes (softmax CE, no class weights, align_corners=False)."""
+        from .. import ce as hip_ce
+        from ..losses import CrossEntropyLoss
+        crit = self.loss_decode
+        if not (isinstance(crit, CrossEntropyLoss) and crit.class_weight is None and not self.align_corners and self.ignore_index is not None
+                and not torch.is_autocast_enabled() and hip_ce.supported(seg_logit, seg_label.shape[2:])):
+            return None
+        loss_pix, hits = hip_ce.fused_ce_up(seg_logit, seg_label, self.ignore_index)
+        if crit.reduction == 'mean':
+            loss = loss_pix.mean()
+        elif crit.reduction == 'sum':
+            loss = loss_pix.sum()
+        else:
+            loss = loss_pix
+        acc = hits.to(torch.float32) * (100.0 / seg_label.numel())
+        return {'loss_seg': crit.loss_weight * loss, 'acc_seg': acc}
+
     def losses(self, seg_logit, seg_label):
+        fused = self._fused_losses(seg_logit, seg_label)
+        if fused is not None:
+            return fused
         seg_logit = resize(seg_logit, size=seg_label.shape[2:], mode='bilinear', align_corners=self.align_corners)
         seg_label = seg_label.squeeze(1)
         return {

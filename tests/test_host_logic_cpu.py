@@ -218,3 +218,25 @@ def test_flat_buffer_dp_matches_single_process_gloo():
     assert torch.allclose(g0, flat, rtol=1e-5, atol=1e-7)   # mean of shard losses == loss of the whole batch (equal shards)
     assert l0['loss'] == pytest.approx(float(loss), rel=1e-5) and l0 == l1
     assert l0['acc'] == pytest.approx(2 * float(loss), rel=1e-5)
+
+
+def test_cross_entropy_known_answers_from_reference_tests():
+    """Known answers held by the reference's own tests/test_models/test_losses.py:55-69 for the softmax
+    CrossEntropyLoss (the sigmoid / mask variants :71-84 are outside the KD path and raise here)."""
+    import segdistill_amd
+    from segdistill_amd.builder import build_loss
+    from segdistill_amd.losses import accuracy
+    segdistill_amd.register_all()
+    pred, label = torch.Tensor([[100, -100]]), torch.Tensor([1]).long()
+    crit = build_loss(dict(type='CrossEntropyLoss', use_sigmoid=False, class_weight=[0.8, 0.2], loss_weight=1.0))
+    assert torch.allclose(crit(pred, label), torch.tensor(40.))
+    crit = build_loss(dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
+    assert torch.allclose(crit(pred, label), torch.tensor(200.))
+    with pytest.raises(NotImplementedError):
+        build_loss(dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0))
+    # accuracy known answers (reference tests/test_models/test_losses.py:89-144)
+    pred = torch.Tensor([[0.2, 0.3, 0.6, 0.5], [0.1, 0.1, 0.2, 0.6], [0.9, 0.0, 0.0, 0.1], [0.4, 0.7, 0.1, 0.1], [0.0, 0.0, 0.99, 0]])
+    assert accuracy(pred, torch.Tensor([2, 3, 0, 1, 2]).long()).item() == pytest.approx(100.)
+    assert accuracy(pred, torch.Tensor([2, 2, 0, 1, 0]).long()).item() == pytest.approx(60.)  # 3 of 5 top-1 hits
+    a1, a2 = accuracy(pred, torch.Tensor([2, 3, 0, 1, 2]).long(), topk=(1, 2))
+    assert a1.item() == pytest.approx(100.) and a2.item() == pytest.approx(100.)
