@@ -60,3 +60,16 @@ def test_missing_library_fails_loudly(built, monkeypatch):
     monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libsegdistill_hip.so')
     with pytest.raises(_lib.SegDistillLibError):
         _lib.lib()
+
+
+def test_ctypes_signatures_match_header_arity(built):
+    """Every ctypes signature has exactly as many arguments as the C prototype in the header."""
+    from segdistill_amd import _lib
+    src = open(os.path.join(ROOT, 'include', 'segdistill_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    for name, (_res, args) in _lib.SIGNATURES.items():
+        m = re.search(r'\b' + name + r'\s*\(([^;]*?)\)\s*;', src, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ('', 'void') else params.count(',') + 1
+        assert n == len(args), f'{name}: header has {n} parameters, ctypes binding {len(args)}'
