@@ -167,6 +167,19 @@ int sd_align1x1_bwd_weight(const void *dY, const void *X, float *dW, float *dbia
                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Weight gradient of nn.Linear on token-major activations: dW [out][in] = dY^T . X with
+ * dY [tokens][out], X [tokens][in].  Replaces the aten::mm of every Linear backward in the MiT
+ * blocks (q / kv / proj / fc1 / fc2, mix_transformer.py:24-27,75-76,84).  At stage 1 these are
+ * tall-skinny GEMMs (tokens = B*128*128 = 131072, out/in = 32..256) that are HBM-bound; the token
+ * axis is split over workgroups (f32 MFMA partial slabs in `workspace`, deterministic combine).
+ */
+size_t sd_linear_wgrad_workspace_bytes(long tokens, int out_features, int in_features);
+
+int sd_linear_wgrad(const void *dY, const void *X, float *dW, int dtype,
+                    long tokens, int out_features, int in_features,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Depth-wise 3x3 convolution (stride 1, zero pad 1) on TOKEN-MAJOR activations [B, H*W, C]: the
  * DWConv inside every MiT Mix-FFN (mix_transformer.py:376-387: transpose to NCHW ->
  * nn.Conv2d(dim, dim, 3, 1, 1, groups=dim) -> flatten/transpose back; called from Mlp.forward :48-55).

@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from ..builder import BACKBONES
 from ..layers import DropPath, trunc_normal_
+from ..linear import call_linear
 
 
 def _mit_init(m):
@@ -71,8 +72,8 @@ class MixFFN(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x, hw):
-        x = self.drop(self.act(self.dwconv(self.fc1(x), hw)))
-        return self.drop(self.fc2(x))
+        x = self.drop(self.act(self.dwconv(call_linear(self.fc1, x), hw)))
+        return self.drop(call_linear(self.fc2, x))
 
 
 class SRAttention(nn.Module):
@@ -98,12 +99,12 @@ class SRAttention(nn.Module):
     def forward(self, x, hw):
         b, n, c = x.shape
         h, d = self.num_heads, c // self.num_heads
-        q = self.Q(self.q(x).reshape(b, n, h, d).transpose(1, 2))
+        q = self.Q(call_linear(self.q, x).reshape(b, n, h, d).transpose(1, 2))
         src = x
         if self.sr_ratio > 1:
             src = self.sr(x.transpose(1, 2).reshape(b, c, *hw)).flatten(2).transpose(1, 2)
             src = self.norm(src)
-        kv = self.kv(src).reshape(b, -1, 2, h, d).permute(2, 0, 3, 1, 4)
+        kv = call_linear(self.kv, src).reshape(b, -1, 2, h, d).permute(2, 0, 3, 1, 4)
         k, v = self.K(kv[0]), self.V(kv[1])
         explicit = bool(self.ATTN._forward_hooks) or (self.training and self.attn_drop.p > 0)
         if explicit:
@@ -112,7 +113,7 @@ class SRAttention(nn.Module):
         else:
             out = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
         out = out.transpose(1, 2).reshape(b, n, c)
-        return self.proj_drop(self.proj(out))
+        return self.proj_drop(call_linear(self.proj, out))
 
 
 class EncoderBlock(nn.Module):

@@ -125,6 +125,24 @@ __global__ __launch_bounds__(256) void slab_reduce(const float *__restrict__ sla
     st1<TC>(out + i, acc);
 }
 
+// out[i] = sum_z slabs[z][i] for MANY slabs: block = 16 slab-groups x 16 outputs, LDS combine (deterministic order)
+__global__ __launch_bounds__(256) void slab_reduce_wide(const float *__restrict__ slabs, float *__restrict__ out, long n, int nz) {
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + o;
+    float acc = 0.f;
+    if (i < n)
+        for (int z = grp; z < nz; z += 16) acc += slabs[(long)z * n + i];
+    red[grp][o] = acc;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) t += red[g2][o];
+        out[i] = t;
+    }
+}
+
 // db[c] = sum over (b, p) of dY[b][c][p]; one workgroup per channel
 template <typename T>
 __global__ __launch_bounds__(256) void bias_grad(const T *__restrict__ dY, float *__restrict__ db, int B, int C, long P) {
@@ -184,6 +202,39 @@ int align_bwd_weight(const void *dY, const void *X, float *dW, float *db, void *
     return (int)hipGetLastError();
 }
 
+// dW[M x N] = dY^T . X for token-major dY [T][M], X [T][N] (the weight gradient of nn.Linear):
+// both operands K-major, K = T split over workgroups, partial slabs combined deterministically.
+struct WgradPlan {
+    int nsplit, klen;
+};
+WgradPlan linear_wgrad_plan(long T, int M, int N) {
+    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    long nsplit = 1024 / tiles;
+    if (nsplit > T / 256) nsplit = T / 256;
+    if (nsplit < 1) nsplit = 1;
+    long klen = ((T + nsplit - 1) / nsplit + BK - 1) / BK * BK;
+    nsplit = (T + klen - 1) / klen;
+    return {(int)nsplit, (int)klen};
+}
+
+template <typename T>
+int linear_wgrad(const void *dY, const void *X, float *dW, void *ws, size_t ws_bytes, long Tn, int M, int N, hipStream_t st) {
+    const WgradPlan p = linear_wgrad_plan(Tn, M, N);
+    const long slab = (long)M * N;
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, p.nsplit);
+    if (p.nsplit == 1) {
+        hipLaunchKernelGGL((gemm_mfma_f32<T, T, float, true, true>), grid, dim3(256), 0, st, (const T *)dY, (const T *)X, dW, nullptr, M, N,
+                           (int)Tn, (long)M, (long)N, (long)N, 0L, 0L, 0L, 1, (int)Tn);
+        return (int)hipGetLastError();
+    }
+    if (ws_bytes < (size_t)p.nsplit * slab * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
+    float *slabs = static_cast<float *>(ws);
+    hipLaunchKernelGGL((gemm_mfma_f32<T, T, float, true, true>), grid, dim3(256), 0, st, (const T *)dY, (const T *)X, slabs, nullptr, M, N,
+                       (int)Tn, (long)M, (long)N, (long)N, 0L, 0L, slab, p.nsplit, p.klen);
+    hipLaunchKernelGGL(slab_reduce_wide, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, slabs, dW, slab, p.nsplit);
+    return (int)hipGetLastError();
+}
+
 int check_align(const void *a, const void *b, const void *c, int dtype, int B, int Cs, int Ct, int h, int w) {
     if (!a || !b || !c) return SD_E_NULL;
     if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
@@ -200,6 +251,22 @@ size_t sd_align1x1_workspace_bytes(int B, int Cs, int Ct, int h, int w) {
     if (B <= 0 || Cs <= 0 || Ct <= 0 || h <= 0 || w <= 0) return 0;
     const long P = (long)h * w;
     return (size_t)B * sd::wgrad_splits(B, P) * Ct * Cs * sizeof(float) + 16;
+}
+
+size_t sd_linear_wgrad_workspace_bytes(long tokens, int out_features, int in_features) {
+    if (tokens <= 0 || out_features <= 0 || in_features <= 0) return 0;
+    const sd::WgradPlan p = sd::linear_wgrad_plan(tokens, out_features, in_features);
+    return (size_t)p.nsplit * out_features * in_features * sizeof(float) + 16;
+}
+
+int sd_linear_wgrad(const void *dY, const void *X, float *dW, int dtype, long tokens, int out_features, int in_features, void *workspace,
+                    size_t workspace_bytes, void *stream) {
+    if (!dY || !X || !dW) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (tokens <= 0 || tokens > 0x7fffffffL || out_features <= 0 || in_features <= 0) return SD_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32) return sd::linear_wgrad<float>(dY, X, dW, workspace, workspace_bytes, tokens, out_features, in_features, st);
+    return sd::linear_wgrad<sd::bf16_t>(dY, X, dW, workspace, workspace_bytes, tokens, out_features, in_features, st);
 }
 
 int sd_align1x1_fwd(const void *X, const float *W, const float *bias, void *Y, int dtype, int B, int Cs, int Ct, int h, int w, void *stream) {

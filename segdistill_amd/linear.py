@@ -1,0 +1,61 @@
+"""nn.Linear on token-major activations with the weight gradient computed by the split-K MFMA kernel
+(csrc/align1x1.hip: sd_linear_wgrad).  Forward and the input gradient stay on hipBLASLt (they are well-shaped
+GEMMs); only dW = dY^T . X -- tall-skinny at the high-resolution MiT stages, where the library kernels run
+30x off the HBM roofline (profiles/r01_train_step_kernels_*.txt) -- is replaced."""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .ops import _DT, _stream_ptr
+
+MIN_TOKENS = 4096  # below this the library GEMM is fine
+
+
+class _TokenLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dw = db = None
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ weight).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            x2 = x.reshape(-1, x.shape[-1])
+            if not x2.is_contiguous():
+                x2 = x2.contiguous()
+            dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
+            T, M, N = x2.shape[0], weight.shape[0], weight.shape[1]
+            L = _lib.lib()
+            dw32 = torch.empty(M, N, dtype=torch.float32, device=x.device)
+            wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+            _lib.check(L.sd_linear_wgrad(dyc.data_ptr(), x2.data_ptr(), dw32.data_ptr(), _DT[x.dtype], T, M, N, ws.data_ptr(), wsb, _stream_ptr()),
+                       'sd_linear_wgrad')
+            dw = dw32.to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
+def token_linear(x, weight, bias=None):
+    """F.linear with the HIP weight-gradient kernel when it pays (GPU, fp32/bf16 storage, many tokens, training)."""
+    use = (x.is_cuda and x.dtype in _DT and x.dtype == weight.dtype and weight.requires_grad and torch.is_grad_enabled()
+           and not torch.is_autocast_enabled() and x.numel() // x.shape[-1] >= MIN_TOKENS)
+    if use:
+        return _TokenLinear.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
+def call_linear(module, x):
+    """Apply an nn.Linear through token_linear unless somebody hooked the module (taps must see a module call)."""
+    if module._forward_hooks or module._forward_pre_hooks:
+        return module(x)
+    return token_linear(x, module.weight, module.bias)
