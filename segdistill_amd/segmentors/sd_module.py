@@ -77,6 +77,10 @@ class SDModule(BaseSegmentor):
         self.test_cfg = test_cfg
         self.test_mode = 'whole'
         self.cnt = 0
+        # MI355X: the frozen-teacher forward is independent of the student forward, and both are chains of many
+        # small kernels that do not fill 256 CUs one at a time -> run the teacher on its own HIP stream.
+        self.teacher_on_side_stream = True
+        self._side_stream = None
 
     def train(self, mode=True):
         super().train(mode)
@@ -91,15 +95,32 @@ class SDModule(BaseSegmentor):
         sd = super().state_dict(*args, **kwargs)
         return sd
 
+    def _teacher_forward(self, img, img_metas, gt_semantic_seg):
+        with torch.no_grad():
+            if self.teacher_train_mode:
+                self.teacher(img, img_metas, return_loss=True, gt_semantic_seg=gt_semantic_seg)  # reference behaviour
+            else:
+                self.teacher.forward_features_only(img, run_aux=self._teacher_needs_aux)
+
     def forward_train(self, img, img_metas=None, gt_semantic_seg=None):
         self.cnt += 1
+        side = None
+        if self.distillation and self.teacher_on_side_stream and img.is_cuda:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=img.device)
+            side, main = self._side_stream, torch.cuda.current_stream(img.device)
+            side.wait_stream(main)                      # img / weights are ready
+            with torch.cuda.stream(side):
+                self._teacher_forward(img, img_metas, gt_semantic_seg)
         loss_dict = self.student(img, img_metas, return_loss=True, gt_semantic_seg=gt_semantic_seg)
         if self.distillation:
-            with torch.no_grad():
-                if self.teacher_train_mode:
-                    self.teacher(img, img_metas, return_loss=True, gt_semantic_seg=gt_semantic_seg)  # reference behaviour
-                else:
-                    self.teacher.forward_features_only(img, run_aux=self._teacher_needs_aux)
+            if side is None:
+                self._teacher_forward(img, img_metas, gt_semantic_seg)
+            else:
+                main.wait_stream(side)
+                for t in self.extractor.teacher_features.values():
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(main)           # allocated on the side stream, consumed on the main one
             kd = self.distillation_loss(self.extractor.student_features, self.extractor.teacher_features, gt_semantic_seg,
                                         self.cnt, self.student, self.teacher)
             loss_dict.update(kd)
