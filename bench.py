@@ -248,7 +248,8 @@ def main():
             if hasattr(c, 'fuse_resize'):
                 c.fuse_resize = False
     opt_cfg = cfg.optimizer.to_dict() if hasattr(cfg.optimizer, 'to_dict') else dict(cfg.optimizer)
-    trainer = KDTrainer(model, opt_cfg, dict(cfg.lr_config), max_iters=int(cfg.runner.max_iters), world=world)
+    trainer = KDTrainer(model, opt_cfg, dict(cfg.lr_config), max_iters=int(cfg.runner.max_iters), world=world,
+                        precision=cfg.get('precision'))
     data = SyntheticADE(B, size=tuple(cfg.get('crop_size', (512, 512))), num_classes=int(cfg.get('num_classes', 150)), seed=0,
                         rank=rank, device=device)
     for _ in range(args.warmup):
@@ -264,7 +265,7 @@ def main():
         line = {
             'metric': 'imgs/sec/node KD train_step, Segformer-B2->B0 512x512', 'value': round(world * B * args.steps / dt, 3),
             'unit': 'imgs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if trainer.bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: Segformer-B0 student + B2 teacher, CGD group=8 T=4 alpha=3, 512x512, 150 classes'
                        if 'cfg2' in os.path.basename(args.config) else os.path.basename(args.config),
                        'config_file': os.path.relpath(args.config, ROOT), 'per_gpu_batch': B, 'global_batch': B * world,

@@ -20,7 +20,7 @@ def _freeze_dead_parameters(model):
 
 
 class KDTrainer:
-    def __init__(self, model, optimizer_cfg, lr_cfg=None, max_iters=160000, world=1, log_interval=50):
+    def __init__(self, model, optimizer_cfg, lr_cfg=None, max_iters=160000, world=1, log_interval=50, precision=None):
         self.model = model
         _freeze_dead_parameters(model)
         self.optimizer = build_optimizer(model, optimizer_cfg)
@@ -34,13 +34,20 @@ class KDTrainer:
         self.log_interval = log_interval
         self.last_log_vars = None
         model.defer_log_sync = True  # host sync only when a log line is due
+        # precision=dict(activations='bf16'): bf16 storage of activations / tapped features (autocast), fp32 master weights,
+        # fp32 accumulation inside every HIP kernel (BASELINE config 5)
+        self.bf16 = bool(precision) and precision.get('activations') == 'bf16'
 
     def step(self, batch):
         self.model.train()
         if self.sched is not None:
             self.sched.step(self.iter)
         self.reducer.zero_grad()
-        out = self.model.train_step(batch, self.optimizer)
+        if self.bf16 and batch['img'].is_cuda:
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                out = self.model.train_step(batch, self.optimizer)
+        else:
+            out = self.model.train_step(batch, self.optimizer)
         out['loss'].backward()
         self.reducer.all_reduce()
         self.optimizer.step()
