@@ -227,6 +227,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=32)
+    ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
+                    help='capture forward+backward into a hipGraph (auto: single-GPU runs only; RCCL SyncBN inside a capture is untested)')
     args = ap.parse_args()
 
     from segdistill_amd.config import Config
@@ -252,7 +254,13 @@ def main():
                         precision=cfg.get('precision'))
     data = SyntheticADE(B, size=tuple(cfg.get('crop_size', (512, 512))), num_classes=int(cfg.get('num_classes', 150)), seed=0,
                         rank=rank, device=device)
-    for _ in range(args.warmup):
+    graphed = False
+    n_eager_warm = max(1, args.warmup // 2)
+    for _ in range(n_eager_warm):            # eager warm-up first (MIOpen find, hipBLASLt heuristics, allocator)
+        trainer.step(data.next())
+    if args.graph == 'on' or (args.graph == 'auto' and world == 1):
+        graphed = trainer.enable_graph(data.next())
+    for _ in range(args.warmup - n_eager_warm):
         trainer.step(data.next())
     dt = timed_steps(trainer, data, args.steps, world)
     t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -269,7 +277,7 @@ def main():
             'config': {'workload': 'BASELINE configs[1]: Segformer-B0 student + B2 teacher, CGD group=8 T=4 alpha=3, 512x512, 150 classes'
                        if 'cfg2' in os.path.basename(args.config) else os.path.basename(args.config),
                        'config_file': os.path.relpath(args.config, ROOT), 'per_gpu_batch': B, 'global_batch': B * world,
-                       'parallelism': f'dp{world}', 'kd_path': args.kd_path, 'weights': 'random-init (no checkpoints offline)',
+                       'parallelism': f'dp{world}', 'kd_path': args.kd_path, 'hip_graph': graphed, 'weights': 'random-init (no checkpoints offline)',
                        'grad_allreduce_bytes': trainer.reducer.nbytes},
             'final_log_vars': {k: round(v, 5) for k, v in logs.items()},
         }

@@ -44,6 +44,16 @@ class KLDLoss(nn.Module):
         self.earlydecay_config = earlydecay_config
         self.fuse_resize = True   # use the fused-upsample kernels when the resize is bilinear/align_corners=False
         self.last_perm = None     # permutation used by the most recent shuffle iteration (for tests / logging)
+        # hipGraph support: host-side decisions (alpha schedule, shuffle draw) are made by host_prepare(n_iter) and
+        # reach the kernels as DATA (a 1-element alpha tensor, a permutation table that is the identity on
+        # non-shuffle iterations), so that a captured step can be replayed while they change.
+        self.graph_safe = False
+        self._prepared_for = None
+        self._perm_host = None
+        self._alpha_t = None
+        self._perm_t = None
+        self._alpha_synced = None
+        self._perm_synced = 'unset'
 
     # ---- host-side schedule: same state machine as reference losses.py:61-92 -------------------
     def warmup(self, n_iter):
@@ -76,24 +86,76 @@ class KLDLoss(nn.Module):
         elif n_iter >= end:
             self.alpha = 0
 
-    def _draw_perm(self, channels, n_iter, device):
-        """reference :38-41 draws torch.randperm(C) from the CPU global RNG on every rank
-        independently; ranks are made to agree by broadcasting rank 0's draw."""
+    def _draw_perm_host(self, channels, n_iter):
+        """reference :38-41 draws torch.randperm(C) from the CPU global RNG on every rank independently (SURVEY Q5);
+        ranks are made to agree by broadcasting rank 0's draw."""
         if not self.shuffle_config or n_iter % self.shuffle_config['interval'] != 0:
             return None
         perm = torch.randperm(channels)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            p = perm.to(device)
-            dist.broadcast(p, src=0)
-            perm = p.cpu()
+            if dist.get_backend() == 'nccl':
+                p = perm.cuda()
+                dist.broadcast(p, src=0)
+                perm = p.cpu()
+            else:
+                dist.broadcast(perm, src=0)
         self.last_perm = perm
-        return perm.to(device=device, dtype=torch.int32)
+        return perm
 
-    def forward(self, x_student, x_teacher, gt, n_iter):
+    def host_prepare(self, n_iter, channels):
+        """All host-side per-iteration decisions of reference :96-99 and :38 (idempotent per n_iter)."""
+        if self._prepared_for == n_iter:
+            return
         if self.warmup_config:
             self.warmup(n_iter)
         if self.earlydecay_config:
             self.earlydecay(n_iter)
+        self._perm_host = self._draw_perm_host(channels, n_iter) if self.shuffle_config else None
+        self._prepared_for = n_iter
+
+    def sync_device_state(self, channels, device):
+        """graph_safe mode: push alpha / permutation into the static device buffers the captured kernels read
+        (only when they changed: a steady-state step issues no copy at all)."""
+        if self._alpha_t is None or self._alpha_t.device != device:
+            self._alpha_t = torch.empty((), dtype=torch.float32, device=device)
+            self._alpha_synced = None
+        if self._alpha_synced != float(self.alpha):
+            self._alpha_t.fill_(float(self.alpha))
+            self._alpha_synced = float(self.alpha)
+        if self.shuffle_config:
+            if self._perm_t is None or self._perm_t.numel() != channels or self._perm_t.device != device:
+                self._perm_t = torch.empty(channels, dtype=torch.int32, device=device)
+                self._perm_synced = 'unset'
+            want = None if self._perm_host is None else tuple(self._perm_host.tolist())
+            if self._perm_synced != want:
+                src = torch.arange(channels) if want is None else self._perm_host
+                self._perm_t.copy_(src.to(torch.int32))
+                self._perm_synced = want
+
+    def prepare_replay(self, n_iter):
+        """Called by the trainer before replaying a captured step: same host work as forward() would do."""
+        channels, device = self._seen
+        self.host_prepare(n_iter, channels)
+        self.sync_device_state(channels, device)
+
+    def forward(self, x_student, x_teacher, gt, n_iter):
+        channels = x_student.shape[1]
+        self._seen = (channels, x_student.device)
+        capturing = x_student.is_cuda and torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self.host_prepare(n_iter, channels)
+            if self.graph_safe:
+                self.sync_device_state(channels, x_student.device)
+        if self.graph_safe:
+            alpha, alpha_t = 1.0, self._alpha_t
+            perm = self._perm_t if self.shuffle_config else None
+        else:
+            alpha, alpha_t = self.alpha, None
+            perm = None if self._perm_host is None else self._perm_host.to(device=x_student.device, dtype=torch.int32)
+        loss = self._device_part(x_student, x_teacher, gt, alpha, perm)
+        return loss if alpha_t is None else loss * alpha_t
+
+    def _device_part(self, x_student, x_teacher, gt, alpha, perm):
         out_size = None
         if self.resize_config:
             # reference :101-102 resizes BOTH tensors to the label size; 'target': 'teacher' (an extension used
@@ -109,29 +171,28 @@ class KLDLoss(nn.Module):
                 if tuple(x_teacher.shape[2:]) != out_size:
                     x_teacher = F.interpolate(x_teacher, size=out_size, mode=mode, align_corners=ac)
                 out_size = None
-        perm = self._draw_perm(x_student.shape[1], n_iter, x_student.device) if self.shuffle_config else None
         kind = self.transform_config['loss_type'] if self.transform_config else None
         if kind == 'channel':
             g = self.transform_config['group_size']
             if out_size is not None:
-                return ops.cgd_kl_up(x_student, x_teacher, out_size, group_size=g, tau=self.tau, alpha=self.alpha, perm=perm)
-            return ops.cgd_kl(x_student, x_teacher, group_size=g, tau=self.tau, alpha=self.alpha, perm=perm)
+                return ops.cgd_kl_up(x_student, x_teacher, out_size, group_size=g, tau=self.tau, alpha=alpha, perm=perm)
+            return ops.cgd_kl(x_student, x_teacher, group_size=g, tau=self.tau, alpha=alpha, perm=perm)
+        if perm is not None:  # the remaining row layouts have no permutation-table kernel: gather as the reference does
+            idx = perm.long()
+            x_student, x_teacher = x_student[:, idx].contiguous(), x_teacher[:, idx].contiguous()
         if kind == 'pixel':
             if out_size is not None:
                 x_student, x_teacher = _bilinear(x_student, out_size), _bilinear(x_teacher, out_size)
-            return ops.pix_kl(x_student, x_teacher, tau=self.tau, alpha=self.alpha)
+            return ops.pix_kl(x_student, x_teacher, tau=self.tau, alpha=alpha)
         if kind is None:
             # reference :108-111 on an untransformed 4-D tensor: softmax over the LAST axis,
             # rows = B*C*H.  Same kernel, seen as B*C*H single-plane rows of W elements.
             if out_size is not None:
                 x_student, x_teacher = _bilinear(x_student, out_size), _bilinear(x_teacher, out_size)
-            if perm is not None:
-                idx = perm.long()
-                x_student, x_teacher = x_student[:, idx].contiguous(), x_teacher[:, idx].contiguous()
             w = x_student.shape[-1]
             s2 = x_student.reshape(1, -1, 1, w)
             t2 = x_teacher.reshape(1, -1, 1, w)
-            return ops.cgd_kl(s2, t2, group_size=1, tau=self.tau, alpha=self.alpha)
+            return ops.cgd_kl(s2, t2, group_size=1, tau=self.tau, alpha=alpha)
         raise ValueError(f'unknown loss_type {kind!r}')
 
 

@@ -110,6 +110,16 @@ class DistillationLoss(nn.Module):
                 self.aligns[str(i)] = FeatureAlign(cs, ct)
         self.distillation = distillation
 
+    def set_graph_safe(self, flag=True):
+        for c in self.criteria:
+            if hasattr(c, 'graph_safe'):
+                c.graph_safe = flag
+
+    def prepare_replay(self, step):
+        for c in self.criteria:
+            if hasattr(c, 'prepare_replay'):
+                c.prepare_replay(step)
+
     def forward(self, student_features, teacher_features, gt_semantic_seg, step, student=None, teacher=None):
         out = {}
         for i, entry in enumerate(self.distillation):

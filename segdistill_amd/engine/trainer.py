@@ -38,7 +38,81 @@ class KDTrainer:
         # fp32 accumulation inside every HIP kernel (BASELINE config 5)
         self.bf16 = bool(precision) and precision.get('activations') == 'bf16'
 
+    # ---- hipGraph mode ------------------------------------------------------------------------------------------------
+    # The KD step is ~1300 kernel launches; eager host enqueue costs ~24 ms/step on the GPU box (tools/host_probe.py),
+    # about as much as the GPU work itself.  Forward + backward are therefore captured ONCE into a hipGraph (static
+    # input buffers; the teacher's side stream forks/joins inside the capture) and replayed; everything that changes
+    # per iteration reaches the kernels as data (alpha scalar, permutation table -- distillation/losses.py), the
+    # gradient all-reduce and the fused optimizer step stay outside the graph.
+    def enable_graph(self, example_batch):
+        """Capture forward+backward for batches shaped like `example_batch`.  Returns True on success; on any failure the
+        trainer stays in eager mode (and says why)."""
+        import warnings
+        if not example_batch['img'].is_cuda:
+            return False
+        m = self.model
+        try:
+            self._static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in example_batch.items()}
+            if hasattr(m, 'distillation_loss'):
+                m.distillation_loss.set_graph_safe(True)
+            m.train()
+            cnt0 = getattr(m, 'cnt', 0)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):   # warm-up on a non-default stream, as graph capture requires
+                for _ in range(2):
+                    self.reducer.zero_grad()
+                    self._fwd_bwd(self._static)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            m.cnt = cnt0                    # the warm-up passes do not count as training iterations
+            m.external_step = True
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self.reducer.flat.zero_()
+                self._graph_out = self._fwd_bwd(self._static)
+            torch.cuda.synchronize()
+            return True
+        except Exception as e:  # noqa: BLE001 -- any capture problem must degrade to eager, not kill the run
+            warnings.warn(f'hipGraph capture failed ({type(e).__name__}: {e}); continuing in eager mode')
+            self._graph = None
+            m.external_step = False
+            if hasattr(m, 'distillation_loss'):
+                m.distillation_loss.set_graph_safe(False)
+            torch.cuda.synchronize()
+            return False
+
+    def _fwd_bwd(self, batch):
+        if self.bf16 and batch['img'].is_cuda:
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                out = self.model.train_step(batch, self.optimizer)
+        else:
+            out = self.model.train_step(batch, self.optimizer)
+        out['loss'].backward()
+        return out
+
+    def _graph_step(self, batch):
+        m = self.model
+        for k, v in batch.items():
+            if isinstance(v, torch.Tensor):
+                self._static[k].copy_(v, non_blocking=True)
+        m.cnt += 1
+        if hasattr(m, 'distillation_loss'):
+            m.distillation_loss.prepare_replay(m.cnt)
+        self._graph.replay()
+        return self._graph_out
+
     def step(self, batch):
+        if getattr(self, '_graph', None) is not None:
+            self.model.train()
+            if self.sched is not None:
+                self.sched.step(self.iter)
+            out = self._graph_step(batch)
+            self.reducer.all_reduce()
+            self.optimizer.step()
+            self.iter += 1
+            self.last_log_vars = out['log_vars']
+            return out
         self.model.train()
         if self.sched is not None:
             self.sched.step(self.iter)

@@ -81,6 +81,7 @@ class SDModule(BaseSegmentor):
         # small kernels that do not fill 256 CUs one at a time -> run the teacher on its own HIP stream.
         self.teacher_on_side_stream = True
         self._side_stream = None
+        self.external_step = False  # True while a trainer replays captured steps: it advances `cnt` itself
 
     def train(self, mode=True):
         super().train(mode)
@@ -103,7 +104,8 @@ class SDModule(BaseSegmentor):
                 self.teacher.forward_features_only(img, run_aux=self._teacher_needs_aux)
 
     def forward_train(self, img, img_metas=None, gt_semantic_seg=None):
-        self.cnt += 1
+        if not self.external_step:
+            self.cnt += 1
         side = None
         if self.distillation and self.teacher_on_side_stream and img.is_cuda:
             if self._side_stream is None:
@@ -118,9 +120,10 @@ class SDModule(BaseSegmentor):
                 self._teacher_forward(img, img_metas, gt_semantic_seg)
             else:
                 main.wait_stream(side)
-                for t in self.extractor.teacher_features.values():
-                    if isinstance(t, torch.Tensor):
-                        t.record_stream(main)           # allocated on the side stream, consumed on the main one
+                if not torch.cuda.is_current_stream_capturing():
+                    for t in self.extractor.teacher_features.values():
+                        if isinstance(t, torch.Tensor):
+                            t.record_stream(main)       # allocated on the side stream, consumed on the main one
             kd = self.distillation_loss(self.extractor.student_features, self.extractor.teacher_features, gt_semantic_seg,
                                         self.cnt, self.student, self.teacher)
             loss_dict.update(kd)

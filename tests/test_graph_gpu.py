@@ -1,0 +1,73 @@
+"""hipGraph replay of the KD step == eager execution, including an alpha schedule and shuffle iterations
+(host-side state reaches the captured kernels as data)."""
+import copy
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model():
+    import segdistill_amd
+    from segdistill_amd.builder import build_segmentor
+    from segdistill_amd.segmentors import sd_module
+    segdistill_amd.register_all()
+    norm = dict(type='SyncBN', requires_grad=True)
+
+    def seg(v, ch, e):
+        return dict(type='EncoderDecoder', pretrained=None, backbone=dict(type=f'mit_{v}', style='pytorch'),
+                    decode_head=dict(type='SegFormerHead', in_channels=ch, in_index=[0, 1, 2, 3], feature_strides=[4, 8, 16, 32], channels=128,
+                                     dropout_ratio=1e-12, num_classes=150, norm_cfg=norm, align_corners=False, decoder_params=dict(embed_dim=e),
+                                     loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)))
+    bil = dict(mode='bilinear', align_corners=False)
+    cfg = dict(type='SDModule', cfg_s=seg('b0', [32, 64, 160, 256], 256), cfg_t=seg('b0', [32, 64, 160, 256], 256),
+               distillation=[dict(student_layer='decode_head.linear_pred', teacher_layer='decode_head.linear_pred', loss_name='KLDLoss',
+                                  loss_config=dict(alpha=3, tau=4, resize_config=bil, shuffle_config={'interval': 3},
+                                                   transform_config={'loss_type': 'channel', 'group_size': 8},
+                                                   warmup_config={'mode': 'linear', 'warmup_iters': 5}))],
+               t_pretrain=None, train_cfg=dict(), test_cfg=dict(mode='whole'))
+    sd_module.SYNTHETIC_WEIGHTS_OK = True
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            torch.manual_seed(0)
+            m = build_segmentor(cfg)
+    finally:
+        sd_module.SYNTHETIC_WEIGHTS_OK = False
+    m.student.backbone.reset_drop_path(0.)
+    return m.cuda()
+
+
+def test_graph_replay_matches_eager():
+    from segdistill_amd.engine import KDTrainer, SyntheticADE
+    opt = dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+    ref = _model()
+    gra = copy.deepcopy(ref)
+    t_e = KDTrainer(ref, opt, dict(policy='poly', power=1.0, min_lr=0.0, by_epoch=False))
+    t_g = KDTrainer(gra, opt, dict(policy='poly', power=1.0, min_lr=0.0, by_epoch=False))
+    data_e = SyntheticADE(2, size=(128, 128), device='cuda:0', pool=3, seed=1)
+    data_g = SyntheticADE(2, size=(128, 128), device='cuda:0', pool=3, seed=1)
+    assert t_g.enable_graph(data_g._pool[0] and dict(img=data_g._pool[0][0], img_metas=None, gt_semantic_seg=data_g._pool[0][1]))
+    assert gra.cnt == 0
+    perms = []
+    for it in range(7):                         # crosses the warm-up end (5) and two shuffle iterations (3, 6)
+        torch.manual_seed(100 + it)            # the shuffle draws torch.randperm from the CPU RNG
+        oe = t_e.step(data_e.next())
+        pe = ref.distillation_loss.criteria[0].last_perm
+        torch.manual_seed(100 + it)
+        og = t_g.step(data_g.next())
+        ve, vg = t_e.log_values(), t_g.log_values()
+        assert list(ve) == list(vg)
+        for k in ve:
+            tol = 100.0 * 8 / (2 * 128 * 128) if 'acc' in k else 1e-4 * max(1.0, abs(ve[k]))
+            assert vg[k] == pytest.approx(ve[k], abs=tol), (it, k, ve[k], vg[k])
+        assert ref.cnt == gra.cnt == it + 1
+        assert ref.distillation_loss.criteria[0].alpha == pytest.approx(gra.distillation_loss.criteria[0].alpha)
+        perms.append(pe)
+    assert perms[2] is not None                 # iteration 3 drew a permutation
+    # after 7 optimizer steps the two students still agree closely
+    num = sum(float((a - b).pow(2).sum()) for a, b in zip(ref.student.parameters(), gra.student.parameters()))
+    den = sum(float(a.pow(2).sum()) for a in ref.student.parameters())
+    assert (num / den) ** 0.5 < 1e-4
