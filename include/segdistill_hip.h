@@ -219,6 +219,19 @@ int sd_ce_up_bwd(const void *logits, const int32_t *label, const float *pix_lse2
                  const float *upstream, int upstream_is_map, float gscale, void *dlogits,
                  int dtype, int B, int C, int h, int w, int H, int W, int ignore_index, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * SegFormer head: y = z1 + up(z2) + up(z3) + up(z4) + bias on token-major tensors, one pass.
+ * Replaces the three resize() calls, the torch.cat and (together with the per-branch fuse GEMMs done
+ * by the binding) the linear_fuse 1x1 conv input path of segformer_head.py:82-91.
+ * z1 [B,H*W,E]; z_i [B,(H/f_i)*(W/f_i),E], f_i in {2,4,8}; bias [E] fp32 or NULL; y [B,H*W,E].
+ * sd_upsum_bwd: gradient w.r.t. ONE coarse branch, dz [B,h*w,E] from dy [B,(F*h)*(F*w),E]
+ * (transposed bilinear interpolation as a gather; dz1 = dy needs no kernel).
+ */
+int sd_upsum_fwd(const void *z1, const void *z2, const void *z3, const void *z4, const float *bias, void *y,
+                 int dtype, int B, int H, int W, int E, int f2, int f3, int f4, void *stream);
+
+int sd_upsum_bwd(const void *dy, void *dz, int dtype, int B, int h, int w, int E, int F, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,8 @@ SIGNATURES = {
     'sd_dwconv3x3_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'sd_dwconv3x3_bwd_data': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'sd_dwconv3x3_bwd_weight': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'sd_upsum_fwd': (_i, [_vp] * 6 + [_i] * 8 + [_vp]),
+    'sd_upsum_bwd': (_i, [_vp, _vp] + [_i] * 6 + [_vp]),
     'sd_ce_up_supported': (_i, [_i, _i, _i, _i]),
     'sd_ce_up_fwd': (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     'sd_ce_up_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp] + [_i] * 8 + [_vp]),

@@ -58,12 +58,13 @@ class SegFormerHead(BaseDecodeHead):
         return ((feats[3], self.linear_c4), (feats[2], self.linear_c3), (feats[1], self.linear_c2), (feats[0], self.linear_c1))
 
     def _fused_sum(self, feats):
+        from .. import headfuse
         c1 = feats[0]
         n, size = c1.shape[0], c1.shape[2:]
         w = self.linear_fuse.conv.weight  # [E, 4E, 1, 1], input channel blocks ordered (c4, c3, c2, c1)
         e = w.shape[0]
         fold = (not self.training) and not any(m._forward_hooks or m.proj._forward_hooks for _, m in self._branches(feats))
-        total = None
+        zs, sizes = [], []
         for i, (feat, mlp) in enumerate(self._branches(feats)):
             wi = w[:, i * e:(i + 1) * e, 0, 0]                      # [E, E]
             tokens = feat.flatten(2).transpose(1, 2)                  # [B, hw, Cin]
@@ -71,13 +72,22 @@ class SegFormerHead(BaseDecodeHead):
                 z = torch.addmm(wi @ mlp.proj.bias, tokens.reshape(-1, tokens.shape[-1]), (wi @ mlp.proj.weight).t())
             else:
                 z = mlp(feat).reshape(-1, e) @ wi.t()                 # module call keeps forward hooks (taps) alive
-            z = z.reshape(n, feat.shape[2], feat.shape[3], e).permute(0, 3, 1, 2)
-            if z.shape[2:] != size:
+            zs.append(z.reshape(n, -1, e))                            # token-major [B, h_i*w_i, E]
+            sizes.append(tuple(feat.shape[2:]))
+        zs, sizes = zs[::-1], sizes[::-1]                             # finest (c1) first
+        bias = self.linear_fuse.conv.bias
+        if headfuse.supported(zs, sizes) and not torch.is_autocast_enabled():
+            # MI355X path (csrc/headfuse.hip): one pass, y = z1 + up(z2) + up(z3) + up(z4) + bias, token-major
+            y = headfuse.upsum(zs[0], zs[1], zs[2], zs[3], bias, sizes)
+            return y.reshape(n, size[0], size[1], e).permute(0, 3, 1, 2)   # NCHW view with channels-last strides
+        total = None
+        for z, (h_, w_) in zip(zs, sizes):
+            z = z.reshape(n, h_, w_, e).permute(0, 3, 1, 2)
+            if (h_, w_) != tuple(size):
                 z = resize(z, size=size, mode='bilinear', align_corners=False)
             total = z if total is None else total + z
-        conv = self.linear_fuse.conv
-        if conv.bias is not None:
-            total = total + conv.bias.view(1, -1, 1, 1)
+        if bias is not None:
+            total = total + bias.view(1, -1, 1, 1)
         return total
 
     def forward(self, inputs):

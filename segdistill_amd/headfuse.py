@@ -1,0 +1,60 @@
+"""autograd binding of the SegFormer-head up-sample-and-sum kernels (csrc/headfuse.hip)."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .ops import _DT, _stream_ptr
+
+
+def supported(zs, sizes):
+    """zs: four token-major tensors [B, h_i*w_i, E] (finest first); sizes: their (h_i, w_i)."""
+    z1 = zs[0]
+    if not z1.is_cuda or z1.dtype not in _DT or any(z.dtype != z1.dtype or z.dim() != 3 for z in zs):
+        return False
+    E = z1.shape[-1]
+    if E % (4 if z1.dtype == torch.float32 else 8):
+        return False
+    H, W = sizes[0]
+    for (h, w) in sizes[1:]:
+        if h <= 0 or w <= 0 or H % h or W % w or H // h != W // w or H // h not in (2, 4, 8):
+            return False
+    return True
+
+
+class _UpSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z1, z2, z3, z4, bias, sizes):
+        zs = [z.contiguous() for z in (z1, z2, z3, z4)]
+        B, _, E = zs[0].shape
+        (H, W) = sizes[0]
+        fs = [H // h for (h, w) in sizes[1:]]
+        y = torch.empty_like(zs[0])
+        b = None if bias is None else bias.detach().float().contiguous()
+        rc = _lib.lib().sd_upsum_fwd(zs[0].data_ptr(), zs[1].data_ptr(), zs[2].data_ptr(), zs[3].data_ptr(), None if b is None else b.data_ptr(),
+                                     y.data_ptr(), _DT[y.dtype], B, H, W, E, fs[0], fs[1], fs[2], _stream_ptr())
+        _lib.check(rc, 'sd_upsum_fwd')
+        ctx.sizes, ctx.fs, ctx.has_bias = sizes, fs, bias is not None
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        B, _, E = dy.shape
+        L = _lib.lib()
+        grads = [dy if ctx.needs_input_grad[0] else None]
+        for i, ((h, w), F) in enumerate(zip(ctx.sizes[1:], ctx.fs)):
+            if not ctx.needs_input_grad[i + 1]:
+                grads.append(None)
+                continue
+            dz = torch.empty(B, h * w, E, dtype=dy.dtype, device=dy.device)
+            _lib.check(L.sd_upsum_bwd(dy.data_ptr(), dz.data_ptr(), _DT[dy.dtype], B, h, w, E, F, _stream_ptr()), 'sd_upsum_bwd')
+            grads.append(dz)
+        db = dy.sum(dim=(0, 1)).to(ctx.bias_dtype) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
+        return grads[0], grads[1], grads[2], grads[3], db, None
+
+
+def upsum(z1, z2, z3, z4, bias, sizes):
+    """y[B, H*W, E] = z1 + up(z2) + up(z3) + up(z4) + bias, all token-major."""
+    return _UpSum.apply(z1, z2, z3, z4, bias, tuple(tuple(int(v) for v in s) for s in sizes))

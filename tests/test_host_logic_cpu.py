@@ -240,3 +240,58 @@ def test_cross_entropy_known_answers_from_reference_tests():
     assert accuracy(pred, torch.Tensor([2, 2, 0, 1, 0]).long()).item() == pytest.approx(60.)  # 3 of 5 top-1 hits
     a1, a2 = accuracy(pred, torch.Tensor([2, 3, 0, 1, 2]).long(), topk=(1, 2))
     assert a1.item() == pytest.approx(100.) and a2.item() == pytest.approx(100.)
+
+
+def _engine_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import warnings
+    import segdistill_amd
+    from oracle.eager_modules import swap_in_eager_criteria
+    from segdistill_amd.builder import build_segmentor
+    from segdistill_amd.distillation import CGDLoss
+    from segdistill_amd.engine import KDTrainer, SyntheticADE, init_distributed
+    from segdistill_amd.segmentors import sd_module
+    torch.set_num_threads(2)
+    init_distributed(backend='gloo')
+    segdistill_amd.register_all()
+    sd_module.SYNTHETIC_WEIGHTS_OK = True
+    torch.manual_seed(1234 + rank)            # different initial weights per rank: the trainer must broadcast rank 0's
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = build_segmentor(_tiny_sd_cfg())
+    swap_in_eager_criteria(model)
+    opt = dict(type='AdamW', lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01,
+               paramwise_cfg=dict(custom_keys={'norm': dict(decay_mult=0.), 'head': dict(lr_mult=10.)}))
+    tr = KDTrainer(model, opt, dict(policy='poly', power=1.0, min_lr=0.0, by_epoch=False), world=world)
+    data = SyntheticADE(1, size=(64, 64), device='cpu', pool=2, seed=0, rank=rank)
+    logs = []
+    for _ in range(2):
+        tr.step(data.next())
+        logs.append(tr.log_values())
+    # the product criterion's shuffle draw is broadcast from rank 0
+    torch.manual_seed(rank)
+    crit = CGDLoss()
+    perm = crit._draw_perm_host(150, 1000)
+    digest = torch.cat([p.detach().reshape(-1)[:50] for p in model.student.parameters()])
+    q.put((rank, digest, logs, perm.tolist(), float(data._pool[0][0].sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_kd_engine_two_ranks_gloo():
+    world, port = 2, 29743
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, d0, l0, p0, s0), (_, d1, l1, p1, s1) = res
+    assert torch.equal(d0, d1)          # replicas stay bit-identical: same broadcast start, same averaged gradients
+    assert l0 == l1                     # log vars are the cross-rank means on every rank
+    assert p0 == p1 and sorted(p0) == list(range(150))
+    assert s0 != s1                     # ...although each rank trained on its own shard of the data
