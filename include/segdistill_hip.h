@@ -220,6 +220,22 @@ int sd_ce_up_bwd(const void *logits, const int32_t *label, const float *pix_lse2
                  int dtype, int B, int C, int h, int w, int H, int W, int ignore_index, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * LayerNorm over the channel axis of token-major activations [rows][C] (C % 4 == 0, C <= 1024).
+ * Replaces the nn.LayerNorm calls of the MiT encoders (mix_transformer.py:96,139,169-171,214 and the
+ * stage norms :336-365) and their autograd.  gamma/beta fp32; mean/rstd [rows] fp32 saved by the
+ * forward for the backward; dgamma/dbeta via per-workgroup partials in `workspace` (deterministic).
+ */
+int sd_layernorm_supported(int C);
+size_t sd_layernorm_workspace_bytes(long rows, int C);
+
+int sd_layernorm_fwd(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd,
+                     int dtype, long rows, int C, float eps, void *stream);
+
+int sd_layernorm_bwd(const void *x, const void *dy, const float *gamma, const float *mean, const float *rstd,
+                     void *dx, float *dgamma, float *dbeta, int dtype, long rows, int C,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------
  * SegFormer head: y = z1 + up(z2) + up(z3) + up(z4) + bias on token-major tensors, one pass.
  * Replaces the three resize() calls, the torch.cat and (together with the per-branch fuse GEMMs done
  * by the binding) the linear_fuse 1x1 conv input path of segformer_head.py:82-91.

@@ -49,6 +49,10 @@ SIGNATURES = {
     'sd_dwconv3x3_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'sd_dwconv3x3_bwd_data': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'sd_dwconv3x3_bwd_weight': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'sd_layernorm_supported': (_i, [_i]),
+    'sd_layernorm_workspace_bytes': (_sz, [C.c_long, _i]),
+    'sd_layernorm_fwd': (_i, [_vp] * 6 + [_i, C.c_long, _i, _f, _vp]),
+    'sd_layernorm_bwd': (_i, [_vp] * 8 + [_i, C.c_long, _i, _vp, _sz, _vp]),
     'sd_upsum_fwd': (_i, [_vp] * 6 + [_i] * 8 + [_vp]),
     'sd_upsum_bwd': (_i, [_vp, _vp] + [_i] * 6 + [_vp]),
     'sd_ce_up_supported': (_i, [_i, _i, _i, _i]),

@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from ..builder import BACKBONES
 from ..layers import DropPath, trunc_normal_
+from ..layernorm import HipLayerNorm
 from ..linear import call_linear
 
 
@@ -94,7 +95,7 @@ class SRAttention(nn.Module):
         self.sr_ratio = sr_ratio
         if sr_ratio > 1:
             self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
-            self.norm = nn.LayerNorm(dim)
+            self.norm = HipLayerNorm(dim)
 
     def forward(self, x, hw):
         b, n, c = x.shape
@@ -139,7 +140,7 @@ class OverlapPatchEmbed(nn.Module):
     def __init__(self, patch_size, stride, in_chans, embed_dim):
         super().__init__()
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride, padding=patch_size // 2)
-        self.norm = nn.LayerNorm(embed_dim)
+        self.norm = HipLayerNorm(embed_dim)
 
     def forward(self, x):
         x = self.proj(x)
@@ -211,7 +212,7 @@ _VARIANTS = {  # embed_dims, depths  (reference mix_transformer.py:392-441)
 def _make_variant(name, dims, depths):
     def __init__(self, **kwargs):  # extra config keys such as style='pytorch' are accepted and ignored, as in the reference
         MixVisionTransformer.__init__(self, patch_size=4, embed_dims=dims, num_heads=(1, 2, 5, 8), mlp_ratios=(4, 4, 4, 4),
-                                      qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), depths=depths,
+                                      qkv_bias=True, norm_layer=partial(HipLayerNorm, eps=1e-6), depths=depths,
                                       sr_ratios=(8, 4, 2, 1), drop_rate=0.0, drop_path_rate=0.1)
     cls = type(name, (MixVisionTransformer,), {'__init__': __init__, '__doc__': f'SegFormer {name} encoder.'})
     return BACKBONES.register_module()(cls)

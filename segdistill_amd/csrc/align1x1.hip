@@ -82,18 +82,24 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32(const TA *__restrict__ A, c
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // which of this wave's four 32x32 sub-tiles hold real rows/columns (skinny problems leave most of them empty;
+    // issuing f32 MFMAs on zero padding would make a 32x32 weight gradient MFMA-bound instead of HBM-bound)
+    const bool am0 = m0 + wm < M, am1 = m0 + wm + 32 < M;
+    const bool bn0 = n0 + wn < N, bn1 = n0 + wn + 32 < N;
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         stage<TA, A_KMAJOR>(As, A, lda, m0, M, k0, k_end);
         stage<TB, B_KMAJOR>(Bs, B, ldb, n0, N, k0, k_end);
         __syncthreads();
+        if (am0 && bn0) {
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = As[kk + kh][wm + r], a1 = As[kk + kh][wm + 32 + r];
-            const float b0 = Bs[kk + kh][wn + r], b1 = Bs[kk + kh][wn + 32 + r];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a0 = As[kk + kh][wm + r], a1 = As[kk + kh][wm + 32 + r];
+                const float b0 = Bs[kk + kh][wn + r], b1 = Bs[kk + kh][wn + 32 + r];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                if (bn1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                if (am1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                if (am1 && bn1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
         __syncthreads();
     }

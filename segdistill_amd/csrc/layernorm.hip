@@ -1,0 +1,284 @@
+// layernorm.hip -- LayerNorm over the last (channel) axis of token-major activations [rows, C],
+// forward and backward, gfx950.
+//
+// The MiT encoders normalise tokens 83 times per KD step (every block's norm1/norm2, the SR-attention norm,
+// the patch-embed norm and the stage norm: reference mix_transformer.py:96,139,169-171,214,336-365) with small
+// C (32..512) and up to 131072 rows.  That is HBM-bound byte work (read x once, write y once), but the generic
+// ATen kernels spend 38 us on average where the largest instance needs ~6-11 us of traffic; after the depth-wise
+// and loss kernels were replaced LayerNorm was the largest single item of the step (11 % of GPU time).
+//
+// Mapping: a row is handled by a GROUP of G lanes (G = power of two <= 64, G*4*V >= C), each lane holding V
+// float4 vectors of the row in registers; mean / variance (two-pass, in registers) by xor-shuffles inside the
+// group, so a wave processes 64/G rows at once and small C does not idle lanes.
+//   fwd:  y = (x - mean) * rstd * gamma + beta ; saves mean, rstd [rows]
+//   bwd:  dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ;
+//         dgamma = sum_rows dy*xhat, dbeta = sum_rows dy  (per-workgroup partials, deterministic second pass)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cgd_device.h"
+
+namespace sd {
+
+namespace {
+
+constexpr int kLnThreads = 256;
+
+template <typename T> struct LV;
+template <> struct LV<float> {
+    static __device__ __forceinline__ float4 load(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ void store(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+};
+template <> struct LV<bf16_t> {  // 4 bf16 = 8 bytes
+    static __device__ __forceinline__ float4 load(const bf16_t *p) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(p);
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                           __uint_as_float(v.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ void store(bf16_t *p, float4 v) {
+        uint2 o;
+        o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+        o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2 *>(p) = o;
+    }
+};
+
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// grid: ceil(rows / rows_per_block); rows_per_block = kLnThreads / G
+template <typename T, int G, int V>
+__global__ __launch_bounds__(kLnThreads) void ln_fwd(const T *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                      T *__restrict__ y, float *__restrict__ mean_out, float *__restrict__ rstd_out,
+                                                      long rows, int C, float eps) {
+    const int gl = threadIdx.x % G;
+    const long row = (long)blockIdx.x * (kLnThreads / G) + threadIdx.x / G;
+    const bool live = row < rows;
+    const int cv = C / 4;
+    float4 v[V];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int j = gl + i * G;
+        v[i] = (live && j < cv) ? LV<T>::load(x + row * C + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = group_sum<G>(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int j = gl + i * G;
+        if (j < cv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b * b + c * c + d * d;
+        }
+    }
+    const float rstd = rsqrtf(group_sum<G>(q) / C + eps);
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int j = gl + i * G;
+        if (j < cv) {
+            const float4 g = *reinterpret_cast<const float4 *>(gamma + 4 * j), b = *reinterpret_cast<const float4 *>(beta + 4 * j);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + b.x;
+            o.y = (v[i].y - mean) * rstd * g.y + b.y;
+            o.z = (v[i].z - mean) * rstd * g.z + b.z;
+            o.w = (v[i].w - mean) * rstd * g.w + b.w;
+            LV<T>::store(y + row * C + 4 * j, o);
+        }
+    }
+    if (gl == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// grid: nblk workgroups, each walking rows blockIdx.x*RPB + k*gridDim.x*RPB ...; partial dgamma/dbeta per workgroup in
+// part[blk][2][C] (gamma first).
+template <typename T, int G, int V>
+__global__ __launch_bounds__(kLnThreads) void ln_bwd(const T *__restrict__ x, const T *__restrict__ dy, const float *__restrict__ gamma,
+                                                      const float *__restrict__ mean_in, const float *__restrict__ rstd_in, T *__restrict__ dx,
+                                                      float *__restrict__ part, long rows, int C) {
+    extern __shared__ float red[];  // [RPB][2][C]
+    constexpr int RPB = kLnThreads / G;
+    const int gl = threadIdx.x % G, rg = threadIdx.x / G;
+    const int cv = C / 4;
+    float4 gam[V], ag[V], ab[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int j = gl + i * G;
+        gam[i] = j < cv ? *reinterpret_cast<const float4 *>(gamma + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long row = (long)blockIdx.x * RPB + rg; row < rows; row += (long)gridDim.x * RPB) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float4 xh[V], g[V];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int j = gl + i * G;
+            if (j < cv) {
+                const float4 xv = LV<T>::load(x + row * C + 4 * j), dv = LV<T>::load(dy + row * C + 4 * j);
+                xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+                g[i] = make_float4(dv.x * gam[i].x, dv.y * gam[i].y, dv.z * gam[i].z, dv.w * gam[i].w);
+                s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+                s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+                ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
+                ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
+            }
+        }
+        const float m1 = group_sum<G>(s1) / C, m2 = group_sum<G>(s2) / C;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int j = gl + i * G;
+            if (j < cv) {
+                float4 o;
+                o.x = rstd * (g[i].x - m1 - xh[i].x * m2);
+                o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
+                o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
+                o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
+                LV<T>::store(dx + row * C + 4 * j, o);
+            }
+        }
+    }
+    // combine the RPB row-groups of this workgroup
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int j = gl + i * G;
+        if (j < cv) {
+            float *pg = red + ((size_t)rg * 2 + 0) * C + 4 * j, *pb = red + ((size_t)rg * 2 + 1) * C + 4 * j;
+            pg[0] = ag[i].x; pg[1] = ag[i].y; pg[2] = ag[i].z; pg[3] = ag[i].w;
+            pb[0] = ab[i].x; pb[1] = ab[i].y; pb[2] = ab[i].z; pb[3] = ab[i].w;
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += kLnThreads) {
+        float s = 0.f;
+        for (int r = 0; r < RPB; ++r) s += red[(size_t)r * 2 * C + e];
+        part[(size_t)blockIdx.x * 2 * C + e] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_param_reduce(const float *__restrict__ part, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                        int nblk, int C) {
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + o;
+    float acc = 0.f;
+    if (e < 2 * C)
+        for (int p = grp; p < nblk; p += 16) acc += part[(size_t)p * 2 * C + e];
+    red[grp][o] = acc;
+    __syncthreads();
+    if (grp == 0 && e < 2 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) t += red[g2][o];
+        if (e < C) dgamma[e] = t;
+        else dbeta[e - C] = t;
+    }
+}
+
+struct LnPlan {
+    int G, V;
+};
+LnPlan ln_plan(int C) {
+    const int cv = C / 4;
+    int G = 1;
+    while (G < cv && G < 64) G <<= 1;
+    if (G < 8) G = 8;
+    const int V = (cv + G - 1) / G;
+    return {G, V};
+}
+int ln_bwd_blocks(long rows, int G) {
+    const long rpb = kLnThreads / G;
+    long n = (rows + rpb - 1) / rpb;
+    if (n > 2048) n = 2048;
+    return (int)(n < 1 ? 1 : n);
+}
+
+#define SD_LN_DISPATCH(CALL)                                                  \
+    do {                                                                      \
+        if (p.G == 8 && p.V == 1) { CALL(8, 1); }                             \
+        else if (p.G == 16 && p.V == 1) { CALL(16, 1); }                      \
+        else if (p.G == 32 && p.V == 1) { CALL(32, 1); }                      \
+        else if (p.G == 64 && p.V == 1) { CALL(64, 1); }                      \
+        else if (p.G == 64 && p.V == 2) { CALL(64, 2); }                      \
+        else if (p.G == 64 && p.V <= 4) { CALL(64, 4); }                      \
+        else return SD_E_UNSUPPORTED;                                         \
+    } while (0)
+
+template <typename T>
+int ln_fwd_launch(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd, long rows, int C, float eps,
+                  hipStream_t st) {
+    const LnPlan p = ln_plan(C);
+#define SD_CALL(GG, VV)                                                                                                              \
+    hipLaunchKernelGGL((ln_fwd<T, GG, VV>), dim3((unsigned)((rows + kLnThreads / GG - 1) / (kLnThreads / GG))), dim3(kLnThreads), 0, st, \
+                       (const T *)x, gamma, beta, (T *)y, mean, rstd, rows, C, eps)
+    SD_LN_DISPATCH(SD_CALL);
+#undef SD_CALL
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int ln_bwd_launch(const void *x, const void *dy, const float *gamma, const float *mean, const float *rstd, void *dx, float *dgamma,
+                  float *dbeta, void *ws, size_t ws_bytes, long rows, int C, hipStream_t st) {
+    const LnPlan p = ln_plan(C);
+    const int nblk = ln_bwd_blocks(rows, p.G);
+    if (ws_bytes < (size_t)nblk * 2 * C * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
+    float *part = static_cast<float *>(ws);
+    const size_t lds = (size_t)(kLnThreads / p.G) * 2 * C * sizeof(float);
+    if (lds > 64 * 1024) return SD_E_UNSUPPORTED;
+#define SD_CALL(GG, VV)                                                                                                              \
+    hipLaunchKernelGGL((ln_bwd<T, GG, VV>), dim3(nblk), dim3(kLnThreads), lds, st, (const T *)x, (const T *)dy, gamma, mean, rstd, (T *)dx, \
+                       part, rows, C)
+    SD_LN_DISPATCH(SD_CALL);
+#undef SD_CALL
+    hipLaunchKernelGGL(ln_param_reduce, dim3((2 * C + 15) / 16), dim3(256), 0, st, part, dgamma, dbeta, nblk, C);
+    return (int)hipGetLastError();
+}
+
+int check_ln(const void *a, const void *b, int dtype, long rows, int C) {
+    if (!a || !b) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (rows <= 0 || C <= 0) return SD_E_SHAPE;
+    if (C % 4 || C > 1024) return SD_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return SD_E_ALIGN;
+    return SD_OK;
+}
+
+}  // namespace
+}  // namespace sd
+
+extern "C" {
+
+int sd_layernorm_supported(int C) { return (C > 0 && C % 4 == 0 && C <= 1024) ? 1 : 0; }
+
+size_t sd_layernorm_workspace_bytes(long rows, int C) {
+    if (rows <= 0 || C <= 0 || C % 4) return 0;
+    const sd::LnPlan p = sd::ln_plan(C);
+    return (size_t)sd::ln_bwd_blocks(rows, p.G) * 2 * C * sizeof(float) + 16;
+}
+
+int sd_layernorm_fwd(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd, int dtype, long rows, int C,
+                     float eps, void *stream) {
+    int rc = sd::check_ln(x, y, dtype, rows, C);
+    if (rc) return rc;
+    if (!gamma || !beta || !mean || !rstd) return SD_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32) return sd::ln_fwd_launch<float>(x, gamma, beta, y, mean, rstd, rows, C, eps, st);
+    return sd::ln_fwd_launch<sd::bf16_t>(x, gamma, beta, y, mean, rstd, rows, C, eps, st);
+}
+
+int sd_layernorm_bwd(const void *x, const void *dy, const float *gamma, const float *mean, const float *rstd, void *dx, float *dgamma,
+                     float *dbeta, int dtype, long rows, int C, void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = sd::check_ln(x, dy, dtype, rows, C);
+    if (rc) return rc;
+    if (!gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return SD_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32) return sd::ln_bwd_launch<float>(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, workspace, workspace_bytes, rows, C, st);
+    return sd::ln_bwd_launch<sd::bf16_t>(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, workspace, workspace_bytes, rows, C, st);
+}
+
+}  // extern "C"
