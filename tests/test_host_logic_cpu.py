@@ -186,7 +186,8 @@ def _dp_worker(rank, world, port, q):
     loss.backward()
     red.all_reduce()
     _, logs = parse_losses({'loss_a': loss, 'acc': loss.detach() * 2})
-    q.put((rank, red.flat.clone(), [p.detach().clone() for p in net.parameters()], logs))
+    # numpy (pickled by value): torch tensors travel through shared-memory handles that die with the child
+    q.put((rank, red.flat.numpy().copy(), [p.detach().numpy().copy() for p in net.parameters()], logs))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -203,6 +204,8 @@ def test_flat_buffer_dp_matches_single_process_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, g0, p0, l0), (_, g1, p1, l1) = res
+    g0, g1 = torch.from_numpy(g0), torch.from_numpy(g1)
+    p0, p1 = [torch.from_numpy(a) for a in p0], [torch.from_numpy(a) for a in p1]
     assert torch.equal(g0, g1)                       # every rank holds the same averaged gradient
     for a, b in zip(p0, p1):
         assert torch.equal(a, b)                     # parameters were broadcast from rank 0
@@ -274,7 +277,7 @@ def _engine_worker(rank, world, port, q):
     crit = CGDLoss()
     perm = crit._draw_perm_host(150, 1000)
     digest = torch.cat([p.detach().reshape(-1)[:50] for p in model.student.parameters()])
-    q.put((rank, digest, logs, perm.tolist(), float(data._pool[0][0].sum())))
+    q.put((rank, digest.numpy().copy(), logs, perm.tolist(), float(data._pool[0][0].sum())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -291,7 +294,7 @@ def test_kd_engine_two_ranks_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, d0, l0, p0, s0), (_, d1, l1, p1, s1) = res
-    assert torch.equal(d0, d1)          # replicas stay bit-identical: same broadcast start, same averaged gradients
+    assert np.array_equal(d0, d1)       # replicas stay bit-identical: same broadcast start, same averaged gradients
     assert l0 == l1                     # log vars are the cross-rank means on every rank
     assert p0 == p1 and sorted(p0) == list(range(150))
     assert s0 != s1                     # ...although each rank trained on its own shard of the data
