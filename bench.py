@@ -227,8 +227,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=32)
-    ap.add_argument('--graph', choices=['auto', 'on', 'off'], default='auto',
-                    help='capture forward+backward into a hipGraph (auto: single-GPU runs only; RCCL SyncBN inside a capture is untested)')
+    ap.add_argument('--graph', choices=['auto', 'on', 'hybrid', 'off'], default='auto',
+                    help='on: capture the whole forward+backward into one hipGraph; hybrid: capture only the collective-free pieces '
+                         '(teacher forward, student backbone fwd/bwd) -- safe with SyncBN over RCCL; auto: on for 1 GPU, hybrid otherwise')
     args = ap.parse_args()
 
     from segdistill_amd.config import Config
@@ -258,8 +259,11 @@ def main():
     n_eager_warm = max(1, args.warmup // 2)
     for _ in range(n_eager_warm):            # eager warm-up first (MIOpen find, hipBLASLt heuristics, allocator)
         trainer.step(data.next())
-    if args.graph == 'on' or (args.graph == 'auto' and world == 1):
-        graphed = trainer.enable_graph(data.next())
+    mode = args.graph if args.graph != 'auto' else ('on' if world == 1 else 'hybrid')
+    if mode == 'on':
+        graphed = 'full' if trainer.enable_graph(data.next()) else False
+    elif mode == 'hybrid':
+        graphed = 'hybrid' if trainer.enable_hybrid_graph(data.next()) else False
     for _ in range(args.warmup - n_eager_warm):
         trainer.step(data.next())
     dt = timed_steps(trainer, data, args.steps, world)

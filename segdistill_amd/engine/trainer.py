@@ -9,6 +9,17 @@ from .dp import DataParallelReducer
 from .optim import PolyLR, build_optimizer
 
 
+class _TupleOut(torch.nn.Module):
+    """make_graphed_callables wants tuple outputs; MiT / ResNet backbones return a list or tuple of feature maps."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+
+    def forward(self, x):
+        return tuple(self.inner(x))
+
+
 def _freeze_dead_parameters(model):
     """SegFormerHead never uses the conv_seg it inherits: keep it in the state dict,
     keep it out of the optimizer / reducer."""
@@ -79,6 +90,59 @@ class KDTrainer:
             m.external_step = False
             if hasattr(m, 'distillation_loss'):
                 m.distillation_loss.set_graph_safe(False)
+            torch.cuda.synchronize()
+            return False
+
+    # ---- hybrid graph mode (safe at any world size) -----------------------------------------------------------------------
+    # The full-step capture above would have to record the student's SyncBatchNorm collectives (RCCL inside a hipGraph
+    # capture) when world > 1.  The hybrid mode captures only collective-free pieces, which still hold most of the launches:
+    #   * the frozen teacher's forward (one forward-only graph on the side stream; its tapped features are static outputs);
+    #   * the student BACKBONE's forward and backward (torch.cuda.make_graphed_callables: replayed from inside eager autograd).
+    # The SegFormer/PSP head (SyncBN), the loss kernels, the gradient all-reduce and the optimizer stay eager.
+    def enable_hybrid_graph(self, example_batch):
+        import warnings
+        m = self.model
+        img = example_batch['img']
+        if not img.is_cuda or not hasattr(m, 'student'):
+            return False
+        try:
+            tapped_s = list(m.extractor.hooked['student']) if hasattr(m, 'extractor') else []
+            if any(n.startswith('backbone') for n in tapped_s):
+                raise RuntimeError('a student tap lives inside the backbone: its hook would not fire during graph replay')
+            m.train()
+            cnt0 = m.cnt
+            h_img = img.clone()
+            # (1) student backbone: forward + backward graphs, replayed from inside eager autograd
+            wrapper = _TupleOut(m.student.backbone)
+            wrapper.train()
+            torch.cuda.make_graphed_callables(wrapper, (h_img,), num_warmup_iters=2)
+            object.__setattr__(m.student, '_graphed_backbone', wrapper)   # not registered as a sub-module (state dict unchanged)
+            # (2) teacher: forward-only graph on the side stream; its tapped features are static outputs
+            side = m._side_stream or torch.cuda.Stream(device=img.device)
+            m._side_stream = side
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    m._teacher_forward(h_img, None, None)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            m.extractor.teacher_features.clear()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                m._teacher_forward(h_img, None, None)
+            outs = dict(m.extractor.teacher_features)
+            m.extractor.clear()
+            if not outs:
+                raise RuntimeError('the teacher capture produced no tapped feature')
+            m._graphed_teacher = (g, outs, h_img)
+            m.cnt = cnt0
+            torch.cuda.synchronize()
+            return True
+        except Exception as e:  # noqa: BLE001
+            warnings.warn(f'hybrid hipGraph capture failed ({type(e).__name__}: {e}); continuing in eager mode')
+            m._graphed_teacher = None
+            if hasattr(m, 'student') and getattr(m.student, '_graphed_backbone', None) is not None:
+                object.__setattr__(m.student, '_graphed_backbone', None)
             torch.cuda.synchronize()
             return False
 

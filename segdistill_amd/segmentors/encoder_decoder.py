@@ -6,6 +6,7 @@ extract_feat :77-82, encode_decode :84-94, forward_train :136-166); loss keys ar
 """
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
 
 from .. import builder
@@ -42,7 +43,11 @@ class EncoderDecoder(BaseSegmentor):
                 h.init_weights()
 
     def extract_feat(self, img):
-        x = self.backbone(img)
+        graphed = getattr(self, '_graphed_backbone', None)   # set by KDTrainer.enable_hybrid_graph
+        if graphed is not None and self.training and torch.is_grad_enabled() and img.is_cuda:
+            x = graphed(img)
+        else:
+            x = self.backbone(img)
         return self.neck(x) if self.with_neck else x
 
     def encode_decode(self, img, img_metas=None):

@@ -82,6 +82,7 @@ class SDModule(BaseSegmentor):
         self.teacher_on_side_stream = True
         self._side_stream = None
         self.external_step = False  # True while a trainer replays captured steps: it advances `cnt` itself
+        self._graphed_teacher = None  # (graph, static tapped features, static image) set by KDTrainer.enable_hybrid_graph
 
     def train(self, mode=True):
         super().train(mode)
@@ -107,7 +108,16 @@ class SDModule(BaseSegmentor):
         if not self.external_step:
             self.cnt += 1
         side = None
-        if self.distillation and self.teacher_on_side_stream and img.is_cuda:
+        gt_graph = self._graphed_teacher if (self.distillation and img.is_cuda and not self.teacher_train_mode) else None
+        if gt_graph is not None:
+            graph, static_taps, static_img = gt_graph
+            side, main = self._side_stream, torch.cuda.current_stream(img.device)
+            static_img.copy_(img)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                graph.replay()
+            self.extractor.teacher_features.update(static_taps)
+        elif self.distillation and self.teacher_on_side_stream and img.is_cuda:
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=img.device)
             side, main = self._side_stream, torch.cuda.current_stream(img.device)
@@ -120,7 +130,7 @@ class SDModule(BaseSegmentor):
                 self._teacher_forward(img, img_metas, gt_semantic_seg)
             else:
                 main.wait_stream(side)
-                if not torch.cuda.is_current_stream_capturing():
+                if gt_graph is None and not torch.cuda.is_current_stream_capturing():
                     for t in self.extractor.teacher_features.values():
                         if isinstance(t, torch.Tensor):
                             t.record_stream(main)       # allocated on the side stream, consumed on the main one

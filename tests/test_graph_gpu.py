@@ -40,7 +40,8 @@ def _model():
     return m.cuda()
 
 
-def test_graph_replay_matches_eager():
+@pytest.mark.parametrize('mode', ['full', 'hybrid'])
+def test_graph_replay_matches_eager(mode):
     from segdistill_amd.engine import KDTrainer, SyntheticADE
     opt = dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
     ref = _model()
@@ -49,7 +50,8 @@ def test_graph_replay_matches_eager():
     t_g = KDTrainer(gra, opt, dict(policy='poly', power=1.0, min_lr=0.0, by_epoch=False))
     data_e = SyntheticADE(2, size=(128, 128), device='cuda:0', pool=3, seed=1)
     data_g = SyntheticADE(2, size=(128, 128), device='cuda:0', pool=3, seed=1)
-    assert t_g.enable_graph(data_g._pool[0] and dict(img=data_g._pool[0][0], img_metas=None, gt_semantic_seg=data_g._pool[0][1]))
+    example = dict(img=data_g._pool[0][0], img_metas=None, gt_semantic_seg=data_g._pool[0][1])
+    assert (t_g.enable_graph(example) if mode == 'full' else t_g.enable_hybrid_graph(example))
     assert gra.cnt == 0
     perms = []
     for it in range(7):                         # crosses the warm-up end (5) and two shuffle iterations (3, 6)
