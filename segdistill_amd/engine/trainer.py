@@ -112,6 +112,11 @@ class KDTrainer:
             m.train()
             cnt0 = m.cnt
             h_img = img.clone()
+            # graphed backward nodes run on the capture side stream while AccumulateGrad lives on the main one: benign here
+            try:
+                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+            except AttributeError:
+                pass
             # (1) student backbone: forward + backward graphs, replayed from inside eager autograd
             wrapper = _TupleOut(m.student.backbone)
             wrapper.train()
