@@ -97,14 +97,26 @@ class SRAttention(nn.Module):
             self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
             self.norm = HipLayerNorm(dim)
 
+    def _spatial_reduce(self, x, hw):
+        """The SR conv has kernel == stride == r, i.e. it is a Linear over non-overlapping r x r patches.  On token-major
+        input that is ONE gather of the patches ([B, H/r, W/r, r*r*C]) and a GEMM; the reference's NCHW route costs a
+        transpose copy in, an (often poorly supported) strided conv, and a transpose copy out."""
+        r, conv = self.sr_ratio, self.sr
+        b, n, c = x.shape
+        H, W = hw
+        if conv._forward_hooks or H % r or W % r:
+            return conv(x.transpose(1, 2).reshape(b, c, H, W)).flatten(2).transpose(1, 2)
+        patches = x.reshape(b, H // r, r, W // r, r, c).permute(0, 1, 3, 2, 4, 5).reshape(b, (H // r) * (W // r), r * r * c)
+        w2 = conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c)   # (ky, kx, cin) order to match the patches
+        return F.linear(patches, w2, conv.bias)
+
     def forward(self, x, hw):
         b, n, c = x.shape
         h, d = self.num_heads, c // self.num_heads
         q = self.Q(call_linear(self.q, x).reshape(b, n, h, d).transpose(1, 2))
         src = x
         if self.sr_ratio > 1:
-            src = self.sr(x.transpose(1, 2).reshape(b, c, *hw)).flatten(2).transpose(1, 2)
-            src = self.norm(src)
+            src = self.norm(self._spatial_reduce(x, hw))
         kv = call_linear(self.kv, src).reshape(b, -1, 2, h, d).permute(2, 0, 3, 1, 4)
         k, v = self.K(kv[0]), self.V(kv[1])
         explicit = bool(self.ATTN._forward_hooks) or (self.training and self.attn_drop.p > 0)

@@ -208,36 +208,125 @@ int align_bwd_weight(const void *dY, const void *X, float *dW, float *db, void *
     return (int)hipGetLastError();
 }
 
+// Skinny weight gradient straight from global memory: the MFMA 32x32x2 operand layout (lane&31 -> row/col,
+// lane>>5 -> k) IS a coalesced access pattern for K-major operands (32 consecutive floats of token t for lanes 0-31,
+// of token t+1 for lanes 32-63), so no LDS staging / barriers are needed at all.  Each wave owns one 64x64 output
+// region (2x2 accumulators); a workgroup covers up to four regions, and when the problem has fewer than four the
+// spare waves split the token range instead (more slabs).  slab index = blockIdx.x * ksubs + ksub.
+template <typename T>
+__global__ __launch_bounds__(256) void linear_wgrad_direct(const T *__restrict__ dY, const T *__restrict__ X, float *__restrict__ slabs, int M,
+                                                            int N, long Tn, int klen, int regions_m, int regions_n, int regions_per_wg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, kh = lane >> 5;
+    const int ksubs = 4 / regions_per_wg;
+    const int region = blockIdx.y * regions_per_wg + wave % regions_per_wg;
+    const int ksub = wave / regions_per_wg;
+    if (region >= regions_m * regions_n) return;
+    const int m0 = (region / regions_n) * 64, n0 = (region % regions_n) * 64;
+    const long k_begin = (long)blockIdx.x * klen + (long)ksub * (klen / ksubs);
+    const long k_end = min(Tn, ksub == ksubs - 1 ? (long)(blockIdx.x + 1) * klen : k_begin + klen / ksubs);
+    const bool am0 = m0 + r < M, am1 = m0 + 32 + r < M, bn0 = n0 + r < N, bn1 = n0 + 32 + r < N;
+    const bool tm1 = m0 + 32 < M, tn1 = n0 + 32 < N;  // wave-uniform: does the second 32-block exist at all
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    constexpr int U = 8;  // token pairs per unrolled step: up to 32 dword loads in flight per lane
+    for (long t0 = k_begin; t0 < k_end; t0 += 2 * U) {
+        float a0[U], a1[U], b0[U], b1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long t = t0 + 2 * u + kh;
+            const bool in = t < k_end;
+            const T *pa = dY + t * M + m0 + r, *pb = X + t * N + n0 + r;
+            a0[u] = (in && am0) ? ld1<T>(pa) : 0.f;
+            a1[u] = (in && am1) ? ld1<T>(pa + 32) : 0.f;
+            b0[u] = (in && bn0) ? ld1<T>(pb) : 0.f;
+            b1[u] = (in && bn1) ? ld1<T>(pb + 32) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
+            if (tn1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
+            if (tm1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
+            if (tm1 && tn1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
+        }
+    }
+    float *C = slabs + ((long)blockIdx.x * ksubs + ksub) * (long)M * N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (m < M && n < N) C[(long)m * N + n] = acc[i][j][e];
+            }
+        }
+}
+
 // dW[M x N] = dY^T . X for token-major dY [T][M], X [T][N] (the weight gradient of nn.Linear):
 // both operands K-major, K = T split over workgroups, partial slabs combined deterministically.
 struct WgradPlan {
-    int nsplit, klen;
+    bool direct;
+    int nsplit, klen, regions_m, regions_n, regions_per_wg, nslabs;
 };
 WgradPlan linear_wgrad_plan(long T, int M, int N) {
+    WgradPlan p{};
+    p.regions_m = (M + 63) / 64;
+    p.regions_n = (N + 63) / 64;
+    const int regions = p.regions_m * p.regions_n;
+    p.direct = T >= 8192 && regions <= 16;      // many tokens, small weight: the HBM-bound tall-skinny case
+    if (p.direct) {
+        p.regions_per_wg = regions >= 4 ? 4 : (regions >= 2 ? 2 : 1);
+        const int wg_y = (regions + p.regions_per_wg - 1) / p.regions_per_wg;
+        long nsplit = 512 / wg_y;
+        if (nsplit > T / 128) nsplit = T / 128;
+        if (nsplit < 1) nsplit = 1;
+        long klen = ((T + nsplit - 1) / nsplit + 63) / 64 * 64;  // multiple of 64: every k-sub-range stays even-aligned
+        p.nsplit = (int)((T + klen - 1) / klen);
+        p.klen = (int)klen;
+        p.nslabs = p.nsplit * (4 / p.regions_per_wg);
+        return p;
+    }
     const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     long nsplit = 1024 / tiles;
     if (nsplit > T / 256) nsplit = T / 256;
     if (nsplit < 1) nsplit = 1;
     long klen = ((T + nsplit - 1) / nsplit + BK - 1) / BK * BK;
-    nsplit = (T + klen - 1) / klen;
-    return {(int)nsplit, (int)klen};
+    p.nsplit = (int)((T + klen - 1) / klen);
+    p.klen = (int)klen;
+    p.nslabs = p.nsplit;
+    return p;
 }
 
 template <typename T>
 int linear_wgrad(const void *dY, const void *X, float *dW, void *ws, size_t ws_bytes, long Tn, int M, int N, hipStream_t st) {
     const WgradPlan p = linear_wgrad_plan(Tn, M, N);
     const long slab = (long)M * N;
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, p.nsplit);
-    if (p.nsplit == 1) {
+    if (!p.direct && p.nsplit == 1) {
+        dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, 1);
         hipLaunchKernelGGL((gemm_mfma_f32<T, T, float, true, true>), grid, dim3(256), 0, st, (const T *)dY, (const T *)X, dW, nullptr, M, N,
                            (int)Tn, (long)M, (long)N, (long)N, 0L, 0L, 0L, 1, (int)Tn);
         return (int)hipGetLastError();
     }
-    if (ws_bytes < (size_t)p.nsplit * slab * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
+    if (ws_bytes < (size_t)p.nslabs * slab * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
     float *slabs = static_cast<float *>(ws);
-    hipLaunchKernelGGL((gemm_mfma_f32<T, T, float, true, true>), grid, dim3(256), 0, st, (const T *)dY, (const T *)X, slabs, nullptr, M, N,
-                       (int)Tn, (long)M, (long)N, (long)N, 0L, 0L, slab, p.nsplit, p.klen);
-    hipLaunchKernelGGL(slab_reduce_wide, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, slabs, dW, slab, p.nsplit);
+    if (p.direct) {
+        const int regions = p.regions_m * p.regions_n;
+        dim3 grid(p.nsplit, (regions + p.regions_per_wg - 1) / p.regions_per_wg);
+        hipLaunchKernelGGL((linear_wgrad_direct<T>), grid, dim3(256), 0, st, (const T *)dY, (const T *)X, slabs, M, N, Tn, p.klen, p.regions_m,
+                           p.regions_n, p.regions_per_wg);
+    } else {
+        dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, p.nsplit);
+        hipLaunchKernelGGL((gemm_mfma_f32<T, T, float, true, true>), grid, dim3(256), 0, st, (const T *)dY, (const T *)X, slabs, nullptr, M, N,
+                           (int)Tn, (long)M, (long)N, (long)N, 0L, 0L, slab, p.nsplit, p.klen);
+    }
+    hipLaunchKernelGGL(slab_reduce_wide, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, slabs, dW, slab, p.nslabs);
     return (int)hipGetLastError();
 }
 
@@ -262,7 +351,7 @@ size_t sd_align1x1_workspace_bytes(int B, int Cs, int Ct, int h, int w) {
 size_t sd_linear_wgrad_workspace_bytes(long tokens, int out_features, int in_features) {
     if (tokens <= 0 || out_features <= 0 || in_features <= 0) return 0;
     const sd::WgradPlan p = sd::linear_wgrad_plan(tokens, out_features, in_features);
-    return (size_t)p.nsplit * out_features * in_features * sizeof(float) + 16;
+    return (size_t)p.nslabs * out_features * in_features * sizeof(float) + 16;
 }
 
 int sd_linear_wgrad(const void *dY, const void *X, float *dW, int dtype, long tokens, int out_features, int in_features, void *workspace,

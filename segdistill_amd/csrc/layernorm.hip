@@ -194,7 +194,7 @@ LnPlan ln_plan(int C) {
 int ln_bwd_blocks(long rows, int G) {
     const long rpb = kLnThreads / G;
     long n = (rows + rpb - 1) / rpb;
-    if (n > 2048) n = 2048;
+    if (n > 512) n = 512;  // 2 workgroups per CU; keeps the parameter-gradient partial array (and its reduce pass) small
     return (int)(n < 1 ? 1 : n);
 }
 

@@ -95,7 +95,8 @@ def test_feature_align_module_in_distillation_loss():
     assert _err(s.grad, s64.grad) < 1e-4
 
 
-@pytest.mark.parametrize('shape', [(131072, 32, 32), (32768, 128, 32), (5000, 37, 21), (8192, 256, 64), (4096, 512, 2048), (300, 16, 8)])
+@pytest.mark.parametrize('shape', [(131072, 32, 32), (32768, 128, 32), (5000, 37, 21), (8192, 256, 64), (4096, 512, 2048), (300, 16, 8),
+                                   (20001, 100, 70), (16384, 256, 256), (9000, 33, 129), (8193, 64, 64)])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_linear_wgrad_kernel(shape, dtype):
     """dW = dY^T . X (split-K MFMA) vs fp64 matmul of the same (rounded) operands."""
