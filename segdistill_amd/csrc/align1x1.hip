@@ -284,7 +284,7 @@ WgradPlan linear_wgrad_plan(long T, int M, int N) {
     if (p.direct) {
         p.regions_per_wg = regions >= 4 ? 4 : (regions >= 2 ? 2 : 1);
         const int wg_y = (regions + p.regions_per_wg - 1) / p.regions_per_wg;
-        long nsplit = 512 / wg_y;
+        long nsplit = 256 / wg_y;  // x (4 / regions_per_wg) k-sub-ranges: ~1024 waves, and few enough slabs that the combine stays cheap
         if (nsplit > T / 128) nsplit = T / 128;
         if (nsplit < 1) nsplit = 1;
         long klen = ((T + nsplit - 1) / nsplit + 63) / 64 * 64;  // multiple of 64: every k-sub-range stays even-aligned
