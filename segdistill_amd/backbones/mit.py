@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..builder import BACKBONES
-from ..layers import DropPath, trunc_normal_
+from ..layers import DropPath, nchw_view_of_tokens, tokens_of, trunc_normal_
 from ..layernorm import HipLayerNorm
 from ..linear import call_linear
 
@@ -157,7 +157,7 @@ class OverlapPatchEmbed(nn.Module):
     def forward(self, x):
         x = self.proj(x)
         hw = tuple(x.shape[2:])
-        return self.norm(x.flatten(2).transpose(1, 2)), hw
+        return self.norm(tokens_of(x)), hw
 
 
 class MixVisionTransformer(nn.Module):
@@ -203,7 +203,9 @@ class MixVisionTransformer(nn.Module):
             for blk in getattr(self, f'block{s}'):
                 x = blk(x, hw)
             x = getattr(self, f'norm{s}')(x)
-            x = x.reshape(x.shape[0], hw[0], hw[1], -1).permute(0, 3, 1, 2).contiguous()
+            # logically [B,C,H,W] like the reference (:340,:347,...), but as a channels-last VIEW of the tokens on the GPU:
+            # the next stage's conv and the head consume it without the two transpose copies per stage
+            x = nchw_view_of_tokens(x, hw) if x.is_cuda else x.reshape(x.shape[0], hw[0], hw[1], -1).permute(0, 3, 1, 2).contiguous()
             feats.append(x)
         return feats
 

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from ..builder import HEADS, build_loss
-from ..layers import ConvModule, resize
+from ..layers import ConvModule, resize, tokens_of
 from .decode_head import BaseDecodeHead
 
 
@@ -67,7 +67,7 @@ class SegFormerHead(BaseDecodeHead):
         zs, sizes = [], []
         for i, (feat, mlp) in enumerate(self._branches(feats)):
             wi = w[:, i * e:(i + 1) * e, 0, 0]                      # [E, E]
-            tokens = feat.flatten(2).transpose(1, 2)                  # [B, hw, Cin]
+            tokens = tokens_of(feat)                                  # [B, hw, Cin] (a view for channels-last features)
             if fold:
                 z = torch.addmm(wi @ mlp.proj.bias, tokens.reshape(-1, tokens.shape[-1]), (wi @ mlp.proj.weight).t())
             else:

@@ -154,3 +154,19 @@ def resize(input, size=None, scale_factor=None, mode='nearest', align_corners=No
 def add_prefix(d, prefix):
     """reference mmseg/core/utils/misc.py:1 -- names the decode./aux. loss keys."""
     return {f'{prefix}.{k}': v for k, v in d.items()}
+
+
+def tokens_of(x):
+    """[B,C,H,W] -> token-major [B, H*W, C].  For a channels-last tensor (what MIOpen convs return for channels-last
+    input, and what ``nchw_view_of_tokens`` produces) this is a VIEW; for a contiguous NCHW tensor it is the usual
+    flatten(2).transpose(1,2) (a strided view that the next op materialises)."""
+    b, c, h, w = x.shape
+    if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+        return x.permute(0, 2, 3, 1).reshape(b, h * w, c)
+    return x.flatten(2).transpose(1, 2)
+
+
+def nchw_view_of_tokens(tokens, hw):
+    """token-major [B, H*W, C] -> [B,C,H,W] WITHOUT a copy: a logically-NCHW tensor with channels-last strides."""
+    b, n, c = tokens.shape
+    return tokens.reshape(b, hw[0], hw[1], c).permute(0, 3, 1, 2)
