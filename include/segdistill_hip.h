@@ -57,7 +57,7 @@ const char *sd_error_string(int code);
 
 /* Tunables (process-wide, for benchmarking only; defaults are the shipped values).
  * keys: "cgd_fwd_chunk_iters" / "cgd_bwd_chunk_iters" (rounds of 4 x 16-byte loads per
- *       operand per lane per workgroup), "cgd_bwd_nt_store" (0|1),
+ *       operand per lane per workgroup), "cgd_bwd_nt_store" (0|1), "cgd_bwd_unroll" (2|4|8),
  *       "cgd_up_band_rows" (tap rows per workgroup of the fused-upsample kernels). */
 int sd_set_tunable(const char *key, int value);
 int sd_get_tunable(const char *key);

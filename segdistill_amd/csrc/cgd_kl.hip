@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void cgd_fwd_loss(const float *__restrict
 
 // ---- backward -------------------------------------------------------------------------------
 // dS_i = k (2^{s_i c2 - lse2_s} - 2^{t_i c2 - lse2_t}),  k = coef * upstream.
-template <typename T, bool VECTOR, bool NT>
+template <typename T, bool VECTOR, bool NT, int U>
 __global__ __launch_bounds__(kThreads) void cgd_bwd(const T *__restrict__ S, const T *__restrict__ Tt, const int32_t *__restrict__ perm,
                                                      const float *__restrict__ row_lse2, const float *__restrict__ upstream,
                                                      T *__restrict__ dS, int C, int HW, int g, int G, int nchunk, int iters,
@@ -155,14 +155,14 @@ __global__ __launch_bounds__(kThreads) void cgd_bwd(const T *__restrict__ S, con
     const size_t base = ((size_t)b * C + ch) * (size_t)HW;
     const T *ps = S + base, *pt = Tt + base;
     T *pd = dS + base;
-    const int chunk = kThreads * N * kUnroll * iters;
+    const int chunk = kThreads * N * U * iters;
     const int lo = k * chunk;
     const int hi = min(lo + chunk, HW);
     for (int it = 0; it < iters; ++it) {
-        const int e0 = lo + (it * kUnroll * kThreads + threadIdx.x) * N;
-        float s[kUnroll][N], t[kUnroll][N];
+        const int e0 = lo + (it * U * kThreads + threadIdx.x) * N;
+        float s[U][N], t[U][N];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int e = e0 + u * kThreads * N;
             if (e < hi) {
                 if constexpr (VECTOR) {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void cgd_bwd(const T *__restrict__ S, con
             }
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < U; ++u) {
             const int e = e0 + u * kThreads * N;
             if (e < hi) {
                 float d[N];
@@ -190,6 +190,7 @@ __global__ __launch_bounds__(kThreads) void cgd_bwd(const T *__restrict__ S, con
 
 int g_fwd_iters = 4;   // tunable "cgd_fwd_chunk_iters": 4096 float4 per operand per workgroup
 int g_bwd_iters = 1;   // tunable "cgd_bwd_chunk_iters"
+int g_bwd_unroll = 4; // tunable "cgd_bwd_unroll": 16-byte loads per operand in flight per lane (2 | 4 | 8)
 int g_bwd_nt = 1;      // tunable "cgd_bwd_nt_store": dS is consumed by a later kernel, never re-read here
 
 struct Geo {
@@ -198,7 +199,7 @@ struct Geo {
 };
 
 template <typename T>
-Geo geometry(const void *S, const void *Tt, const void *dS, int C, int H, int W, int g, int B, int want_iters) {
+Geo geometry(const void *S, const void *Tt, const void *dS, int C, int H, int W, int g, int B, int want_iters, int unroll = kUnroll) {
     Geo q;
     const long HW = (long)H * W;
     const int VN = VecIO<T>::N;
@@ -206,7 +207,7 @@ Geo geometry(const void *S, const void *Tt, const void *dS, int C, int H, int W,
     q.vec = (HW % VN == 0) && al(S) && al(Tt) && al(dS);
     q.N = q.vec ? VN : 1;
     int iters = want_iters;
-    const long per_iter = (long)kThreads * q.N * kUnroll;
+    const long per_iter = (long)kThreads * q.N * unroll;
     const long need = (HW + per_iter - 1) / per_iter;
     if (iters > need) iters = (int)need;
     if (iters < 1) iters = 1;
@@ -251,20 +252,29 @@ int fwd_impl(const void *S, const void *Tt, int B, int C, int H, int W, int g, f
 template <typename T>
 int bwd_impl(const void *S, const void *Tt, int B, int C, int H, int W, int g, float inv_tau, float coef, const int32_t *perm,
              const float *row_lse2, const float *upstream, void *dS, hipStream_t st) {
-    const Geo q = geometry<T>(S, Tt, dS, C, H, W, g, B, g_bwd_iters);
+    const int U = g_bwd_unroll;
+    const Geo q = geometry<T>(S, Tt, dS, C, H, W, g, B, g_bwd_iters, U);
     const long nwg = (long)B * C * q.nchunk;
     if (nwg > 0x7fffffffL) return SD_E_SHAPE;
     const float c2 = inv_tau * 1.44269504088896340736f;
     const int HW = H * W;
-    if (q.vec && g_bwd_nt)
-        hipLaunchKernelGGL((cgd_bwd<T, true, true>), dim3((unsigned)nwg), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, perm,
-                           row_lse2, upstream, (T *)dS, C, HW, g, q.G, q.nchunk, q.iters, c2, coef);
-    else if (q.vec)
-        hipLaunchKernelGGL((cgd_bwd<T, true, false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, perm,
-                           row_lse2, upstream, (T *)dS, C, HW, g, q.G, q.nchunk, q.iters, c2, coef);
-    else
-        hipLaunchKernelGGL((cgd_bwd<T, false, false>), dim3((unsigned)nwg), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, perm,
-                           row_lse2, upstream, (T *)dS, C, HW, g, q.G, q.nchunk, q.iters, c2, coef);
+#define SD_BWD(VEC, NTS, UU)                                                                                                          \
+    hipLaunchKernelGGL((cgd_bwd<T, VEC, NTS, UU>), dim3((unsigned)nwg), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, perm, row_lse2, \
+                       upstream, (T *)dS, C, HW, g, q.G, q.nchunk, q.iters, c2, coef)
+    if (q.vec && g_bwd_nt) {
+        if (U == 2) SD_BWD(true, true, 2);
+        else if (U == 8) SD_BWD(true, true, 8);
+        else SD_BWD(true, true, 4);
+    } else if (q.vec) {
+        if (U == 2) SD_BWD(true, false, 2);
+        else if (U == 8) SD_BWD(true, false, 8);
+        else SD_BWD(true, false, 4);
+    } else {
+        if (U == 2) SD_BWD(false, false, 2);
+        else if (U == 8) SD_BWD(false, false, 8);
+        else SD_BWD(false, false, 4);
+    }
+#undef SD_BWD
     return (int)hipGetLastError();
 }
 
@@ -285,6 +295,10 @@ int cgd_tunable(const char *key, int set, int v) {
     if (!strcmp(key, "cgd_fwd_chunk_iters")) p = &g_fwd_iters;
     else if (!strcmp(key, "cgd_bwd_chunk_iters")) p = &g_bwd_iters;
     else if (!strcmp(key, "cgd_bwd_nt_store")) { p = &g_bwd_nt; lo = 0; hi = 1; }
+    else if (!strcmp(key, "cgd_bwd_unroll")) {
+        if (set && v != 2 && v != 4 && v != 8) return SD_E_SHAPE;
+        p = &g_bwd_unroll; lo = 2; hi = 8;
+    }
     if (!p) return SD_E_UNSUPPORTED;
     if (!set) return *p;
     if (v < lo || v > hi) return SD_E_SHAPE;

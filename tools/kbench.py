@@ -35,7 +35,8 @@ def main():
     ap.add_argument('--tau', type=float, default=4.0)
     ap.add_argument('--iters', default='1,2,4,8,16,32')
     ap.add_argument('--dtype', default='f32')
-    ap.add_argument('--nt', type=int, default=0)
+    ap.add_argument('--nt', type=int, default=1)
+    ap.add_argument('--bwd-unroll', type=int, default=4)
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     dt = torch.float32 if a.dtype == 'f32' else torch.bfloat16
@@ -60,6 +61,7 @@ def main():
         _lib.set_tunable('cgd_fwd_chunk_iters', it)
         _lib.set_tunable('cgd_bwd_chunk_iters', it)
         _lib.set_tunable('cgd_bwd_nt_store', a.nt)
+        _lib.set_tunable('cgd_bwd_unroll', a.bwd_unroll)
         wsb = L.sd_cgd_kl_workspace_bytes(a.B, a.C, a.HW, a.HW, a.g)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 
