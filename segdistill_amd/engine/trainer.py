@@ -198,6 +198,41 @@ class KDTrainer:
         self.last_log_vars = out['log_vars']
         return out
 
+    # ---- checkpoint / resume -----------------------------------------------------------------------------------------
+    # The reference checkpoints the whole SDModule including the frozen teacher (mmcv CheckpointHook) and loses the
+    # distillation step counter on resume (warm-up / early-decay / shuffle schedules restart).  Here the
+    # checkpoint holds the STUDENT (plus trainable align projections), the optimizer state, the iteration and `cnt`.
+    def state_dict(self):
+        m = self.model
+        sd = {'iter': self.iter, 'cnt': getattr(m, 'cnt', self.iter), 'optimizer': self.optimizer.state_dict()}
+        if hasattr(m, 'student'):
+            sd['student'] = m.student.state_dict()
+            sd['distillation_loss'] = m.distillation_loss.state_dict()
+        else:
+            sd['model'] = m.state_dict()
+        return sd
+
+    def load_state_dict(self, sd):
+        m = self.model
+        if 'student' in sd:
+            m.student.load_state_dict(sd['student'])
+            m.distillation_loss.load_state_dict(sd.get('distillation_loss', {}), strict=False)
+        else:
+            m.load_state_dict(sd['model'])
+        self.optimizer.load_state_dict(sd['optimizer'])
+        self.iter = int(sd['iter'])
+        if hasattr(m, 'cnt'):
+            m.cnt = int(sd['cnt'])
+
+    def save(self, path):
+        import os
+        tmp = path + '.tmp'
+        torch.save(self.state_dict(), tmp)
+        os.replace(tmp, path)
+
+    def resume(self, path, map_location=None):
+        self.load_state_dict(torch.load(path, map_location=map_location, weights_only=False))
+
     def log_values(self):
         """Host copies of the most recent log variables (one device->host sync)."""
         if self.last_log_vars is None:

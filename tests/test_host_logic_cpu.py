@@ -298,3 +298,42 @@ def test_kd_engine_two_ranks_gloo():
     assert l0 == l1                     # log vars are the cross-rank means on every rank
     assert p0 == p1 and sorted(p0) == list(range(150))
     assert s0 != s1                     # ...although each rank trained on its own shard of the data
+
+
+def test_checkpoint_resume_restores_iteration_and_distillation_step(tmp_path):
+    """Q4 of SURVEY section 3.4: the reference loses the KD step counter on resume; here iter, cnt, the student,
+    the optimizer state survive a save / resume round trip and the teacher is not part of the checkpoint."""
+    import segdistill_amd
+    from oracle.eager_modules import swap_in_eager_criteria
+    from segdistill_amd.builder import build_segmentor
+    from segdistill_amd.engine import KDTrainer, SyntheticADE
+    from segdistill_amd.segmentors import sd_module
+    segdistill_amd.register_all()
+    opt = dict(type='AdamW', lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+
+    def make(seed):
+        sd_module.SYNTHETIC_WEIGHTS_OK = True
+        try:
+            torch.manual_seed(seed)
+            m = build_segmentor(_tiny_sd_cfg())
+        finally:
+            sd_module.SYNTHETIC_WEIGHTS_OK = False
+        swap_in_eager_criteria(m)
+        return m, KDTrainer(m, opt, dict(policy='poly', power=1.0, min_lr=0.0, by_epoch=False))
+
+    m1, t1 = make(0)
+    data = SyntheticADE(1, size=(64, 64), device='cpu', pool=1)
+    for _ in range(2):
+        t1.step(data.next())
+    path = str(tmp_path / 'latest.pth')
+    t1.save(path)
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {'iter', 'cnt', 'optimizer', 'student', 'distillation_loss'} and ck['iter'] == 2 and ck['cnt'] == 2
+    assert not any(k.startswith('teacher') for k in ck['student'])
+    m2, t2 = make(1)                      # different init: everything must come from the checkpoint
+    t2.resume(path)
+    assert t2.iter == 2 and m2.cnt == 2
+    for a, b in zip(m1.student.parameters(), m2.student.parameters()):
+        assert torch.equal(a, b)
+    s1, s2 = t1.optimizer.state_dict()['state'], t2.optimizer.state_dict()['state']
+    assert s1.keys() == s2.keys() and all(torch.equal(s1[k]['exp_avg'], s2[k]['exp_avg']) for k in s1)

@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""KD training driver (the role of the reference's tools/train.py + mmseg/apis/train.py for the SDModule path).
+
+    python tools/train.py CONFIG [--iters N] [--work-dir DIR] [--resume-from CKPT] [--seed S] [--graph auto|on|hybrid|off]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py CONFIG --launcher pytorch
+
+CONFIG is a reference-dialect config file (the reference's local_configs/** KD configs load unchanged, or configs/kd/*.py).
+Data: synthetic ADE20K-shaped batches (the dataset pipeline is outside the scope of this repository).
+Per iteration, like mmcv's IterBasedRunner + OptimizerHook: lr update -> zero grad -> train_step -> backward ->
+gradient all-reduce -> optimizer step; a text log line every log_config.interval iterations; a checkpoint every
+checkpoint_config.interval iterations (student + optimizer + iteration + distillation step counter)."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('config')
+    ap.add_argument('--work-dir', default=None)
+    ap.add_argument('--iters', type=int, default=None, help='stop after this many iterations (default: runner.max_iters)')
+    ap.add_argument('--resume-from', default=None)
+    ap.add_argument('--seed', type=int, default=42)
+    ap.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
+    ap.add_argument('--graph', choices=['auto', 'on', 'hybrid', 'off'], default='auto')
+    ap.add_argument('--synthetic-weights', action='store_true', help='train from random init when checkpoints named by the config are absent')
+    ap.add_argument('--options', nargs='*', default=[], help='config overrides key=value (dotted keys)')
+    args = ap.parse_args()
+
+    import segdistill_amd
+    from segdistill_amd.builder import build_segmentor
+    from segdistill_amd.config import Config
+    from segdistill_amd.engine import KDTrainer, SyntheticADE, init_distributed
+    from segdistill_amd.segmentors import sd_module
+    rank, local, world = init_distributed() if args.launcher == 'pytorch' or int(os.environ.get('WORLD_SIZE', '1')) > 1 else (0, 0, 1)
+    device = torch.device('cuda', local) if torch.cuda.is_available() else torch.device('cpu')
+    if device.type == 'cuda':
+        torch.cuda.set_device(device)
+        torch.backends.cudnn.benchmark = True
+    cfg = Config.fromfile(args.config)
+    if args.options:
+        import ast
+        over = {}
+        for kv in args.options:
+            k, v = kv.split('=', 1)
+            try:
+                over[k] = ast.literal_eval(v)
+            except (ValueError, SyntaxError):
+                over[k] = v
+        cfg.merge_from_dict(over)
+    segdistill_amd.register_all()
+    sd_module.SYNTHETIC_WEIGHTS_OK = args.synthetic_weights
+    torch.manual_seed(args.seed)
+    model = build_segmentor(dict(cfg.model)).to(device)
+    max_iters = int(cfg.runner.max_iters) if 'runner' in cfg else 160000
+    n_iters = args.iters or max_iters
+    log_every = int(cfg.get('log_config', {}).get('interval', 50))
+    ckpt_every = int(cfg.get('checkpoint_config', {}).get('interval', 4000))
+    trainer = KDTrainer(model, dict(cfg.optimizer), dict(cfg.lr_config), max_iters=max_iters, world=world, log_interval=log_every,
+                        precision=cfg.get('precision'))
+    if args.resume_from:
+        trainer.resume(args.resume_from, map_location=device)
+        if rank == 0:
+            print(f'resumed from {args.resume_from}: iter {trainer.iter}, distillation step {model.cnt}')
+    B = int(cfg.data.samples_per_gpu)
+    data = SyntheticADE(B, size=tuple(cfg.get('crop_size', (512, 512))), num_classes=int(cfg.get('num_classes', 150)), seed=args.seed,
+                        rank=rank, device=device)
+    work = args.work_dir or os.path.join(ROOT, 'work_dirs', os.path.splitext(os.path.basename(args.config))[0])
+    if rank == 0:
+        os.makedirs(work, exist_ok=True)
+    mode = args.graph if args.graph != 'auto' else ('on' if world == 1 else 'hybrid')
+    warm = 0
+    t0 = time.perf_counter()
+    while trainer.iter < n_iters:
+        trainer.step(data.next())
+        warm += 1
+        if warm == 3 and device.type == 'cuda' and mode != 'off':
+            (trainer.enable_graph if mode == 'on' else trainer.enable_hybrid_graph)(data.next())
+        it = trainer.iter
+        if it % log_every == 0 or it == n_iters:
+            vals = trainer.log_values()  # the only device->host sync
+            if rank == 0:
+                dt = (time.perf_counter() - t0) / max(1, log_every)
+                t0 = time.perf_counter()
+                lr = trainer.optimizer.param_groups[0]['lr']
+                print(f'Iter [{it}/{n_iters}]\tlr: {lr:.3e}, time: {dt:.3f}, ' + ', '.join(f'{k}: {v:.4f}' for k, v in vals.items()), flush=True)
+        if rank == 0 and (it % ckpt_every == 0 or it == n_iters):
+            trainer.save(os.path.join(work, 'latest.pth'))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
