@@ -115,4 +115,24 @@ class SegFormerHead(BaseDecodeHead):
                         fused = r
         if self.dropout is not None:
             fused = self.dropout(fused)
-        return self.linear_pred(fused)
+        return self._predict(fused)
+
+    def _predict(self, fused):
+        """linear_pred (1x1 conv, segformer_head.py:73,96).  When `fused` is a channels-last view of tokens the conv would
+        return channels-last logits, and the loss kernels (which read NCHW planes) would have to copy them; computing
+        W . tokens^T instead yields contiguous [B, classes, H*W] directly.  Forward hooks on the module (it is THE tap of
+        every shipped KD config) are fired by hand with the same output tensor."""
+        pred = self.linear_pred
+        if fused.is_contiguous() or pred._forward_pre_hooks or not fused.is_cuda:
+            return pred(fused)
+        b, e, h, w = fused.shape
+        tokens = tokens_of(fused)                                              # [B, HW, E] view
+        out = torch.matmul(pred.weight.view(pred.out_channels, e), tokens.transpose(1, 2))   # [B, classes, HW], contiguous
+        if pred.bias is not None:
+            out = out + pred.bias.view(1, -1, 1)
+        out = out.view(b, pred.out_channels, h, w)
+        for hook in pred._forward_hooks.values():
+            r = hook(pred, (fused,), out)
+            if r is not None:
+                out = r
+        return out

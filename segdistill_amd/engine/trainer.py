@@ -79,8 +79,8 @@ class KDTrainer:
             m.cnt = cnt0                    # the warm-up passes do not count as training iterations
             m.external_step = True
             self._graph = torch.cuda.CUDAGraph()
+            self.reducer.zero_grad()        # .grad = None: the captured backward creates the (static) gradient tensors
             with torch.cuda.graph(self._graph):
-                self.reducer.flat.zero_()
                 self._graph_out = self._fwd_bwd(self._static)
             torch.cuda.synchronize()
             return True
