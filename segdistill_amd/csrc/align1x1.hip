@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void slab_reduce(const float *__restrict__ sla
 }
 
 // out[i] = sum_z slabs[z][i] for MANY slabs: block = 16 slab-groups x 16 outputs, LDS combine (deterministic order)
-__global__ __launch_bounds__(256) void slab_reduce_wide(const float *__restrict__ slabs, float *__restrict__ out, long n, int nz) {
+__global__ __launch_bounds__(256) void slab_reduce_wide(const float *__restrict__ slabs, float *__restrict__ out, long n, int nz,
+                                                         float *__restrict__ out2 = nullptr, long n_first = 0) {
     __shared__ float red[16][17];
     const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const long i = (long)blockIdx.x * 16 + o;
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(256) void slab_reduce_wide(const float *__restrict_
         float t = 0.f;
 #pragma unroll
         for (int g2 = 0; g2 < 16; ++g2) t += red[g2][o];
-        out[i] = t;
+        if (out2 && i >= n_first) out2[i - n_first] = t;   // tail of the slab (bias partials) goes to a second output
+        else out[i] = t;
     }
 }
 
@@ -215,7 +217,8 @@ int align_bwd_weight(const void *dY, const void *X, float *dW, float *db, void *
 // spare waves split the token range instead (more slabs).  slab index = blockIdx.x * ksubs + ksub.
 template <typename T>
 __global__ __launch_bounds__(256) void linear_wgrad_direct(const T *__restrict__ dY, const T *__restrict__ X, float *__restrict__ slabs, int M,
-                                                            int N, long Tn, int klen, int regions_m, int regions_n, int regions_per_wg) {
+                                                            int N, long Tn, int klen, int regions_m, int regions_n, int regions_per_wg,
+                                                            int with_bias) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, kh = lane >> 5;
     const int ksubs = 4 / regions_per_wg;
@@ -235,6 +238,9 @@ __global__ __launch_bounds__(256) void linear_wgrad_direct(const T *__restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     constexpr int U = 8;  // token pairs per unrolled step: up to 32 dword loads in flight per lane
+    // bias gradient = column sums of dY: the A operands ARE dY, so the waves of the first n-region add them up on the side
+    const bool do_bias = with_bias && (region % regions_n) == 0;
+    float bs0 = 0.f, bs1 = 0.f;
     for (long t0 = k_begin; t0 < k_end; t0 += 2 * U) {
         float a0[U], a1[U], b0[U], b1[U];
 #pragma unroll
@@ -247,6 +253,10 @@ __global__ __launch_bounds__(256) void linear_wgrad_direct(const T *__restrict__
             b0[u] = (in && bn0) ? ld1<T>(pb) : 0.f;
             b1[u] = (in && bn1) ? ld1<T>(pb + 32) : 0.f;
         }
+        if (do_bias) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) { bs0 += a0[u]; bs1 += a1[u]; }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
@@ -255,7 +265,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_direct(const T *__restrict__
             if (tm1 && tn1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
         }
     }
-    float *C = slabs + ((long)blockIdx.x * ksubs + ksub) * (long)M * N;
+    const long slab_elems = (long)M * N + (with_bias ? M : 0);   // a slab = the M x N partial, then (optionally) M bias partials
+    float *C = slabs + ((long)blockIdx.x * ksubs + ksub) * slab_elems;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -267,6 +278,14 @@ __global__ __launch_bounds__(256) void linear_wgrad_direct(const T *__restrict__
                 if (m < M && n < N) C[(long)m * N + n] = acc[i][j][e];
             }
         }
+    if (do_bias) {
+        bs0 += __shfl_xor(bs0, 32, 64);   // the two token parities
+        bs1 += __shfl_xor(bs1, 32, 64);
+        if (kh == 0) {
+            if (am0) C[(long)M * N + m0 + r] = bs0;
+            if (am1) C[(long)M * N + m0 + 32 + r] = bs1;
+        }
+    }
 }
 
 // dW[M x N] = dY^T . X for token-major dY [T][M], X [T][N] (the weight gradient of nn.Linear):
@@ -305,9 +324,10 @@ WgradPlan linear_wgrad_plan(long T, int M, int N) {
 }
 
 template <typename T>
-int linear_wgrad(const void *dY, const void *X, float *dW, void *ws, size_t ws_bytes, long Tn, int M, int N, hipStream_t st) {
+int linear_wgrad(const void *dY, const void *X, float *dW, float *dbias, void *ws, size_t ws_bytes, long Tn, int M, int N, hipStream_t st) {
     const WgradPlan p = linear_wgrad_plan(Tn, M, N);
-    const long slab = (long)M * N;
+    if (dbias && !p.direct) return SD_E_UNSUPPORTED;   // ask sd_linear_wgrad_fuses_bias() first
+    const long slab = (long)M * N + (dbias ? M : 0);
     if (!p.direct && p.nsplit == 1) {
         dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, 1);
         hipLaunchKernelGGL((gemm_mfma_f32<T, T, float, true, true>), grid, dim3(256), 0, st, (const T *)dY, (const T *)X, dW, nullptr, M, N,
@@ -320,13 +340,13 @@ int linear_wgrad(const void *dY, const void *X, float *dW, void *ws, size_t ws_b
         const int regions = p.regions_m * p.regions_n;
         dim3 grid(p.nsplit, (regions + p.regions_per_wg - 1) / p.regions_per_wg);
         hipLaunchKernelGGL((linear_wgrad_direct<T>), grid, dim3(256), 0, st, (const T *)dY, (const T *)X, slabs, M, N, Tn, p.klen, p.regions_m,
-                           p.regions_n, p.regions_per_wg);
+                           p.regions_n, p.regions_per_wg, dbias ? 1 : 0);
     } else {
         dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, p.nsplit);
         hipLaunchKernelGGL((gemm_mfma_f32<T, T, float, true, true>), grid, dim3(256), 0, st, (const T *)dY, (const T *)X, slabs, nullptr, M, N,
                            (int)Tn, (long)M, (long)N, (long)N, 0L, 0L, slab, p.nsplit, p.klen);
     }
-    hipLaunchKernelGGL(slab_reduce_wide, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, slabs, dW, slab, p.nslabs);
+    hipLaunchKernelGGL(slab_reduce_wide, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, slabs, dW, slab, p.nslabs, dbias, (long)M * N);
     return (int)hipGetLastError();
 }
 
@@ -351,17 +371,22 @@ size_t sd_align1x1_workspace_bytes(int B, int Cs, int Ct, int h, int w) {
 size_t sd_linear_wgrad_workspace_bytes(long tokens, int out_features, int in_features) {
     if (tokens <= 0 || out_features <= 0 || in_features <= 0) return 0;
     const sd::WgradPlan p = sd::linear_wgrad_plan(tokens, out_features, in_features);
-    return (size_t)p.nslabs * out_features * in_features * sizeof(float) + 16;
+    return (size_t)p.nslabs * ((size_t)out_features * in_features + out_features) * sizeof(float) + 16;
 }
 
-int sd_linear_wgrad(const void *dY, const void *X, float *dW, int dtype, long tokens, int out_features, int in_features, void *workspace,
-                    size_t workspace_bytes, void *stream) {
+int sd_linear_wgrad_fuses_bias(long tokens, int out_features, int in_features) {
+    if (tokens <= 0 || out_features <= 0 || in_features <= 0) return 0;
+    return sd::linear_wgrad_plan(tokens, out_features, in_features).direct ? 1 : 0;
+}
+
+int sd_linear_wgrad(const void *dY, const void *X, float *dW, float *dbias, int dtype, long tokens, int out_features, int in_features,
+                    void *workspace, size_t workspace_bytes, void *stream) {
     if (!dY || !X || !dW) return SD_E_NULL;
     if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
     if (tokens <= 0 || tokens > 0x7fffffffL || out_features <= 0 || in_features <= 0) return SD_E_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == SD_F32) return sd::linear_wgrad<float>(dY, X, dW, workspace, workspace_bytes, tokens, out_features, in_features, st);
-    return sd::linear_wgrad<sd::bf16_t>(dY, X, dW, workspace, workspace_bytes, tokens, out_features, in_features, st);
+    if (dtype == SD_F32) return sd::linear_wgrad<float>(dY, X, dW, dbias, workspace, workspace_bytes, tokens, out_features, in_features, st);
+    return sd::linear_wgrad<sd::bf16_t>(dY, X, dW, dbias, workspace, workspace_bytes, tokens, out_features, in_features, st);
 }
 
 int sd_align1x1_fwd(const void *X, const float *W, const float *bias, void *Y, int dtype, int B, int Cs, int Ct, int h, int w, void *stream) {

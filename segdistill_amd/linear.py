@@ -27,6 +27,7 @@ class _TokenLinear(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         if ctx.needs_input_grad[0]:
             dx = (dy2 @ weight).reshape(x.shape)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             x2 = x.reshape(-1, x.shape[-1])
             if not x2.is_contiguous():
@@ -35,12 +36,16 @@ class _TokenLinear(torch.autograd.Function):
             T, M, N = x2.shape[0], weight.shape[0], weight.shape[1]
             L = _lib.lib()
             dw32 = torch.empty(M, N, dtype=torch.float32, device=x.device)
+            fuse_b = want_db and bool(L.sd_linear_wgrad_fuses_bias(T, M, N))
+            db32 = torch.empty(M, dtype=torch.float32, device=x.device) if fuse_b else None
             wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
             ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-            _lib.check(L.sd_linear_wgrad(dyc.data_ptr(), x2.data_ptr(), dw32.data_ptr(), _DT[x.dtype], T, M, N, ws.data_ptr(), wsb, _stream_ptr()),
-                       'sd_linear_wgrad')
+            _lib.check(L.sd_linear_wgrad(dyc.data_ptr(), x2.data_ptr(), dw32.data_ptr(), None if db32 is None else db32.data_ptr(),
+                                         _DT[x.dtype], T, M, N, ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_wgrad')
             dw = dw32.to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if fuse_b:
+                db = db32.to(weight.dtype)
+        if want_db and db is None:
             db = dy2.sum(0)
         return dx, dw, db
 

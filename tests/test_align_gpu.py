@@ -111,11 +111,18 @@ def test_linear_wgrad_kernel(shape, dtype):
     dyg, xg = dy.to(dev), x.to(dev)
     L = _lib.lib()
     dw = torch.empty(M, N, device=dev)
+    fuse = bool(L.sd_linear_wgrad_fuses_bias(T, M, N))
+    db = torch.empty(M, device=dev) if fuse else None
     wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    rc = L.sd_linear_wgrad(dyg.data_ptr(), xg.data_ptr(), dw.data_ptr(), _DT[dtype], T, M, N, ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream)
+    rc = L.sd_linear_wgrad(dyg.data_ptr(), xg.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(), _DT[dtype], T, M, N,
+                           ws.data_ptr(), wsb, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     assert _err(dw, ref) < 2e-5
+    if fuse:
+        assert _err(db, dy.double().sum(0)) < 2e-5
+    else:  # the tiled kernel does not produce the bias gradient and says so
+        assert L.sd_linear_wgrad(dyg.data_ptr(), xg.data_ptr(), dw.data_ptr(), dw.data_ptr(), _DT[dtype], T, M, N, ws.data_ptr(), wsb, None) == -6
 
 
 def test_token_linear_autograd_matches_f_linear():

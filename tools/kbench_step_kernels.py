@@ -81,6 +81,6 @@ for (M, N) in ((32, 32), (128, 32), (32, 128), (256, 64)):
     L = _lib.lib(); dw = torch.empty(M, N, device=dev)
     wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    ms = t_ms(lambda: L.sd_linear_wgrad(dyl.data_ptr(), xl.data_ptr(), dw.data_ptr(), 0, T, M, N, ws.data_ptr(), wsb, st))
+    ms = t_ms(lambda: L.sd_linear_wgrad(dyl.data_ptr(), xl.data_ptr(), dw.data_ptr(), None, 0, T, M, N, ws.data_ptr(), wsb, st))
     ref = t_ms(lambda: dyl.t() @ xl)
     row(f'linear_wgrad T={T} out={M} in={N}', ms, T * (M + N) * 4, ref)
