@@ -194,6 +194,11 @@ size_t sd_dwconv3x3_workspace_bytes(int dtype, int B, int H, int W, int C);
 int sd_dwconv3x3_fwd(const void *x, const float *w_tap_major, const float *bias /* or NULL */, void *y,
                      int dtype, int B, int H, int W, int C, void *stream);
 
+/* inference-only: y = GELU(dwconv(x) + bias) (exact erf GELU), i.e. DWConv followed by the Mix-FFN activation
+ * (mix_transformer.py:50-51) in one pass; used for the frozen teacher, which never needs the pre-activation */
+int sd_dwconv3x3_gelu_fwd(const void *x, const float *w_tap_major, const float *bias /* or NULL */, void *y,
+                          int dtype, int B, int H, int W, int C, void *stream);
+
 int sd_dwconv3x3_bwd_data(const void *dy, const float *w_tap_major, void *dx,
                           int dtype, int B, int H, int W, int C, void *stream);
 

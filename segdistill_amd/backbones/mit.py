@@ -73,8 +73,16 @@ class MixFFN(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x, hw):
-        x = self.drop(self.act(self.dwconv(call_linear(self.fc1, x), hw)))
-        return self.drop(call_linear(self.fc2, x))
+        h = call_linear(self.fc1, x)
+        conv = self.dwconv.dwconv
+        from .. import dwconv as hip_dw
+        if (not torch.is_grad_enabled() and isinstance(self.act, nn.GELU) and getattr(self.act, 'approximate', 'none') == 'none'
+                and hip_dw.supported(h, conv.weight) and not torch.is_autocast_enabled()
+                and not (self.dwconv._forward_hooks or conv._forward_hooks or self.act._forward_hooks)):
+            h = hip_dw.dwconv3x3_gelu_tokens_inference(h, conv.weight, conv.bias, hw[0], hw[1])   # frozen-teacher path
+        else:
+            h = self.act(self.dwconv(h, hw))
+        return self.drop(call_linear(self.fc2, self.drop(h)))
 
 
 class SRAttention(nn.Module):

@@ -70,7 +70,10 @@ __device__ __forceinline__ void load_w(const float *__restrict__ w, int C, int c
 
 // grid: (ceil(strips_per_row * (C/N) / 256), B*H).  A thread produces kStrip consecutive pixels of one row
 // for one channel vector; per input row it loads the kStrip+2 columns once (1.5 loads per tap-row-pixel).
-template <typename T, bool FLIP, bool BIAS>
+// exact (erf) GELU, the nn.GELU() default used by the Mix-FFN (mix_transformer.py:20, act_layer=nn.GELU)
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+
+template <typename T, bool FLIP, bool BIAS, bool GELU = false>
 __global__ __launch_bounds__(256) void dw3x3_fwd(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
                                                   T *__restrict__ y, int H, int W, int C) {
     constexpr int N = CV<T>::N;
@@ -125,6 +128,12 @@ __global__ __launch_bounds__(256) void dw3x3_fwd(const T *__restrict__ x, const 
 #pragma unroll
                 for (int i = 0; i < N; ++i) acc[p][i] = fmaf(wv[i], col[p + kx][i], acc[p][i]);
         }
+    }
+    if constexpr (GELU) {  // inference-only epilogue: the frozen teacher never needs the pre-activation
+#pragma unroll
+        for (int p = 0; p < kStrip; ++p)
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[p][i] = gelu_erf(acc[p][i]);
     }
 #pragma unroll
     for (int p = 0; p < kStrip; ++p)
@@ -270,11 +279,14 @@ int check_dw(const void *a, const void *b, int dtype, int B, int H, int W, int C
 }
 
 template <typename T>
-int fwd_launch(const void *x, const float *w, const float *bias, void *y, int B, int H, int W, int C, bool flip, hipStream_t st) {
+int fwd_launch(const void *x, const float *w, const float *bias, void *y, int B, int H, int W, int C, bool flip, hipStream_t st,
+               bool gelu = false) {
     const int cv = C / CV<T>::N;
     const int spr = (W + kStrip - 1) / kStrip;
     dim3 grid((spr * cv + 255) / 256, B * H);
-    if (flip) hipLaunchKernelGGL((dw3x3_fwd<T, true, false>), grid, dim3(256), 0, st, (const T *)x, w, nullptr, (T *)y, H, W, C);
+    if (gelu && bias) hipLaunchKernelGGL((dw3x3_fwd<T, false, true, true>), grid, dim3(256), 0, st, (const T *)x, w, bias, (T *)y, H, W, C);
+    else if (gelu) hipLaunchKernelGGL((dw3x3_fwd<T, false, false, true>), grid, dim3(256), 0, st, (const T *)x, w, nullptr, (T *)y, H, W, C);
+    else if (flip) hipLaunchKernelGGL((dw3x3_fwd<T, true, false>), grid, dim3(256), 0, st, (const T *)x, w, nullptr, (T *)y, H, W, C);
     else if (bias) hipLaunchKernelGGL((dw3x3_fwd<T, false, true>), grid, dim3(256), 0, st, (const T *)x, w, bias, (T *)y, H, W, C);
     else hipLaunchKernelGGL((dw3x3_fwd<T, false, false>), grid, dim3(256), 0, st, (const T *)x, w, nullptr, (T *)y, H, W, C);
     return (int)hipGetLastError();
@@ -320,6 +332,16 @@ int sd_dwconv3x3_fwd(const void *x, const float *w_tap_major, const float *bias,
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == SD_F32) return sd::fwd_launch<float>(x, w_tap_major, bias, y, B, H, W, C, false, st);
     return sd::fwd_launch<sd::bf16_t>(x, w_tap_major, bias, y, B, H, W, C, false, st);
+}
+
+int sd_dwconv3x3_gelu_fwd(const void *x, const float *w_tap_major, const float *bias, void *y, int dtype, int B, int H, int W, int C,
+                          void *stream) {
+    int rc = sd::check_dw(x, y, dtype, B, H, W, C);
+    if (rc) return rc;
+    if (!w_tap_major) return SD_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32) return sd::fwd_launch<float>(x, w_tap_major, bias, y, B, H, W, C, false, st, true);
+    return sd::fwd_launch<sd::bf16_t>(x, w_tap_major, bias, y, B, H, W, C, false, st, true);
 }
 
 int sd_dwconv3x3_bwd_data(const void *dy, const float *w_tap_major, void *dx, int dtype, int B, int H, int W, int C, void *stream) {

@@ -60,3 +60,16 @@ def supported(tokens, weight):
 
 def dwconv3x3_tokens(tokens, weight, bias, H, W):
     return _DWConv3x3Tokens.apply(tokens, weight, bias, H, W)
+
+
+def dwconv3x3_gelu_tokens_inference(tokens, weight, bias, H, W):
+    """GELU(dwconv(tokens) + bias) in one kernel; no autograd (frozen-teacher path)."""
+    x = tokens.contiguous()
+    B, N, C = x.shape
+    w_t = weight.detach().reshape(C, 9).t().contiguous().float()
+    b = None if bias is None else bias.detach().contiguous().float()
+    y = torch.empty_like(x)
+    rc = _lib.lib().sd_dwconv3x3_gelu_fwd(x.data_ptr(), w_t.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), _DT[x.dtype], B, H, W,
+                                          C, _stream_ptr())
+    _lib.check(rc, 'sd_dwconv3x3_gelu_fwd')
+    return y

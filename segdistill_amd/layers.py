@@ -126,7 +126,7 @@ class DropPath(nn.Module):
             return x
         keep = 1.0 - self.drop_prob
         mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
-        return x.div(keep) * mask
+        return x * mask.div_(keep)   # same value as x/keep * mask with one pass over x instead of two
 
     def extra_repr(self):
         return f'p={self.drop_prob}'

@@ -68,3 +68,15 @@ def test_mit_block_uses_hip_dwconv_and_matches_torch_path():
     y2 = ffn.fc2(ffn.act(h))
     y2.sum().backward()
     assert _err(y, y2) < 1e-5 and _err(gx, x.grad) < 1e-4 and _err(gw, ffn.dwconv.dwconv.weight.grad) < 1e-4
+
+
+def test_dwconv_gelu_inference_kernel():
+    from segdistill_amd.dwconv import dwconv3x3_gelu_tokens_inference
+    B, H, W, C = 2, 20, 18, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H * W, C, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) / 3
+    b = torch.randn(C, generator=g)
+    ref = F.gelu(F.conv2d(x.double().transpose(1, 2).reshape(B, C, H, W), w.double(), b.double(), padding=1, groups=C)).flatten(2).transpose(1, 2)
+    y = dwconv3x3_gelu_tokens_inference(x.cuda(), w.cuda(), b.cuda(), H, W)
+    assert _err(y, ref) < 1e-5
