@@ -182,6 +182,18 @@ int sd_linear_wgrad(const void *dY, const void *X, float *dW, float *dbias /* [o
                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Forward of a Linear with a LONG reduction axis and a small output: Y [rows][out] (fp32) = X [rows][in] . W[out][in]^T + bias.
+ * Used for the SR-attention spatial reduction (mix_transformer.py:86-88,112-116: Conv2d(dim, dim, r, stride=r) ==
+ * Linear over r*r*dim patch features, in = up to 4096, out = dim, rows = B*256): the reduction axis is split over
+ * workgroups (f32 MFMA partial slabs in `workspace`, deterministic combine that also adds the bias).
+ */
+size_t sd_linear_longk_workspace_bytes(int rows, int out_features, int in_features);
+
+int sd_linear_longk_fwd(const void *X, const float *W, const float *bias /* or NULL */, float *Y, int dtype,
+                        int rows, int out_features, int in_features,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Depth-wise 3x3 convolution (stride 1, zero pad 1) on TOKEN-MAJOR activations [B, H*W, C]: the
  * DWConv inside every MiT Mix-FFN (mix_transformer.py:376-387: transpose to NCHW ->
  * nn.Conv2d(dim, dim, 3, 1, 1, groups=dim) -> flatten/transpose back; called from Mlp.forward :48-55).

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from ..builder import BACKBONES
 from ..layers import DropPath, nchw_view_of_tokens, tokens_of, trunc_normal_
 from ..layernorm import HipLayerNorm
-from ..linear import call_linear
+from ..linear import call_linear, longk_linear
 
 
 def _mit_init(m):
@@ -116,7 +116,7 @@ class SRAttention(nn.Module):
             return conv(x.transpose(1, 2).reshape(b, c, H, W)).flatten(2).transpose(1, 2)
         patches = x.reshape(b, H // r, r, W // r, r, c).permute(0, 1, 3, 2, 4, 5).reshape(b, (H // r) * (W // r), r * r * c)
         w2 = conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c)   # (ky, kx, cin) order to match the patches
-        return F.linear(patches, w2, conv.bias)
+        return longk_linear(patches, w2, conv.bias)
 
     def forward(self, x, hw):
         b, n, c = x.shape

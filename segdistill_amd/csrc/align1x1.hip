@@ -350,6 +350,49 @@ int linear_wgrad(const void *dY, const void *X, float *dW, float *dbias, void *w
     return (int)hipGetLastError();
 }
 
+// Y[M x N] = X[M x K] . W[N x K]^T + bias[N] for LONG K and a small output (the SR-attention patch projection:
+// K = r*r*C up to 4096, N = C, M = B*256 tokens): the library picks an un-split 32x64 tiling with 64 workgroups;
+// here K is split over workgroups (both operands X-major, f32 MFMA slabs) and the combine adds the bias.
+__global__ __launch_bounds__(256) void slab_reduce_bias(const float *__restrict__ slabs, float *__restrict__ out, const float *__restrict__ bias,
+                                                         long n, int nz, int N) {
+    __shared__ float red[16][17];
+    const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + o;
+    float acc = 0.f;
+    if (i < n)
+        for (int z = grp; z < nz; z += 16) acc += slabs[(long)z * n + i];
+    red[grp][o] = acc;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float t = bias ? bias[i % N] : 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 16; ++g2) t += red[g2][o];
+        out[i] = t;
+    }
+}
+
+int longk_splits(int M, int N, int K) {
+    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    long nsplit = 512 / tiles;
+    if (nsplit > K / 64) nsplit = K / 64;
+    return (int)(nsplit < 1 ? 1 : nsplit);
+}
+
+template <typename T>
+int gemm_nt_longk(const void *X, const void *W, const float *bias, float *Y, void *ws, size_t ws_bytes, int M, int N, int K, hipStream_t st) {
+    int nsplit = longk_splits(M, N, K);
+    const int klen = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
+    nsplit = (K + klen - 1) / klen;
+    const long slab = (long)M * N;
+    if (ws_bytes < (size_t)nsplit * slab * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
+    float *slabs = static_cast<float *>(ws);
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nsplit);
+    hipLaunchKernelGGL((gemm_mfma_f32<T, float, float, false, false>), grid, dim3(256), 0, st, (const T *)X, (const float *)W, slabs, nullptr, M,
+                       N, K, (long)K, (long)K, (long)N, 0L, 0L, slab, nsplit, klen);
+    hipLaunchKernelGGL(slab_reduce_bias, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, slabs, Y, bias, slab, nsplit, N);
+    return (int)hipGetLastError();
+}
+
 int check_align(const void *a, const void *b, const void *c, int dtype, int B, int Cs, int Ct, int h, int w) {
     if (!a || !b || !c) return SD_E_NULL;
     if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
@@ -372,6 +415,21 @@ size_t sd_linear_wgrad_workspace_bytes(long tokens, int out_features, int in_fea
     if (tokens <= 0 || out_features <= 0 || in_features <= 0) return 0;
     const sd::WgradPlan p = sd::linear_wgrad_plan(tokens, out_features, in_features);
     return (size_t)p.nslabs * ((size_t)out_features * in_features + out_features) * sizeof(float) + 16;
+}
+
+size_t sd_linear_longk_workspace_bytes(int rows, int out_features, int in_features) {
+    if (rows <= 0 || out_features <= 0 || in_features <= 0) return 0;
+    return (size_t)sd::longk_splits(rows, out_features, in_features) * rows * out_features * sizeof(float) + 16;
+}
+
+int sd_linear_longk_fwd(const void *X, const float *W, const float *bias, float *Y, int dtype, int rows, int out_features, int in_features,
+                        void *workspace, size_t workspace_bytes, void *stream) {
+    if (!X || !W || !Y || !workspace) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (rows <= 0 || out_features <= 0 || in_features <= 0) return SD_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32) return sd::gemm_nt_longk<float>(X, W, bias, Y, workspace, workspace_bytes, rows, out_features, in_features, st);
+    return sd::gemm_nt_longk<sd::bf16_t>(X, W, bias, Y, workspace, workspace_bytes, rows, out_features, in_features, st);
 }
 
 int sd_linear_wgrad_fuses_bias(long tokens, int out_features, int in_features) {

@@ -64,3 +64,44 @@ def call_linear(module, x):
     if module._forward_hooks or module._forward_pre_hooks:
         return module(x)
     return token_linear(x, module.weight, module.bias)
+
+
+class _LongKLinear(torch.autograd.Function):
+    """y = x . W^T + b for a long reduction axis and a small output (SR-attention patch projection): split-K MFMA forward;
+    the two backward products are ordinary library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w = weight.contiguous()
+        M, K, N = x2.shape[0], x2.shape[1], w.shape[0]
+        L = _lib.lib()
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        wsb = L.sd_linear_longk_workspace_bytes(M, N, K)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+        b = None if bias is None else bias.detach().float().contiguous()
+        _lib.check(L.sd_linear_longk_fwd(x2.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), _DT[x2.dtype], M, N, K,
+                                         ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_longk_fwd')
+        ctx.save_for_backward(x2, w)
+        ctx.shape, ctx.has_bias = x.shape, bias is not None
+        return y.to(x.dtype).reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = (dy2 @ w).reshape(ctx.shape) if ctx.needs_input_grad[0] else None
+        dw = (dy2.t() @ x2) if ctx.needs_input_grad[1] else None
+        db = dy2.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def longk_linear(x, weight, bias=None):
+    """F.linear for in_features >= 1024 with few rows/outputs on the GPU (fp32 weights); otherwise F.linear."""
+    rows = x.numel() // x.shape[-1]
+    if (x.is_cuda and x.dtype in _DT and weight.dtype == torch.float32 and x.shape[-1] >= 1024 and weight.shape[0] <= 512 and rows <= 16384
+            and not torch.is_autocast_enabled()):
+        return _LongKLinear.apply(x, weight, bias)
+    return F.linear(x, weight, bias)

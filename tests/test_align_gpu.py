@@ -139,3 +139,23 @@ def test_token_linear_autograd_matches_f_linear():
     torch.nn.functional.linear(x, w, b).square().mean().backward()
     for a, r in zip(g, (x.grad, w.grad, b.grad)):
         assert _err(a, r) < 1e-4
+
+
+@pytest.mark.parametrize('shape', [(2048, 64, 4096), (2048, 32, 2048), (2048, 128, 2048), (500, 37, 1030), (2048, 320, 1280)])
+def test_longk_linear(shape):
+    """split-K forward of the SR patch projection vs fp64; autograd through it vs F.linear."""
+    from segdistill_amd.linear import longk_linear
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(4, M // 4, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    dev = torch.device('cuda:0')
+    xg, wg, bg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = longk_linear(xg, wg, bg)
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    assert _err(y, ref) < 2e-5
+    y.square().mean().backward()
+    x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    torch.nn.functional.linear(x64, w64, b64).square().mean().backward()
+    assert _err(xg.grad, x64.grad) < 1e-4 and _err(wg.grad, w64.grad) < 1e-4 and _err(bg.grad, b64.grad) < 1e-4
