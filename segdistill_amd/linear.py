@@ -4,6 +4,8 @@ GEMMs); only dW = dY^T . X -- tall-skinny at the high-resolution MiT stages, whe
 30x off the HBM roofline (profiles/r01_train_step_kernels_*.txt) -- is replaced."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -11,6 +13,10 @@ from . import _lib
 from .ops import _DT, _stream_ptr
 
 MIN_TOKENS = 4096  # below this the library GEMM is fine
+# A/B on MI355X (config 2, same box, 30 steps): 19.9 ms/step with the split-K kernel vs 19.4 ms with the library GEMM -- the
+# library's un-split 64-workgroup kernel is slow in isolation (183 us) but leaves the chip to the concurrently running
+# student/teacher stream, while the split-K version occupies all CUs.  Kept as an opt-in (SEGDISTILL_LONGK=1).
+_LONGK_ENABLED = os.environ.get('SEGDISTILL_LONGK') == '1'
 
 
 class _TokenLinear(torch.autograd.Function):
@@ -101,7 +107,7 @@ class _LongKLinear(torch.autograd.Function):
 def longk_linear(x, weight, bias=None):
     """F.linear for in_features >= 1024 with few rows/outputs on the GPU (fp32 weights); otherwise F.linear."""
     rows = x.numel() // x.shape[-1]
-    if (x.is_cuda and x.dtype in _DT and weight.dtype == torch.float32 and x.shape[-1] >= 1024 and weight.shape[0] <= 512 and rows <= 16384
+    if (_LONGK_ENABLED and x.is_cuda and x.dtype in _DT and weight.dtype == torch.float32 and x.shape[-1] >= 1024 and weight.shape[0] <= 512 and rows <= 16384
             and not torch.is_autocast_enabled()):
         return _LongKLinear.apply(x, weight, bias)
     return F.linear(x, weight, bias)

@@ -144,7 +144,9 @@ def test_token_linear_autograd_matches_f_linear():
 @pytest.mark.parametrize('shape', [(2048, 64, 4096), (2048, 32, 2048), (2048, 128, 2048), (500, 37, 1030), (2048, 320, 1280)])
 def test_longk_linear(shape):
     """split-K forward of the SR patch projection vs fp64; autograd through it vs F.linear."""
+    from segdistill_amd import linear as lin
     from segdistill_amd.linear import longk_linear
+    lin._LONGK_ENABLED = True   # opt-in path (off by default, see linear.py)
     M, N, K = shape
     g = torch.Generator().manual_seed(M + N)
     x = torch.randn(4, M // 4, K, generator=g)
