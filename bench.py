@@ -52,8 +52,11 @@ def timed_steps(trainer, data, steps, world):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    cur = data.next()
     for _ in range(steps):
-        trainer.step(data.next())
+        nxt = data.next()            # the data pipeline knows the next batch: the frozen teacher runs one batch ahead
+        trainer.step(cur, nxt)
+        cur = nxt
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -56,14 +56,17 @@ class KDTrainer:
     # per iteration reaches the kernels as data (alpha scalar, permutation table -- distillation/losses.py), the
     # gradient all-reduce and the fused optimizer step stay outside the graph.
     def enable_graph(self, example_batch):
-        """Capture forward+backward for batches shaped like `example_batch`.  Returns True on success; on any failure the
-        trainer stays in eager mode (and says why)."""
+        """Capture the step for batches shaped like `example_batch` as TWO graphs: the frozen teacher's forward (side
+        stream; replayed one iteration AHEAD when the next batch is known, so it overlaps the current backward) and the
+        student's forward + losses + backward (main stream; reads the teacher taps from static buffers).  Returns True
+        on success; on any failure the trainer stays in eager mode (and says why)."""
         import warnings
         if not example_batch['img'].is_cuda:
             return False
         m = self.model
         try:
             self._static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in example_batch.items()}
+            has_kd = hasattr(m, 'distillation_loss') and bool(getattr(m, 'distillation', None))
             if hasattr(m, 'distillation_loss'):
                 m.distillation_loss.set_graph_safe(True)
             m.train()
@@ -76,10 +79,29 @@ class KDTrainer:
                     self._fwd_bwd(self._static)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            m.cnt = cnt0                    # the warm-up passes do not count as training iterations
+            if hasattr(m, 'cnt'):
+                m.cnt = cnt0                # the warm-up passes do not count as training iterations
+            if has_kd:
+                # (1) teacher graph on the model's side stream; its tapped features are static outputs
+                ts = m._side_stream or torch.cuda.Stream(device=example_batch['img'].device)
+                m._side_stream = ts
+                self._t_img = example_batch['img'].clone()
+                m._prefetched = None
+                m.extractor.teacher_features.clear()
+                gt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gt, stream=ts):
+                    m._teacher_forward(self._t_img, None, None)
+                self._t_out = dict(m.extractor.teacher_features)
+                m.extractor.clear()
+                if not self._t_out:
+                    raise RuntimeError('the teacher capture produced no tapped feature')
+                self._t_graph = gt
+                self._t_cur = {k: torch.empty_like(v) for k, v in self._t_out.items()}
+                m._taps_override = self._t_cur   # the captured student step reads the taps from these buffers
+                self._primed = None
             m.external_step = True
-            self._graph = torch.cuda.CUDAGraph()
             self.reducer.zero_grad()        # .grad = None: the captured backward creates the (static) gradient tensors
+            self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._graph_out = self._fwd_bwd(self._static)
             torch.cuda.synchronize()
@@ -88,6 +110,8 @@ class KDTrainer:
             warnings.warn(f'hipGraph capture failed ({type(e).__name__}: {e}); continuing in eager mode')
             self._graph = None
             m.external_step = False
+            if hasattr(m, '_taps_override'):
+                m._taps_override = None
             if hasattr(m, 'distillation_loss'):
                 m.distillation_loss.set_graph_safe(False)
             torch.cuda.synchronize()
@@ -160,8 +184,37 @@ class KDTrainer:
         out['loss'].backward()
         return out
 
-    def _graph_step(self, batch):
+    def _replay_teacher(self, img):
+        """side stream: copy the image into the teacher graph's input and replay it; returns the completion event."""
+        side = self.model._side_stream
+        with torch.cuda.stream(side):
+            self._t_img.copy_(img, non_blocking=True)
+            self._t_graph.replay()
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return ev
+
+    def _graph_step(self, batch, next_batch=None):
         m = self.model
+        main = torch.cuda.current_stream()
+        if getattr(self, '_t_graph', None) is not None:
+            img = batch['img']
+            key = (img.data_ptr(), img._version)
+            if self._primed is not None and self._primed[0] == key:
+                ev = self._primed[1]                                   # replayed during the previous iteration
+            else:
+                m._side_stream.wait_stream(main)
+                ev = self._replay_teacher(img)
+            main.wait_event(ev)
+            for k, v in self._t_out.items():                           # free the teacher graph's outputs for the next replay
+                self._t_cur[k].copy_(v, non_blocking=True)
+            self._primed = None
+            if next_batch is not None:
+                copied = torch.cuda.Event()
+                copied.record(main)
+                m._side_stream.wait_event(copied)
+                nimg = next_batch['img']
+                self._primed = ((nimg.data_ptr(), nimg._version), self._replay_teacher(nimg))   # overlaps everything below
         for k, v in batch.items():
             if isinstance(v, torch.Tensor):
                 self._static[k].copy_(v, non_blocking=True)
@@ -171,27 +224,24 @@ class KDTrainer:
         self._graph.replay()
         return self._graph_out
 
-    def step(self, batch):
-        if getattr(self, '_graph', None) is not None:
-            self.model.train()
-            if self.sched is not None:
-                self.sched.step(self.iter)
-            out = self._graph_step(batch)
-            self.reducer.all_reduce()
-            self.optimizer.step()
-            self.iter += 1
-            self.last_log_vars = out['log_vars']
-            return out
+    def step(self, batch, next_batch=None):
+        """One training iteration.  `next_batch` (optional) lets the frozen teacher's forward for the NEXT iteration be
+        launched now, overlapping this iteration's backward (the teacher never depends on the optimizer step)."""
         self.model.train()
         if self.sched is not None:
             self.sched.step(self.iter)
-        self.reducer.zero_grad()
-        if self.bf16 and batch['img'].is_cuda:
-            with torch.autocast('cuda', dtype=torch.bfloat16):
-                out = self.model.train_step(batch, self.optimizer)
+        if getattr(self, '_graph', None) is not None:
+            out = self._graph_step(batch, next_batch)
         else:
-            out = self.model.train_step(batch, self.optimizer)
-        out['loss'].backward()
+            self.reducer.zero_grad()
+            if self.bf16 and batch['img'].is_cuda:
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    out = self.model.train_step(batch, self.optimizer)
+            else:
+                out = self.model.train_step(batch, self.optimizer)
+            if next_batch is not None and hasattr(self.model, 'prefetch_teacher') and not self.bf16:
+                self.model.prefetch_teacher(next_batch['img'])
+            out['loss'].backward()
         self.reducer.all_reduce()
         self.optimizer.step()
         self.iter += 1

@@ -82,7 +82,9 @@ class SDModule(BaseSegmentor):
         self.teacher_on_side_stream = True
         self._side_stream = None
         self.external_step = False  # True while a trainer replays captured steps: it advances `cnt` itself
-        self._graphed_teacher = None  # (graph, static tapped features, static image) set by KDTrainer.enable_hybrid_graph
+        self._graphed_teacher = None  # (graph, static tapped features, static image) set by KDTrainer.enable_*graph
+        self._prefetched = None       # (img identity, taps, event) of a teacher forward launched ahead of its iteration
+        self._taps_override = None    # static teacher taps while a captured student step is being recorded / replayed
 
     def train(self, mode=True):
         super().train(mode)
@@ -104,38 +106,72 @@ class SDModule(BaseSegmentor):
             else:
                 self.teacher.forward_features_only(img, run_aux=self._teacher_needs_aux)
 
+    # ---- teacher taps: inline, side-stream, graphed, or PREFETCHED for the next batch -------------------------------------
+    # The teacher is frozen, so its features for batch k+1 do not depend on the optimizer step of iteration k: a trainer
+    # that knows the next batch calls prefetch_teacher(next_img) and the whole teacher forward overlaps with the current
+    # iteration's backward instead of sitting on the critical path in front of the KD loss.
+    def _launch_teacher(self, img, img_metas=None, gt_semantic_seg=None):
+        """Enqueue the teacher forward for `img` on the side stream; returns (taps dict, event)."""
+        main = torch.cuda.current_stream(img.device)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=img.device)
+        side = self._side_stream
+        gt_graph = self._graphed_teacher if not self.teacher_train_mode else None
+        if gt_graph is not None:
+            graph, static_out, static_img = gt_graph
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                static_img.copy_(img, non_blocking=True)
+                graph.replay()
+                # the graph's outputs are overwritten by the next replay: hand out copies (a few tens of MB)
+                taps = {k: v.clone() for k, v in static_out.items()}
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return taps, ev
+        side.wait_stream(main)                          # img / weights are ready
+        with torch.cuda.stream(side):
+            self.extractor.teacher_features.clear()
+            self._teacher_forward(img, img_metas, gt_semantic_seg)
+            taps = dict(self.extractor.teacher_features)
+            self.extractor.teacher_features.clear()
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return taps, ev
+
+    def prefetch_teacher(self, img):
+        """Start the teacher forward for a FUTURE batch now (no-op on CPU / when there is nothing to distil)."""
+        if not (self.distillation and img.is_cuda) or self._taps_override is not None:
+            return
+        taps, ev = self._launch_teacher(img)
+        self._prefetched = (img.data_ptr(), img._version, tuple(img.shape), taps, ev)
+
     def forward_train(self, img, img_metas=None, gt_semantic_seg=None):
         if not self.external_step:
             self.cnt += 1
-        side = None
-        gt_graph = self._graphed_teacher if (self.distillation and img.is_cuda and not self.teacher_train_mode) else None
-        if gt_graph is not None:
-            graph, static_taps, static_img = gt_graph
-            side, main = self._side_stream, torch.cuda.current_stream(img.device)
-            static_img.copy_(img)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                graph.replay()
-            self.extractor.teacher_features.update(static_taps)
-        elif self.distillation and self.teacher_on_side_stream and img.is_cuda:
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=img.device)
-            side, main = self._side_stream, torch.cuda.current_stream(img.device)
-            side.wait_stream(main)                      # img / weights are ready
-            with torch.cuda.stream(side):
-                self._teacher_forward(img, img_metas, gt_semantic_seg)
+        pending = None
+        if self.distillation and self._taps_override is None:
+            pre = self._prefetched
+            self._prefetched = None
+            if pre is not None and pre[:3] == (img.data_ptr(), img._version, tuple(img.shape)):
+                pending = (pre[3], pre[4])                                  # launched during the previous iteration
+            elif img.is_cuda and self.teacher_on_side_stream:
+                pending = self._launch_teacher(img, img_metas, gt_semantic_seg)   # overlaps with the student forward below
         loss_dict = self.student(img, img_metas, return_loss=True, gt_semantic_seg=gt_semantic_seg)
         if self.distillation:
-            if side is None:
-                self._teacher_forward(img, img_metas, gt_semantic_seg)
+            if self._taps_override is not None:
+                teacher_feats = self._taps_override                          # static buffers filled by the trainer (graph replay)
+            elif pending is not None:
+                teacher_feats, ev = pending
+                main = torch.cuda.current_stream(img.device)
+                main.wait_event(ev)
+                for t in teacher_feats.values():
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(main)                                # allocated on the side stream, consumed on the main one
             else:
-                main.wait_stream(side)
-                if gt_graph is None and not torch.cuda.is_current_stream_capturing():
-                    for t in self.extractor.teacher_features.values():
-                        if isinstance(t, torch.Tensor):
-                            t.record_stream(main)       # allocated on the side stream, consumed on the main one
-            kd = self.distillation_loss(self.extractor.student_features, self.extractor.teacher_features, gt_semantic_seg,
-                                        self.cnt, self.student, self.teacher)
+                self.extractor.teacher_features.clear()
+                self._teacher_forward(img, img_metas, gt_semantic_seg)
+                teacher_feats = dict(self.extractor.teacher_features)
+            kd = self.distillation_loss(self.extractor.student_features, teacher_feats, gt_semantic_seg, self.cnt, self.student, self.teacher)
             loss_dict.update(kd)
             self.extractor.clear()
         return loss_dict

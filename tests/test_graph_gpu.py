@@ -40,7 +40,7 @@ def _model():
     return m.cuda()
 
 
-@pytest.mark.parametrize('mode', ['full', 'hybrid'])
+@pytest.mark.parametrize('mode', ['full', 'hybrid', 'eager_prefetch'])
 def test_graph_replay_matches_eager(mode):
     from segdistill_amd.engine import KDTrainer, SyntheticADE
     opt = dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
@@ -51,15 +51,19 @@ def test_graph_replay_matches_eager(mode):
     data_e = SyntheticADE(2, size=(128, 128), device='cuda:0', pool=3, seed=1)
     data_g = SyntheticADE(2, size=(128, 128), device='cuda:0', pool=3, seed=1)
     example = dict(img=data_g._pool[0][0], img_metas=None, gt_semantic_seg=data_g._pool[0][1])
-    assert (t_g.enable_graph(example) if mode == 'full' else t_g.enable_hybrid_graph(example))
+    if mode != 'eager_prefetch':
+        assert (t_g.enable_graph(example) if mode == 'full' else t_g.enable_hybrid_graph(example))
     assert gra.cnt == 0
     perms = []
+    cur_g = data_g.next()
     for it in range(7):                         # crosses the warm-up end (5) and two shuffle iterations (3, 6)
         torch.manual_seed(100 + it)            # the shuffle draws torch.randperm from the CPU RNG
         oe = t_e.step(data_e.next())
         pe = ref.distillation_loss.criteria[0].last_perm
         torch.manual_seed(100 + it)
-        og = t_g.step(data_g.next())
+        nxt_g = data_g.next()
+        og = t_g.step(cur_g, nxt_g if it != 4 else None)   # teacher one batch ahead (and one iteration without a hint)
+        cur_g = nxt_g
         ve, vg = t_e.log_values(), t_g.log_values()
         assert list(ve) == list(vg)
         for k in ve:
