@@ -178,6 +178,11 @@ __global__ void ce_up_bwd(const T *__restrict__ s, const int32_t *__restrict__ l
     }
 }
 
+// Zero the hit counter with a kernel, not hipMemsetAsync: inside a captured hipGraph a memset becomes a memset NODE, and when two
+// graphs are replayed concurrently on different streams (teacher graph || student-step graph, engine/trainer.py) the fill value of
+// such nodes was observed to be taken from the OTHER graph's memset (counter came back as 0x01010101 + hits on ROCm 7.2 / gfx950).
+__global__ void zero_counter(int *p) { *p = 0; }
+
 int ce_factor(int h, int w, int H, int W) {
     if (h <= 0 || w <= 0 || H % h || W % w) return 0;
     const int f = H / h;
@@ -205,8 +210,7 @@ int sd_ce_up_fwd(const void *logits, const int32_t *label, float *loss_pix, floa
     hipStream_t st = static_cast<hipStream_t>(stream);
     // the forward keeps no state across gaps (the channel loop is innermost), so one gap per workgroup maximises parallelism
     const int R = 1, nband = h, threads = (w + 63) / 64 * 64;
-    hipError_t e = hipMemsetAsync(correct, 0, sizeof(int), st);
-    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(sd::zero_counter, dim3(1), dim3(1), 0, st, correct);
     dim3 grid(nband, B);
     // wide register budget (16 pixels of softmax state per lane) needs <= 256-thread workgroups; wider taps use
     // half the pixels per pass

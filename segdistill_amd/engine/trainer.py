@@ -9,6 +9,23 @@ from .dp import DataParallelReducer
 from .optim import PolyLR, build_optimizer
 
 
+def _issues_memsets(fn):
+    """True if running `fn` enqueues any hipMemset command (seen through the torch profiler).
+
+    Why it matters (tools/memset_graph_probe.py, ROCm 7.x runtime bundled with PyTorch 2.10): a memset NODE inside a
+    replayed hipGraph takes its fill pattern from a staging area shared with every other memset on the device; a
+    hipMemsetAsync issued on ANOTHER stream while the node is pending makes the node write garbage (kernel-argument
+    words of the other memset) instead of its value.  Two pieces of work may therefore only overlap on different
+    streams if at most one of them contains memsets.  The MiT/ResNet/Swin teacher forward contains none (checked here
+    at capture time); the student's fwd+bwd contains ~30 (zero-initialised autograd buffers)."""
+    from torch.profiler import ProfilerActivity, profile
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    return any('emset' in r.key for r in prof.key_averages())
+
+
 class _TupleOut(torch.nn.Module):
     """make_graphed_callables wants tuple outputs; MiT / ResNet backbones return a list or tuple of feature maps."""
 
@@ -96,6 +113,11 @@ class KDTrainer:
                 if not self._t_out:
                     raise RuntimeError('the teacher capture produced no tapped feature')
                 self._t_graph = gt
+                # overlap teacher(k+1) with the student step k only if the teacher forward issues no memset (see _issues_memsets)
+                self._overlap_teacher = not _issues_memsets(lambda: m._teacher_forward(self._t_img, None, None))
+                m.extractor.teacher_features.clear()
+                if not self._overlap_teacher:
+                    warnings.warn('the teacher forward issues hipMemset commands: its graph will not be overlapped with the student graph')
                 self._t_cur = {k: torch.empty_like(v) for k, v in self._t_out.items()}
                 m._taps_override = self._t_cur   # the captured student step reads the taps from these buffers
                 self._primed = None
@@ -164,6 +186,8 @@ class KDTrainer:
             if not outs:
                 raise RuntimeError('the teacher capture produced no tapped feature')
             m._graphed_teacher = (g, outs, h_img)
+            m.prefetch_ok = not _issues_memsets(lambda: m._teacher_forward(h_img, None, None))
+            m.extractor.teacher_features.clear()
             m.cnt = cnt0
             torch.cuda.synchronize()
             return True
@@ -209,7 +233,7 @@ class KDTrainer:
             for k, v in self._t_out.items():                           # free the teacher graph's outputs for the next replay
                 self._t_cur[k].copy_(v, non_blocking=True)
             self._primed = None
-            if next_batch is not None:
+            if next_batch is not None and self._overlap_teacher:
                 copied = torch.cuda.Event()
                 copied.record(main)
                 m._side_stream.wait_event(copied)

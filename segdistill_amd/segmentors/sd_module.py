@@ -85,6 +85,7 @@ class SDModule(BaseSegmentor):
         self._graphed_teacher = None  # (graph, static tapped features, static image) set by KDTrainer.enable_*graph
         self._prefetched = None       # (img identity, taps, event) of a teacher forward launched ahead of its iteration
         self._taps_override = None    # static teacher taps while a captured student step is being recorded / replayed
+        self.prefetch_ok = True       # cleared by the trainer if overlapping the teacher with graph replays would be unsafe
 
     def train(self, mode=True):
         super().train(mode)
@@ -140,7 +141,7 @@ class SDModule(BaseSegmentor):
 
     def prefetch_teacher(self, img):
         """Start the teacher forward for a FUTURE batch now (no-op on CPU / when there is nothing to distil)."""
-        if not (self.distillation and img.is_cuda) or self._taps_override is not None:
+        if not (self.distillation and img.is_cuda) or self._taps_override is not None or not self.prefetch_ok:
             return
         taps, ev = self._launch_teacher(img)
         self._prefetched = (img.data_ptr(), img._version, tuple(img.shape), taps, ev)
