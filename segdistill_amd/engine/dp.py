@@ -23,12 +23,16 @@ def init_distributed(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('SEGDISTILL_FORCE_DEVICE') is not None:
+        local = int(os.environ['SEGDISTILL_FORCE_DEVICE'])
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # SEGDISTILL_DIST_BACKEND=gloo lets several ranks share ONE GPU (RCCL refuses duplicate devices): used to exercise the
+            # multi-rank GPU code path -- SyncBN, flat all-reduce, hybrid graphs -- on a single-GPU box; never for measurements
+            backend = os.environ.get('SEGDISTILL_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
