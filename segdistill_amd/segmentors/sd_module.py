@@ -96,10 +96,6 @@ class SDModule(BaseSegmentor):
     def my_resume(self, iter):
         self.cnt = iter
 
-    def state_dict(self, *args, **kwargs):
-        sd = super().state_dict(*args, **kwargs)
-        return sd
-
     def _teacher_forward(self, img, img_metas, gt_semantic_seg):
         with torch.no_grad():
             if self.teacher_train_mode:
