@@ -296,3 +296,57 @@ def test_at_ifvd_pd_against_reference_golden(golden):
     loss = KLDLoss(alpha=1.5, tau=2)(s, torch.tensor(t0, dtype=torch.float32, device=dev), gt, 1)
     ref = kd_ref.eager_kld(torch.tensor(s0), torch.tensor(t0), alpha=1.5, tau=2, loss_type=None, group_size=None)
     assert float(loss) == pytest.approx(float(ref), rel=LOSS_RTOL)
+
+
+# ------------------------------------------------------------------ degenerate / extreme shapes
+@pytest.mark.parametrize('case', [
+    (1, 1, 1, 1, 1),        # a single element: softmax of one value, KL == 0
+    (1, 1, 1, 1, 5),        # group larger than the channel count, single pixel
+    (2, 3, 1, 7, 2),        # one-row images, ragged group (3 % 2 != 0)
+    (1, 2, 3, 1, 2),        # one-column images
+    (5, 1, 2, 2, 1),        # C == 1
+    (1, 700, 2, 2, 64),     # many channels, many groups, tiny planes
+])
+def test_r1_degenerate_shapes(case):
+    B, C, H, W, g = case
+    S, T = wavy_pair((B, C, H, W))
+    ref = kd_ref.rowwise_kld(S, T, alpha=2.0, tau=1.5, group_size=g)
+    loss, rows, grad = _run_hip(S, T, g, 1.5, 2.0)
+    assert loss == pytest.approx(ref['loss'], rel=LOSS_RTOL, abs=1e-7)
+    np.testing.assert_allclose(rows, ref['row_kl'], rtol=1e-4, atol=1e-6)
+    if np.abs(ref['grad_S']).max() > 0:
+        assert _rel_l2(grad, ref['grad_S']) < GRAD_RL2
+    else:
+        assert np.abs(grad).max() < 1e-7
+
+
+@pytest.mark.parametrize('case', [(1, 1, 1, 1, 2, 1), (1, 3, 1, 1, 8, 2), (2, 2, 1, 5, 4, 1), (1, 2, 3, 1, 2, 2)])
+def test_r2_degenerate_shapes(case):
+    B, C, h, w, F, g = case
+    s, t = wavy_pair((B, C, h, w))
+    ref = kd_ref.full_kld(s, t, out_size=(h * F, w * F), alpha=1.0, tau=2.0, group_size=g)
+    loss, rows, grad = _run_hip_up(s, t, F, g, 2.0, 1.0)
+    assert loss == pytest.approx(ref['loss'], rel=LOSS_RTOL, abs=1e-7)
+    if np.abs(ref['grad_s']).max() > 0:
+        assert _rel_l2(grad, ref['grad_s']) < GRAD_RL2
+
+
+def test_extreme_logit_magnitudes_and_pad_semantics():
+    """Huge logits (the reference pads with -1e9) and fully saturated softmaxes stay finite and match the oracle; a REAL channel
+    holding the pad value -1e9 behaves exactly like the virtual padding."""
+    S, T = wavy_pair((1, 4, 8, 8))
+    S = S.copy(); T = T.copy()
+    S[0, 0] *= 50.0
+    T[0, 1] = T[0, 1] * 40.0 - 300.0
+    ref = kd_ref.rowwise_kld(S, T, alpha=1.0, tau=1.0, group_size=2)
+    loss, rows, grad = _run_hip(S, T, 2, 1.0, 1.0)
+    assert np.isfinite(loss) and np.isfinite(grad).all()
+    assert loss == pytest.approx(ref['loss'], rel=1e-4)
+    assert _rel_l2(grad, ref['grad_S']) < 1e-3
+    # C=3, g=2: the second group is {channel 2, virtual pad}; materialising the pad as a 4th channel of -1e9 (what the reference
+    # does, losses.py:55-58) must give the same loss
+    S3, T3 = wavy_pair((1, 3, 8, 8))
+    loss_virtual, _, _ = _run_hip(S3, T3, 2, 2.0, 1.0)
+    pad = np.full((1, 1, 8, 8), -1e9, np.float32)
+    loss_real, _, _ = _run_hip(np.concatenate([S3, pad], 1), np.concatenate([T3, pad], 1), 2, 2.0, 1.0)
+    assert loss_real == pytest.approx(loss_virtual, rel=1e-6)

@@ -337,3 +337,30 @@ def test_checkpoint_resume_restores_iteration_and_distillation_step(tmp_path):
         assert torch.equal(a, b)
     s1, s2 = t1.optimizer.state_dict()['state'], t2.optimizer.state_dict()['state']
     assert s1.keys() == s2.keys() and all(torch.equal(s1[k]['exp_avg'], s2[k]['exp_avg']) for k in s1)
+
+
+def test_extractor_and_loss_dispatch_errors_and_naming():
+    import segdistill_amd
+    from segdistill_amd.distillation import DistillationLoss, Extractor
+    segdistill_amd.register_all()
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.ReLU())
+    with pytest.raises(KeyError, match='no module named'):
+        Extractor(net, net, [dict(student_layer='nope', teacher_layer='0', loss_name='CDLoss', loss_config={})])
+    ex = Extractor(net, copy_net := torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.ReLU()),
+                   [dict(student_layer='0', teacher_layer='1', loss_name='CDLoss', loss_config={})])
+    x = torch.randn(1, 3, 5, 5)
+    ex.train()
+    net(x); copy_net(x)
+    assert list(ex.student_features) == ['0'] and list(ex.teacher_features) == ['1']
+    ex.clear(); ex.eval()
+    net(x); copy_net(x)
+    assert not ex.student_features and not ex.teacher_features      # taps are recorded only while training (opts.py:67)
+    with pytest.raises(KeyError, match='not a registered distillation loss'):
+        DistillationLoss([dict(student_layer='a', teacher_layer='b', loss_name='os.system', loss_config={})])  # no eval() of config strings
+    dl = DistillationLoss([dict(student_layer='a', teacher_layer='b', loss_name='CGDLoss', loss_config=({'group_size': 4},))])   # 1-tuple config
+    assert dl.criteria[0].transform_config['group_size'] == 4
+    with pytest.raises(ValueError, match='square map'):
+        from segdistill_amd.distillation.opts import _to_nchw
+        _to_nchw(torch.zeros(1, 10, 4))
+    from segdistill_amd.distillation.opts import _to_nchw
+    assert _to_nchw(torch.zeros(2, 16, 7)).shape == (2, 7, 4, 4)
