@@ -55,7 +55,7 @@ class _DepthwiseConv(nn.Module):
     def forward(self, tokens, hw):
         from .. import dwconv as hip_dw
         conv = self.dwconv
-        if hip_dw.supported(tokens, conv.weight) and not torch.is_autocast_enabled():
+        if hip_dw.supported(tokens, conv.weight):   # fp32 or bf16 storage (autocast hands over bf16 tokens), fp32 accumulation
             # MI355X path: token-major depth-wise kernels, no NCHW round trip (csrc/dwconv.hip)
             return hip_dw.dwconv3x3_tokens(tokens, conv.weight, conv.bias, hw[0], hw[1])
         b, n, c = tokens.shape
@@ -77,7 +77,7 @@ class MixFFN(nn.Module):
         conv = self.dwconv.dwconv
         from .. import dwconv as hip_dw
         if (not torch.is_grad_enabled() and isinstance(self.act, nn.GELU) and getattr(self.act, 'approximate', 'none') == 'none'
-                and hip_dw.supported(h, conv.weight) and not torch.is_autocast_enabled()
+                and hip_dw.supported(h, conv.weight)
                 and not (self.dwconv._forward_hooks or conv._forward_hooks or self.act._forward_hooks)):
             h = hip_dw.dwconv3x3_gelu_tokens_inference(h, conv.weight, conv.bias, hw[0], hw[1])   # frozen-teacher path
         else:

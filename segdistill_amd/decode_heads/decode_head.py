@@ -88,7 +88,7 @@ class BaseDecodeHead(nn.Module, metaclass=ABCMeta):
         from ..losses import CrossEntropyLoss
         crit = self.loss_decode
         if not (isinstance(crit, CrossEntropyLoss) and crit.class_weight is None and not self.align_corners and self.ignore_index is not None
-                and not torch.is_autocast_enabled() and hip_ce.supported(seg_logit, seg_label.shape[2:])):
+                and hip_ce.supported(seg_logit, seg_label.shape[2:])):
             return None
         loss_pix, hits = hip_ce.fused_ce_up(seg_logit, seg_label, self.ignore_index)
         if crit.reduction == 'mean':

@@ -76,7 +76,7 @@ class SegFormerHead(BaseDecodeHead):
             sizes.append(tuple(feat.shape[2:]))
         zs, sizes = zs[::-1], sizes[::-1]                             # finest (c1) first
         bias = self.linear_fuse.conv.bias
-        if headfuse.supported(zs, sizes) and not torch.is_autocast_enabled():
+        if headfuse.supported(zs, sizes):
             # MI355X path (csrc/headfuse.hip): one pass, y = z1 + up(z2) + up(z3) + up(z4) + bias, token-major
             y = headfuse.upsum(zs[0], zs[1], zs[2], zs[3], bias, sizes)
             return y.reshape(n, size[0], size[1], e).permute(0, 3, 1, 2)   # NCHW view with channels-last strides

@@ -48,6 +48,6 @@ class _LayerNormFn(torch.autograd.Function):
 class HipLayerNorm(nn.LayerNorm):
     def forward(self, x):
         if (x.is_cuda and x.dtype in _DT and self.elementwise_affine and self.bias is not None and len(self.normalized_shape) == 1
-                and not torch.is_autocast_enabled() and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024 and x.numel() > 0):
+                and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024 and x.numel() > 0):
             return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
         return super().forward(x)
