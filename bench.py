@@ -278,7 +278,8 @@ def main():
 
     if rank == 0:
         line = {
-            'metric': 'imgs/sec/node KD train_step, Segformer-B2->B0 512x512', 'value': round(world * B * args.steps / dt, 3),
+            'metric': 'imgs/sec/node KD train_step, ' + ('Segformer-B2->B0 512x512' if 'cfg2' in os.path.basename(args.config)
+                                                          else os.path.basename(args.config)), 'value': round(world * B * args.steps / dt, 3),
             'unit': 'imgs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if trainer.bf16 else 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: Segformer-B0 student + B2 teacher, CGD group=8 T=4 alpha=3, 512x512, 150 classes'

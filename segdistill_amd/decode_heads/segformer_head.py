@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ..builder import HEADS, build_loss
 from ..layers import ConvModule, resize, tokens_of
@@ -127,9 +128,16 @@ class SegFormerHead(BaseDecodeHead):
             return pred(fused)
         b, e, h, w = fused.shape
         tokens = tokens_of(fused)                                              # [B, HW, E] view
-        out = torch.matmul(pred.weight.view(pred.out_channels, e), tokens.transpose(1, 2))   # [B, classes, HW], contiguous
-        if pred.bias is not None:
-            out = out + pred.bias.view(1, -1, 1)
+        w2d = pred.weight.view(pred.out_channels, e)
+        if torch.is_autocast_enabled() or fused.dtype != torch.float32:
+            # ROCm 7.0 hipBLASLt: the bf16 form W[150,E] x tokens^T (batched, E=768, HW=16384) selects a stream-K kernel that
+            # reads out of bounds (tools/gemm_fault_probe.py reproduces the GPU memory fault).  The plain Linear form is
+            # safe; its [B, HW, classes] result is transposed with one small copy.
+            out = F.linear(tokens, w2d, pred.bias).transpose(1, 2).contiguous()
+        else:
+            out = torch.matmul(w2d, tokens.transpose(1, 2))                    # [B, classes, HW], contiguous
+            if pred.bias is not None:
+                out = out + pred.bias.view(1, -1, 1)
         out = out.view(b, pred.out_channels, h, w)
         for hook in pred._forward_hooks.values():
             r = hook(pred, (fused,), out)

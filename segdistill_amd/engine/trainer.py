@@ -3,6 +3,8 @@ OptimizerHook: ``zero_grad -> train_step -> loss.backward -> step``, reference
 mmseg/apis/train.py:97-138 and SURVEY.md Appendix B), on the MI355X-first DP substrate."""
 from __future__ import annotations
 
+import contextlib
+
 import torch
 
 from .dp import DataParallelReducer
@@ -65,6 +67,8 @@ class KDTrainer:
         # precision=dict(activations='bf16'): bf16 storage of activations / tapped features (autocast), fp32 master weights,
         # fp32 accumulation inside every HIP kernel (BASELINE config 5)
         self.bf16 = bool(precision) and precision.get('activations') == 'bf16'
+        if self.bf16 and hasattr(model, 'activation_dtype'):
+            model.activation_dtype = torch.bfloat16     # the teacher forward opens its own autocast region (sd_module.py)
 
     # ---- hipGraph mode ------------------------------------------------------------------------------------------------
     # The KD step is ~1300 kernel launches; eager host enqueue costs ~24 ms/step on the GPU box (tools/host_probe.py),
@@ -166,7 +170,8 @@ class KDTrainer:
             # (1) student backbone: forward + backward graphs, replayed from inside eager autograd
             wrapper = _TupleOut(m.student.backbone)
             wrapper.train()
-            torch.cuda.make_graphed_callables(wrapper, (h_img,), num_warmup_iters=2)
+            with self._autocast(cache_enabled=False):   # graphed callables must not share autocast's weight-cast cache
+                torch.cuda.make_graphed_callables(wrapper, (h_img,), num_warmup_iters=2)
             object.__setattr__(m.student, '_graphed_backbone', wrapper)   # not registered as a sub-module (state dict unchanged)
             # (2) teacher: forward-only graph on the side stream; its tapped features are static outputs
             side = m._side_stream or torch.cuda.Stream(device=img.device)
@@ -199,11 +204,13 @@ class KDTrainer:
             torch.cuda.synchronize()
             return False
 
+    def _autocast(self, cache_enabled=True):
+        if self.bf16 and torch.cuda.is_available():
+            return torch.autocast('cuda', dtype=torch.bfloat16, cache_enabled=cache_enabled)
+        return contextlib.nullcontext()
+
     def _fwd_bwd(self, batch):
-        if self.bf16 and batch['img'].is_cuda:
-            with torch.autocast('cuda', dtype=torch.bfloat16):
-                out = self.model.train_step(batch, self.optimizer)
-        else:
+        with (self._autocast() if batch['img'].is_cuda else contextlib.nullcontext()):
             out = self.model.train_step(batch, self.optimizer)
         out['loss'].backward()
         return out
@@ -258,12 +265,9 @@ class KDTrainer:
             out = self._graph_step(batch, next_batch)
         else:
             self.reducer.zero_grad()
-            if self.bf16 and batch['img'].is_cuda:
-                with torch.autocast('cuda', dtype=torch.bfloat16):
-                    out = self.model.train_step(batch, self.optimizer)
-            else:
+            with (self._autocast() if batch['img'].is_cuda else contextlib.nullcontext()):
                 out = self.model.train_step(batch, self.optimizer)
-            if next_batch is not None and hasattr(self.model, 'prefetch_teacher') and not self.bf16:
+            if next_batch is not None and hasattr(self.model, 'prefetch_teacher'):
                 self.model.prefetch_teacher(next_batch['img'])
             out['loss'].backward()
         self.reducer.all_reduce()

@@ -16,6 +16,7 @@ Deliberate differences:
 """
 from __future__ import annotations
 
+import contextlib
 import copy
 import os
 import warnings
@@ -86,6 +87,7 @@ class SDModule(BaseSegmentor):
         self._prefetched = None       # (img identity, taps, event) of a teacher forward launched ahead of its iteration
         self._taps_override = None    # static teacher taps while a captured student step is being recorded / replayed
         self.prefetch_ok = True       # cleared by the trainer if overlapping the teacher with graph replays would be unsafe
+        self.activation_dtype = None  # torch.bfloat16 when the trainer runs the networks under autocast (precision cfg)
 
     def train(self, mode=True):
         super().train(mode)
@@ -97,7 +99,11 @@ class SDModule(BaseSegmentor):
         self.cnt = iter
 
     def _teacher_forward(self, img, img_metas, gt_semantic_seg):
-        with torch.no_grad():
+        # the teacher is launched from several places (inline, side stream, prefetch, graph capture): it carries its own
+        # autocast region so that its taps have the student's activation dtype wherever the call comes from
+        amp = (torch.autocast('cuda', dtype=self.activation_dtype) if self.activation_dtype is not None and img.is_cuda
+               else contextlib.nullcontext())
+        with torch.no_grad(), amp:
             if self.teacher_train_mode:
                 self.teacher(img, img_metas, return_loss=True, gt_semantic_seg=gt_semantic_seg)  # reference behaviour
             else:

@@ -77,3 +77,35 @@ def test_graph_replay_matches_eager(mode):
     num = sum(float((a - b).pow(2).sum()) for a, b in zip(ref.student.parameters(), gra.student.parameters()))
     den = sum(float(a.pow(2).sum()) for a in ref.student.parameters())
     assert (num / den) ** 0.5 < 3e-4
+
+
+@pytest.mark.parametrize('mode', ['full', 'hybrid', 'eager_prefetch'])
+def test_bf16_graph_modes_match_eager(mode):
+    """precision=dict(activations='bf16') (BASELINE config 5): the teacher graph / prefetch must run under the same
+    autocast as the student, whichever mode launches it; the first iteration is bit-comparable up to bf16 reordering."""
+    from segdistill_amd.engine import KDTrainer, SyntheticADE
+    opt = dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+    prec = dict(activations='bf16')
+    ref = _model()
+    gra = copy.deepcopy(ref)
+    t_e = KDTrainer(ref, opt, None, precision=prec)
+    t_g = KDTrainer(gra, opt, None, precision=prec)
+    assert t_g.bf16 and gra.activation_dtype == torch.bfloat16
+    data_e = SyntheticADE(2, size=(128, 128), device='cuda:0', pool=3, seed=1)
+    data_g = SyntheticADE(2, size=(128, 128), device='cuda:0', pool=3, seed=1)
+    example = dict(img=data_g._pool[0][0], img_metas=None, gt_semantic_seg=data_g._pool[0][1])
+    if mode != 'eager_prefetch':
+        assert (t_g.enable_graph(example) if mode == 'full' else t_g.enable_hybrid_graph(example))
+    cur_g = data_g.next()
+    for it in range(3):
+        torch.manual_seed(100 + it)
+        t_e.step(data_e.next())
+        torch.manual_seed(100 + it)
+        nxt_g = data_g.next()
+        t_g.step(cur_g, nxt_g)
+        cur_g = nxt_g
+        ve, vg = t_e.log_values(), t_g.log_values()
+        assert list(ve) == list(vg)
+        for k in ve:
+            tol = 100.0 * 64 / (2 * 128 * 128) if 'acc' in k else 2e-2 * max(1.0, abs(ve[k]))
+            assert vg[k] == pytest.approx(ve[k], abs=tol), (it, k, ve[k], vg[k])
