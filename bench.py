@@ -48,7 +48,7 @@ def build_model(cfg, device):
 
 
 def timed_steps(trainer, data, steps, world):
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -58,7 +58,7 @@ def timed_steps(trainer, data, steps, world):
         trainer.step(cur, nxt)
         cur = nxt
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     return time.perf_counter() - t0
 
@@ -262,7 +262,7 @@ def main():
     n_eager_warm = max(1, args.warmup // 2)
     for _ in range(n_eager_warm):            # eager warm-up first (MIOpen find, hipBLASLt heuristics, allocator)
         trainer.step(data.next())
-    mode = args.graph if args.graph != 'auto' else ('on' if world == 1 else 'hybrid')
+    mode = args.graph if args.graph != 'auto' else ('on' if world == 1 and not dist.is_initialized() else 'hybrid')
     if mode == 'on':
         graphed = 'full' if trainer.enable_graph(data.next()) else False
     elif mode == 'hybrid':
@@ -271,7 +271,7 @@ def main():
         trainer.step(data.next())
     dt = timed_steps(trainer, data, args.steps, world)
     t = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     logs = trainer.log_values()
@@ -297,7 +297,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline_leg(cfg, max_threads=args.cpu_threads)
         print(json.dumps(line))
         sys.stdout.flush()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -17,6 +17,10 @@ import torch
 import torch.distributed as dist
 
 
+def force_collectives():
+    return os.environ.get('SEGDISTILL_FORCE_COLLECTIVES') == '1'
+
+
 def init_distributed(backend=None):
     """Initialise from torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
     Returns (rank, local_rank, world)."""
@@ -25,7 +29,10 @@ def init_distributed(backend=None):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if os.environ.get('SEGDISTILL_FORCE_DEVICE') is not None:
         local = int(os.environ['SEGDISTILL_FORCE_DEVICE'])
-    if world > 1 and not dist.is_initialized():
+    # SEGDISTILL_FORCE_COLLECTIVES=1: create the process group and issue the gradient all-reduce even with ONE rank, so
+    # that RCCL initialisation, the flat all-reduce and hipGraph capture next to RCCL's watchdog thread can be exercised on a
+    # single-GPU box (tests/test_rccl_single_rank_gpu.py)
+    if (world > 1 or force_collectives()) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -53,6 +60,7 @@ class DataParallelReducer:
         if not self.params:
             raise ValueError('no trainable parameters')
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.collective = self.world > 1 or (force_collectives() and dist.is_initialized())
         dev, dt = self.params[0].device, self.params[0].dtype
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, device=dev, dtype=dt)
@@ -72,12 +80,12 @@ class DataParallelReducer:
             p.grad = None
 
     def broadcast_parameters(self, module):
-        if self.world > 1:
+        if self.collective:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=0)
 
     def all_reduce(self):
-        if self.world <= 1:
+        if not self.collective:
             return
         grads, views = [], []
         for p, v in zip(self.params, self.views):
