@@ -254,6 +254,41 @@ int sd_layernorm_bwd(const void *x, const void *dy, const float *gamma, const fl
                      void *dx, float *dgamma, float *dbeta, int dtype, long rows, int C,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* Residual form: the encoder block's "x = x + drop_path(f(x))" (mix_transformer.py:150-151; timm DropPath: per-sample
+ * factor mask/keep_prob) fused with the LayerNorm that consumes the sum (the block's norm2, the next block's norm1 or the
+ * stage norm :336-365):
+ *   fwd   xsum = x + s * res,  y = LayerNorm(xsum);   s = row_scale[row / rows_per_sample] (row_scale NULL -> 1)
+ *   bwd   dx = dLayerNorm(dy) + dres (dres NULL -> 0): gradient of x;  dr = s * dx: gradient of res (dr NULL when row_scale is
+ *         NULL -- then dx is also the gradient of res);  dgamma / dbeta as sd_layernorm_bwd.  Same workspace size. */
+int sd_add_layernorm_fwd(const void *x, const void *res, const float *row_scale /* [rows/rows_per_sample] or NULL */,
+                         long rows_per_sample, void *xsum, const float *gamma, const float *beta, void *y,
+                         float *mean, float *rstd, int dtype, long rows, int C, float eps, void *stream);
+
+int sd_add_layernorm_bwd(const void *xsum, const void *dy, const float *gamma, const float *mean, const float *rstd,
+                         const void *dres /* or NULL */, const float *row_scale /* or NULL */, long rows_per_sample,
+                         void *dx, void *dr /* or NULL */, float *dgamma, float *dbeta, int dtype, long rows, int C,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * MiT spatial-reduction attention (mix_transformer.py:107-133: q Linear :75, kv Linear :76 on the sr-conv reduced map
+ * :112-116, softmax(scale * q k^T) v :119-123), forward and backward, all heads in one launch.
+ *   q    [B, N, heads*D]      the q Linear output as it is
+ *   kv   [B, KV, 2*heads*D]   the kv Linear output as it is (inner order: k|v, head, D -- the reference's reshape :116)
+ *   out  [B, N, heads*D]      what the proj Linear consumes (the reference's transpose(1,2).reshape :123)
+ *   lse  [B, heads, N] fp32   base-2 log-sum-exp of the scaled scores (saved for the backward)
+ * head_dim D in {32, 64}; any N; KV <= 256 (K and V of a head are staged in LDS; KV = 256 at 512x512).  fp32-exact MFMA
+ * (v_mfma_f32_32x32x2_f32), bf16 storage optional.  dkv has kv's layout.
+ */
+int sd_sra_supported(int head_dim);
+size_t sd_sra_workspace_bytes(int B, int N, int KV, int heads, int D);   /* backward only */
+
+int sd_sra_fwd(const void *q, const void *kv, void *out, float *lse, int dtype,
+               int B, int N, int KV, int heads, int D, float scale, void *stream);
+
+int sd_sra_bwd(const void *q, const void *kv, const void *out, const void *dout, const float *lse,
+               void *dq, void *dkv, int dtype, int B, int N, int KV, int heads, int D, float scale,
+               void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------
  * SegFormer head: y = z1 + up(z2) + up(z3) + up(z4) + bias on token-major tensors, one pass.
  * Replaces the three resize() calls, the torch.cat and (together with the per-branch fuse GEMMs done

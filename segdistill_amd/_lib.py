@@ -57,6 +57,12 @@ SIGNATURES = {
     'sd_layernorm_workspace_bytes': (_sz, [C.c_long, _i]),
     'sd_layernorm_fwd': (_i, [_vp] * 6 + [_i, C.c_long, _i, _f, _vp]),
     'sd_layernorm_bwd': (_i, [_vp] * 8 + [_i, C.c_long, _i, _vp, _sz, _vp]),
+    'sd_sra_supported': (_i, [_i]),
+    'sd_sra_workspace_bytes': (_sz, [_i] * 5),
+    'sd_sra_fwd': (_i, [_vp] * 4 + [_i] * 6 + [_f, _vp]),
+    'sd_sra_bwd': (_i, [_vp] * 7 + [_i] * 6 + [_f, _vp, _sz, _vp]),
+    'sd_add_layernorm_fwd': (_i, [_vp] * 3 + [C.c_long] + [_vp] * 6 + [_i, C.c_long, _i, _f, _vp]),
+    'sd_add_layernorm_bwd': (_i, [_vp] * 7 + [C.c_long] + [_vp] * 4 + [_i, C.c_long, _i, _vp, _sz, _vp]),
     'sd_upsum_fwd': (_i, [_vp] * 6 + [_i] * 8 + [_vp]),
     'sd_upsum_bwd': (_i, [_vp, _vp] + [_i] * 6 + [_vp]),
     'sd_ce_up_supported': (_i, [_i, _i, _i, _i]),

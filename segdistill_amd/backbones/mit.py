@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from ..builder import BACKBONES
 from ..layers import DropPath, nchw_view_of_tokens, tokens_of, trunc_normal_
-from ..layernorm import HipLayerNorm
+from ..layernorm import HipLayerNorm, add_layernorm, add_layernorm_supported
 from ..linear import call_linear, longk_linear
 
 
@@ -119,15 +119,25 @@ class SRAttention(nn.Module):
         return longk_linear(patches, w2, conv.bias)
 
     def forward(self, x, hw):
+        from .. import sra as hip_sra
         b, n, c = x.shape
         h, d = self.num_heads, c // self.num_heads
-        q = self.Q(call_linear(self.q, x).reshape(b, n, h, d).transpose(1, 2))
+        q_lin = call_linear(self.q, x)
         src = x
         if self.sr_ratio > 1:
             src = self.norm(self._spatial_reduce(x, hw))
-        kv = call_linear(self.kv, src).reshape(b, -1, 2, h, d).permute(2, 0, 3, 1, 4)
+        kv_lin = call_linear(self.kv, src)
+        observed = any(t._forward_hooks or t._forward_pre_hooks for t in (self.ATTN, self.Q, self.K, self.V))
+        dropping = self.training and self.attn_drop.p > 0
+        if not observed and not dropping and hip_sra.supported(q_lin, kv_lin, h) and hip_sra.preferred(n, kv_lin.shape[1], d, q_lin):
+            # MI355X path (csrc/sra_attn.hip): all heads in one launch straight from the Linear outputs -- no head transposes,
+            # no [B,heads,N,KV] score tensor
+            out = hip_sra.sr_attention(q_lin, kv_lin, h, self.scale)
+            return self.proj_drop(call_linear(self.proj, out))
+        q = self.Q(q_lin.reshape(b, n, h, d).transpose(1, 2))
+        kv = kv_lin.reshape(b, -1, 2, h, d).permute(2, 0, 3, 1, 4)
         k, v = self.K(kv[0]), self.V(kv[1])
-        explicit = bool(self.ATTN._forward_hooks) or (self.training and self.attn_drop.p > 0)
+        explicit = bool(self.ATTN._forward_hooks) or dropping
         # measured on MI355X (tools/attn_probe.py, fp32): the fused SDPA kernels win everywhere in the forward, but their
         # backward parallelises over the 256 keys only; with >= 8192 queries the explicit form's fwd+bwd is 1.7-2.2x faster
         explicit = explicit or (n >= 8192 and torch.is_grad_enabled() and x.requires_grad)
@@ -154,6 +164,33 @@ class EncoderBlock(nn.Module):
         x = x + self.drop_path(self.attn(self.norm1(x), hw))
         x = x + self.drop_path(self.mlp(self.norm2(x), hw))
         return self.FEA(x)
+
+    def _observed(self):
+        """True when somebody hooks this block or a module whose output the fused stage loop never materialises on its own."""
+        mods = (self, self.norm1, self.norm2, self.drop_path, self.FEA)
+        return any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in mods)
+
+    def _scale(self, x):
+        return self.drop_path.sample_scale(x) if isinstance(self.drop_path, DropPath) else None
+
+
+def _run_stage(x, hw, blocks, stage_norm):
+    """blocks + stage norm on tokens x.  MI355X path: every residual add (with its stochastic-depth factor) is fused with the
+    LayerNorm that consumes the sum -- the block's norm2, the next block's norm1, or the stage norm -- so the residual stream
+    is read and written once per half-block instead of three times (csrc/layernorm.hip, residual form).  Falls back to the
+    literal block-by-block form when a hook observes an intermediate or the shape is unsupported."""
+    norms = [b.norm1 for b in blocks[1:]] + [stage_norm]
+    fused = (len(blocks) > 0 and not any(b._observed() for b in blocks)
+             and all(add_layernorm_supported(x, x, n) for b, nx in zip(blocks, norms) for n in (b.norm2, nx)))
+    if not fused:
+        for blk in blocks:
+            x = blk(x, hw)
+        return stage_norm(x)
+    n = blocks[0].norm1(x)
+    for blk, nxt in zip(blocks, norms):
+        x, n = add_layernorm(x, blk.attn(n, hw), blk.norm2, blk._scale(x))
+        x, n = add_layernorm(x, blk.mlp(n, hw), nxt, blk._scale(x))
+    return n
 
 
 class OverlapPatchEmbed(nn.Module):
@@ -208,9 +245,7 @@ class MixVisionTransformer(nn.Module):
         feats = []
         for s in range(1, 5):
             x, hw = getattr(self, f'patch_embed{s}')(x)
-            for blk in getattr(self, f'block{s}'):
-                x = blk(x, hw)
-            x = getattr(self, f'norm{s}')(x)
+            x = _run_stage(x, hw, list(getattr(self, f'block{s}')), getattr(self, f'norm{s}'))
             # logically [B,C,H,W] like the reference (:340,:347,...), but as a channels-last VIEW of the tokens on the GPU:
             # the next stage's conv and the head consume it without the two transpose copies per stage
             x = nchw_view_of_tokens(x, hw) if x.is_cuda else x.reshape(x.shape[0], hw[0], hw[1], -1).permute(0, 3, 1, 2).contiguous()

@@ -28,6 +28,7 @@ template <typename T> struct LV;
 template <> struct LV<float> {
     static __device__ __forceinline__ float4 load(const float *p) { return *reinterpret_cast<const float4 *>(p); }
     static __device__ __forceinline__ void store(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+    static __device__ __forceinline__ float4 round(float4 v) { return v; }
 };
 template <> struct LV<bf16_t> {  // 4 bf16 = 8 bytes
     static __device__ __forceinline__ float4 load(const bf16_t *p) {
@@ -41,6 +42,10 @@ template <> struct LV<bf16_t> {  // 4 bf16 = 8 bytes
         o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
         *reinterpret_cast<uint2 *>(p) = o;
     }
+    static __device__ __forceinline__ float4 round(float4 v) {  // value after a store/load round trip
+        return make_float4(__uint_as_float((unsigned)f32_to_bf16(v.x) << 16), __uint_as_float((unsigned)f32_to_bf16(v.y) << 16),
+                           __uint_as_float((unsigned)f32_to_bf16(v.z) << 16), __uint_as_float((unsigned)f32_to_bf16(v.w) << 16));
+    }
 };
 
 template <int G> __device__ __forceinline__ float group_sum(float v) {
@@ -50,20 +55,31 @@ template <int G> __device__ __forceinline__ float group_sum(float v) {
 }
 
 // grid: ceil(rows / rows_per_block); rows_per_block = kLnThreads / G
+// Residual form (res != nullptr): the row that is normalised is  xsum = x + scale * res  (scale = row_scale[row / rows_per_sample],
+// the stochastic-depth factor of that sample, or 1), and xsum is written out as well -- the block's "x = x + drop_path(f(x))"
+// followed by the next LayerNorm in ONE pass (reference mix_transformer.py:150-151).
 template <typename T, int G, int V>
-__global__ __launch_bounds__(kLnThreads) void ln_fwd(const T *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                      T *__restrict__ y, float *__restrict__ mean_out, float *__restrict__ rstd_out,
-                                                      long rows, int C, float eps) {
+__global__ __launch_bounds__(kLnThreads) void ln_fwd(const T *__restrict__ x, const T *__restrict__ res, const float *__restrict__ row_scale,
+                                                      long rows_per_sample, T *__restrict__ xsum, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, T *__restrict__ y, float *__restrict__ mean_out,
+                                                      float *__restrict__ rstd_out, long rows, int C, float eps) {
     const int gl = threadIdx.x % G;
     const long row = (long)blockIdx.x * (kLnThreads / G) + threadIdx.x / G;
     const bool live = row < rows;
     const int cv = C / 4;
     float4 v[V];
     float s = 0.f;
+    const float sc = (res && row_scale && live) ? row_scale[row / rows_per_sample] : 1.f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int j = gl + i * G;
         v[i] = (live && j < cv) ? LV<T>::load(x + row * C + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res && live && j < cv) {
+            const float4 rv = LV<T>::load(res + row * C + 4 * j);
+            v[i].x = fmaf(sc, rv.x, v[i].x); v[i].y = fmaf(sc, rv.y, v[i].y); v[i].z = fmaf(sc, rv.z, v[i].z); v[i].w = fmaf(sc, rv.w, v[i].w);
+            LV<T>::store(xsum + row * C + 4 * j, v[i]);
+            v[i] = LV<T>::round(v[i]);   // normalise exactly what later passes will read back
+        }
         s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
     const float mean = group_sum<G>(s) / C;
@@ -96,10 +112,13 @@ __global__ __launch_bounds__(kLnThreads) void ln_fwd(const T *__restrict__ x, co
 
 // grid: nblk workgroups, each walking rows blockIdx.x*RPB + k*gridDim.x*RPB ...; partial dgamma/dbeta per workgroup in
 // part[blk][2][C] (gamma first).
+// Residual form: dres (nullable) is the gradient that reaches the normalised row from its OTHER consumer (the residual path) and is
+// added into dx; dr (nullable) receives row_scale * dx, the gradient of the scaled residual branch.
 template <typename T, int G, int V>
 __global__ __launch_bounds__(kLnThreads) void ln_bwd(const T *__restrict__ x, const T *__restrict__ dy, const float *__restrict__ gamma,
-                                                      const float *__restrict__ mean_in, const float *__restrict__ rstd_in, T *__restrict__ dx,
-                                                      float *__restrict__ part, long rows, int C) {
+                                                      const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
+                                                      const T *__restrict__ dres, const float *__restrict__ row_scale, long rows_per_sample,
+                                                      T *__restrict__ dx, T *__restrict__ dr, float *__restrict__ part, long rows, int C) {
     extern __shared__ float red[];  // [RPB][2][C]
     constexpr int RPB = kLnThreads / G;
     const int gl = threadIdx.x % G, rg = threadIdx.x / G;
@@ -130,6 +149,7 @@ __global__ __launch_bounds__(kLnThreads) void ln_bwd(const T *__restrict__ x, co
             }
         }
         const float m1 = group_sum<G>(s1) / C, m2 = group_sum<G>(s2) / C;
+        const float sc = (dr && row_scale) ? row_scale[row / rows_per_sample] : 1.f;
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const int j = gl + i * G;
@@ -139,7 +159,15 @@ __global__ __launch_bounds__(kLnThreads) void ln_bwd(const T *__restrict__ x, co
                 o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
                 o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
                 o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
+                if (dres) {
+                    const float4 e = LV<T>::load(dres + row * C + 4 * j);
+                    o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+                }
                 LV<T>::store(dx + row * C + 4 * j, o);
+                if (dr) {
+                    o = LV<T>::round(o);
+                    LV<T>::store(dr + row * C + 4 * j, make_float4(sc * o.x, sc * o.y, sc * o.z, sc * o.w));
+                }
             }
         }
     }
@@ -210,20 +238,21 @@ int ln_bwd_blocks(long rows, int G) {
     } while (0)
 
 template <typename T>
-int ln_fwd_launch(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd, long rows, int C, float eps,
-                  hipStream_t st) {
+int ln_fwd_launch(const void *x, const void *res, const float *row_scale, long rows_per_sample, void *xsum, const float *gamma,
+                  const float *beta, void *y, float *mean, float *rstd, long rows, int C, float eps, hipStream_t st) {
     const LnPlan p = ln_plan(C);
 #define SD_CALL(GG, VV)                                                                                                              \
     hipLaunchKernelGGL((ln_fwd<T, GG, VV>), dim3((unsigned)((rows + kLnThreads / GG - 1) / (kLnThreads / GG))), dim3(kLnThreads), 0, st, \
-                       (const T *)x, gamma, beta, (T *)y, mean, rstd, rows, C, eps)
+                       (const T *)x, (const T *)res, row_scale, rows_per_sample, (T *)xsum, gamma, beta, (T *)y, mean, rstd, rows, C, eps)
     SD_LN_DISPATCH(SD_CALL);
 #undef SD_CALL
     return (int)hipGetLastError();
 }
 
 template <typename T>
-int ln_bwd_launch(const void *x, const void *dy, const float *gamma, const float *mean, const float *rstd, void *dx, float *dgamma,
-                  float *dbeta, void *ws, size_t ws_bytes, long rows, int C, hipStream_t st) {
+int ln_bwd_launch(const void *x, const void *dy, const float *gamma, const float *mean, const float *rstd, const void *dres,
+                  const float *row_scale, long rows_per_sample, void *dx, void *dr, float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
+                  long rows, int C, hipStream_t st) {
     const LnPlan p = ln_plan(C);
     const int nblk = ln_bwd_blocks(rows, p.G);
     if (ws_bytes < (size_t)nblk * 2 * C * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
@@ -231,8 +260,8 @@ int ln_bwd_launch(const void *x, const void *dy, const float *gamma, const float
     const size_t lds = (size_t)(kLnThreads / p.G) * 2 * C * sizeof(float);
     if (lds > 64 * 1024) return SD_E_UNSUPPORTED;
 #define SD_CALL(GG, VV)                                                                                                              \
-    hipLaunchKernelGGL((ln_bwd<T, GG, VV>), dim3(nblk), dim3(kLnThreads), lds, st, (const T *)x, (const T *)dy, gamma, mean, rstd, (T *)dx, \
-                       part, rows, C)
+    hipLaunchKernelGGL((ln_bwd<T, GG, VV>), dim3(nblk), dim3(kLnThreads), lds, st, (const T *)x, (const T *)dy, gamma, mean, rstd,      \
+                       (const T *)dres, row_scale, rows_per_sample, (T *)dx, (T *)dr, part, rows, C)
     SD_LN_DISPATCH(SD_CALL);
 #undef SD_CALL
     hipLaunchKernelGGL(ln_param_reduce, dim3((2 * C + 15) / 16), dim3(256), 0, st, part, dgamma, dbeta, nblk, C);
@@ -267,8 +296,22 @@ int sd_layernorm_fwd(const void *x, const float *gamma, const float *beta, void 
     if (rc) return rc;
     if (!gamma || !beta || !mean || !rstd) return SD_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == SD_F32) return sd::ln_fwd_launch<float>(x, gamma, beta, y, mean, rstd, rows, C, eps, st);
-    return sd::ln_fwd_launch<sd::bf16_t>(x, gamma, beta, y, mean, rstd, rows, C, eps, st);
+    if (dtype == SD_F32) return sd::ln_fwd_launch<float>(x, nullptr, nullptr, 1, nullptr, gamma, beta, y, mean, rstd, rows, C, eps, st);
+    return sd::ln_fwd_launch<sd::bf16_t>(x, nullptr, nullptr, 1, nullptr, gamma, beta, y, mean, rstd, rows, C, eps, st);
+}
+
+int sd_add_layernorm_fwd(const void *x, const void *res, const float *row_scale, long rows_per_sample, void *xsum, const float *gamma,
+                         const float *beta, void *y, float *mean, float *rstd, int dtype, long rows, int C, float eps, void *stream) {
+    int rc = sd::check_ln(x, y, dtype, rows, C);
+    if (rc) return rc;
+    rc = sd::check_ln(res, xsum, dtype, rows, C);
+    if (rc) return rc;
+    if (!gamma || !beta || !mean || !rstd) return SD_E_NULL;
+    if (row_scale && (rows_per_sample <= 0 || rows % rows_per_sample)) return SD_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32)
+        return sd::ln_fwd_launch<float>(x, res, row_scale, rows_per_sample, xsum, gamma, beta, y, mean, rstd, rows, C, eps, st);
+    return sd::ln_fwd_launch<sd::bf16_t>(x, res, row_scale, rows_per_sample, xsum, gamma, beta, y, mean, rstd, rows, C, eps, st);
 }
 
 int sd_layernorm_bwd(const void *x, const void *dy, const float *gamma, const float *mean, const float *rstd, void *dx, float *dgamma,
@@ -277,8 +320,27 @@ int sd_layernorm_bwd(const void *x, const void *dy, const float *gamma, const fl
     if (rc) return rc;
     if (!gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return SD_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == SD_F32) return sd::ln_bwd_launch<float>(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, workspace, workspace_bytes, rows, C, st);
-    return sd::ln_bwd_launch<sd::bf16_t>(x, dy, gamma, mean, rstd, dx, dgamma, dbeta, workspace, workspace_bytes, rows, C, st);
+    if (dtype == SD_F32)
+        return sd::ln_bwd_launch<float>(x, dy, gamma, mean, rstd, nullptr, nullptr, 1, dx, nullptr, dgamma, dbeta, workspace, workspace_bytes,
+                                        rows, C, st);
+    return sd::ln_bwd_launch<sd::bf16_t>(x, dy, gamma, mean, rstd, nullptr, nullptr, 1, dx, nullptr, dgamma, dbeta, workspace, workspace_bytes,
+                                         rows, C, st);
+}
+
+int sd_add_layernorm_bwd(const void *xsum, const void *dy, const float *gamma, const float *mean, const float *rstd, const void *dres,
+                         const float *row_scale, long rows_per_sample, void *dx, void *dr, float *dgamma, float *dbeta, int dtype, long rows,
+                         int C, void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = sd::check_ln(xsum, dy, dtype, rows, C);
+    if (rc) return rc;
+    if (!gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return SD_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dres) | reinterpret_cast<uintptr_t>(dr)) & 15) return SD_E_ALIGN;
+    if (row_scale && (rows_per_sample <= 0 || rows % rows_per_sample)) return SD_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32)
+        return sd::ln_bwd_launch<float>(xsum, dy, gamma, mean, rstd, dres, row_scale, rows_per_sample, dx, dr, dgamma, dbeta, workspace,
+                                        workspace_bytes, rows, C, st);
+    return sd::ln_bwd_launch<sd::bf16_t>(xsum, dy, gamma, mean, rstd, dres, row_scale, rows_per_sample, dx, dr, dgamma, dbeta, workspace,
+                                         workspace_bytes, rows, C, st);
 }
 
 }  // extern "C"

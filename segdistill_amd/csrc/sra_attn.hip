@@ -1,0 +1,476 @@
+// sra_attn.hip -- MiT "spatial-reduction" attention, forward and backward, gfx950.
+//
+// Reference mix_transformer.py:107-133: per head  O = softmax(scale * Q K^T) V  with N queries (16384 ... 256 tokens)
+// but only KV = (H/32)*(W/32) keys (256 at 512x512) and head_dim 32 or 64.  With so few keys the op is nothing like
+// LLM attention: the whole K and V of a head fit in LDS (64-128 KB of the CU's 160 KB), every query needs all of them, and
+// nothing has to be tiled or re-scaled across key blocks.  ATen runs it either as bmm -> scale -> softmax -> bmm (a
+// [B,heads,N,KV] score tensor, 134 MB per stage-1 layer, written and re-read five times fwd+bwd) or as a generic flash
+// kernel whose backward parallelises over the 256 keys only.  Here (fp32-exact v_mfma_f32_32x32x2_f32 throughout):
+//   * a wave owns 32 queries and computes the TRANSPOSED score tile S^T = K Q^T (keys x queries): in the MFMA C layout a
+//     lane then holds one query column, so the softmax needs no cross-lane work except one exchange with lane^32, and the
+//     probabilities are already in the B-operand layout of the second product O^T = V^T P^T -- no LDS round trip for P;
+//   * K and V are staged in LDS once per workgroup (128 queries); q / dO rows stay in registers;
+//   * backward = two kernels: dq (same S^T form, one key block at a time: S^T, dP^T, dS^T, dQ^T += K^T dS^T) and dk/dv
+//     (S form: each wave keeps two 32-key column blocks of K and V in registers, query tiles stream through LDS; chunk
+//     partials are combined by a deterministic second pass).
+// q [B,N,heads*D] and kv [B,KV,2*heads*D] are the q / kv Linear outputs as they are (no head transpose copies); the output
+// is [B,N,heads*D], what the proj Linear consumes.  Exponentials in base 2 (scale*log2e folded into q / k).
+// (A first version with one thread per query and K/V rows fed through the scalar cache as SGPR operands of v_pk_fma_f32
+// was limited by scalar-load latency x the ~100 SGPRs of a wave: 110-130 us per stage-1 layer, slower than the library.)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cgd_device.h"
+
+namespace sd {
+namespace {
+
+constexpr int kSraThreads = 256;
+constexpr int kSraKeys = 256;        // keys held in LDS (8 blocks of 32)
+constexpr float kLog2e = 1.4426950408889634f;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// MFMA 32x32x2 layouts (lane l): A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31]; C element e: row crow(e, l >> 5), col l & 31
+__device__ __forceinline__ int crow(int e, int half) { return (e & 3) + 8 * (e >> 2) + 4 * half; }
+
+// 4 consecutive elements
+template <typename T> struct Q4;
+template <> struct Q4<float> {
+    static __device__ __forceinline__ float4 load(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+    static __device__ __forceinline__ void store(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+};
+template <> struct Q4<bf16_t> {
+    static __device__ __forceinline__ float4 load(const bf16_t *p) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(p);
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                           __uint_as_float(v.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ void store(bf16_t *p, float4 v) {
+        uint2 o;
+        o.x = (unsigned)f32_to_bf16(v.x) | ((unsigned)f32_to_bf16(v.y) << 16);
+        o.y = (unsigned)f32_to_bf16(v.z) | ((unsigned)f32_to_bf16(v.w) << 16);
+        *reinterpret_cast<uint2 *>(p) = o;
+    }
+};
+
+// n consecutive elements (n % 4 == 0) of a row into registers
+template <typename T, int NE> __device__ __forceinline__ void load_span(const T *p, float (&o)[NE]) {
+#pragma unroll
+    for (int i = 0; i < NE; i += 4) {
+        const float4 v = Q4<T>::load(p + i);
+        o[i] = v.x; o[i + 1] = v.y; o[i + 2] = v.z; o[i + 3] = v.w;
+    }
+}
+
+// K and V of head h of image b -> LDS [rows][PD] (rows >= KV zero-filled up to `rows`)
+template <typename T, int D, int PD>
+__device__ __forceinline__ void stage_kv(const T *__restrict__ kv, float *Ks, float *Vs, int b, int h, int KV, int heads, int rows) {
+    const int C = heads * D;
+    constexpr int G = D / 4;
+    for (int idx = threadIdx.x; idx < rows * G; idx += kSraThreads) {
+        const int j = idx / G, c4 = (idx % G) * 4;
+        float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
+        if (j < KV) {
+            const T *row = kv + ((size_t)b * KV + j) * 2 * C + h * D + c4;
+            k4 = Q4<T>::load(row);
+            v4 = Q4<T>::load(row + C);
+        }
+        *reinterpret_cast<float4 *>(Ks + j * PD + c4) = k4;
+        *reinterpret_cast<float4 *>(Vs + j * PD + c4) = v4;
+    }
+}
+
+// one 32x32 tile of the transposed product  (rows = the 32 LDS rows starting at row0, cols = this wave's 32 register rows):
+// acc += M[row0 + i][:] . r[:]  with the reduction axis split as (half, t): lane l reads M[row0 + (l&31)][half*D/2 + t]
+template <int D, int PD> __device__ __forceinline__ f32x16 tile_t(const float *M, int row0, const float (&r)[D / 2], int c, int half) {
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float *row = M + (row0 + c) * PD + half * (D / 2);
+#pragma unroll
+    for (int t = 0; t < D / 2; t += 4) {
+        const float4 a = *reinterpret_cast<const float4 *>(row + t);
+        acc = mfma(a.x, r[t], acc);
+        acc = mfma(a.y, r[t + 1], acc);
+        acc = mfma(a.z, r[t + 2], acc);
+        acc = mfma(a.w, r[t + 3], acc);
+    }
+    return acc;
+}
+
+// ---- forward: grid (ceil(N/128), heads, B); a wave owns 32 queries ------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(kSraThreads) void sra_fwd(const T *__restrict__ q, const T *__restrict__ kv, T *__restrict__ out,
+                                                        float *__restrict__ lse, int N, int KV, int heads, float cs /* scale*log2e */) {
+    constexpr int PD = D + 4, DB = D / 32;
+    extern __shared__ float smem[];
+    const int nblk = (KV + 31) / 32;
+    float *Ks = smem, *Vs = smem + nblk * 32 * PD;
+    const int h = blockIdx.y, b = blockIdx.z, C = heads * D;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, half = l >> 5;
+    const int n = blockIdx.x * 128 + w * 32 + c;
+    const bool live = n < N;
+    float qv[D / 2];
+#pragma unroll
+    for (int t = 0; t < D / 2; ++t) qv[t] = 0.f;
+    if (live) load_span<T, D / 2>(q + ((size_t)b * N + n) * C + h * D + half * (D / 2), qv);
+#pragma unroll
+    for (int t = 0; t < D / 2; ++t) qv[t] *= cs;
+    stage_kv<T, D, PD>(kv, Ks, Vs, b, h, KV, heads, nblk * 32);
+    __syncthreads();
+    f32x16 S[8];
+    float m = kNegBig;
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk) {
+        if (blk < nblk) {
+            S[blk] = tile_t<D, PD>(Ks, blk * 32, qv, c, half);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                if (blk * 32 + crow(e, half) >= KV) S[blk][e] = kNegBig;
+                m = fmaxf(m, S[blk][e]);
+            }
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float lsum = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk) {
+        if (blk < nblk) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                S[blk][e] = ex2(S[blk][e] - m);
+                lsum += S[blk][e];
+            }
+        }
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    f32x16 O[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) O[db][e] = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk) {
+        if (blk < nblk) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float *vrow = Vs + (blk * 32 + crow(e, half)) * PD + c;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) O[db] = mfma(vrow[db * 32], S[blk][e], O[db]);
+            }
+        }
+    }
+    if (!live) return;
+    const float inv = 1.f / lsum;
+    T *orow = out + ((size_t)b * N + n) * C + h * D;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            Q4<T>::store(orow + db * 32 + 8 * g + 4 * half,
+                         make_float4(O[db][4 * g] * inv, O[db][4 * g + 1] * inv, O[db][4 * g + 2] * inv, O[db][4 * g + 3] * inv));
+    if (half == 0) lse[((size_t)b * heads + h) * N + n] = m + __builtin_amdgcn_logf(lsum);   // base-2 lse of the scaled scores
+}
+
+// ---- backward, queries: dq and delta = sum_d dO*O.  Same grid / ownership as the forward ------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(kSraThreads) void sra_bwd_dq(const T *__restrict__ q, const T *__restrict__ kv, const T *__restrict__ out,
+                                                           const T *__restrict__ dout, const float *__restrict__ lse, T *__restrict__ dq,
+                                                           float *__restrict__ delta, int N, int KV, int heads, float cs, float scale) {
+    constexpr int PD = D + 4, DB = D / 32;
+    extern __shared__ float smem[];
+    const int nblk = (KV + 31) / 32;
+    float *Ks = smem, *Vs = smem + nblk * 32 * PD;
+    const int h = blockIdx.y, b = blockIdx.z, C = heads * D;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, half = l >> 5;
+    const int n = blockIdx.x * 128 + w * 32 + c;
+    const bool live = n < N;
+    float qv[D / 2], gv[D / 2];
+#pragma unroll
+    for (int t = 0; t < D / 2; ++t) { qv[t] = 0.f; gv[t] = 0.f; }
+    float dl = 0.f, L = 0.f;
+    if (live) {
+        const size_t row = ((size_t)b * N + n) * C + h * D + half * (D / 2);
+        load_span<T, D / 2>(q + row, qv);
+        load_span<T, D / 2>(dout + row, gv);
+        float ov[D / 2];
+        load_span<T, D / 2>(out + row, ov);
+#pragma unroll
+        for (int t = 0; t < D / 2; ++t) dl = fmaf(gv[t], ov[t], dl);
+        L = lse[((size_t)b * heads + h) * N + n];
+    }
+    dl += __shfl_xor(dl, 32, 64);
+#pragma unroll
+    for (int t = 0; t < D / 2; ++t) qv[t] *= cs;
+    stage_kv<T, D, PD>(kv, Ks, Vs, b, h, KV, heads, nblk * 32);
+    __syncthreads();
+    f32x16 G[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) G[db][e] = 0.f;
+    for (int blk = 0; blk < nblk; ++blk) {
+        f32x16 s = tile_t<D, PD>(Ks, blk * 32, qv, c, half);
+        const f32x16 dp = tile_t<D, PD>(Vs, blk * 32, gv, c, half);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float p = (blk * 32 + crow(e, half) < KV) ? ex2(s[e] - L) : 0.f;
+            s[e] = p * (dp[e] - dl);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float *krow = Ks + (blk * 32 + crow(e, half)) * PD + c;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) G[db] = mfma(krow[db * 32], s[e], G[db]);
+        }
+    }
+    if (!live) return;
+    T *grow = dq + ((size_t)b * N + n) * C + h * D;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            Q4<T>::store(grow + db * 32 + 8 * g + 4 * half, make_float4(G[db][4 * g] * scale, G[db][4 * g + 1] * scale,
+                                                                          G[db][4 * g + 2] * scale, G[db][4 * g + 3] * scale));
+    if (half == 0) delta[((size_t)b * heads + h) * N + n] = dl;
+}
+
+// ---- backward, keys.  grid (nchunk, heads, B): a workgroup walks `qchunk` queries (32 at a time through LDS); wave w keeps the
+// key columns 64w .. 64w+63 (two 32-column blocks) of K and V in registers and accumulates their dK^T / dV^T tiles.
+// part: [b][h][chunk][2 (k,v)][KV][D] fp32
+template <typename T, int D>
+__global__ __launch_bounds__(kSraThreads) void sra_bwd_dkv(const T *__restrict__ q, const T *__restrict__ kv, const T *__restrict__ dout,
+                                                            const float *__restrict__ lse, const float *__restrict__ delta,
+                                                            float *__restrict__ part, int N, int KV, int heads, int nchunk, int qchunk,
+                                                            float cs, float scale) {
+    constexpr int PD = D + 4, DB = D / 32, G4 = D / 4;
+    __shared__ float Qs[32 * PD], Gs[32 * PD], Ls[32], Ds[32];
+    const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z, C = heads * D;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, half = l >> 5;
+    float kreg[2][D / 2], vreg[2][D / 2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int j = 64 * w + 32 * cb + c;
+#pragma unroll
+        for (int t = 0; t < D / 2; ++t) { kreg[cb][t] = 0.f; vreg[cb][t] = 0.f; }
+        if (j < KV) {
+            const T *row = kv + ((size_t)b * KV + j) * 2 * C + h * D + half * (D / 2);
+            load_span<T, D / 2>(row, kreg[cb]);
+            load_span<T, D / 2>(row + C, vreg[cb]);
+        }
+#pragma unroll
+        for (int t = 0; t < D / 2; ++t) kreg[cb][t] *= cs;
+    }
+    f32x16 aK[2][DB], aV[2][DB];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { aK[cb][db][e] = 0.f; aV[cb][db][e] = 0.f; }
+    const bool wave_live = 64 * w < KV;                       // waves whose key columns are all padding only help with the staging
+    const int i0 = chunk * qchunk, i1 = min(N, i0 + qchunk);
+    const T *qb = q + (size_t)b * N * C + h * D;
+    const T *gb = dout + (size_t)b * N * C + h * D;
+    const float *lb = lse + ((size_t)b * heads + h) * N;
+    const float *db_ = delta + ((size_t)b * heads + h) * N;
+    for (int t0 = i0; t0 < i1; t0 += 32) {
+        __syncthreads();                                      // the previous tile has been consumed
+        for (int idx = threadIdx.x; idx < 32 * G4; idx += kSraThreads) {
+            const int r = idx / G4, c4 = (idx % G4) * 4;
+            float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = q4;
+            if (t0 + r < i1) {
+                q4 = Q4<T>::load(qb + (size_t)(t0 + r) * C + c4);
+                g4 = Q4<T>::load(gb + (size_t)(t0 + r) * C + c4);
+            }
+            *reinterpret_cast<float4 *>(Qs + r * PD + c4) = q4;
+            *reinterpret_cast<float4 *>(Gs + r * PD + c4) = g4;
+        }
+        if (threadIdx.x < 32) Ls[threadIdx.x] = (t0 + threadIdx.x < i1) ? lb[t0 + threadIdx.x] : 0.f;
+        else if (threadIdx.x < 64) Ds[threadIdx.x - 32] = (t0 + threadIdx.x - 32 < i1) ? db_[t0 + threadIdx.x - 32] : 0.f;
+        __syncthreads();
+        if (!wave_live) continue;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            // S tile (rows = queries of the LDS tile, cols = this block's keys): A = Q rows from LDS, B = K columns in registers
+            f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dp = s;
+            const float *qrow = Qs + c * PD + half * (D / 2), *grow = Gs + c * PD + half * (D / 2);
+#pragma unroll
+            for (int t = 0; t < D / 2; t += 4) {
+                const float4 a = *reinterpret_cast<const float4 *>(qrow + t), g = *reinterpret_cast<const float4 *>(grow + t);
+                s = mfma(a.x, kreg[cb][t], s);      dp = mfma(g.x, vreg[cb][t], dp);
+                s = mfma(a.y, kreg[cb][t + 1], s);  dp = mfma(g.y, vreg[cb][t + 1], dp);
+                s = mfma(a.z, kreg[cb][t + 2], s);  dp = mfma(g.z, vreg[cb][t + 2], dp);
+                s = mfma(a.w, kreg[cb][t + 3], s);  dp = mfma(g.w, vreg[cb][t + 3], dp);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = crow(e, half);
+                const float p = ex2(s[e] - Ls[r]);            // padded query rows: q = dO = 0, lse = delta = 0 -> contribute exactly 0
+                dp[e] = p * (dp[e] - Ds[r]);
+                s[e] = p;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = crow(e, half);
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    aV[cb][db] = mfma(Gs[r * PD + db * 32 + c], s[e], aV[cb][db]);    // dV^T += dO^T P
+                    aK[cb][db] = mfma(Qs[r * PD + db * 32 + c], dp[e], aK[cb][db]);   // dK^T += Q^T dS
+                }
+            }
+        }
+    }
+    float *pk = part + (((size_t)b * heads + h) * nchunk + chunk) * 2 * KV * D;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int j = 64 * w + 32 * cb + c;
+        if (j >= KV) continue;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float *dst = pk + (size_t)j * D + db * 32 + 8 * g + 4 * half;
+                *reinterpret_cast<float4 *>(dst) = make_float4(aK[cb][db][4 * g] * scale, aK[cb][db][4 * g + 1] * scale,
+                                                               aK[cb][db][4 * g + 2] * scale, aK[cb][db][4 * g + 3] * scale);
+                *reinterpret_cast<float4 *>(dst + (size_t)KV * D) =
+                    make_float4(aV[cb][db][4 * g], aV[cb][db][4 * g + 1], aV[cb][db][4 * g + 2], aV[cb][db][4 * g + 3]);
+            }
+    }
+}
+
+// dkv[b][j][which][h][d] = sum_chunk part[b][h][chunk][which][j][d].  one thread per 4 output elements
+template <typename T>
+__global__ __launch_bounds__(256) void sra_dkv_reduce(const float *__restrict__ part, T *__restrict__ dkv, int B, int KV, int heads, int D,
+                                                       int nchunk) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int dv = D / 4;
+    const size_t total = (size_t)B * KV * 2 * heads * dv;
+    if (t >= total) return;
+    const int d = (int)(t % dv) * 4;
+    size_t r = t / dv;
+    const int h = (int)(r % heads); r /= heads;
+    const int which = (int)(r % 2); r /= 2;
+    const int j = (int)(r % KV);
+    const int b = (int)(r / KV);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *p = part + ((((size_t)b * heads + h) * nchunk) * 2 + which) * KV * D + (size_t)j * D + d;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + (size_t)ch * 2 * KV * D);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    T *o = dkv + (((size_t)b * KV + j) * 2 + which) * heads * D + (size_t)h * D + d;
+    VecIO<T>::store1(o, a.x); VecIO<T>::store1(o + 1, a.y); VecIO<T>::store1(o + 2, a.z); VecIO<T>::store1(o + 3, a.w);
+}
+
+struct SraPlan {
+    int nchunk, qchunk;
+};
+SraPlan sra_plan(int B, int N, int KV, int heads) {
+    SraPlan p;
+    const long groups = (long)B * heads;
+    long want = (512 + groups - 1) / groups;            // ~2 workgroups per CU
+    const long most = (N + 127) / 128;                  // at least 128 queries (4 LDS tiles) per workgroup
+    if (want > most) want = most;
+    if (want < 1) want = 1;
+    p.qchunk = (int)(((N + want - 1) / want + 31) / 32 * 32);
+    p.nchunk = (N + p.qchunk - 1) / p.qchunk;
+    return p;
+}
+template <int D> size_t sra_lds_bytes(int KV) { return (size_t)2 * ((KV + 31) / 32) * 32 * (D + 4) * sizeof(float); }
+// K+V of 256 keys need 72 KB (D=32) / 136 KB (D=64) of the CU's 160 KB: raise the kernel's dynamic-LDS cap once per process
+template <typename K> int sra_raise_lds(K kernel, bool &raised) {
+    if (raised) return 0;
+    const int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised = rc == 0;
+    return rc;
+}
+
+int sra_check(const void *q, const void *kv, const void *o, int dtype, int B, int N, int KV, int heads, int D) {
+    if (!q || !kv || !o) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (B <= 0 || N <= 0 || KV <= 0 || heads <= 0) return SD_E_SHAPE;
+    if ((D != 32 && D != 64) || KV > kSraKeys) return SD_E_UNSUPPORTED;
+    if (B > 65535 || heads > 65535) return SD_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(kv) | reinterpret_cast<uintptr_t>(o)) & 15) return SD_E_ALIGN;
+    return SD_OK;
+}
+
+template <typename T, int D>
+int sra_fwd_launch(const void *q, const void *kv, void *out, float *lse, int B, int N, int KV, int heads, float scale, hipStream_t st) {
+    const dim3 grid((N + 127) / 128, heads, B);
+    const size_t lds = sra_lds_bytes<D>(KV);
+    static bool raised = false;
+    int rc = sra_raise_lds(sra_fwd<T, D>, raised);
+    if (rc) return rc;
+    hipLaunchKernelGGL((sra_fwd<T, D>), grid, dim3(kSraThreads), lds, st, (const T *)q, (const T *)kv, (T *)out, lse, N, KV, heads,
+                       scale * kLog2e);
+    return (int)hipGetLastError();
+}
+
+template <typename T, int D>
+int sra_bwd_launch(const void *q, const void *kv, const void *out, const void *dout, const float *lse, void *dq, void *dkv, int B, int N,
+                   int KV, int heads, float scale, void *ws, hipStream_t st) {
+    const SraPlan p = sra_plan(B, N, KV, heads);
+    float *delta = static_cast<float *>(ws);
+    float *part = delta + (((size_t)B * heads * N + 3) & ~(size_t)3);
+    const dim3 gq((N + 127) / 128, heads, B);
+    const size_t lds = sra_lds_bytes<D>(KV);
+    static bool raised = false;
+    int rc = sra_raise_lds(sra_bwd_dq<T, D>, raised);
+    if (rc) return rc;
+    hipLaunchKernelGGL((sra_bwd_dq<T, D>), gq, dim3(kSraThreads), lds, st, (const T *)q, (const T *)kv, (const T *)out, (const T *)dout, lse,
+                       (T *)dq, delta, N, KV, heads, scale * kLog2e, scale);
+    const dim3 gk(p.nchunk, heads, B);
+    hipLaunchKernelGGL((sra_bwd_dkv<T, D>), gk, dim3(kSraThreads), 0, st, (const T *)q, (const T *)kv, (const T *)dout, lse, delta, part, N, KV,
+                       heads, p.nchunk, p.qchunk, scale * kLog2e, scale);
+    const size_t total = (size_t)B * KV * 2 * heads * (D / 4);
+    hipLaunchKernelGGL((sra_dkv_reduce<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, (T *)dkv, B, KV, heads, D,
+                       p.nchunk);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+}  // namespace sd
+
+extern "C" {
+
+int sd_sra_supported(int head_dim) { return (head_dim == 32 || head_dim == 64) ? 1 : 0; }
+
+size_t sd_sra_workspace_bytes(int B, int N, int KV, int heads, int D) {
+    if (B <= 0 || N <= 0 || KV <= 0 || heads <= 0 || D <= 0) return 0;
+    const sd::SraPlan p = sd::sra_plan(B, N, KV, heads);
+    const size_t delta = (((size_t)B * heads * N + 3) & ~(size_t)3) * sizeof(float);
+    return delta + (size_t)B * heads * p.nchunk * 2 * KV * D * sizeof(float) + 16;
+}
+
+int sd_sra_fwd(const void *q, const void *kv, void *out, float *lse, int dtype, int B, int N, int KV, int heads, int D, float scale,
+               void *stream) {
+    int rc = sd::sra_check(q, kv, out, dtype, B, N, KV, heads, D);
+    if (rc) return rc;
+    if (!lse) return SD_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32)
+        return D == 32 ? sd::sra_fwd_launch<float, 32>(q, kv, out, lse, B, N, KV, heads, scale, st)
+                       : sd::sra_fwd_launch<float, 64>(q, kv, out, lse, B, N, KV, heads, scale, st);
+    return D == 32 ? sd::sra_fwd_launch<sd::bf16_t, 32>(q, kv, out, lse, B, N, KV, heads, scale, st)
+                   : sd::sra_fwd_launch<sd::bf16_t, 64>(q, kv, out, lse, B, N, KV, heads, scale, st);
+}
+
+int sd_sra_bwd(const void *q, const void *kv, const void *out, const void *dout, const float *lse, void *dq, void *dkv, int dtype, int B,
+               int N, int KV, int heads, int D, float scale, void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = sd::sra_check(q, kv, out, dtype, B, N, KV, heads, D);
+    if (rc) return rc;
+    if (!dout || !lse || !dq || !dkv || !workspace) return SD_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(dkv) |
+         reinterpret_cast<uintptr_t>(workspace)) & 15)
+        return SD_E_ALIGN;
+    if (workspace_bytes < sd_sra_workspace_bytes(B, N, KV, heads, D)) return SD_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32)
+        return D == 32 ? sd::sra_bwd_launch<float, 32>(q, kv, out, dout, lse, dq, dkv, B, N, KV, heads, scale, workspace, st)
+                       : sd::sra_bwd_launch<float, 64>(q, kv, out, dout, lse, dq, dkv, B, N, KV, heads, scale, workspace, st);
+    return D == 32 ? sd::sra_bwd_launch<sd::bf16_t, 32>(q, kv, out, dout, lse, dq, dkv, B, N, KV, heads, scale, workspace, st)
+                   : sd::sra_bwd_launch<sd::bf16_t, 64>(q, kv, out, dout, lse, dq, dkv, B, N, KV, heads, scale, workspace, st);
+}
+
+}  // extern "C"

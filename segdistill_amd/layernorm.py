@@ -51,3 +51,69 @@ class HipLayerNorm(nn.LayerNorm):
                 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024 and x.numel() > 0):
             return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
         return super().forward(x)
+
+
+class _AddLayerNormFn(torch.autograd.Function):
+    """(xsum, y) = (x + s*res, LayerNorm(x + s*res)); s = per-sample stochastic-depth factor or None."""
+
+    @staticmethod
+    def forward(ctx, x, res, scale, weight, bias, eps):
+        xc, rc_ = x.contiguous(), res.contiguous()
+        C = xc.shape[-1]
+        rows = xc.numel() // C
+        xsum, y = torch.empty_like(xc), torch.empty_like(xc)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        sc = None if scale is None else scale.detach().float().contiguous()
+        rps = rows // xc.shape[0]
+        rc = _lib.lib().sd_add_layernorm_fwd(xc.data_ptr(), rc_.data_ptr(), None if sc is None else sc.data_ptr(), rps, xsum.data_ptr(),
+                                             w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _DT[xc.dtype], rows, C,
+                                             float(eps), _stream_ptr())
+        _lib.check(rc, 'sd_add_layernorm_fwd')
+        ctx.save_for_backward(xsum, w, mean, rstd, sc)
+        ctx.pdtype, ctx.rps = weight.dtype, rps
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(mean, rstd)
+        return xsum, y
+
+    @staticmethod
+    def backward(ctx, g_xsum, g_y):
+        xsum, w, mean, rstd, sc = ctx.saved_tensors
+        C = xsum.shape[-1]
+        rows = xsum.numel() // C
+        if g_y is None:      # the normalised output was not used: plain residual gradient
+            if g_xsum is None:
+                return None, None, None, None, None, None
+            g_res = g_xsum if sc is None else g_xsum * sc.view(-1, *([1] * (g_xsum.dim() - 1))).to(g_xsum.dtype)
+            return g_xsum, g_res, None, None, None, None
+        L = _lib.lib()
+        dy = g_y.contiguous()
+        dres = None if g_xsum is None else g_xsum.contiguous()
+        dx = torch.empty_like(xsum)
+        dr = None if sc is None else torch.empty_like(xsum)
+        dg = torch.empty(C, dtype=torch.float32, device=xsum.device)
+        db = torch.empty(C, dtype=torch.float32, device=xsum.device)
+        wsb = L.sd_layernorm_workspace_bytes(rows, C)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=xsum.device)
+        rc = L.sd_add_layernorm_bwd(xsum.data_ptr(), dy.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                    None if dres is None else dres.data_ptr(), None if sc is None else sc.data_ptr(), ctx.rps, dx.data_ptr(),
+                                    None if dr is None else dr.data_ptr(), dg.data_ptr(), db.data_ptr(), _DT[xsum.dtype], rows, C, ws.data_ptr(),
+                                    wsb, _stream_ptr())
+        _lib.check(rc, 'sd_add_layernorm_bwd')
+        return dx, (dx if dr is None else dr), None, dg.to(ctx.pdtype), db.to(ctx.pdtype), None
+
+
+def add_layernorm_supported(x, res, norm):
+    return (isinstance(norm, HipLayerNorm) and x.is_cuda and x.dtype in _DT and res.dtype == x.dtype and res.shape == x.shape and x.dim() == 3
+            and norm.elementwise_affine and norm.bias is not None and len(norm.normalized_shape) == 1 and norm.normalized_shape[0] == x.shape[-1]
+            and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024 and x.numel() > 0
+            and not (norm._forward_hooks or norm._forward_pre_hooks or norm._backward_hooks))
+
+
+def add_layernorm(x, res, norm, scale=None):
+    """x [B, N, C] + scale[b] * res, and `norm` applied to the sum: returns (xsum, normed).  One kernel each way."""
+    if res.dtype != x.dtype:   # autocast can hand over a bf16 branch output for an fp32 residual stream (or the reverse)
+        dt = torch.promote_types(x.dtype, res.dtype)
+        x, res = x.to(dt), res.to(dt)
+    return _AddLayerNormFn.apply(x, res, scale, norm.weight, norm.bias, norm.eps)

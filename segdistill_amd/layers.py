@@ -128,6 +128,14 @@ class DropPath(nn.Module):
         mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
         return x * mask.div_(keep)   # same value as x/keep * mask with one pass over x instead of two
 
+    def sample_scale(self, x):
+        """The per-sample factor [B] (fp32) this module would multiply `x` by, or None when it is the identity -- for callers
+        that fuse the multiplication into another kernel (layernorm.add_layernorm)."""
+        if not self.training or self.drop_prob == 0.:
+            return None
+        keep = 1.0 - self.drop_prob
+        return torch.empty(x.shape[0], dtype=torch.float32, device=x.device).bernoulli_(keep).div_(keep)
+
     def extra_repr(self):
         return f'p={self.drop_prob}'
 

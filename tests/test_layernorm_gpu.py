@@ -49,3 +49,79 @@ def test_hip_layernorm_is_a_layernorm_and_falls_back_on_cpu():
     assert isinstance(ln, nn.LayerNorm) and sorted(ln.state_dict()) == ['bias', 'weight']
     x = torch.randn(3, 7, 48)
     assert torch.allclose(ln(x), F.layer_norm(x, (48,), ln.weight, ln.bias, ln.eps))
+
+
+@pytest.mark.parametrize('shape', [(2, 4096, 32), (3, 77, 160), (2, 100, 320), (1, 65, 512), (8, 16384, 64), (4, 5, 128)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('scaled', [False, True])
+@pytest.mark.parametrize('use_xsum', [True, False])
+def test_add_layernorm_fwd_bwd(shape, dtype, scaled, use_xsum):
+    """Residual form: (xsum, y) = (x + s*res, LN(x + s*res)) and its gradients, against fp64 torch on the CPU.  `use_xsum=False`
+    is the last half-block of a stage, whose residual stream has no other consumer (no gradient arrives for xsum)."""
+    from segdistill_amd.layernorm import HipLayerNorm, add_layernorm, add_layernorm_supported
+    B, N, C = shape
+    g = torch.Generator().manual_seed(N + C)
+    x = (2 * torch.randn(B, N, C, generator=g) + 0.5).to(dtype)
+    r = torch.randn(B, N, C, generator=g).to(dtype)
+    s = (torch.rand(B, generator=g) > 0.3).float() / 0.7 if scaled else None
+    w = 1 + 0.1 * torch.randn(C, generator=g)
+    b = 0.1 * torch.randn(C, generator=g)
+    dy = torch.randn(B, N, C, generator=g).to(dtype)
+    dxs = torch.randn(B, N, C, generator=g).to(dtype)
+    x64, r64 = x.double().requires_grad_(True), r.double().requires_grad_(True)
+    w64, b64 = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    xs64 = x64 + (r64 if s is None else r64 * s.double().view(B, 1, 1))
+    if dtype == torch.bfloat16:   # the kernel normalises the STORED (bf16-rounded) sum: mirror it, keeping the graph
+        xs64 = xs64 + (xs64.detach().to(dtype).double() - xs64.detach())
+    y64 = F.layer_norm(xs64, (C,), w64, b64, 1e-6)
+    ((y64 * dy.double()).sum() + ((xs64 * dxs.double()).sum() if use_xsum else 0.)).backward()
+    dev = torch.device('cuda:0')
+    ln = HipLayerNorm(C, eps=1e-6).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(w)
+        ln.bias.copy_(b)
+    xg, rg = x.to(dev).requires_grad_(True), r.to(dev).requires_grad_(True)
+    assert add_layernorm_supported(xg, rg, ln)
+    xsum, y = add_layernorm(xg, rg, ln, None if s is None else s.to(dev))
+    ((y.float() * dy.to(dev).float()).sum() + ((xsum.float() * dxs.to(dev).float()).sum() if use_xsum else 0.)).backward()
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert xsum.dtype == dtype and y.dtype == dtype
+    assert _err(xsum, xs64.detach()) < (1e-6 if dtype == torch.float32 else 4e-3)
+    assert _err(y, y64.detach()) < tol
+    assert _err(xg.grad, x64.grad) < tol
+    assert _err(rg.grad, r64.grad) < tol
+    assert _err(ln.weight.grad, w64.grad) < (1e-4 if dtype == torch.float32 else 1.5e-2)
+    assert _err(ln.bias.grad, b64.grad) < (1e-4 if dtype == torch.float32 else 1.5e-2)
+
+
+def test_fused_stage_loop_equals_block_by_block():
+    """MiT stage with the residual adds fused into the LayerNorms == the literal per-block form (which a forward hook on any
+    block forces), forward and parameter gradients, drop-path off."""
+    import segdistill_amd
+    from segdistill_amd import layernorm
+    from segdistill_amd.builder import build_backbone
+    segdistill_amd.register_all()
+    torch.manual_seed(0)
+    net = build_backbone(dict(type='mit_b0')).cuda()
+    net.reset_drop_path(0.)
+    net.train()
+    img = torch.randn(2, 3, 128, 128, device='cuda')
+    calls, real = [], layernorm._AddLayerNormFn.apply
+    layernorm._AddLayerNormFn.apply = lambda *a: (calls.append(1), real(*a))[1]
+    try:
+        outs = net(img)
+    finally:
+        layernorm._AddLayerNormFn.apply = real
+    assert len(calls) == 2 * sum(net.depths)          # every residual add of every block went through the fused kernel
+    sum(o.float().pow(2).mean() for o in outs).backward()
+    g_fused = {n: p.grad.clone() for n, p in net.named_parameters()}
+    net.zero_grad(set_to_none=True)
+    handles = [blk.register_forward_hook(lambda m, i, o: None) for s in range(1, 5) for blk in getattr(net, f'block{s}')]
+    outs2 = net(img)
+    sum(o.float().pow(2).mean() for o in outs2).backward()
+    for h in handles:
+        h.remove()
+    for a, b2 in zip(outs, outs2):
+        assert _err(a, b2) < 1e-5
+    for n, p in net.named_parameters():
+        assert _err(g_fused[n], p.grad) < 2e-4, n

@@ -25,3 +25,10 @@ tot = sum(r.self_device_time_total for r in rows)
 print(f'total device time {tot/3/1e3:.2f} ms/step')
 for r in rows[:int(sys.argv[1]) if len(sys.argv) > 1 else 45]:
     print(f'{r.self_device_time_total/3/1e3:8.3f} ms  {r.count/3:6.1f}x  {r.key[:44]:44s} {str(r.input_shapes)[:110]}')
+if len(sys.argv) > 2:   # second argument: comma-separated substrings -> op rows (total device time, incl. children) matching any of them
+    pats = sys.argv[2].split(',')
+    sel = [r for r in prof.key_averages(group_by_input_shape=True) if any(p in r.key for p in pats)]
+    sel.sort(key=lambda r: -r.device_time_total)
+    print(f'--- ops matching {pats}: total {sum(r.device_time_total for r in sel)/3/1e3:.3f} ms/step (nested ops counted more than once)')
+    for r in sel[:60]:
+        print(f'{r.device_time_total/3/1e3:8.3f} ms  {r.count/3:6.1f}x  {r.key[:30]:30s} {str(r.input_shapes)[:150]}')

@@ -56,8 +56,26 @@ def main():
             agg[k][0] += e - s
             agg[k][1] += 1
             busy += e - s
+    # union of the kernel intervals (at least one kernel resident) and the idle gaps between them
+    union, cur_s, cur_e, gaps = 0, None, None, []
+    for s, e, n in rows:
+        if not (t0 <= s < t1):
+            continue
+        if cur_e is None or s > cur_e:
+            if cur_e is not None:
+                union += cur_e - cur_s
+                gaps.append(s - cur_e)
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    if cur_e is not None:
+        union += cur_e - cur_s
+    gaps.sort()
+    gap_note = (f'idle gaps: {len(gaps) / nsteps:.0f}/step, total {sum(gaps) / nsteps / 1e6:.3f} ms/step, median {gaps[len(gaps) // 2] / 1e3:.1f} us'
+                if gaps else 'no idle gaps')
     lines = [f'# rocprofv3 kernel trace, steady state: {nsteps} KD steps, wall {(t1 - t0) / nsteps / 1e6:.3f} ms/step, '
              f'GPU busy {busy / nsteps / 1e6:.3f} ms/step, {sum(v[1] for v in agg.values()) / nsteps:.0f} kernel launches/step',
+             f'# at least one kernel resident {union / nsteps / 1e6:.3f} ms/step (sum of durations / that = {busy / max(union, 1):.2f}x overlap); {gap_note}',
              f'{"kernel":92s} {"ms/step":>9s} {"%busy":>7s} {"calls/step":>10s} {"avg us":>9s}']
     for k, (ns, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:a.top]:
         lines.append(f'{k:92s} {ns / nsteps / 1e6:9.3f} {100 * ns / busy:7.2f} {c / nsteps:10.1f} {ns / c / 1e3:9.1f}')
