@@ -68,7 +68,7 @@ template <typename T, int D, int PD>
 __device__ __forceinline__ void stage_kv(const T *__restrict__ kv, float *Ks, float *Vs, int b, int h, int KV, int heads, int rows) {
     const int C = heads * D;
     constexpr int G = D / 4;
-    for (int idx = threadIdx.x; idx < rows * G; idx += kSraThreads) {
+    for (int idx = threadIdx.x; idx < rows * G; idx += blockDim.x) {
         const int j = idx / G, c4 = (idx % G) * 4;
         float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
         if (j < KV) {
@@ -97,9 +97,10 @@ template <int D, int PD> __device__ __forceinline__ f32x16 tile_t(const float *M
     return acc;
 }
 
-// ---- forward: grid (ceil(N/128), heads, B); a wave owns 32 queries ------------------------------------------------------
-template <typename T, int D>
-__global__ __launch_bounds__(kSraThreads) void sra_fwd(const T *__restrict__ q, const T *__restrict__ kv, T *__restrict__ out,
+// ---- forward: grid (ceil(N/(32*NW)), heads, B); a wave owns 32 queries, the NW waves of a workgroup share K/V in LDS ---------
+// (NW = 8 puts two waves on every SIMD of the CU that holds the K/V copy: one wave's softmax overlaps the other's MFMAs)
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void sra_fwd(const T *__restrict__ q, const T *__restrict__ kv, T *__restrict__ out,
                                                         float *__restrict__ lse, int N, int KV, int heads, float cs /* scale*log2e */) {
     constexpr int PD = D + 4, DB = D / 32;
     extern __shared__ float smem[];
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(kSraThreads) void sra_fwd(const T *__restrict__ q, 
     float *Ks = smem, *Vs = smem + nblk * 32 * PD;
     const int h = blockIdx.y, b = blockIdx.z, C = heads * D;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, half = l >> 5;
-    const int n = blockIdx.x * 128 + w * 32 + c;
+    const int n = blockIdx.x * (NW * 32) + w * 32 + c;
     const bool live = n < N;
     float qv[D / 2];
 #pragma unroll
@@ -172,8 +173,8 @@ __global__ __launch_bounds__(kSraThreads) void sra_fwd(const T *__restrict__ q, 
 }
 
 // ---- backward, queries: dq and delta = sum_d dO*O.  Same grid / ownership as the forward ------------------------------------
-template <typename T, int D>
-__global__ __launch_bounds__(kSraThreads) void sra_bwd_dq(const T *__restrict__ q, const T *__restrict__ kv, const T *__restrict__ out,
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void sra_bwd_dq(const T *__restrict__ q, const T *__restrict__ kv, const T *__restrict__ out,
                                                            const T *__restrict__ dout, const float *__restrict__ lse, T *__restrict__ dq,
                                                            float *__restrict__ delta, int N, int KV, int heads, float cs, float scale) {
     constexpr int PD = D + 4, DB = D / 32;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(kSraThreads) void sra_bwd_dq(const T *__restrict__ 
     float *Ks = smem, *Vs = smem + nblk * 32 * PD;
     const int h = blockIdx.y, b = blockIdx.z, C = heads * D;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, half = l >> 5;
-    const int n = blockIdx.x * 128 + w * 32 + c;
+    const int n = blockIdx.x * (NW * 32) + w * 32 + c;
     const bool live = n < N;
     float qv[D / 2], gv[D / 2];
 #pragma unroll
@@ -395,16 +396,23 @@ int sra_check(const void *q, const void *kv, const void *o, int dtype, int B, in
     return SD_OK;
 }
 
-template <typename T, int D>
-int sra_fwd_launch(const void *q, const void *kv, void *out, float *lse, int B, int N, int KV, int heads, float scale, hipStream_t st) {
-    const dim3 grid((N + 127) / 128, heads, B);
+inline bool sra_wide(int N) { return N >= 1024; }   // 8-wave workgroups once there are enough queries to fill them
+
+template <typename T, int D, int NW>
+int sra_fwd_launch_nw(const void *q, const void *kv, void *out, float *lse, int B, int N, int KV, int heads, float scale, hipStream_t st) {
+    const dim3 grid((N + NW * 32 - 1) / (NW * 32), heads, B);
     const size_t lds = sra_lds_bytes<D>(KV);
     static bool raised = false;
-    int rc = sra_raise_lds(sra_fwd<T, D>, raised);
+    int rc = sra_raise_lds(sra_fwd<T, D, NW>, raised);
     if (rc) return rc;
-    hipLaunchKernelGGL((sra_fwd<T, D>), grid, dim3(kSraThreads), lds, st, (const T *)q, (const T *)kv, (T *)out, lse, N, KV, heads,
+    hipLaunchKernelGGL((sra_fwd<T, D, NW>), grid, dim3(NW * 64), lds, st, (const T *)q, (const T *)kv, (T *)out, lse, N, KV, heads,
                        scale * kLog2e);
     return (int)hipGetLastError();
+}
+template <typename T, int D>
+int sra_fwd_launch(const void *q, const void *kv, void *out, float *lse, int B, int N, int KV, int heads, float scale, hipStream_t st) {
+    return sra_wide(N) ? sra_fwd_launch_nw<T, D, 8>(q, kv, out, lse, B, N, KV, heads, scale, st)
+                       : sra_fwd_launch_nw<T, D, 4>(q, kv, out, lse, B, N, KV, heads, scale, st);
 }
 
 template <typename T, int D>
@@ -413,13 +421,16 @@ int sra_bwd_launch(const void *q, const void *kv, const void *out, const void *d
     const SraPlan p = sra_plan(B, N, KV, heads);
     float *delta = static_cast<float *>(ws);
     float *part = delta + (((size_t)B * heads * N + 3) & ~(size_t)3);
-    const dim3 gq((N + 127) / 128, heads, B);
     const size_t lds = sra_lds_bytes<D>(KV);
-    static bool raised = false;
-    int rc = sra_raise_lds(sra_bwd_dq<T, D>, raised);
+    static bool raised4 = false, raised8 = false;
+    int rc = sra_wide(N) ? sra_raise_lds(sra_bwd_dq<T, D, 8>, raised8) : sra_raise_lds(sra_bwd_dq<T, D, 4>, raised4);
     if (rc) return rc;
-    hipLaunchKernelGGL((sra_bwd_dq<T, D>), gq, dim3(kSraThreads), lds, st, (const T *)q, (const T *)kv, (const T *)out, (const T *)dout, lse,
-                       (T *)dq, delta, N, KV, heads, scale * kLog2e, scale);
+    if (sra_wide(N))
+        hipLaunchKernelGGL((sra_bwd_dq<T, D, 8>), dim3((N + 255) / 256, heads, B), dim3(512), lds, st, (const T *)q, (const T *)kv,
+                           (const T *)out, (const T *)dout, lse, (T *)dq, delta, N, KV, heads, scale * kLog2e, scale);
+    else
+        hipLaunchKernelGGL((sra_bwd_dq<T, D, 4>), dim3((N + 127) / 128, heads, B), dim3(256), lds, st, (const T *)q, (const T *)kv,
+                           (const T *)out, (const T *)dout, lse, (T *)dq, delta, N, KV, heads, scale * kLog2e, scale);
     const dim3 gk(p.nchunk, heads, B);
     hipLaunchKernelGGL((sra_bwd_dkv<T, D>), gk, dim3(kSraThreads), 0, st, (const T *)q, (const T *)kv, (const T *)dout, lse, delta, part, N, KV,
                        heads, p.nchunk, p.qchunk, scale * kLog2e, scale);
