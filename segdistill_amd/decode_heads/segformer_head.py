@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from ..builder import HEADS, build_loss
 from ..layers import ConvModule, resize, tokens_of
+from ..linear import call_linear, token_linear
 from .decode_head import BaseDecodeHead
 
 
@@ -27,7 +28,7 @@ class MLP(nn.Module):
         self.proj = nn.Linear(input_dim, embed_dim)
 
     def forward(self, x):
-        return self.proj(x.flatten(2).transpose(1, 2))
+        return call_linear(self.proj, tokens_of(x))          # split-K weight gradient at 16384+ tokens per image (linear.py)
 
 
 @HEADS.register_module()
@@ -72,7 +73,7 @@ class SegFormerHead(BaseDecodeHead):
             if fold:
                 z = torch.addmm(wi @ mlp.proj.bias, tokens.reshape(-1, tokens.shape[-1]), (wi @ mlp.proj.weight).t())
             else:
-                z = mlp(feat).reshape(-1, e) @ wi.t()                 # module call keeps forward hooks (taps) alive
+                z = token_linear(mlp(feat).reshape(-1, e), wi)        # module call keeps forward hooks (taps) alive
             zs.append(z.reshape(n, -1, e))                            # token-major [B, h_i*w_i, E]
             sizes.append(tuple(feat.shape[2:]))
         zs, sizes = zs[::-1], sizes[::-1]                             # finest (c1) first
@@ -119,25 +120,20 @@ class SegFormerHead(BaseDecodeHead):
         return self._predict(fused)
 
     def _predict(self, fused):
-        """linear_pred (1x1 conv, segformer_head.py:73,96).  When `fused` is a channels-last view of tokens the conv would
-        return channels-last logits, and the loss kernels (which read NCHW planes) would have to copy them; computing
-        W . tokens^T instead yields contiguous [B, classes, H*W] directly.  Forward hooks on the module (it is THE tap of
-        every shipped KD config) are fired by hand with the same output tensor."""
+        """linear_pred (1x1 conv, segformer_head.py:73,96).  When `fused` is a channels-last view of tokens the conv is a Linear
+        over the tokens; its [B, HW, classes] result is transposed once into the contiguous NCHW planes the loss kernels
+        read.  Forward hooks on the module (it is THE tap of every shipped KD config) are fired by hand with that tensor."""
         pred = self.linear_pred
         if fused.is_contiguous() or pred._forward_pre_hooks or not fused.is_cuda:
             return pred(fused)
         b, e, h, w = fused.shape
         tokens = tokens_of(fused)                                              # [B, HW, E] view
         w2d = pred.weight.view(pred.out_channels, e)
-        if torch.is_autocast_enabled() or fused.dtype != torch.float32:
-            # ROCm 7.0 hipBLASLt: the bf16 form W[150,E] x tokens^T (batched, E=768, HW=16384) selects a stream-K kernel that
-            # reads out of bounds (tools/gemm_fault_probe.py reproduces the GPU memory fault).  The plain Linear form is
-            # safe; its [B, HW, classes] result is transposed with one small copy.
-            out = F.linear(tokens, w2d, pred.bias).transpose(1, 2).contiguous()
-        else:
-            out = torch.matmul(w2d, tokens.transpose(1, 2))                    # [B, classes, HW], contiguous
-            if pred.bias is not None:
-                out = out + pred.bias.view(1, -1, 1)
+        # Linear form + one transpose copy (39-79 MB) rather than W x tokens^T: (a) its weight gradient -- a 150 x E product over
+        # 131072 tokens -- then runs on the split-K kernel instead of a 20-workgroup library GEMM (0.39 ms at config 2);
+        # (b) ROCm 7.0 hipBLASLt's bf16 kernel for the batched W x tokens^T form (E=768, HW=16384) reads out of bounds
+        # (tools/gemm_fault_probe.py reproduces the GPU memory fault).
+        out = token_linear(tokens, w2d, pred.bias).transpose(1, 2).contiguous()
         out = out.view(b, pred.out_channels, h, w)
         for hook in pred._forward_hooks.values():
             r = hook(pred, (fused,), out)
