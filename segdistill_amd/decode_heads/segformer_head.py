@@ -103,18 +103,24 @@ class SegFormerHead(BaseDecodeHead):
                 m = proj(feat).permute(0, 2, 1).reshape(c1.shape[0], -1, feat.shape[2], feat.shape[3])
                 maps.append(m if m.shape[2:] == c1.shape[2:] else resize(m, size=c1.shape[2:], mode='bilinear', align_corners=False))
             fused = fuse(torch.cat(maps, dim=1))
-        else:
-            y = self._fused_sum(feats)
-            if fuse.with_norm:
-                y = fuse.norm(y)
-            if fuse.with_activation:
-                y = fuse.activate(y)
-            fused = y
-            if fuse._forward_hooks:  # a tap on linear_fuse itself sees the same output tensor
-                for hook in fuse._forward_hooks.values():
-                    r = hook(fuse, (None,), fused)
-                    if r is not None:
-                        fused = r
+            if self.dropout is not None:
+                fused = self.dropout(fused)
+            return self._predict(fused)
+        return self.finish(self._fused_sum(feats))
+
+    def finish(self, y):
+        """SyncBN -> ReLU -> dropout -> linear_pred on the summed branch maps (the part of the head that may communicate)."""
+        fuse = self.linear_fuse
+        if fuse.with_norm:
+            y = fuse.norm(y)
+        if fuse.with_activation:
+            y = fuse.activate(y)
+        fused = y
+        if fuse._forward_hooks:  # a tap on linear_fuse itself sees the same output tensor
+            for hook in fuse._forward_hooks.values():
+                r = hook(fuse, (None,), fused)
+                if r is not None:
+                    fused = r
         if self.dropout is not None:
             fused = self.dropout(fused)
         return self._predict(fused)
