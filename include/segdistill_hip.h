@@ -142,6 +142,14 @@ int sd_pix_kl_bwd(const void *S, const void *T, int dtype, int B, int C, int H, 
                   float inv_tau, float coef, const float *pix_lse2,
                   const float *upstream, void *dS, void *stream);
 
+/* ATLoss (losses.py:175-197: nn.MSELoss between x.mean(dim=1) maps + the class-softmax KL, tau = 1) fused into the same two
+ * passes: loss = mean_{b,p}(mean_c S - mean_c T)^2 + 1/(B*H*W) * sum_pixels KL.  planes: [3][B*H*W] fp32 (base-2 lse of S and
+ * T, channel-mean difference), written by fwd, read by bwd.  Workspace: sd_pix_kl_workspace_bytes. */
+int sd_at_kl_fwd(const void *S, const void *T, int dtype, int B, int C, int H, int W,
+                 float *planes, float *loss, void *workspace, size_t workspace_bytes, void *stream);
+int sd_at_kl_bwd(const void *S, const void *T, int dtype, int B, int C, int H, int W,
+                 const float *planes, const float *upstream /* d loss, device scalar, or NULL = 1 */, void *dS, void *stream);
+
 /* ---------------------------------------------------------------------------
  * 1x1 feature-alignment projection of the student feature: the
  * `channel_nums=(Cs,Ct)` option documented at opts.py:25-27 of the reference (its live code

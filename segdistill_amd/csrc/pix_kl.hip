@@ -32,18 +32,22 @@ __device__ __forceinline__ void online2(float x, float diff, float &m, float &z,
 }
 
 // grid = (ceil(HW / (kThreads*N)), B).  Writes lse2 planes [2][B*HW] and one partial KL sum per workgroup.
-template <typename T, bool VECTOR>
+// AT = true adds the attention-transfer term of ATLoss (reference losses.py:191-192: MSE between the channel-MEAN maps of
+// student and teacher) to the same pass: the per-pixel channel sums ride along the online softmax, the difference of the
+// means is stored as a third plane for the backward, and at_ratio * dm^2 joins the pixel's KL in the workgroup sum.
+template <typename T, bool VECTOR, bool AT>
 __global__ __launch_bounds__(kThreads) void pix_fwd(const T *__restrict__ S, const T *__restrict__ Tt, float *__restrict__ lse2,
-                                                     double *__restrict__ wg_sum, int C, int HW, long BHW, float c2, float inv_tau) {
+                                                     double *__restrict__ wg_sum, int C, int HW, long BHW, float c2, float inv_tau,
+                                                     float at_ratio) {
     constexpr int N = VECTOR ? VecIO<T>::N : 1;
     const int b = blockIdx.y;
     const int p0 = (blockIdx.x * kThreads + threadIdx.x) * N;
     float kl = 0.f;
     if (p0 < HW) {
         const T *ps = S + (size_t)b * C * HW + p0, *pt = Tt + (size_t)b * C * HW + p0;
-        float ms[N], zs[N], mt[N], zt[N], a[N];
+        float ms[N], zs[N], mt[N], zt[N], a[N], sd_[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) { ms[i] = mt[i] = kNegBig; zs[i] = zt[i] = a[i] = 0.f; }
+        for (int i = 0; i < N; ++i) { ms[i] = mt[i] = kNegBig; zs[i] = zt[i] = a[i] = sd_[i] = 0.f; }
         int c = 0;
         for (; c + kCU <= C; c += kCU) {
             float s[kCU][N], t[kCU][N];
@@ -63,6 +67,7 @@ __global__ __launch_bounds__(kThreads) void pix_fwd(const T *__restrict__ S, con
                 for (int i = 0; i < N; ++i) {
                     online1(s[u][i], ms[i], zs[i], c2);
                     online2(t[u][i], t[u][i] - s[u][i], mt[i], zt[i], a[i], c2);
+                    if constexpr (AT) sd_[i] += s[u][i] - t[u][i];
                 }
         }
         for (; c < C; ++c) {
@@ -78,6 +83,7 @@ __global__ __launch_bounds__(kThreads) void pix_fwd(const T *__restrict__ S, con
             for (int i = 0; i < N; ++i) {
                 online1(s[i], ms[i], zs[i], c2);
                 online2(t[i], t[i] - s[i], mt[i], zt[i], a[i], c2);
+                if constexpr (AT) sd_[i] += s[i] - t[i];
             }
         }
         const float ln2 = 0.69314718055994531f;
@@ -87,6 +93,11 @@ __global__ __launch_bounds__(kThreads) void pix_fwd(const T *__restrict__ S, con
             lse2[(size_t)b * HW + p0 + i] = l2s;
             lse2[BHW + (size_t)b * HW + p0 + i] = l2t;
             kl += a[i] * inv_tau / zt[i] + (l2s - l2t) * ln2;
+            if constexpr (AT) {
+                const float dm = sd_[i] / (float)C;
+                lse2[2 * BHW + (size_t)b * HW + p0 + i] = dm;
+                kl = fmaf(at_ratio * dm, dm, kl);
+            }
         }
     }
     __shared__ double acc[kThreads / 64];
@@ -117,18 +128,23 @@ __global__ __launch_bounds__(kThreads) void pix_loss(const double *__restrict__ 
     }
 }
 
-template <typename T, bool VECTOR>
+template <typename T, bool VECTOR, bool AT>
 __global__ __launch_bounds__(kThreads) void pix_bwd(const T *__restrict__ S, const T *__restrict__ Tt, const float *__restrict__ lse2,
                                                      const float *__restrict__ upstream, T *__restrict__ dS, int C, int HW, long BHW,
-                                                     int cpb, float c2, float coef) {
+                                                     int cpb, float c2, float coef, float at_coef) {
     constexpr int N = VECTOR ? VecIO<T>::N : 1;
     const int b = blockIdx.y;
     const int p0 = (blockIdx.x * kThreads + threadIdx.x) * N;
     if (p0 >= HW) return;
     const float kk = upstream ? coef * upstream[0] : coef;
-    float ls[N], lt[N];
+    float ls[N], lt[N], ad[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) { ls[i] = lse2[(size_t)b * HW + p0 + i]; lt[i] = lse2[BHW + (size_t)b * HW + p0 + i]; }
+    for (int i = 0; i < N; ++i) {
+        ls[i] = lse2[(size_t)b * HW + p0 + i];
+        lt[i] = lse2[BHW + (size_t)b * HW + p0 + i];
+        ad[i] = 0.f;
+        if constexpr (AT) ad[i] = (upstream ? at_coef * upstream[0] : at_coef) * lse2[2 * BHW + (size_t)b * HW + p0 + i];   // same for every channel
+    }
     const int c_lo = blockIdx.z * cpb, c_hi = min(C, c_lo + cpb);
     const size_t off = (size_t)b * C * HW + p0;
     for (int c = c_lo; c < c_hi; ++c) {
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(kThreads) void pix_bwd(const T *__restrict__ S, con
             t[0] = VecIO<T>::load1(Tt + off + (size_t)c * HW);
         }
 #pragma unroll
-        for (int i = 0; i < N; ++i) d[i] = kk * (ex2(fmaf(s[i], c2, -ls[i])) - ex2(fmaf(t[i], c2, -lt[i])));
+        for (int i = 0; i < N; ++i) d[i] = fmaf(kk, ex2(fmaf(s[i], c2, -ls[i])) - ex2(fmaf(t[i], c2, -lt[i])), ad[i]);
         if constexpr (VECTOR) VecIO<T>::template store<true>(dS + off + (size_t)c * HW, d);
         else VecIO<T>::store1(dS + off + (size_t)c * HW, d[0]);
     }
@@ -162,9 +178,9 @@ int check_pix(const void *S, const void *Tt, int dtype, int B, int C, int H, int
     return SD_OK;
 }
 
-template <typename T>
-int pix_fwd_impl(const void *S, const void *Tt, int B, int C, int H, int W, float inv_tau, float loss_scale, float *lse2, float *loss,
-                 void *ws, size_t ws_bytes, hipStream_t st) {
+template <typename T, bool AT>
+int pix_fwd_impl(const void *S, const void *Tt, int B, int C, int H, int W, float inv_tau, float loss_scale, float at_ratio, float *lse2,
+                 float *loss, void *ws, size_t ws_bytes, hipStream_t st) {
     const long HW = (long)H * W;
     const bool vec = vec_ok<T>(S, Tt, nullptr, HW);
     const int N = vec ? VecIO<T>::N : 1;
@@ -173,16 +189,16 @@ int pix_fwd_impl(const void *S, const void *Tt, int B, int C, int H, int W, floa
     if (ws_bytes < need || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
     const float c2 = inv_tau * 1.44269504088896340736f;
     double *sums = static_cast<double *>(ws);
-    if (vec) hipLaunchKernelGGL((pix_fwd<T, true>), dim3(gx, B), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, lse2, sums, C, (int)HW,
-                                (long)B * HW, c2, inv_tau);
-    else hipLaunchKernelGGL((pix_fwd<T, false>), dim3(gx, B), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, lse2, sums, C, (int)HW,
-                            (long)B * HW, c2, inv_tau);
+    if (vec) hipLaunchKernelGGL((pix_fwd<T, true, AT>), dim3(gx, B), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, lse2, sums, C, (int)HW,
+                                (long)B * HW, c2, inv_tau, at_ratio);
+    else hipLaunchKernelGGL((pix_fwd<T, false, AT>), dim3(gx, B), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, lse2, sums, C, (int)HW,
+                            (long)B * HW, c2, inv_tau, at_ratio);
     hipLaunchKernelGGL(pix_loss, dim3(1), dim3(kThreads), 0, st, sums, loss, gx * B, loss_scale);
     return (int)hipGetLastError();
 }
 
-template <typename T>
-int pix_bwd_impl(const void *S, const void *Tt, int B, int C, int H, int W, float inv_tau, float coef, const float *lse2,
+template <typename T, bool AT>
+int pix_bwd_impl(const void *S, const void *Tt, int B, int C, int H, int W, float inv_tau, float coef, float at_coef, const float *lse2,
                  const float *upstream, void *dS, hipStream_t st) {
     const long HW = (long)H * W;
     const bool vec = vec_ok<T>(S, Tt, dS, HW);
@@ -194,10 +210,10 @@ int pix_bwd_impl(const void *S, const void *Tt, int B, int C, int H, int W, floa
     const int cpb = (C + gz - 1) / gz;
     gz = (C + cpb - 1) / cpb;
     const float c2 = inv_tau * 1.44269504088896340736f;
-    if (vec) hipLaunchKernelGGL((pix_bwd<T, true>), dim3(gx, B, gz), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, lse2, upstream,
-                                (T *)dS, C, (int)HW, (long)B * HW, cpb, c2, coef);
-    else hipLaunchKernelGGL((pix_bwd<T, false>), dim3(gx, B, gz), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, lse2, upstream,
-                            (T *)dS, C, (int)HW, (long)B * HW, cpb, c2, coef);
+    if (vec) hipLaunchKernelGGL((pix_bwd<T, true, AT>), dim3(gx, B, gz), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, lse2, upstream,
+                                (T *)dS, C, (int)HW, (long)B * HW, cpb, c2, coef, at_coef);
+    else hipLaunchKernelGGL((pix_bwd<T, false, AT>), dim3(gx, B, gz), dim3(kThreads), 0, st, (const T *)S, (const T *)Tt, lse2, upstream,
+                            (T *)dS, C, (int)HW, (long)B * HW, cpb, c2, coef, at_coef);
     return (int)hipGetLastError();
 }
 
@@ -219,8 +235,9 @@ int sd_pix_kl_fwd(const void *S, const void *T, int dtype, int B, int C, int H, 
     if (rc) return rc;
     if (!pix_lse2 || !loss || !workspace) return SD_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == SD_F32) return sd::pix_fwd_impl<float>(S, T, B, C, H, W, inv_tau, loss_scale, pix_lse2, loss, workspace, workspace_bytes, st);
-    return sd::pix_fwd_impl<sd::bf16_t>(S, T, B, C, H, W, inv_tau, loss_scale, pix_lse2, loss, workspace, workspace_bytes, st);
+    if (dtype == SD_F32)
+        return sd::pix_fwd_impl<float, false>(S, T, B, C, H, W, inv_tau, loss_scale, 0.f, pix_lse2, loss, workspace, workspace_bytes, st);
+    return sd::pix_fwd_impl<sd::bf16_t, false>(S, T, B, C, H, W, inv_tau, loss_scale, 0.f, pix_lse2, loss, workspace, workspace_bytes, st);
 }
 
 int sd_pix_kl_bwd(const void *S, const void *T, int dtype, int B, int C, int H, int W, float inv_tau, float coef, const float *pix_lse2,
@@ -229,8 +246,35 @@ int sd_pix_kl_bwd(const void *S, const void *T, int dtype, int B, int C, int H, 
     if (rc) return rc;
     if (!pix_lse2 || !dS) return SD_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == SD_F32) return sd::pix_bwd_impl<float>(S, T, B, C, H, W, inv_tau, coef, pix_lse2, upstream, dS, st);
-    return sd::pix_bwd_impl<sd::bf16_t>(S, T, B, C, H, W, inv_tau, coef, pix_lse2, upstream, dS, st);
+    if (dtype == SD_F32) return sd::pix_bwd_impl<float, false>(S, T, B, C, H, W, inv_tau, coef, 0.f, pix_lse2, upstream, dS, st);
+    return sd::pix_bwd_impl<sd::bf16_t, false>(S, T, B, C, H, W, inv_tau, coef, 0.f, pix_lse2, upstream, dS, st);
+}
+
+/* ATLoss (reference losses.py:175-197) in one pass each way:
+ *   loss = mean_{b,p} (mean_c S - mean_c T)^2  +  1/(B*H*W) * sum_pixels KL(softmax_C(T) || softmax_C(S))
+ * planes: [3][B*H*W] fp32 (base-2 lse of S, of T, and the channel-mean difference). */
+int sd_at_kl_fwd(const void *S, const void *T, int dtype, int B, int C, int H, int W, float *planes, float *loss, void *workspace,
+                 size_t workspace_bytes, void *stream) {
+    int rc = sd::check_pix(S, T, dtype, B, C, H, W);
+    if (rc) return rc;
+    if (!planes || !loss || !workspace) return SD_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float inv_rows = 1.f / ((float)B * (float)H * (float)W);
+    if (dtype == SD_F32)
+        return sd::pix_fwd_impl<float, true>(S, T, B, C, H, W, 1.f, inv_rows, 1.f, planes, loss, workspace, workspace_bytes, st);
+    return sd::pix_fwd_impl<sd::bf16_t, true>(S, T, B, C, H, W, 1.f, inv_rows, 1.f, planes, loss, workspace, workspace_bytes, st);
+}
+
+int sd_at_kl_bwd(const void *S, const void *T, int dtype, int B, int C, int H, int W, const float *planes, const float *upstream, void *dS,
+                 void *stream) {
+    int rc = sd::check_pix(S, T, dtype, B, C, H, W);
+    if (rc) return rc;
+    if (!planes || !dS) return SD_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float inv_rows = 1.f / ((float)B * (float)H * (float)W);
+    const float at_coef = 2.f * inv_rows / (float)C;          // d/dS[b,c,p] of mean_{b,p} dm^2, dm = (sum_c S - sum_c T) / C
+    if (dtype == SD_F32) return sd::pix_bwd_impl<float, true>(S, T, B, C, H, W, 1.f, inv_rows, at_coef, planes, upstream, dS, st);
+    return sd::pix_bwd_impl<sd::bf16_t, true>(S, T, B, C, H, W, 1.f, inv_rows, at_coef, planes, upstream, dS, st);
 }
 
 }  // extern "C"

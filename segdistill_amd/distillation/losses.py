@@ -242,8 +242,7 @@ class ATLoss(nn.Module):
     the class-softmax KL (tau=1, alpha=1) of the un-resized logits."""
 
     def forward(self, x_student, x_teacher, gt, step):
-        at = F.mse_loss(x_student.mean(dim=1), x_teacher.mean(dim=1))
-        return at + ops.pix_kl(x_student, x_teacher, tau=1.0, alpha=1.0)
+        return ops.at_kl(x_student, x_teacher)      # both terms in one pass over the logits each way (csrc/pix_kl.hip, AT form)
 
 
 @DISTILL_LOSSES.register_module()

@@ -188,6 +188,45 @@ def pix_kl(S, T, *, tau, alpha):
     return _PixKLFunction.apply(S, T, tau, alpha)
 
 
+class _ATKLFunction(torch.autograd.Function):
+    """ATLoss: mean_{b,p}(mean_c S - mean_c T)^2 + 1/(B*H*W) * sum_pixels KL(softmax_C(T) || softmax_C(S)), one pass each way."""
+
+    @staticmethod
+    def forward(ctx, S, T):
+        _require_gpu(S, T)
+        if S.shape != T.shape or S.dim() != 4:
+            raise ValueError(f'expected equal 4-D shapes, got {tuple(S.shape)} and {tuple(T.shape)}')
+        if S.dtype != T.dtype or S.dtype not in _DT:
+            raise TypeError(f'unsupported dtypes {S.dtype}/{T.dtype}')
+        S, T = S.contiguous(), T.contiguous()
+        B, Cc, H, W = S.shape
+        L = _lib.lib()
+        ws_bytes = L.sd_pix_kl_workspace_bytes(B, Cc, H, W)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=S.device)
+        planes = torch.empty(3, B * H * W, dtype=torch.float32, device=S.device)
+        loss = torch.empty((), dtype=torch.float32, device=S.device)
+        rc = L.sd_at_kl_fwd(S.data_ptr(), T.data_ptr(), _DT[S.dtype], B, Cc, H, W, planes.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws_bytes,
+                            _stream_ptr())
+        _lib.check(rc, 'sd_at_kl_fwd')
+        ctx.save_for_backward(S, T, planes)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        S, T, planes = ctx.saved_tensors
+        B, Cc, H, W = S.shape
+        dS = torch.empty_like(S)
+        up = grad_loss.to(torch.float32).contiguous()
+        rc = _lib.lib().sd_at_kl_bwd(S.data_ptr(), T.data_ptr(), _DT[S.dtype], B, Cc, H, W, planes.data_ptr(), up.data_ptr(), dS.data_ptr(),
+                                     _stream_ptr())
+        _lib.check(rc, 'sd_at_kl_bwd')
+        return dS, None
+
+
+def at_kl(S, T):
+    return _ATKLFunction.apply(S, T)
+
+
 def align1x1(x, weight, bias=None):
     """Y[b,:,p] = W[Ct,Cs] . X[b,:,p] + bias  (MFMA GEMM kernel; see csrc/align1x1.hip)."""
     from .align import align1x1 as _impl

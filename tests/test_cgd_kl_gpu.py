@@ -350,3 +350,23 @@ def test_extreme_logit_magnitudes_and_pad_semantics():
     pad = np.full((1, 1, 8, 8), -1e9, np.float32)
     loss_real, _, _ = _run_hip(np.concatenate([S3, pad], 1), np.concatenate([T3, pad], 1), 2, 2.0, 1.0)
     assert loss_real == pytest.approx(loss_virtual, rel=1e-6)
+
+
+@pytest.mark.parametrize('shape', [(2, 150, 32, 32), (1, 19, 7, 9), (3, 6, 16, 16)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_at_kl_fused_matches_oracle(shape, dtype):
+    """ATLoss as ONE HIP pass each way (channel-mean MSE riding on the pixel-KL kernels) vs the oracle's eager restatement
+    of losses.py:187-197, in fp64 on the same (storage-rounded) inputs; upstream gradient != 1."""
+    from segdistill_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    s = (2 * torch.randn(*shape, generator=g)).to(dtype)
+    t = (2 * torch.randn(*shape, generator=g) + 0.3).to(dtype)
+    s64 = s.double().requires_grad_(True)
+    ref = kd_ref.eager_at(s64, t.double())
+    (1.7 * ref).backward()
+    sg = s.to(_dev()).requires_grad_(True)
+    loss = ops.at_kl(sg, t.to(_dev()))
+    (1.7 * loss).backward()
+    ltol, gtol = (LOSS_RTOL, GRAD_RL2) if dtype == torch.float32 else (2e-3, 1e-2)
+    assert float(loss) == pytest.approx(float(ref), rel=ltol)
+    assert _rel_l2(sg.grad.float().cpu().numpy(), s64.grad.numpy()) < gtol
