@@ -30,6 +30,8 @@ def main():
     ap.add_argument('--launcher', choices=['none', 'pytorch'], default='none')
     ap.add_argument('--graph', choices=['auto', 'on', 'hybrid', 'off'], default='auto')
     ap.add_argument('--synthetic-weights', action='store_true', help='train from random init when checkpoints named by the config are absent')
+    ap.add_argument('--data-root', default=None, help='dataset directory for configs with data.train (overrides its data_root); '
+                                                      'without a data.train entry synthetic ADE20K-shaped batches are used')
     ap.add_argument('--options', nargs='*', default=[], help='config overrides key=value (dotted keys)')
     args = ap.parse_args()
 
@@ -69,8 +71,22 @@ def main():
         if rank == 0:
             print(f'resumed from {args.resume_from}: iter {trainer.iter}, distillation step {model.cnt}')
     B = int(cfg.data.samples_per_gpu)
-    data = SyntheticADE(B, size=tuple(cfg.get('crop_size', (512, 512))), num_classes=int(cfg.get('num_classes', 150)), seed=args.seed,
-                        rank=rank, device=device)
+    if cfg.data.get('train') is not None:
+        # real data: the reference's dataset + pipeline configs (segdistill_amd/data), one loader per rank
+        from segdistill_amd.data import build_dataloader, build_dataset
+        from segdistill_amd.data.feed import LoaderFeed
+        tcfg = cfg.data.train.to_dict() if hasattr(cfg.data.train, 'to_dict') else dict(cfg.data.train)
+        inner = tcfg['dataset'] if tcfg.get('type') == 'RepeatDataset' else tcfg
+        if args.data_root:
+            inner['data_root'] = args.data_root
+        dataset = build_dataset(tcfg)
+        loader = build_dataloader(dataset, B, int(cfg.data.get('workers_per_gpu', 2)), world=world, rank=rank, seed=args.seed)
+        data = LoaderFeed(loader, device)
+        if rank == 0:
+            print(f'dataset: {len(dataset)} samples ({type(dataset).__name__}), {B} per GPU, {world} rank(s)')
+    else:
+        data = SyntheticADE(B, size=tuple(cfg.get('crop_size', (512, 512))), num_classes=int(cfg.get('num_classes', 150)), seed=args.seed,
+                            rank=rank, device=device)
     work = args.work_dir or os.path.join(ROOT, 'work_dirs', os.path.splitext(os.path.basename(args.config))[0])
     if rank == 0:
         os.makedirs(work, exist_ok=True)
