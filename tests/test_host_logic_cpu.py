@@ -364,3 +364,34 @@ def test_extractor_and_loss_dispatch_errors_and_naming():
         _to_nchw(torch.zeros(1, 10, 4))
     from segdistill_amd.distillation.opts import _to_nchw
     assert _to_nchw(torch.zeros(2, 16, 7)).shape == (2, 7, 4, 4)
+
+
+def test_swin_public_checkpoint_adaptations(tmp_path):
+    """Loading a Swin checkpoint trained with another window size / stored in the public layouts: the relative-position-bias
+    tables are resized bicubically, a [1, L, C] absolute position embedding is re-laid-out, MoBY's 'encoder.' prefix is
+    stripped (reference mmcv_custom/checkpoint.py:314-343)."""
+    import torch.nn.functional as F
+    from segdistill_amd.backbones.swin import SwinTransformer
+    from segdistill_amd.checkpoint import load_checkpoint
+    torch.manual_seed(0)
+    kw = dict(pretrain_img_size=64, embed_dim=16, depths=[1, 1], num_heads=[2, 4], out_indices=(0, 1), ape=True, drop_path_rate=0.)
+    src = SwinTransformer(window_size=4, **kw)
+    dst = SwinTransformer(window_size=7, **kw)
+    sd = {('encoder.' + k): v.clone() for k, v in src.state_dict().items()}
+    ape = sd['encoder.absolute_pos_embed']                                   # [1, C, H, W] -> the public [1, L, C] layout
+    sd['encoder.absolute_pos_embed'] = ape.permute(0, 2, 3, 1).reshape(1, -1, ape.shape[1])
+    sd['projector.weight'] = torch.zeros(3)                                  # MoBY's other branch: dropped with the prefix filter
+    path = tmp_path / 'swin_w4.pth'
+    torch.save({'model': sd}, path)
+    result = load_checkpoint(dst, str(path), strict=False)
+    assert not result.unexpected_keys
+    assert all(k.endswith('relative_position_index') for k in result.missing_keys)      # window-size buffers: the model keeps its own
+    key = 'layers.0.blocks.0.attn.relative_position_bias_table'
+    t4, t7 = src.state_dict()[key], dst.state_dict()[key]
+    assert t4.shape == (49, 2) and t7.shape == (169, 2)
+    want = F.interpolate(t4.permute(1, 0).view(1, 2, 7, 7), size=(13, 13), mode='bicubic').view(2, 169).permute(1, 0)
+    assert torch.allclose(t7, want)
+    assert torch.equal(dst.state_dict()['absolute_pos_embed'], src.state_dict()['absolute_pos_embed'])
+    assert torch.equal(dst.state_dict()['patch_embed.proj.weight'], src.state_dict()['patch_embed.proj.weight'])
+    x = torch.randn(1, 3, 64, 64)
+    assert all(torch.isfinite(o).all() for o in dst(x))
