@@ -151,6 +151,28 @@ int sd_at_kl_bwd(const void *S, const void *T, int dtype, int B, int C, int H, i
                  const float *planes, const float *upstream /* d loss, device scalar, or NULL = 1 */, void *dS, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * IFVDLoss, intra-class feature-variation term (losses.py:221-235): cosine similarity of every pixel's feature to the mean
+ * feature of its class (per image), matched between student and teacher: 10 * mean_p (sim_S - sim_T)^2, and its gradient
+ * with respect to the student feature INCLUDING the path through the class means (as the reference's autograd does).
+ * The caller sorts the pixels of each image by class once:  order [B][HW] int32 (pixel indices, classes 0..K-1 first),
+ * offsets [B][K+1] int32 (run boundaries); cls [B][HW] int32 is the class of each pixel (-1 / >= K: no class).
+ *   sd_ifvd_seg_sum  out[b,k,c] = sum_{p in run k} wgt[b,p] * X[b,c,p]   (wgt NULL -> 1; mean_mode: / (n_k + 1e-6))
+ *   sd_ifvd_cos      sim[b,p] = cos(X[b,:,p], mean[b,cls,:]) (eps 1e-8 per norm, F.cosine_similarity); with sim_ref (student
+ *                    pass) also loss = 10 * mean (sim - sim_ref)^2 and coefs [3][B*HW] = alpha, beta, gamma for the backward
+ *   sd_ifvd_bwd      dS = upstream * (alpha*mu_k - gamma*S + (A_k - mu_k*B_k)/(n_k + 1e-6)),  A = seg_sum(S, alpha), B = seg_sum(beta)
+ * Deterministic (no float atomics).  X, dS: [B,C,HW] in `dtype`; everything else fp32 / int32.
+ */
+size_t sd_ifvd_workspace_bytes(int B, int HW);
+int sd_ifvd_seg_sum(const void *X, int dtype, const float *wgt, const int *order, const int *offsets, float *out,
+                    int B, int C, int HW, int K, int mean_mode, void *stream);
+int sd_ifvd_cos(const void *X, int dtype, const int *cls, const float *mean, const float *sim_ref /* or NULL */, float *sim,
+                float *coefs /* [3][B*HW], with sim_ref */, float *loss /* with sim_ref */, void *workspace, size_t workspace_bytes,
+                int B, int C, int HW, int K, void *stream);
+int sd_ifvd_bwd(const void *X, int dtype, const int *cls, const float *mean, const float *coefs, const float *A, const float *Bk,
+                const int *offsets, const float *upstream /* device scalar or NULL */, void *dS,
+                int B, int C, int HW, int K, void *stream);
+
+/* ---------------------------------------------------------------------------
  * 1x1 feature-alignment projection of the student feature: the
  * `channel_nums=(Cs,Ct)` option documented at opts.py:25-27 of the reference (its live code
  * never builds the nn.Conv2d(Cs, Ct, 1) it describes; the commented generation did, at

@@ -272,6 +272,10 @@ class IFVDLoss(nn.Module):
         n_cls = feat_T.shape[1]
         pd = ops.pix_kl(preds_S, feat_T, tau=1.0, alpha=1.0)
         lab = F.interpolate(target.float(), size=preds_S.shape[2:], mode='nearest')
+        if preds_S.is_cuda:
+            # csrc/ifvd.hip: class means as sorted-run gathers, cosine pass, gradient through the centres -- no mask loop, no atomics
+            cls = torch.where((lab >= 0) & (lab < n_cls) & (lab == lab.floor()), lab, torch.full_like(lab, -1.)).to(torch.int32)
+            return ops.ifvd_term(preds_S, feat_T.detach(), cls, n_cls) + pd
         sim_s = F.cosine_similarity(preds_S, self._centres(preds_S, lab, n_cls), dim=1)
         sim_t = F.cosine_similarity(feat_T, self._centres(feat_T, lab, n_cls), dim=1)
         return 10 * F.mse_loss(sim_s, sim_t) + pd

@@ -227,6 +227,69 @@ def at_kl(S, T):
     return _ATKLFunction.apply(S, T)
 
 
+class _IFVDFunction(torch.autograd.Function):
+    """10 * mean_p (cos(S_p, centre^S_label(p)) - cos(T_p, centre^T_label(p)))^2 with class centres = per-image class means."""
+
+    @staticmethod
+    def forward(ctx, S, T, cls, n_cls):
+        _require_gpu(S, T)
+        if S.shape != T.shape or S.dim() != 4:
+            raise ValueError(f'expected equal 4-D shapes, got {tuple(S.shape)} and {tuple(T.shape)}')
+        if S.dtype != T.dtype or S.dtype not in _DT:
+            raise TypeError(f'unsupported dtypes {S.dtype}/{T.dtype}')
+        S, T = S.contiguous(), T.contiguous()
+        B, Cc, H, W = S.shape
+        HW, K = H * W, int(n_cls)
+        cls = cls.reshape(B, HW).to(torch.int32).contiguous()
+        valid = (cls >= 0) & (cls < K)
+        key = torch.where(valid, cls, torch.full_like(cls, K)).long()
+        order = key.argsort(dim=1, stable=True).to(torch.int32).contiguous()          # pixels grouped by class, once for all channels
+        counts = torch.zeros(B, K + 1, dtype=torch.int64, device=S.device).scatter_add_(1, key, torch.ones_like(key))
+        offsets = torch.zeros(B, K + 1, dtype=torch.int32, device=S.device)
+        offsets[:, 1:] = counts[:, :K].cumsum(1).to(torch.int32)
+        L, dt, st = _lib.lib(), _DT[S.dtype], _stream_ptr()
+        f32 = dict(dtype=torch.float32, device=S.device)
+        mean_s, mean_t = torch.empty(B, K, Cc, **f32), torch.empty(B, K, Cc, **f32)
+        _lib.check(L.sd_ifvd_seg_sum(S.data_ptr(), dt, None, order.data_ptr(), offsets.data_ptr(), mean_s.data_ptr(), B, Cc, HW, K, 1, st), 'sd_ifvd_seg_sum')
+        _lib.check(L.sd_ifvd_seg_sum(T.data_ptr(), dt, None, order.data_ptr(), offsets.data_ptr(), mean_t.data_ptr(), B, Cc, HW, K, 1, st), 'sd_ifvd_seg_sum')
+        sim_t, sim_s = torch.empty(B, HW, **f32), torch.empty(B, HW, **f32)
+        coefs = torch.empty(3, B * HW, **f32)
+        loss = torch.empty((), **f32)
+        wsb = L.sd_ifvd_workspace_bytes(B, HW)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=S.device)
+        _lib.check(L.sd_ifvd_cos(T.data_ptr(), dt, cls.data_ptr(), mean_t.data_ptr(), None, sim_t.data_ptr(), None, None, None, 0, B, Cc, HW, K, st),
+                   'sd_ifvd_cos')
+        _lib.check(L.sd_ifvd_cos(S.data_ptr(), dt, cls.data_ptr(), mean_s.data_ptr(), sim_t.data_ptr(), sim_s.data_ptr(), coefs.data_ptr(),
+                                 loss.data_ptr(), ws.data_ptr(), wsb, B, Cc, HW, K, st), 'sd_ifvd_cos')
+        ctx.save_for_backward(S, cls, mean_s, coefs, order, offsets)
+        ctx.K = K
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        S, cls, mean_s, coefs, order, offsets = ctx.saved_tensors
+        B, Cc, H, W = S.shape
+        HW, K = H * W, ctx.K
+        L, dt, st = _lib.lib(), _DT[S.dtype], _stream_ptr()
+        f32 = dict(dtype=torch.float32, device=S.device)
+        A, Bk = torch.empty(B, K, Cc, **f32), torch.empty(B, K, 1, **f32)
+        alpha, beta = coefs[0], coefs[1]
+        _lib.check(L.sd_ifvd_seg_sum(S.data_ptr(), dt, alpha.data_ptr(), order.data_ptr(), offsets.data_ptr(), A.data_ptr(), B, Cc, HW, K, 0, st),
+                   'sd_ifvd_seg_sum')
+        _lib.check(L.sd_ifvd_seg_sum(beta.data_ptr(), _DT[torch.float32], None, order.data_ptr(), offsets.data_ptr(), Bk.data_ptr(), B, 1, HW, K, 0, st),
+                   'sd_ifvd_seg_sum')
+        dS = torch.empty_like(S)
+        up = grad_loss.to(torch.float32).contiguous()
+        _lib.check(L.sd_ifvd_bwd(S.data_ptr(), dt, cls.data_ptr(), mean_s.data_ptr(), coefs.data_ptr(), A.data_ptr(), Bk.data_ptr(),
+                                 offsets.data_ptr(), up.data_ptr(), dS.data_ptr(), B, Cc, HW, K, st), 'sd_ifvd_bwd')
+        return dS, None, None, None
+
+
+def ifvd_term(S, T, cls, n_cls):
+    """cls: integer class per pixel [B,H,W] (or [B,1,H,W]); values outside [0, n_cls) mean "no class"."""
+    return _IFVDFunction.apply(S, T, cls, n_cls)
+
+
 def align1x1(x, weight, bias=None):
     """Y[b,:,p] = W[Ct,Cs] . X[b,:,p] + bias  (MFMA GEMM kernel; see csrc/align1x1.hip)."""
     from .align import align1x1 as _impl

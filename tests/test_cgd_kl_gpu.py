@@ -370,3 +370,27 @@ def test_at_kl_fused_matches_oracle(shape, dtype):
     ltol, gtol = (LOSS_RTOL, GRAD_RL2) if dtype == torch.float32 else (2e-3, 1e-2)
     assert float(loss) == pytest.approx(float(ref), rel=ltol)
     assert _rel_l2(sg.grad.float().cpu().numpy(), s64.grad.numpy()) < gtol
+
+
+@pytest.mark.parametrize('shape', [(2, 19, 16, 16), (1, 150, 32, 32), (3, 6, 7, 9)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_ifvd_kernels_match_oracle(shape, dtype):
+    """IFVDLoss through the HIP class-mean / cosine / backward kernels vs the oracle's literal restatement of the reference's
+    mask loop (losses.py:211-238) in fp64: labels at twice the feature resolution (nearest-resized), some ignored (255) and
+    some classes absent; the gradient includes the path through the class centres."""
+    from segdistill_amd.distillation import IFVDLoss
+    B, C, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    s = (torch.randn(*shape, generator=g) + 0.5).to(dtype)
+    t = (torch.randn(*shape, generator=g) + 0.5).to(dtype)
+    lab = torch.randint(0, max(2, C // 2), (B, 1, 2 * h, 2 * w), generator=g)
+    lab[torch.rand(B, 1, 2 * h, 2 * w, generator=g) < 0.1] = 255
+    s64 = s.double().requires_grad_(True)
+    ref = kd_ref.eager_ifvd(s64, t.double(), lab)
+    (1.3 * ref).backward()
+    sg = s.to(_dev()).requires_grad_(True)
+    loss = IFVDLoss()(sg, t.to(_dev()), lab.to(_dev()), 1)
+    (1.3 * loss).backward()
+    ltol, gtol = (LOSS_RTOL, GRAD_RL2) if dtype == torch.float32 else (3e-3, 2e-2)
+    assert float(loss) == pytest.approx(float(ref), rel=ltol)
+    assert _rel_l2(sg.grad.float().cpu().numpy(), s64.grad.numpy()) < gtol
