@@ -330,6 +330,13 @@ int sd_sra_bwd(const void *q, const void *kv, const void *out, const void *dout,
 int sd_upsum_fwd(const void *z1, const void *z2, const void *z3, const void *z4, const float *bias, void *y,
                  int dtype, int B, int H, int W, int E, int f2, int f3, int f4, void *stream);
 
+/* Inference form for a frozen network: the eval-mode BatchNorm (an affine map per channel: scale = gamma / sqrt(var + eps),
+ * shift = beta - mean * scale) and the ReLU that follow the sum in `linear_fuse` (segformer_head.py:66-71, :93-94) applied in
+ * the same pass: y = max(0, (z1 + up(z2) + up(z3) + up(z4) + bias) * scale + shift)  (relu = 0: no clamp). */
+int sd_upsum_affine_fwd(const void *z1, const void *z2, const void *z3, const void *z4, const float *bias /* or NULL */,
+                        const float *scale, const float *shift, int relu, void *y, int dtype,
+                        int B, int H, int W, int E, int f2, int f3, int f4, void *stream);
+
 int sd_upsum_bwd(const void *dy, void *dz, int dtype, int B, int h, int w, int E, int F, void *stream);
 
 #ifdef __cplusplus

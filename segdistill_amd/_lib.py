@@ -70,6 +70,7 @@ SIGNATURES = {
     'sd_add_layernorm_fwd': (_i, [_vp] * 3 + [C.c_long] + [_vp] * 6 + [_i, C.c_long, _i, _f, _vp]),
     'sd_add_layernorm_bwd': (_i, [_vp] * 7 + [C.c_long] + [_vp] * 4 + [_i, C.c_long, _i, _vp, _sz, _vp]),
     'sd_upsum_fwd': (_i, [_vp] * 6 + [_i] * 8 + [_vp]),
+    'sd_upsum_affine_fwd': (_i, [_vp] * 7 + [_i] + [_vp] + [_i] * 8 + [_vp]),
     'sd_upsum_bwd': (_i, [_vp, _vp] + [_i] * 6 + [_vp]),
     'sd_ce_up_supported': (_i, [_i, _i, _i, _i]),
     'sd_ce_up_fwd': (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),

@@ -81,10 +81,13 @@ __device__ __forceinline__ void add_branch(float (&acc)[HV<T>::N], const T *__re
 }
 
 // y[b,Y,X,:] = z1[b,Y,X,:] + up(z2) + up(z3) + up(z4) (+ bias).  grid: ceil(B*H*W*(E/N) / 256)
+// Inference epilogue (scale != nullptr): y = max(0, y * scale[c] + shift[c]) -- the eval-mode BatchNorm (folded to an affine
+// map per channel) and the ReLU that follow the sum in linear_fuse (segformer_head.py:66-71), for the frozen teacher.
 template <typename T>
 __global__ __launch_bounds__(256) void upsum_fwd(const T *__restrict__ z1, const T *__restrict__ z2, const T *__restrict__ z3,
-                                                  const T *__restrict__ z4, const float *__restrict__ bias, T *__restrict__ y, int B, int H,
-                                                  int W, int E, int f2, int f3, int f4) {
+                                                  const T *__restrict__ z4, const float *__restrict__ bias, const float *__restrict__ scale,
+                                                  const float *__restrict__ shift, int relu, T *__restrict__ y, int B, int H, int W, int E,
+                                                  int f2, int f3, int f4) {
     constexpr int N = HV<T>::N;
     const int ev = E / N;
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -103,6 +106,13 @@ __global__ __launch_bounds__(256) void upsum_fwd(const T *__restrict__ z1, const
     add_branch<T>(acc, z2, b, Y, X, H, W, f2, E, c);
     add_branch<T>(acc, z3, b, Y, X, H, W, f3, E, c);
     add_branch<T>(acc, z4, b, Y, X, H, W, f4, E, c);
+    if (scale) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            acc[i] = fmaf(acc[i], scale[c + i], shift[c + i]);
+            if (relu) acc[i] = fmaxf(acc[i], 0.f);
+        }
+    }
     HV<T>::store(y + pix * E + c, acc);
 }
 
@@ -154,9 +164,10 @@ bool ok_factor(int f) { return f == 2 || f == 4 || f == 8; }
 
 extern "C" {
 
-int sd_upsum_fwd(const void *z1, const void *z2, const void *z3, const void *z4, const float *bias, void *y, int dtype, int B, int H, int W,
-                 int E, int f2, int f3, int f4, void *stream) {
+static int upsum_fwd_impl(const void *z1, const void *z2, const void *z3, const void *z4, const float *bias, const float *scale,
+                          const float *shift, int relu, void *y, int dtype, int B, int H, int W, int E, int f2, int f3, int f4, void *stream) {
     if (!z1 || !z2 || !z3 || !z4 || !y) return SD_E_NULL;
+    if ((scale == nullptr) != (shift == nullptr)) return SD_E_NULL;
     if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
     if (B <= 0 || H <= 0 || W <= 0 || E <= 0) return SD_E_SHAPE;
     if (!sd::ok_factor(f2) || !sd::ok_factor(f3) || !sd::ok_factor(f4) || H % f2 || W % f2 || H % f3 || W % f3 || H % f4 || W % f4)
@@ -168,11 +179,22 @@ int sd_upsum_fwd(const void *z1, const void *z2, const void *z3, const void *z4,
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (dtype == SD_F32)
         hipLaunchKernelGGL((sd::upsum_fwd<float>), dim3(grid), dim3(256), 0, st, (const float *)z1, (const float *)z2, (const float *)z3,
-                           (const float *)z4, bias, (float *)y, B, H, W, E, f2, f3, f4);
+                           (const float *)z4, bias, scale, shift, relu, (float *)y, B, H, W, E, f2, f3, f4);
     else
         hipLaunchKernelGGL((sd::upsum_fwd<sd::bf16_t>), dim3(grid), dim3(256), 0, st, (const sd::bf16_t *)z1, (const sd::bf16_t *)z2,
-                           (const sd::bf16_t *)z3, (const sd::bf16_t *)z4, bias, (sd::bf16_t *)y, B, H, W, E, f2, f3, f4);
+                           (const sd::bf16_t *)z3, (const sd::bf16_t *)z4, bias, scale, shift, relu, (sd::bf16_t *)y, B, H, W, E, f2, f3, f4);
     return (int)hipGetLastError();
+}
+
+int sd_upsum_fwd(const void *z1, const void *z2, const void *z3, const void *z4, const float *bias, void *y, int dtype, int B, int H, int W,
+                 int E, int f2, int f3, int f4, void *stream) {
+    return upsum_fwd_impl(z1, z2, z3, z4, bias, nullptr, nullptr, 0, y, dtype, B, H, W, E, f2, f3, f4, stream);
+}
+
+int sd_upsum_affine_fwd(const void *z1, const void *z2, const void *z3, const void *z4, const float *bias, const float *scale,
+                        const float *shift, int relu, void *y, int dtype, int B, int H, int W, int E, int f2, int f3, int f4, void *stream) {
+    if (!scale || !shift) return SD_E_NULL;
+    return upsum_fwd_impl(z1, z2, z3, z4, bias, scale, shift, relu, y, dtype, B, H, W, E, f2, f3, f4, stream);
 }
 
 int sd_upsum_bwd(const void *dy, void *dz, int dtype, int B, int h, int w, int E, int F, void *stream) {

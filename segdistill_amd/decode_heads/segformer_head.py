@@ -59,7 +59,8 @@ class SegFormerHead(BaseDecodeHead):
     def _branches(self, feats):
         return ((feats[3], self.linear_c4), (feats[2], self.linear_c3), (feats[1], self.linear_c2), (feats[0], self.linear_c1))
 
-    def _fused_sum(self, feats):
+    def _fused_sum(self, feats, fold_norm=False):
+        """-> (y, normed): the summed branch maps, and whether the eval-mode norm + ReLU were already applied in the same pass."""
         from .. import headfuse
         c1 = feats[0]
         n, size = c1.shape[0], c1.shape[2:]
@@ -78,10 +79,17 @@ class SegFormerHead(BaseDecodeHead):
             sizes.append(tuple(feat.shape[2:]))
         zs, sizes = zs[::-1], sizes[::-1]                             # finest (c1) first
         bias = self.linear_fuse.conv.bias
+        if fold_norm and headfuse.supported(zs, sizes):
+            # frozen network: sum + eval-mode BatchNorm (an affine map per channel) + ReLU in ONE pass; finish() is told to skip them
+            norm = self.linear_fuse.norm
+            scale = norm.weight * torch.rsqrt(norm.running_var + norm.eps)
+            shift = norm.bias - norm.running_mean * scale
+            y = headfuse.upsum_affine_inference(zs, bias, sizes, scale, shift, relu=True)
+            return y.reshape(n, size[0], size[1], e).permute(0, 3, 1, 2), True
         if headfuse.supported(zs, sizes):
             # MI355X path (csrc/headfuse.hip): one pass, y = z1 + up(z2) + up(z3) + up(z4) + bias, token-major
             y = headfuse.upsum(zs[0], zs[1], zs[2], zs[3], bias, sizes)
-            return y.reshape(n, size[0], size[1], e).permute(0, 3, 1, 2)   # NCHW view with channels-last strides
+            return y.reshape(n, size[0], size[1], e).permute(0, 3, 1, 2), False   # NCHW view with channels-last strides
         total = None
         for z, (h_, w_) in zip(zs, sizes):
             z = z.reshape(n, h_, w_, e).permute(0, 3, 1, 2)
@@ -90,7 +98,7 @@ class SegFormerHead(BaseDecodeHead):
             total = z if total is None else total + z
         if bias is not None:
             total = total + bias.view(1, -1, 1, 1)
-        return total
+        return total, False
 
     def forward(self, inputs):
         feats = self._transform_inputs(inputs)
@@ -106,14 +114,24 @@ class SegFormerHead(BaseDecodeHead):
             if self.dropout is not None:
                 fused = self.dropout(fused)
             return self._predict(fused)
-        return self.finish(self._fused_sum(feats))
+        y, normed = self._fused_sum(feats, fold_norm=self._can_fold_norm())
+        return self.finish(y, normed)
 
-    def finish(self, y):
+    def _can_fold_norm(self):
+        """Eval-mode BatchNorm with running statistics + ReLU, no gradient wanted, nobody hooking either module."""
+        fuse = self.linear_fuse
+        norm = getattr(fuse, 'norm', None) if fuse.with_norm else None
+        return (not torch.is_grad_enabled() and isinstance(norm, nn.modules.batchnorm._BatchNorm) and not norm.training
+                and norm.track_running_stats and norm.running_mean is not None and norm.affine and fuse.with_activation
+                and isinstance(fuse.activate, nn.ReLU) and not (norm._forward_hooks or norm._forward_pre_hooks or fuse.activate._forward_hooks
+                                                                 or fuse.activate._forward_pre_hooks))
+
+    def finish(self, y, normed=False):
         """SyncBN -> ReLU -> dropout -> linear_pred on the summed branch maps (the part of the head that may communicate)."""
         fuse = self.linear_fuse
-        if fuse.with_norm:
+        if fuse.with_norm and not normed:
             y = fuse.norm(y)
-        if fuse.with_activation:
+        if fuse.with_activation and not normed:
             y = fuse.activate(y)
         fused = y
         if fuse._forward_hooks:  # a tap on linear_fuse itself sees the same output tensor

@@ -58,3 +58,20 @@ class _UpSum(torch.autograd.Function):
 def upsum(z1, z2, z3, z4, bias, sizes):
     """y[B, H*W, E] = z1 + up(z2) + up(z3) + up(z4) + bias, all token-major."""
     return _UpSum.apply(z1, z2, z3, z4, bias, tuple(tuple(int(v) for v in s) for s in sizes))
+
+
+def upsum_affine_inference(zs, bias, sizes, scale, shift, relu=True):
+    """No-grad form for a frozen network: y = relu((z1 + up(z2) + up(z3) + up(z4) + bias) * scale + shift) in one pass -- the sum,
+    the eval-mode BatchNorm folded to (scale, shift) and the ReLU.  zs: four token-major tensors, finest first."""
+    zs = [z.contiguous() for z in zs]
+    B, _, E = zs[0].shape
+    (H, W) = sizes[0]
+    fs = [H // h for (h, w) in sizes[1:]]
+    y = torch.empty_like(zs[0])
+    b = None if bias is None else bias.detach().float().contiguous()
+    sc, sh = scale.detach().float().contiguous(), shift.detach().float().contiguous()
+    rc = _lib.lib().sd_upsum_affine_fwd(zs[0].data_ptr(), zs[1].data_ptr(), zs[2].data_ptr(), zs[3].data_ptr(), None if b is None else b.data_ptr(),
+                                        sc.data_ptr(), sh.data_ptr(), 1 if relu else 0, y.data_ptr(), _DT[y.dtype], B, H, W, E, fs[0], fs[1],
+                                        fs[2], _stream_ptr())
+    _lib.check(rc, 'sd_upsum_affine_fwd')
+    return y

@@ -61,3 +61,45 @@ def test_segformer_head_gpu_equals_cpu(train):
     hg = copy.deepcopy(head).cuda()
     out_gpu = hg([f.cuda() for f in feats])
     assert _err(out_gpu, out_cpu) < 1e-4
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_frozen_head_folds_norm_and_relu_into_the_sum(dtype):
+    """Eval + no_grad (the frozen teacher): up-sample-sum, BatchNorm(running stats) and ReLU run as ONE kernel; result equals
+    the same head with the separate BatchNorm / ReLU modules (forced by a hook on the norm) and the CPU reference."""
+    import copy
+    import segdistill_amd
+    from segdistill_amd import headfuse
+    from segdistill_amd.builder import build_head
+    segdistill_amd.register_all()
+    torch.manual_seed(1)
+    head = build_head(dict(type='SegFormerHead', in_channels=[32, 64, 160, 256], in_index=[0, 1, 2, 3], feature_strides=[4, 8, 16, 32],
+                           channels=128, dropout_ratio=0.1, num_classes=150, norm_cfg=dict(type='BN'), align_corners=False,
+                           decoder_params=dict(embed_dim=256), loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)))
+    bn = head.linear_fuse.bn
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.5)
+        bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+    head.eval()
+    feats = [torch.randn(2, c, s, s) for c, s in ((32, 32), (64, 16), (160, 8), (256, 4))]
+    with torch.no_grad():
+        out_cpu = head(feats)
+    hg = copy.deepcopy(head).cuda()
+    gf = [f.cuda().to(dtype) for f in feats]
+    calls, real = [], headfuse.upsum_affine_inference
+    headfuse.upsum_affine_inference = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            out_fused = hg(gf)
+            h = hg.linear_fuse.bn.register_forward_hook(lambda m, i, o: None)      # an observer on the norm: literal path
+            out_plain = hg(gf)
+            h.remove()
+            with torch.enable_grad():                                               # gradients wanted: never folded
+                hg(gf)
+    finally:
+        headfuse.upsum_affine_inference = real
+    assert len(calls) == 1
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert _err(out_fused, out_plain) < tol and _err(out_fused, out_cpu) < (1e-4 if dtype == torch.float32 else 5e-2)
