@@ -15,6 +15,7 @@ case the explicit softmax(QK^T*scale)V form is used so the tapped tensor exists.
 from __future__ import annotations
 
 import math
+import os
 from functools import partial
 
 import torch
@@ -22,7 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..builder import BACKBONES
-from ..layers import DropPath, nchw_view_of_tokens, tokens_of, trunc_normal_
+from ..layers import DropPath, frozen_derived, nchw_view_of_tokens, tokens_of, trunc_normal_
 from ..layernorm import HipLayerNorm, add_layernorm, add_layernorm_supported
 from ..linear import call_linear, longk_linear
 
@@ -115,7 +116,8 @@ class SRAttention(nn.Module):
         if conv._forward_hooks or H % r or W % r:
             return conv(x.transpose(1, 2).reshape(b, c, H, W)).flatten(2).transpose(1, 2)
         patches = x.reshape(b, H // r, r, W // r, r, c).permute(0, 1, 3, 2, 4, 5).reshape(b, (H // r) * (W // r), r * r * c)
-        w2 = conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c)   # (ky, kx, cin) order to match the patches
+        # (ky, kx, cin) order to match the patches; the re-layout is cached for a frozen network
+        w2 = frozen_derived(conv.weight, 'sr_patch', lambda: conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c).contiguous())
         return longk_linear(patches, w2, conv.bias)
 
     def forward(self, x, hw):
@@ -200,6 +202,12 @@ class OverlapPatchEmbed(nn.Module):
         self.norm = HipLayerNorm(embed_dim)
 
     def forward(self, x):
+        w = self.proj.weight
+        if (x.is_cuda and os.environ.get('SEGDISTILL_CL_WEIGHTS', '1') == '1' and not w.is_contiguous(memory_format=torch.channels_last)
+                and not torch.cuda.is_current_stream_capturing()):
+            # the stage inputs are channels-last views of tokens, so MIOpen runs its NHWC kernels and ATen re-lays the filter out
+            # on every call (forward and backward): keep the parameter itself in channels-last storage (same values, same shape)
+            w.data = w.data.contiguous(memory_format=torch.channels_last)
         x = self.proj(x)
         hw = tuple(x.shape[2:])
         return self.norm(tokens_of(x)), hw

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..builder import HEADS, build_loss
-from ..layers import ConvModule, resize, tokens_of
+from ..layers import ConvModule, frozen_derived, resize, tokens_of
 from ..linear import call_linear, token_linear
 from .decode_head import BaseDecodeHead
 
@@ -72,7 +72,11 @@ class SegFormerHead(BaseDecodeHead):
             wi = w[:, i * e:(i + 1) * e, 0, 0]                      # [E, E]
             tokens = tokens_of(feat)                                  # [B, hw, Cin] (a view for channels-last features)
             if fold:
-                z = torch.addmm(wi @ mlp.proj.bias, tokens.reshape(-1, tokens.shape[-1]), (wi @ mlp.proj.weight).t())
+                # W_i P_i and W_i b_i: four small products per call -- cached while both parameters are frozen (the teacher)
+                wp, bp = mlp.proj.weight, mlp.proj.bias
+                w_fold = frozen_derived(w, ('fold_w', i), lambda: (wi @ wp).t().contiguous(), wp)
+                b_fold = frozen_derived(w, ('fold_b', i), lambda: wi @ bp, bp)
+                z = torch.addmm(b_fold, tokens.reshape(-1, tokens.shape[-1]), w_fold)
             else:
                 z = token_linear(mlp(feat).reshape(-1, e), wi)        # module call keeps forward hooks (taps) alive
             zs.append(z.reshape(n, -1, e))                            # token-major [B, h_i*w_i, E]
@@ -82,8 +86,10 @@ class SegFormerHead(BaseDecodeHead):
         if fold_norm and headfuse.supported(zs, sizes):
             # frozen network: sum + eval-mode BatchNorm (an affine map per channel) + ReLU in ONE pass; finish() is told to skip them
             norm = self.linear_fuse.norm
-            scale = norm.weight * torch.rsqrt(norm.running_var + norm.eps)
-            shift = norm.bias - norm.running_mean * scale
+            scale = frozen_derived(norm.weight, 'bn_scale', lambda: (norm.weight * torch.rsqrt(norm.running_var + norm.eps)).float(),
+                                   norm.running_var)
+            shift = frozen_derived(norm.bias, 'bn_shift', lambda: (norm.bias - norm.running_mean * scale).float(), norm.running_mean,
+                                   norm.running_var, norm.weight)
             y = headfuse.upsum_affine_inference(zs, bias, sizes, scale, shift, relu=True)
             return y.reshape(n, size[0], size[1], e).permute(0, 3, 1, 2), True
         if headfuse.supported(zs, sizes):

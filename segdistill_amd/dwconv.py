@@ -4,6 +4,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
+from .layers import frozen_derived
 from .ops import _DT, _stream_ptr
 
 
@@ -66,7 +67,7 @@ def dwconv3x3_gelu_tokens_inference(tokens, weight, bias, H, W):
     """GELU(dwconv(tokens) + bias) in one kernel; no autograd (frozen-teacher path)."""
     x = tokens.contiguous()
     B, N, C = x.shape
-    w_t = weight.detach().reshape(C, 9).t().contiguous().float()
+    w_t = frozen_derived(weight, 'dw_taps', lambda: weight.detach().reshape(C, 9).t().contiguous().float())
     b = None if bias is None else bias.detach().contiguous().float()
     y = torch.empty_like(x)
     rc = _lib.lib().sd_dwconv3x3_gelu_fwd(x.data_ptr(), w_t.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), _DT[x.dtype], B, H, W,

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import warnings
 
+import weakref
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -162,6 +164,35 @@ def resize(input, size=None, scale_factor=None, mode='nearest', align_corners=No
 def add_prefix(d, prefix):
     """reference mmseg/core/utils/misc.py:1 -- names the decode./aux. loss keys."""
     return {f'{prefix}.{k}': v for k, v in d.items()}
+
+
+_FROZEN = {}   # id(frozen parameter) -> (weak reference to it, {key: (versions, derived tensor)})
+
+
+def _frozen_slot(param):
+    ent = _FROZEN.get(id(param))
+    if ent is None or ent[0]() is not param:            # first use, or the id was recycled after the parameter died
+        ent = (weakref.ref(param, lambda _, k=id(param): _FROZEN.pop(k, None)), {})
+        _FROZEN[id(param)] = ent
+    return ent[1]
+
+
+def frozen_derived(param, key, fn, *also):
+    """`fn()` -- a re-layout / product derived from `param` (and the tensors in `also`) -- cached for FROZEN parameters
+    (requires_grad False: the teacher), keyed on the in-place version counters so a later checkpoint load invalidates it.
+    A trainable parameter changes every step and is never cached.  Nothing is stored while a hipGraph is being captured
+    (a tensor allocated inside a capture lives in the graph's private pool)."""
+    if param.requires_grad or any(t.requires_grad for t in also) or (param.is_cuda and torch.cuda.is_current_stream_capturing()):
+        return fn()
+    versions = (param._version, param.data_ptr()) + tuple((t._version, t.data_ptr()) for t in also)
+    slot = _frozen_slot(param)
+    hit = slot.get(key)
+    if hit is not None and hit[0] == versions:
+        return hit[1]
+    with torch.no_grad():
+        value = fn()
+    slot[key] = (versions, value)
+    return value
 
 
 def tokens_of(x):

@@ -395,3 +395,32 @@ def test_swin_public_checkpoint_adaptations(tmp_path):
     assert torch.equal(dst.state_dict()['patch_embed.proj.weight'], src.state_dict()['patch_embed.proj.weight'])
     x = torch.randn(1, 3, 64, 64)
     assert all(torch.isfinite(o).all() for o in dst(x))
+
+
+def test_frozen_derived_cache():
+    """Derived weight layouts are cached for frozen parameters only, and invalidated by an in-place update (checkpoint load)."""
+    from segdistill_amd.layers import frozen_derived
+    calls = []
+    w = torch.nn.Parameter(torch.arange(6.).reshape(2, 3), requires_grad=False)
+
+    def relayout():
+        calls.append(1)
+        return w.detach().t().contiguous()
+    a = frozen_derived(w, 't', relayout)
+    b = frozen_derived(w, 't', relayout)
+    assert a is b and len(calls) == 1 and torch.equal(a, w.t())
+    with torch.no_grad():
+        w.mul_(2)                                        # what load_state_dict's copy_ does: bumps the version counter
+    c = frozen_derived(w, 't', relayout)
+    assert c is not a and len(calls) == 2 and torch.equal(c, w.t())
+    w.requires_grad_(True)                               # trainable: changes every step -> never cached
+    frozen_derived(w, 't', relayout)
+    frozen_derived(w, 't', relayout)
+    assert len(calls) == 4
+    other = torch.nn.Parameter(torch.ones(2), requires_grad=False)
+    w.requires_grad_(False)
+    d = frozen_derived(w, 'u', lambda: (w.detach()[:, 0] * other).clone(), other)
+    with torch.no_grad():
+        other.add_(1)
+    e = frozen_derived(w, 'u', lambda: (w.detach()[:, 0] * other).clone(), other)
+    assert not torch.equal(d, e)                         # a dependency changed
