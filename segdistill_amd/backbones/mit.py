@@ -200,14 +200,13 @@ class OverlapPatchEmbed(nn.Module):
         super().__init__()
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride, padding=patch_size // 2)
         self.norm = HipLayerNorm(embed_dim)
+        # The stage inputs are channels-last views of tokens, so MIOpen runs its NHWC kernels and ATen would re-lay the filter out
+        # on every call (forward and backward).  The parameter itself is kept in channels-last STORAGE from construction on
+        # (same shape, same values, same state-dict entry; `.to(device)`, in-place init and checkpoint loads preserve it).
+        if os.environ.get('SEGDISTILL_CL_WEIGHTS', '1') == '1':
+            self.proj.weight.data = self.proj.weight.data.contiguous(memory_format=torch.channels_last)
 
     def forward(self, x):
-        w = self.proj.weight
-        if (x.is_cuda and os.environ.get('SEGDISTILL_CL_WEIGHTS', '1') == '1' and not w.is_contiguous(memory_format=torch.channels_last)
-                and not torch.cuda.is_current_stream_capturing()):
-            # the stage inputs are channels-last views of tokens, so MIOpen runs its NHWC kernels and ATen re-lays the filter out
-            # on every call (forward and backward): keep the parameter itself in channels-last storage (same values, same shape)
-            w.data = w.data.contiguous(memory_format=torch.channels_last)
         x = self.proj(x)
         hw = tuple(x.shape[2:])
         return self.norm(tokens_of(x)), hw

@@ -65,11 +65,32 @@ class DataParallelReducer:
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, device=dev, dtype=dt)
         self.views = []
+        self._strided = []          # parameters kept in a non-default dense layout (channels-last conv filters)
         off = 0
         for p in self.params:
             n = p.numel()
-            self.views.append(self.flat[off:off + n].view_as(p))
+            self.views.append(self._view_like(self.flat[off:off + n], p))
+            if not p.is_contiguous():
+                self._strided.append(p)
             off += n
+
+    @staticmethod
+    def _view_like(segment, p):
+        """A view of the flat segment with p's shape AND strides: the fused optimizer kernels require parameter, gradient and
+        state tensors of identical layout."""
+        if p.is_contiguous():
+            return segment.view_as(p)
+        if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last):
+            n, c, h, w = p.shape
+            return segment.view(n, h, w, c).permute(0, 3, 1, 2)
+        raise ValueError(f'parameter of shape {tuple(p.shape)} with strides {p.stride()} is neither contiguous nor channels-last')
+
+    def match_layouts(self):
+        """Gradients that autograd produced in another dense layout than their parameter (possible for channels-last filters)
+        are re-laid-out; a no-op -- a few stride comparisons -- in the common case."""
+        for p in self._strided:
+            if p.grad is not None and p.grad.stride() != p.stride():
+                p.grad = p.grad.contiguous(memory_format=torch.channels_last)
 
     @property
     def nbytes(self):
@@ -86,6 +107,7 @@ class DataParallelReducer:
 
     def all_reduce(self):
         if not self.collective:
+            self.match_layouts()
             return
         grads, views = [], []
         for p, v in zip(self.params, self.views):
