@@ -78,12 +78,18 @@ __global__ __launch_bounds__(256) void dw3x3_fwd(const T *__restrict__ x, const 
                                                   T *__restrict__ y, int H, int W, int C) {
     constexpr int N = CV<T>::N;
     const int cv = C / N;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    // XCD-aware work order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in linear-id order, and a
+    // row needs its two neighbour rows -- so each XCD is given a CONTIGUOUS band of (row, x-block) items instead of every
+    // 8th one, and the 3x re-read of the input rows is served by that XCD's L2 rather than by the fabric.
+    const unsigned total = gridDim.x * gridDim.y, q8 = total / 8, r8 = total % 8;
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin % 8;
+    const unsigned item = xcd * q8 + (xcd < r8 ? xcd : r8) + lin / 8;      // a bijection of [0, total): XCD x owns q8 (+1) consecutive items
+    const int t = (item % gridDim.x) * 256 + threadIdx.x;
     const int spr = (W + kStrip - 1) / kStrip;
     if (t >= spr * cv) return;
     const int c = (t % cv) * N;
     const int x0 = (t / cv) * kStrip;
-    const int row = blockIdx.y;  // b*H + yy
+    const int row = item / gridDim.x;  // b*H + yy
     const int yy = row % H;
     const size_t img = (size_t)(row - yy) * W;  // pixel index of (b, 0, 0)
 
@@ -151,8 +157,13 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_partials(const T *__restrict_
     constexpr int N = CV<T>::N;
     extern __shared__ float red[];  // [RY][10][LX*N]
     const int lx = threadIdx.x % LX, ry = threadIdx.x / LX;
-    const int c = (blockIdx.x * LX + lx) * N;
-    const int sid = blockIdx.y * RY + ry;
+    // XCD-aware order (see dw3x3_fwd): consecutive segment groups -- neighbouring image rows -- stay on one XCD's L2
+    const unsigned total = gridDim.x * gridDim.y, q8 = total / 8, r8 = total % 8;
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin % 8;
+    const unsigned item = xcd * q8 + (xcd < r8 ? xcd : r8) + lin / 8;
+    const unsigned bx = item % gridDim.x, by = item / gridDim.x;
+    const int c = (bx * LX + lx) * N;
+    const int sid = by * RY + ry;
     const bool live = (c < C) && (sid < nsegs);
     float acc[10][N];
 #pragma unroll
@@ -226,8 +237,8 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_partials(const T *__restrict_
         float s = 0.f;
         for (int r = 0; r < RY; ++r) s += red[r * 10 * LC + e];
         const int k = e / LC, col = e - k * LC;
-        const int cc = blockIdx.x * LC + col;
-        if (cc < C) part[((size_t)blockIdx.y * 10 + k) * C + cc] = s;
+        const int cc = bx * LC + col;
+        if (cc < C) part[((size_t)by * 10 + k) * C + cc] = s;
     }
 }
 

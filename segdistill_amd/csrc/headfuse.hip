@@ -51,6 +51,13 @@ template <> struct HV<bf16_t> {
 };
 
 // bilinear source coordinates of output index o for an integer factor F (align_corners=False, ATen semantics)
+// XCD-aware work order for a 1-D grid: workgroups are dealt round-robin to the 8 XCDs (one L2 each) by linear id; giving XCD x a
+// CONTIGUOUS range of work items keeps the coarse maps an image band gathers from (and neighbouring output rows) in one L2.
+__device__ __forceinline__ size_t xcd_item(unsigned lin, unsigned total) {
+    const unsigned q8 = total / 8, r8 = total % 8, xcd = lin % 8;
+    return (size_t)xcd * q8 + (xcd < r8 ? xcd : r8) + lin / 8;
+}
+
 __device__ __forceinline__ void src_of(int o, int F, int n_in, int &i0, int &i1, float &lam) {
     float s = (o + 0.5f) / F - 0.5f;
     s = s < 0.f ? 0.f : s;
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256) void upsum_fwd(const T *__restrict__ z1, const
                                                   int f2, int f3, int f4) {
     constexpr int N = HV<T>::N;
     const int ev = E / N;
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t t = xcd_item(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (t >= (size_t)B * H * W * ev) return;
     const int c = (int)(t % ev) * N;
     const size_t pix = t / ev;
@@ -121,7 +128,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void upsum_bwd(const T *__restrict__ dy, T *__restrict__ dz, int B, int h, int w, int E, int F) {
     constexpr int N = HV<T>::N;
     const int ev = E / N;
-    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t t = xcd_item(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (t >= (size_t)B * h * w * ev) return;
     const int c = (int)(t % ev) * N;
     const size_t tap = t / ev;
