@@ -123,6 +123,85 @@ __global__ __launch_bounds__(256) void upsum_fwd(const T *__restrict__ z1, const
     HV<T>::store(y + pix * E + c, acc);
 }
 
+// Strip form for the SegFormer geometry (branch factors 2, 4, 8; W % 4 == 0): a thread produces FOUR consecutive output
+// pixels of a row for one channel vector.  The generic kernel above issues 12 gathers per output vector and is bound by
+// L2 -> CU bandwidth (12x the HBM bytes); the four outputs of a strip share their coarse taps -- 4 / 3 / 2 columns x 2
+// rows for the x2 / x4 / x8 branches -- so a strip needs 18 gathers instead of 48.  Border handling: loading the CLAMPED
+// column / row indices with the un-clamped interpolation weights equals ATen's edge-clamped bilinear exactly (the clamped
+// taps coincide, so their weights add up).
+template <typename T, int F, int NC>
+__device__ __forceinline__ void add_branch_strip(float (&acc)[4][HV<T>::N], const T *__restrict__ z, int b, int Y, int X0, int H, int W,
+                                                 int E, int c) {
+    constexpr int N = HV<T>::N;
+    const int h = H / F, w = W / F;
+    const float sy = (Y + 0.5f) / F - 0.5f;
+    const int y0u = (int)floorf(sy);
+    const float ly = sy - (float)y0u;
+    const int y0 = min(max(y0u, 0), h - 1), y1 = min(max(y0u + 1, 0), h - 1);
+    const int base = (int)floorf((X0 + 0.5f) / F - 0.5f);          // un-clamped left tap of the strip's first pixel
+    const T *img = z + (size_t)b * h * w * E + c;
+    float col[NC][N];                                               // vertically interpolated coarse columns base .. base+NC-1
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int x = min(max(base + j, 0), w - 1);
+        float a[N], d[N];
+        HV<T>::load(img + ((size_t)y0 * w + x) * E, a);
+        HV<T>::load(img + ((size_t)y1 * w + x) * E, d);
+#pragma unroll
+        for (int i = 0; i < N; ++i) col[j][i] = fmaf(ly, d[i] - a[i], a[i]);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float sx = (X0 + p + 0.5f) / F - 0.5f;
+        const float lx = sx - floorf(sx);
+        // offset of this pixel's left tap from `base` is static for X0 % 4 == 0:  F=2: 0,1,1,2   F=4: 0,0,1,1   F=8: 0,0,0,0
+        constexpr int kOff2[4] = {0, 1, 1, 2}, kOff4[4] = {0, 0, 1, 1};
+        const int o = F == 2 ? kOff2[p] : (F == 4 ? kOff4[p] : 0);
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[p][i] += fmaf(lx, col[o + 1][i] - col[o][i], col[o][i]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsum_fwd_strip(const T *__restrict__ z1, const T *__restrict__ z2, const T *__restrict__ z3,
+                                                        const T *__restrict__ z4, const float *__restrict__ bias,
+                                                        const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                                                        T *__restrict__ y, int B, int H, int W, int E) {
+    constexpr int N = HV<T>::N;
+    const int ev = E / N, sw = W / 4;
+    const size_t t = xcd_item(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    if (t >= (size_t)B * H * sw * ev) return;
+    const int c = (int)(t % ev) * N;
+    const size_t strip = t / ev;
+    const int X0 = (int)(strip % sw) * 4;
+    const int Y = (int)((strip / sw) % H);
+    const int b = (int)(strip / ((size_t)sw * H));
+    const size_t pix = ((size_t)b * H + Y) * W + X0;
+    float acc[4][N];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        HV<T>::load(z1 + (pix + p) * E + c, acc[p]);
+        if (bias) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[p][i] += bias[c + i];
+        }
+    }
+    add_branch_strip<T, 2, 4>(acc, z2, b, Y, X0, H, W, E, c);
+    add_branch_strip<T, 4, 3>(acc, z3, b, Y, X0, H, W, E, c);
+    add_branch_strip<T, 8, 2>(acc, z4, b, Y, X0, H, W, E, c);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (scale) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                acc[p][i] = fmaf(acc[p][i], scale[c + i], shift[c + i]);
+                if (relu) acc[p][i] = fmaxf(acc[p][i], 0.f);
+            }
+        }
+        HV<T>::store(y + (pix + p) * E + c, acc[p]);
+    }
+}
+
 // dz[b,ky,kx,:] = sum over the outputs that use tap (ky,kx) of weight * dy.  grid: ceil(B*h*w*(E/N) / 256)
 template <typename T>
 __global__ __launch_bounds__(256) void upsum_bwd(const T *__restrict__ dy, T *__restrict__ dz, int B, int h, int w, int E, int F) {
@@ -182,6 +261,17 @@ static int upsum_fwd_impl(const void *z1, const void *z2, const void *z3, const 
     if (E % (dtype == SD_F32 ? 4 : 8)) return SD_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int N = dtype == SD_F32 ? 4 : 8;
+    if (f2 == 2 && f3 == 4 && f4 == 8 && W % 4 == 0) {          // the SegFormer geometry: strip kernel
+        const size_t strips = (size_t)B * H * (W / 4) * (E / N);
+        const unsigned g = (unsigned)((strips + 255) / 256);
+        if (dtype == SD_F32)
+            hipLaunchKernelGGL((sd::upsum_fwd_strip<float>), dim3(g), dim3(256), 0, st, (const float *)z1, (const float *)z2, (const float *)z3,
+                               (const float *)z4, bias, scale, shift, relu, (float *)y, B, H, W, E);
+        else
+            hipLaunchKernelGGL((sd::upsum_fwd_strip<sd::bf16_t>), dim3(g), dim3(256), 0, st, (const sd::bf16_t *)z1, (const sd::bf16_t *)z2,
+                               (const sd::bf16_t *)z3, (const sd::bf16_t *)z4, bias, scale, shift, relu, (sd::bf16_t *)y, B, H, W, E);
+        return (int)hipGetLastError();
+    }
     const size_t total = (size_t)B * H * W * (E / N);
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (dtype == SD_F32)
