@@ -67,17 +67,31 @@ template <typename T, int NE> __device__ __forceinline__ void load_span(const T 
 template <typename T, int D, int PD>
 __device__ __forceinline__ void stage_kv(const T *__restrict__ kv, float *Ks, float *Vs, int b, int h, int KV, int heads, int rows) {
     const int C = heads * D;
-    constexpr int G = D / 4;
-    for (int idx = threadIdx.x; idx < rows * G; idx += blockDim.x) {
-        const int j = idx / G, c4 = (idx % G) * 4;
-        float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
-        if (j < KV) {
-            const T *row = kv + ((size_t)b * KV + j) * 2 * C + h * D + c4;
-            k4 = Q4<T>::load(row);
-            v4 = Q4<T>::load(row + C);
+    constexpr int G = D / 4, U = 4;     // U row-vectors of K and of V in flight per thread: the copy is latency-bound otherwise
+    const int total = rows * G, step = blockDim.x;
+    for (int base = threadIdx.x; base < total; base += U * step) {
+        float4 k4[U], v4[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * step;
+            const int j = idx / G, c4 = (idx % G) * 4;
+            k4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            v4[u] = k4[u];
+            if (idx < total && j < KV) {
+                const T *row = kv + ((size_t)b * KV + j) * 2 * C + h * D + c4;
+                k4[u] = Q4<T>::load(row);
+                v4[u] = Q4<T>::load(row + C);
+            }
         }
-        *reinterpret_cast<float4 *>(Ks + j * PD + c4) = k4;
-        *reinterpret_cast<float4 *>(Vs + j * PD + c4) = v4;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * step;
+            if (idx < total) {
+                const int j = idx / G, c4 = (idx % G) * 4;
+                *reinterpret_cast<float4 *>(Ks + j * PD + c4) = k4[u];
+                *reinterpret_cast<float4 *>(Vs + j * PD + c4) = v4[u];
+            }
+        }
     }
 }
 
@@ -99,77 +113,81 @@ template <int D, int PD> __device__ __forceinline__ f32x16 tile_t(const float *M
 
 // ---- forward: grid (ceil(N/(32*NW)), heads, B); a wave owns 32 queries, the NW waves of a workgroup share K/V in LDS ---------
 // (NW = 8 puts two waves on every SIMD of the CU that holds the K/V copy: one wave's softmax overlaps the other's MFMAs)
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, int QT>
 __global__ __launch_bounds__(NW * 64) void sra_fwd(const T *__restrict__ q, const T *__restrict__ kv, T *__restrict__ out,
-                                                        float *__restrict__ lse, int N, int KV, int heads, float cs /* scale*log2e */) {
+                                                    float *__restrict__ lse, int N, int KV, int heads, float cs /* scale*log2e */) {
     constexpr int PD = D + 4, DB = D / 32;
     extern __shared__ float smem[];
     const int nblk = (KV + 31) / 32;
     float *Ks = smem, *Vs = smem + nblk * 32 * PD;
     const int h = blockIdx.y, b = blockIdx.z, C = heads * D;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, half = l >> 5;
-    const int n = blockIdx.x * (NW * 32) + w * 32 + c;
-    const bool live = n < N;
-    float qv[D / 2];
-#pragma unroll
-    for (int t = 0; t < D / 2; ++t) qv[t] = 0.f;
-    if (live) load_span<T, D / 2>(q + ((size_t)b * N + n) * C + h * D + half * (D / 2), qv);
-#pragma unroll
-    for (int t = 0; t < D / 2; ++t) qv[t] *= cs;
     stage_kv<T, D, PD>(kv, Ks, Vs, b, h, KV, heads, nblk * 32);
     __syncthreads();
-    f32x16 S[8];
-    float m = kNegBig;
+    // QT query tiles per wave: the staged K/V copy is amortised over QT * NW * 32 queries
+    for (int qt = 0; qt < QT; ++qt) {
+        const int n = (blockIdx.x * QT + qt) * (NW * 32) + w * 32 + c;
+        const bool live = n < N;
+        float qv[D / 2];
 #pragma unroll
-    for (int blk = 0; blk < 8; ++blk) {
-        if (blk < nblk) {
-            S[blk] = tile_t<D, PD>(Ks, blk * 32, qv, c, half);
+        for (int t = 0; t < D / 2; ++t) qv[t] = 0.f;
+        if (live) load_span<T, D / 2>(q + ((size_t)b * N + n) * C + h * D + half * (D / 2), qv);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                if (blk * 32 + crow(e, half) >= KV) S[blk][e] = kNegBig;
-                m = fmaxf(m, S[blk][e]);
+        for (int t = 0; t < D / 2; ++t) qv[t] *= cs;
+        f32x16 S[8];
+        float m = kNegBig;
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk) {
+            if (blk < nblk) {
+                S[blk] = tile_t<D, PD>(Ks, blk * 32, qv, c, half);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (blk * 32 + crow(e, half) >= KV) S[blk][e] = kNegBig;
+                    m = fmaxf(m, S[blk][e]);
+                }
             }
         }
-    }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float lsum = 0.f;
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float lsum = 0.f;
 #pragma unroll
-    for (int blk = 0; blk < 8; ++blk) {
-        if (blk < nblk) {
+        for (int blk = 0; blk < 8; ++blk) {
+            if (blk < nblk) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                S[blk][e] = ex2(S[blk][e] - m);
-                lsum += S[blk][e];
+                for (int e = 0; e < 16; ++e) {
+                    S[blk][e] = ex2(S[blk][e] - m);
+                    lsum += S[blk][e];
+                }
             }
         }
-    }
-    lsum += __shfl_xor(lsum, 32, 64);
-    f32x16 O[DB];
+        lsum += __shfl_xor(lsum, 32, 64);
+        f32x16 O[DB];
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) O[db][e] = 0.f;
+            for (int e = 0; e < 16; ++e) O[db][e] = 0.f;
 #pragma unroll
-    for (int blk = 0; blk < 8; ++blk) {
-        if (blk < nblk) {
+        for (int blk = 0; blk < 8; ++blk) {
+            if (blk < nblk) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float *vrow = Vs + (blk * 32 + crow(e, half)) * PD + c;
+                for (int e = 0; e < 16; ++e) {
+                    const float *vrow = Vs + (blk * 32 + crow(e, half)) * PD + c;
 #pragma unroll
-                for (int db = 0; db < DB; ++db) O[db] = mfma(vrow[db * 32], S[blk][e], O[db]);
+                    for (int db = 0; db < DB; ++db) O[db] = mfma(vrow[db * 32], S[blk][e], O[db]);
+                }
             }
         }
+        if (live) {
+            const float inv = 1.f / lsum;
+            T *orow = out + ((size_t)b * N + n) * C + h * D;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    Q4<T>::store(orow + db * 32 + 8 * g + 4 * half,
+                                 make_float4(O[db][4 * g] * inv, O[db][4 * g + 1] * inv, O[db][4 * g + 2] * inv, O[db][4 * g + 3] * inv));
+            if (half == 0) lse[((size_t)b * heads + h) * N + n] = m + __builtin_amdgcn_logf(lsum);   // base-2 lse of the scaled scores
+        }
     }
-    if (!live) return;
-    const float inv = 1.f / lsum;
-    T *orow = out + ((size_t)b * N + n) * C + h * D;
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            Q4<T>::store(orow + db * 32 + 8 * g + 4 * half,
-                         make_float4(O[db][4 * g] * inv, O[db][4 * g + 1] * inv, O[db][4 * g + 2] * inv, O[db][4 * g + 3] * inv));
-    if (half == 0) lse[((size_t)b * heads + h) * N + n] = m + __builtin_amdgcn_logf(lsum);   // base-2 lse of the scaled scores
 }
 
 // ---- backward, queries: dq and delta = sum_d dO*O.  Same grid / ownership as the forward ------------------------------------
@@ -398,21 +416,22 @@ int sra_check(const void *q, const void *kv, const void *o, int dtype, int B, in
 
 inline bool sra_wide(int N) { return N >= 1024; }   // 8-wave workgroups once there are enough queries to fill them
 
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, int QT>
 int sra_fwd_launch_nw(const void *q, const void *kv, void *out, float *lse, int B, int N, int KV, int heads, float scale, hipStream_t st) {
-    const dim3 grid((N + NW * 32 - 1) / (NW * 32), heads, B);
+    const dim3 grid((N + NW * 32 * QT - 1) / (NW * 32 * QT), heads, B);
     const size_t lds = sra_lds_bytes<D>(KV);
     static bool raised = false;
-    int rc = sra_raise_lds(sra_fwd<T, D, NW>, raised);
+    int rc = sra_raise_lds(sra_fwd<T, D, NW, QT>, raised);
     if (rc) return rc;
-    hipLaunchKernelGGL((sra_fwd<T, D, NW>), grid, dim3(NW * 64), lds, st, (const T *)q, (const T *)kv, (T *)out, lse, N, KV, heads,
+    hipLaunchKernelGGL((sra_fwd<T, D, NW, QT>), grid, dim3(NW * 64), lds, st, (const T *)q, (const T *)kv, (T *)out, lse, N, KV, heads,
                        scale * kLog2e);
     return (int)hipGetLastError();
 }
 template <typename T, int D>
 int sra_fwd_launch(const void *q, const void *kv, void *out, float *lse, int B, int N, int KV, int heads, float scale, hipStream_t st) {
-    return sra_wide(N) ? sra_fwd_launch_nw<T, D, 8>(q, kv, out, lse, B, N, KV, heads, scale, st)
-                       : sra_fwd_launch_nw<T, D, 4>(q, kv, out, lse, B, N, KV, heads, scale, st);
+    if (N >= 8192) return sra_fwd_launch_nw<T, D, 8, 2>(q, kv, out, lse, B, N, KV, heads, scale, st);   // 512 queries per K/V copy
+    return sra_wide(N) ? sra_fwd_launch_nw<T, D, 8, 1>(q, kv, out, lse, B, N, KV, heads, scale, st)
+                       : sra_fwd_launch_nw<T, D, 4, 1>(q, kv, out, lse, B, N, KV, heads, scale, st);
 }
 
 template <typename T, int D>
