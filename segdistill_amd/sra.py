@@ -18,15 +18,23 @@ def supported(q, kv, heads):
 
 
 def preferred(n_queries, n_keys, head_dim, q):
-    """Policy: on MI355X the kernels beat both library forms (fused SDPA, bmm+softmax) at every MiT stage shape, forward and
-    forward+backward, fp32 and bf16 (tools/sra_bench.py).  SEGDISTILL_SRA=off|train restricts them (benchmarking / bisecting)."""
+    """Policy, from tools/sra_bench.py on MI355X (profiles/r01_step_kernels_microbench.txt).  fp32: the kernels beat both library
+    forms (fused SDPA, bmm+softmax) at every MiT stage shape, forward and forward+backward.  bf16 storage: the kernels still
+    compute on the fp32 MFMA path while the library's fused kernel uses bf16 MFMA, so they only win where the library's
+    backward collapses -- training with >= 8192 queries (1.3-1.5x); elsewhere the library is used.
+    SEGDISTILL_SRA=off|train|all overrides (benchmarking / bisecting)."""
     import os
-    mode = os.environ.get('SEGDISTILL_SRA', 'all')
+    mode = os.environ.get('SEGDISTILL_SRA', 'auto')
+    training = torch.is_grad_enabled() and q.requires_grad
     if mode == 'off':
         return False
+    if mode == 'all':
+        return True
     if mode == 'train':
-        return torch.is_grad_enabled() and q.requires_grad
-    return True
+        return training
+    if q.dtype == torch.float32:
+        return True
+    return training and n_queries >= 8192
 
 
 class _SRAttention(torch.autograd.Function):
