@@ -20,19 +20,35 @@ _LONGK_ENABLED = os.environ.get('SEGDISTILL_LONGK') == '1'
 
 
 class _TokenLinear(torch.autograd.Function):
+    """Under autocast the forward computes in the autocast dtype exactly as F.linear would (activations and a cast copy of
+    the fp32 master weight in bf16); the bf16 activations are what is saved, so the split-K weight-gradient kernel reads half
+    the bytes, and dW / dbias are produced in fp32 for the fp32 master parameters."""
+
     @staticmethod
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_dtype('cuda')
+            with torch.autocast('cuda', enabled=False):
+                xc = x.to(dt)
+                wc = weight.to(dt)
+                y = F.linear(xc, wc, None if bias is None else bias.to(dt))
+            ctx.save_for_backward(xc, wc)
+        else:
+            y = F.linear(x, weight, bias)
+            ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        ctx.in_dtype, ctx.w_dtype = x.dtype, weight.dtype
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dx = dw = db = None
         dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != x.dtype:
+            dy2 = dy2.to(x.dtype)
         if ctx.needs_input_grad[0]:
-            dx = (dy2 @ weight).reshape(x.shape)
+            dx = (dy2 @ weight).reshape(x.shape).to(ctx.in_dtype)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             x2 = x.reshape(-1, x.shape[-1])
@@ -48,18 +64,19 @@ class _TokenLinear(torch.autograd.Function):
             ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
             _lib.check(L.sd_linear_wgrad(dyc.data_ptr(), x2.data_ptr(), dw32.data_ptr(), None if db32 is None else db32.data_ptr(),
                                          _DT[x.dtype], T, M, N, ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_wgrad')
-            dw = dw32.to(weight.dtype)
+            dw = dw32.to(ctx.w_dtype)
             if fuse_b:
-                db = db32.to(weight.dtype)
+                db = db32.to(ctx.w_dtype)
         if want_db and db is None:
-            db = dy2.sum(0)
+            db = dy2.sum(0, dtype=torch.float32).to(ctx.w_dtype)
         return dx, dw, db
 
 
 def token_linear(x, weight, bias=None):
     """F.linear with the HIP weight-gradient kernel when it pays (GPU, fp32/bf16 storage, many tokens, training)."""
-    use = (x.is_cuda and x.dtype in _DT and x.dtype == weight.dtype and weight.requires_grad and torch.is_grad_enabled()
-           and not torch.is_autocast_enabled() and x.numel() // x.shape[-1] >= MIN_TOKENS)
+    amp = torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
+    use = (x.is_cuda and x.dtype in _DT and (x.dtype == weight.dtype or amp) and weight.requires_grad and torch.is_grad_enabled()
+           and (amp or not torch.is_autocast_enabled()) and x.numel() // x.shape[-1] >= MIN_TOKENS)
     if use:
         return _TokenLinear.apply(x, weight, bias)
     return F.linear(x, weight, bias)

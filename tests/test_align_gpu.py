@@ -161,3 +161,40 @@ def test_longk_linear(shape):
     x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
     torch.nn.functional.linear(x64, w64, b64).square().mean().backward()
     assert _err(xg.grad, x64.grad) < 1e-4 and _err(wg.grad, w64.grad) < 1e-4 and _err(bg.grad, b64.grad) < 1e-4
+
+
+def test_token_linear_under_bf16_autocast_matches_f_linear():
+    """Under autocast the split-K weight-gradient path computes what F.linear + autograd compute: bf16 forward, fp32 master
+    gradients (checked against the fp64 product of the bf16-rounded operands)."""
+    from segdistill_amd.linear import _TokenLinear, token_linear
+    import torch.nn.functional as F
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    x = torch.randn(4, 4096, 64, device=dev, requires_grad=True)
+    w = (torch.randn(96, 64, device=dev) * 0.1).requires_grad_(True)
+    b = torch.randn(96, device=dev).requires_grad_(True)
+    dy = torch.randn(4, 4096, 96, device=dev)
+    calls, real = [], _TokenLinear.apply
+    _TokenLinear.apply = lambda *a: (calls.append(1), real(*a))[1]
+    try:
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = token_linear(x, w, b)
+    finally:
+        _TokenLinear.apply = real
+    assert len(calls) == 1 and y.dtype == torch.bfloat16
+    y.backward(dy.to(torch.bfloat16))
+    got = (x.grad.clone(), w.grad.clone(), b.grad.clone())
+    assert got[0].dtype == torch.float32 and got[1].dtype == torch.float32
+    x.grad = w.grad = b.grad = None
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y2 = F.linear(x, w, b)
+    y2.backward(dy.to(torch.bfloat16))
+    assert torch.equal(y, y2)
+    xb, wb, gb = x.detach().bfloat16().double(), w.detach().bfloat16().double(), dy.bfloat16().double()
+    dw64 = gb.reshape(-1, 96).t() @ xb.reshape(-1, 64)
+    db64 = gb.reshape(-1, 96).sum(0)
+
+    def rel(a, r):
+        return float((a.double() - r).abs().max() / r.abs().max())
+    assert rel(got[1], dw64) < 2e-5 and rel(got[2], db64) < 2e-5          # fp32 accumulation of bf16 products: tighter than the library
+    assert rel(w.grad, dw64) < 2e-2 and rel(got[0], x.grad.double()) < 2e-2

@@ -7,10 +7,10 @@ import bench
 from segdistill_amd.config import Config
 from segdistill_amd.engine import KDTrainer, SyntheticADE
 dev = torch.device('cuda:0')
-cfg = Config.fromfile(os.path.join(bench.ROOT, 'configs/kd/cfg2_segformer_b2_b0_cgd.py'))
+cfg = Config.fromfile(os.environ.get('SEGDISTILL_PROFILE_CONFIG') or os.path.join(bench.ROOT, 'configs/kd/cfg2_segformer_b2_b0_cgd.py'))
 torch.manual_seed(0)
 model = bench.build_model(cfg, dev)
-tr = KDTrainer(model, dict(cfg.optimizer), dict(cfg.lr_config), world=1)
+tr = KDTrainer(model, dict(cfg.optimizer), dict(cfg.lr_config), world=1, precision=cfg.get('precision'))
 data = SyntheticADE(8, device=dev)
 for _ in range(4):
     tr.step(data.next())
