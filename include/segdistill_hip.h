@@ -205,7 +205,8 @@ int sd_align1x1_bwd_weight(const void *dY, const void *X, float *dW, float *dbia
  */
 size_t sd_linear_wgrad_workspace_bytes(long tokens, int out_features, int in_features);
 /* 1 if the kernel chosen for this shape also produces the bias gradient (column sums of dY) for free */
-int sd_linear_wgrad_fuses_bias(long tokens, int out_features, int in_features);
+int sd_linear_wgrad_fuses_bias(long tokens, int out_features, int in_features);                 /* fp32 storage */
+int sd_linear_wgrad_fuses_bias_dtype(int dtype, long tokens, int out_features, int in_features);  /* the kernel choice depends on the storage type */
 
 int sd_linear_wgrad(const void *dY, const void *X, float *dW, float *dbias /* [out] or NULL */, int dtype,
                     long tokens, int out_features, int in_features,

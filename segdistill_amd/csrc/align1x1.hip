@@ -121,6 +121,155 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32(const TA *__restrict__ A, c
         }
 }
 
+// ---- bf16-storage variant: v_mfma_f32_32x32x16_bf16 (16x the math rate of the f32-input MFMA) -------------------------------------
+// Same tiling, arguments and split-K protocol as gemm_mfma_f32; used when the activations are stored in bf16 (config 5).  Products
+// of bf16 values are exact in fp32 and accumulation is fp32, so the only numerical difference to the f32 kernel on widened inputs
+// is that an fp32 master operand (the align weight) is rounded to bf16 on its way into LDS -- what autocast does for a conv.
+// LDS tiles are [128 rows][32 k] bf16, k contiguous (pitch 40 -> conflict-free ds_read_b128): lane l = (r = l&31, h = l>>5) takes
+// the 8 values k = 8h..8h+7 of row r as its A (or B) fragment.  A source whose k axis is strided in memory (KMAJOR: src[k*ld + x])
+// is transposed on the way in: 16-byte loads along x, eight 2-byte LDS stores.
+constexpr int BK16 = 64, PITCH16 = 72;   // 144-byte rows: 16-byte aligned, ds_read_b128 of 8 consecutive rows covers all 32 banks
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> __device__ __forceinline__ unsigned short to_bf16_bits(const T *p);
+template <> __device__ __forceinline__ unsigned short to_bf16_bits<float>(const float *p) { return f32_to_bf16(*p); }
+template <> __device__ __forceinline__ unsigned short to_bf16_bits<bf16_t>(const bf16_t *p) { return p->bits; }
+
+// 8 consecutive source elements -> 8 bf16 (one 16-byte / two 16-byte loads; the pointer must be 16-byte aligned)
+template <typename T> __device__ __forceinline__ uint4 load8_bf16(const T *p);
+template <> __device__ __forceinline__ uint4 load8_bf16<bf16_t>(const bf16_t *p) { return *reinterpret_cast<const uint4 *>(p); }
+template <> __device__ __forceinline__ uint4 load8_bf16<float>(const float *p) {
+    const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+    uint4 o;
+    o.x = (unsigned)f32_to_bf16(a.x) | ((unsigned)f32_to_bf16(a.y) << 16);
+    o.y = (unsigned)f32_to_bf16(a.z) | ((unsigned)f32_to_bf16(a.w) << 16);
+    o.z = (unsigned)f32_to_bf16(b.x) | ((unsigned)f32_to_bf16(b.y) << 16);
+    o.w = (unsigned)f32_to_bf16(b.z) | ((unsigned)f32_to_bf16(b.w) << 16);
+    return o;
+}
+
+// Stage a [128 x 64] tile (rows x0.., k k0..) into dst[128][PITCH16]; out-of-range elements are zero.  256 threads, 32 elements each.
+// `vec`: the source rows are 16-byte aligned and every 8-element group lies on a 16-byte boundary (workgroup-uniform).
+template <typename T, bool KMAJOR>
+__device__ __forceinline__ void stage16(unsigned short (*dst)[PITCH16], const T *__restrict__ src, long ld, int x0, int xmax, int k0, int kmax,
+                                        bool vec) {
+    const int t = threadIdx.x;
+    if constexpr (KMAJOR) {
+        // src[k*ld + x]: a thread takes TWO consecutive k for 8 consecutive x (two 16-byte loads along x) and writes eight 4-byte
+        // (k, k+1) pairs -- the transpose into the k-contiguous LDS image; two such blocks per thread
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int k = 2 * ((t >> 4) + 16 * it), xb = (t & 15) * 8;
+            const T *row = src + (long)(k0 + k) * ld + x0 + xb;
+            if (vec && k0 + k + 1 < kmax && x0 + xb + 7 < xmax) {
+                const uint4 a = load8_bf16<T>(row), c = load8_bf16<T>(row + ld);
+                const unsigned av[4] = {a.x, a.y, a.z, a.w}, cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    *reinterpret_cast<unsigned *>(&dst[xb + 2 * i][k]) = (av[i] & 0xffffu) | (cv[i] << 16);
+                    *reinterpret_cast<unsigned *>(&dst[xb + 2 * i + 1][k]) = (av[i] >> 16) | (cv[i] & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool xin = x0 + xb + i < xmax;
+                    dst[xb + i][k] = (xin && k0 + k < kmax) ? to_bf16_bits<T>(row + i) : (unsigned short)0;
+                    dst[xb + i][k + 1] = (xin && k0 + k + 1 < kmax) ? to_bf16_bits<T>(row + ld + i) : (unsigned short)0;
+                }
+            }
+        }
+    } else {
+        // src[x*ld + k]: thread -> (x = t/2, 32 consecutive k starting at (t%2)*32): four 16-byte loads, four 16-byte LDS stores
+        const int x = t >> 1, kb = (t & 1) * 32;
+        const bool xin = (x0 + x) < xmax;
+        const T *row = src + (long)(x0 + x) * ld + k0 + kb;
+        if (vec && xin && k0 + kb + 31 < kmax) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4 *>(&dst[x][kb + 8 * i]) = load8_bf16<T>(row + 8 * i);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) dst[x][kb + i] = (xin && k0 + kb + i < kmax) ? to_bf16_bits<T>(row + i) : (unsigned short)0;
+        }
+    }
+}
+
+template <typename T> __device__ __forceinline__ bool rows_vectorisable(const T *src, long ld, int k_begin) {
+    // every row start and every 8-group start 16-byte aligned: base, leading dimension and the k origin of this split
+    constexpr int per16 = 16 / (int)sizeof(T);
+    return (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ld % 8 == 0 && k_begin % 8 == 0 && (per16 <= 8);
+}
+
+template <typename TA, typename TB, typename TC, bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_mfma_bf16(const TA *__restrict__ A, const TB *__restrict__ B, TC *__restrict__ C,
+                                                       const float *__restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
+                                                       long strideA, long strideB, long strideC, int nsplit, int klen) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[BM][PITCH16];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[BN][PITCH16];
+    const int z = blockIdx.z, batch = z / nsplit, split = z - batch * nsplit;
+    const int k_begin = split * klen, k_end = min(K, k_begin + klen);
+    A += (long)batch * strideA;
+    B += (long)batch * strideB;
+    C += (long)z * strideC;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int r = lane & 31, kh = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const bool am0 = m0 + wm < M, am1 = m0 + wm + 32 < M;
+    const bool bn0 = n0 + wn < N, bn1 = n0 + wn + 32 < N;
+    const bool vecA = rows_vectorisable<TA>(A, lda, k_begin), vecB = rows_vectorisable<TB>(B, ldb, k_begin);
+    for (int k0 = k_begin; k0 < k_end; k0 += BK16) {
+        stage16<TA, A_KMAJOR>(As, A, lda, m0, M, k0, k_end, vecA);
+        stage16<TB, B_KMAJOR>(Bs, B, ldb, n0, N, k0, k_end, vecB);
+        __syncthreads();
+        if (am0 && bn0) {
+#pragma unroll
+            for (int kq = 0; kq < BK16; kq += 16) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8 *>(&As[wm + r][kq + 8 * kh]);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8 *>(&As[wm + 32 + r][kq + 8 * kh]);
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(&Bs[wn + r][kq + 8 * kh]);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(&Bs[wn + 32 + r][kq + 8 * kh]);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                if (bn1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                if (am1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                if (am1 && bn1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (m < M && n < N) {
+                    float v = acc[i][j][e];
+                    if (bias) v += bias[m];
+                    st1<TC>(C + (long)m * ldc + n, v);
+                }
+            }
+        }
+}
+
+// dispatch: bf16 activations -> bf16 MFMA kernel, otherwise the exact f32 one (same arguments)
+template <typename TA, typename TB, typename TC, bool A_KMAJOR, bool B_KMAJOR, typename... Args>
+void launch_gemm(dim3 grid, hipStream_t st, Args... args) {
+    if constexpr (sizeof(TA) == 2 || sizeof(TB) == 2)
+        hipLaunchKernelGGL((gemm_mfma_bf16<TA, TB, TC, A_KMAJOR, B_KMAJOR>), grid, dim3(256), 0, st, args...);
+    else
+        hipLaunchKernelGGL((gemm_mfma_f32<TA, TB, TC, A_KMAJOR, B_KMAJOR>), grid, dim3(256), 0, st, args...);
+}
+
 // out[i] = sum_z slabs[z][i]  (deterministic split-K combine), i < n
 template <typename TC>
 __global__ __launch_bounds__(256) void slab_reduce(const float *__restrict__ slabs, TC *__restrict__ out, long n, int nz) {
@@ -178,7 +327,7 @@ int wgrad_splits(int B, long P) {
 template <typename T>
 int align_fwd(const void *X, const void *W, const float *bias, void *Y, int B, int Cs, int Ct, long P, hipStream_t st) {
     dim3 grid((unsigned)((P + BN - 1) / BN), (Ct + BM - 1) / BM, B);
-    hipLaunchKernelGGL((gemm_mfma_f32<float, T, T, false, true>), grid, dim3(256), 0, st, (const float *)W, (const T *)X, (T *)Y, bias, Ct,
+    launch_gemm<float, T, T, false, true>(grid, st, (const float *)W, (const T *)X, (T *)Y, bias, Ct,
                        (int)P, Cs, (long)Cs, P, P, 0L, (long)Cs * P, (long)Ct * P, 1, Cs);
     return (int)hipGetLastError();
 }
@@ -187,7 +336,7 @@ template <typename T>
 int align_bwd_data(const void *dY, const void *W, void *dX, int B, int Cs, int Ct, long P, hipStream_t st) {
     // A = W^T given as W [K=Ct][M=Cs] -> K-major
     dim3 grid((unsigned)((P + BN - 1) / BN), (Cs + BM - 1) / BM, B);
-    hipLaunchKernelGGL((gemm_mfma_f32<float, T, T, true, true>), grid, dim3(256), 0, st, (const float *)W, (const T *)dY, (T *)dX, nullptr,
+    launch_gemm<float, T, T, true, true>(grid, st, (const float *)W, (const T *)dY, (T *)dX, nullptr,
                        Cs, (int)P, Ct, (long)Cs, P, P, 0L, (long)Ct * P, (long)Cs * P, 1, Ct);
     return (int)hipGetLastError();
 }
@@ -203,7 +352,7 @@ int align_bwd_weight(const void *dY, const void *X, float *dW, float *db, void *
     float *slabs = static_cast<float *>(ws);
     // A = dY_b [M=Ct][K=P] (X-major), B = X_b^T given as X_b [N=Cs][K=P] (X-major); C = slab z
     dim3 grid((Cs + BN - 1) / BN, (Ct + BM - 1) / BM, nz);
-    hipLaunchKernelGGL((gemm_mfma_f32<T, T, float, false, false>), grid, dim3(256), 0, st, (const T *)dY, (const T *)X, slabs, nullptr, Ct,
+    launch_gemm<T, T, float, false, false>(grid, st, (const T *)dY, (const T *)X, slabs, nullptr, Ct,
                        Cs, (int)P, P, P, (long)Cs, (long)Ct * P, (long)Cs * P, slab, nsplit, klen);
     hipLaunchKernelGGL((slab_reduce<float>), dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, slabs, dW, slab, nz);
     if (db) hipLaunchKernelGGL((bias_grad<T>), dim3(Ct), dim3(256), 0, st, (const T *)dY, db, B, Ct, P);
@@ -294,12 +443,15 @@ struct WgradPlan {
     bool direct;
     int nsplit, klen, regions_m, regions_n, regions_per_wg, nslabs;
 };
-WgradPlan linear_wgrad_plan(long T, int M, int N) {
+WgradPlan linear_wgrad_plan(long T, int M, int N, bool bf16 = false) {
     WgradPlan p{};
     p.regions_m = (M + 63) / 64;
     p.regions_n = (N + 63) / 64;
     const int regions = p.regions_m * p.regions_n;
     p.direct = T >= 8192 && regions <= 16;      // many tokens, small weight: the HBM-bound tall-skinny case
+    // bf16 storage halves the bytes while the direct kernel still multiplies on the f32-input MFMA: beyond ~32 flop/byte
+    // (2MN/(M+N) per bf16 element pair) it is compute-bound there, and the bf16-MFMA split-K GEMM wins
+    if (bf16 && (long)M * N > 32L * (M + N)) p.direct = false;
     if (p.direct) {
         p.regions_per_wg = regions >= 4 ? 4 : (regions >= 2 ? 2 : 1);
         const int wg_y = (regions + p.regions_per_wg - 1) / p.regions_per_wg;
@@ -325,12 +477,12 @@ WgradPlan linear_wgrad_plan(long T, int M, int N) {
 
 template <typename T>
 int linear_wgrad(const void *dY, const void *X, float *dW, float *dbias, void *ws, size_t ws_bytes, long Tn, int M, int N, hipStream_t st) {
-    const WgradPlan p = linear_wgrad_plan(Tn, M, N);
-    if (dbias && !p.direct) return SD_E_UNSUPPORTED;   // ask sd_linear_wgrad_fuses_bias() first
+    const WgradPlan p = linear_wgrad_plan(Tn, M, N, sizeof(T) == 2);
+    if (dbias && !p.direct) return SD_E_UNSUPPORTED;   // ask sd_linear_wgrad_fuses_bias_dtype() first
     const long slab = (long)M * N + (dbias ? M : 0);
     if (!p.direct && p.nsplit == 1) {
         dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, 1);
-        hipLaunchKernelGGL((gemm_mfma_f32<T, T, float, true, true>), grid, dim3(256), 0, st, (const T *)dY, (const T *)X, dW, nullptr, M, N,
+        launch_gemm<T, T, float, true, true>(grid, st, (const T *)dY, (const T *)X, dW, nullptr, M, N,
                            (int)Tn, (long)M, (long)N, (long)N, 0L, 0L, 0L, 1, (int)Tn);
         return (int)hipGetLastError();
     }
@@ -343,7 +495,7 @@ int linear_wgrad(const void *dY, const void *X, float *dW, float *dbias, void *w
                            p.regions_n, p.regions_per_wg, dbias ? 1 : 0);
     } else {
         dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, p.nsplit);
-        hipLaunchKernelGGL((gemm_mfma_f32<T, T, float, true, true>), grid, dim3(256), 0, st, (const T *)dY, (const T *)X, slabs, nullptr, M, N,
+        launch_gemm<T, T, float, true, true>(grid, st, (const T *)dY, (const T *)X, slabs, nullptr, M, N,
                            (int)Tn, (long)M, (long)N, (long)N, 0L, 0L, slab, p.nsplit, p.klen);
     }
     hipLaunchKernelGGL(slab_reduce_wide, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, slabs, dW, slab, p.nslabs, dbias, (long)M * N);
@@ -387,7 +539,7 @@ int gemm_nt_longk(const void *X, const void *W, const float *bias, float *Y, voi
     if (ws_bytes < (size_t)nsplit * slab * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
     float *slabs = static_cast<float *>(ws);
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nsplit);
-    hipLaunchKernelGGL((gemm_mfma_f32<T, float, float, false, false>), grid, dim3(256), 0, st, (const T *)X, (const float *)W, slabs, nullptr, M,
+    launch_gemm<T, float, float, false, false>(grid, st, (const T *)X, (const float *)W, slabs, nullptr, M,
                        N, K, (long)K, (long)K, (long)N, 0L, 0L, slab, nsplit, klen);
     hipLaunchKernelGGL(slab_reduce_bias, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, slabs, Y, bias, slab, nsplit, N);
     return (int)hipGetLastError();
@@ -413,8 +565,9 @@ size_t sd_align1x1_workspace_bytes(int B, int Cs, int Ct, int h, int w) {
 
 size_t sd_linear_wgrad_workspace_bytes(long tokens, int out_features, int in_features) {
     if (tokens <= 0 || out_features <= 0 || in_features <= 0) return 0;
-    const sd::WgradPlan p = sd::linear_wgrad_plan(tokens, out_features, in_features);
-    return (size_t)p.nslabs * ((size_t)out_features * in_features + out_features) * sizeof(float) + 16;
+    const sd::WgradPlan p = sd::linear_wgrad_plan(tokens, out_features, in_features), q = sd::linear_wgrad_plan(tokens, out_features, in_features, true);
+    const int nslabs = p.nslabs > q.nslabs ? p.nslabs : q.nslabs;    // either storage type
+    return (size_t)nslabs * ((size_t)out_features * in_features + out_features) * sizeof(float) + 16;
 }
 
 size_t sd_linear_longk_workspace_bytes(int rows, int out_features, int in_features) {
@@ -430,6 +583,11 @@ int sd_linear_longk_fwd(const void *X, const float *W, const float *bias, float 
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == SD_F32) return sd::gemm_nt_longk<float>(X, W, bias, Y, workspace, workspace_bytes, rows, out_features, in_features, st);
     return sd::gemm_nt_longk<sd::bf16_t>(X, W, bias, Y, workspace, workspace_bytes, rows, out_features, in_features, st);
+}
+
+int sd_linear_wgrad_fuses_bias_dtype(int dtype, long tokens, int out_features, int in_features) {
+    if (tokens <= 0 || out_features <= 0 || in_features <= 0) return 0;
+    return sd::linear_wgrad_plan(tokens, out_features, in_features, dtype == SD_BF16).direct ? 1 : 0;
 }
 
 int sd_linear_wgrad_fuses_bias(long tokens, int out_features, int in_features) {

@@ -58,7 +58,7 @@ class _TokenLinear(torch.autograd.Function):
             T, M, N = x2.shape[0], weight.shape[0], weight.shape[1]
             L = _lib.lib()
             dw32 = torch.empty(M, N, dtype=torch.float32, device=x.device)
-            fuse_b = want_db and bool(L.sd_linear_wgrad_fuses_bias(T, M, N))
+            fuse_b = want_db and bool(L.sd_linear_wgrad_fuses_bias_dtype(_DT[x.dtype], T, M, N))
             db32 = torch.empty(M, dtype=torch.float32, device=x.device) if fuse_b else None
             wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
             ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)

@@ -111,7 +111,7 @@ def test_linear_wgrad_kernel(shape, dtype):
     dyg, xg = dy.to(dev), x.to(dev)
     L = _lib.lib()
     dw = torch.empty(M, N, device=dev)
-    fuse = bool(L.sd_linear_wgrad_fuses_bias(T, M, N))
+    fuse = bool(L.sd_linear_wgrad_fuses_bias_dtype(_DT[dtype], T, M, N))
     db = torch.empty(M, device=dev) if fuse else None
     wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
