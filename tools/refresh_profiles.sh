@@ -18,7 +18,8 @@ cp $(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1) $OUT/bench_kernel
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_step -o step -- python3 $R/bench.py --no-cpu-baseline --no-roofline > /dev/null 2>&1 )
 python tools/prof_summary.py /tmp/prof_step --skip 8 --top 70 --out $OUT/train_step_kernels.txt > /dev/null
 : > $OUT/other_configs.txt
-for c in cfg3_segformer_b2_b0_cgd_cd cfg5_segformer_b4_b1_multistage_bf16 cfg1_pspnet_r101_r18_cd cfg4_pspnet_r18_swin_b_cgd_align; do
+CONFIGS=${CONFIGS:-"cfg3_segformer_b2_b0_cgd_cd cfg5_segformer_b4_b1_multistage_bf16 cfg1_pspnet_r101_r18_cd cfg4_pspnet_r18_swin_b_cgd_align"}
+for c in $CONFIGS; do
   for g in on hybrid; do
     timeout 900 python bench.py --config configs/kd/$c.py --steps 10 --warmup 4 --graph $g --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | \
       python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$c', 'graph=$g', d['config']['hip_graph'], d['value'], 'imgs/s', d['ms_per_step'], 'ms/step', d['dtype'], 'B=%d' % d['config']['per_gpu_batch'])" >> $OUT/other_configs.txt 2>&1
