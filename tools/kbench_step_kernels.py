@@ -33,6 +33,8 @@ def row(name, ms, nbytes, ref_ms=None):
 
 
 B = 8
+print('# HIP-event time around the Python call of each op (autograd Function + ctypes launch included): entries under ~25 us are bounded by that\n'
+      '# launch path, not by the kernel -- GPU durations inside the captured step are in profiles/r01_train_step_kernels_final.txt')
 print('--- depth-wise 3x3, token-major (teacher B2 stage 1: C=256; student B0 stage 1: C=128), fwd')
 for C in (256, 128):
     x = torch.randn(B, 128 * 128, C, device=dev)
