@@ -28,74 +28,72 @@ namespace {
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
 
-// grid: (nband, B); block: round64(w) threads; thread kx owns output columns F*kx .. F*kx+F-1.
-template <typename T, int F, int QB, int MAXT>
-__global__ __launch_bounds__(MAXT) void ce_up_fwd(const T *__restrict__ s, const int32_t *__restrict__ label, float *__restrict__ loss_pix,
-                          float *__restrict__ lse2_out, int *__restrict__ correct, int C, int h, int w, int R, int nband,
-                          int ignore_index) {
-    const int b = blockIdx.y, k = blockIdx.x;
-    const int kx = threadIdx.x;
-    const bool active = kx < w;
-    const int kxc = min(kx, w - 1);
+// Forward: a thread owns ONE output column (its two horizontal taps and weight are fixed) and the F output rows of a gap; the
+// class loop is innermost with an online softmax, the label pick and the running arg-max per pixel.  Coalesced label reads and
+// per-pixel stores.  VALU-bound (~12 vector ops + one exponential per pixel and class; 310 us at config-2 size -- an earlier
+// form with one thread per tap column and F x F pixels per thread ran at the same speed with a quarter of the waves).
+// Arithmetic as up_device.h::hrow, operation for operation: fmaf(lambda, right - left, left).
+// grid: (ceil(W / blockDim), nband, B)
+template <typename T, int F>
+__global__ __launch_bounds__(512) void ce_up_fwd_col(const T *__restrict__ s, const int32_t *__restrict__ label, float *__restrict__ loss_pix,
+                                                      float *__restrict__ lse2_out, int *__restrict__ correct, int C, int h, int w, int nband,
+                                                      int ignore_index) {
+    const int b = blockIdx.z, k = blockIdx.y;
     const int H = F * h, W = F * w;
-    const int j0 = k * R;
-    const int j1 = (k == nband - 1) ? h + 1 : min(h, j0 + R);
+    const int X = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = X < W;
+    const int Xc = min(X, W - 1);
+    const int kx = Xc / F, rx = Xc % F;
+    const bool left = rx < F / 2;
+    const int xa = left ? max(kx - 1, 0) : kx;
+    const int xb = left ? kx : min(kx + 1, w - 1);
+    const float lx = (left ? rx + F / 2 + 0.5f : rx - F / 2 + 0.5f) / F;
+    const int j0 = k, j1 = (k == nband - 1) ? h + 1 : min(h, j0 + 1);
     const size_t plane = (size_t)h * w;
     const T *sb = s + (size_t)b * C * plane;
     const int32_t *lb = label + (size_t)b * H * W;
     int hits = 0;
     for (int j = j0; j < j1; ++j) {
         const int rp = max(j - 1, 0), rc = min(j, h - 1);
-#pragma unroll 1
-        for (int qb = 0; qb < F; qb += QB) {
-            const int Y0 = F * j - F / 2 + qb;  // first output row of this block of QB rows
-            if (Y0 + QB <= 0 || Y0 >= H) continue;
-            int lab[QB][F];
-            float m[QB][F], z[QB][F], xl[QB][F], best[QB][F];
-            int bi[QB][F];
+        const int Y0 = F * j - F / 2;
+        int lab[F], bi[F];
+        float m[F], z[F], xl[F], best[F];
 #pragma unroll
-            for (int q = 0; q < QB; ++q)
+        for (int q = 0; q < F; ++q) {
+            const int Y = Y0 + q;
+            lab[q] = (active && Y >= 0 && Y < H) ? lb[(size_t)Y * W + X] : ignore_index;
+            m[q] = kNegBig; z[q] = 0.f; xl[q] = 0.f; best[q] = kNegBig; bi[q] = -1;
+        }
+        const T *pa = sb + (size_t)rp * w, *pb = sb + (size_t)rc * w;
+        for (int c = 0; c < C; ++c) {
+            const float a0 = VecIO<T>::load1(pa + xa), b0 = VecIO<T>::load1(pa + xb);
+            const float a1 = VecIO<T>::load1(pb + xa), b1 = VecIO<T>::load1(pb + xb);
+            pa += plane;
+            pb += plane;
+            const float sp = fmaf(lx, b0 - a0, a0), sc = fmaf(lx, b1 - a1, a1);
 #pragma unroll
-                for (int rx = 0; rx < F; ++rx) {
-                    const int Y = Y0 + q;
-                    lab[q][rx] = (active && Y >= 0 && Y < H) ? lb[(size_t)Y * W + F * kx + rx] : ignore_index;
-                    m[q][rx] = kNegBig; z[q][rx] = 0.f; xl[q][rx] = 0.f; best[q][rx] = kNegBig; bi[q][rx] = -1;
-                }
-            for (int c = 0; c < C; ++c) {
-                const T *pc = sb + (size_t)c * plane;
-                float sp[F], sc[F];
-                hrow<T, F>(pc + (size_t)rp * w, kxc, w, sp);
-                hrow<T, F>(pc + (size_t)rc * w, kxc, w, sc);
-#pragma unroll
-                for (int q = 0; q < QB; ++q) {
-                    const float lam = (qb + q + 0.5f) / F;
-#pragma unroll
-                    for (int rx = 0; rx < F; ++rx) {
-                        const float v = fmaf(lam, sc[rx] - sp[rx], sp[rx]);
-                        const float d = v - m[q][rx];
-                        const float e = ex2(-fabsf(d) * kLog2e);
-                        z[q][rx] = d > 0.f ? fmaf(z[q][rx], e, 1.f) : z[q][rx] + e;
-                        m[q][rx] = fmaxf(m[q][rx], v);
-                        if (c == lab[q][rx]) xl[q][rx] = v;
-                        if (v > best[q][rx]) { best[q][rx] = v; bi[q][rx] = c; }
-                    }
-                }
+            for (int q = 0; q < F; ++q) {
+                const float lam = (q + 0.5f) / F;
+                const float v = fmaf(lam, sc - sp, sp);
+                const float d = v - m[q];
+                const float e = ex2(-fabsf(d) * kLog2e);
+                z[q] = d > 0.f ? fmaf(z[q], e, 1.f) : z[q] + e;
+                m[q] = fmaxf(m[q], v);
+                if (c == lab[q]) xl[q] = v;
+                if (v > best[q]) { best[q] = v; bi[q] = c; }
             }
-            if (active) {
+        }
+        if (active) {
 #pragma unroll
-                for (int q = 0; q < QB; ++q) {
-                    const int Y = Y0 + q;
-                    if (Y < 0 || Y >= H) continue;
-#pragma unroll
-                    for (int rx = 0; rx < F; ++rx) {
-                        const float l2 = __builtin_amdgcn_logf(z[q][rx]);  // v_log_f32 = log2
-                        const size_t o = (size_t)b * H * W + (size_t)Y * W + F * kx + rx;
-                        const bool valid = lab[q][rx] != ignore_index;
-                        loss_pix[o] = valid ? (m[q][rx] + l2 * kLn2 - xl[q][rx]) : 0.f;
-                        lse2_out[o] = fmaf(m[q][rx], kLog2e, l2);
-                        hits += (bi[q][rx] == lab[q][rx]) ? 1 : 0;
-                    }
-                }
+            for (int q = 0; q < F; ++q) {
+                const int Y = Y0 + q;
+                if (Y < 0 || Y >= H) continue;
+                const float l2 = __builtin_amdgcn_logf(z[q]);  // v_log_f32 = log2
+                const size_t o = (size_t)b * H * W + (size_t)Y * W + X;
+                const bool valid = lab[q] != ignore_index;
+                loss_pix[o] = valid ? (m[q] + l2 * kLn2 - xl[q]) : 0.f;
+                lse2_out[o] = fmaf(m[q], kLog2e, l2);
+                hits += (bi[q] == lab[q]) ? 1 : 0;
             }
         }
     }
@@ -208,29 +206,21 @@ int sd_ce_up_fwd(const void *logits, const int32_t *label, float *loss_pix, floa
     const int F = sd::ce_factor(h, w, H, W);
     if (!F) return SD_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // the forward keeps no state across gaps (the channel loop is innermost), so one gap per workgroup maximises parallelism
-    const int R = 1, nband = h, threads = (w + 63) / 64 * 64;
+    // the forward keeps no state across gaps (the channel loop is innermost): one gap per workgroup row, one output column per thread
+    const int nband = h, threads = W >= 512 ? 512 : (W + 63) / 64 * 64;
     hipLaunchKernelGGL(sd::zero_counter, dim3(1), dim3(1), 0, st, correct);
-    dim3 grid(nband, B);
-    // wide register budget (16 pixels of softmax state per lane) needs <= 256-thread workgroups; wider taps use
-    // half the pixels per pass
-#define SD_CE_FWD(TT, FF, QQ, QQW)                                                                                                   \
-    do {                                                                                                                             \
-        if (threads <= 256)                                                                                                          \
-            hipLaunchKernelGGL((sd::ce_up_fwd<TT, FF, QQ, 256>), grid, dim3(threads), 0, st, (const TT *)logits, label, loss_pix, pix_lse2, \
-                               correct, C, h, w, R, nband, ignore_index);                                                            \
-        else                                                                                                                         \
-            hipLaunchKernelGGL((sd::ce_up_fwd<TT, FF, QQW, 1024>), grid, dim3(threads), 0, st, (const TT *)logits, label, loss_pix, pix_lse2, \
-                               correct, C, h, w, R, nband, ignore_index);                                                            \
-    } while (0)
+    dim3 grid((W + threads - 1) / threads, nband, B);
+#define SD_CE_FWD(TT, FF)                                                                                                            \
+    hipLaunchKernelGGL((sd::ce_up_fwd_col<TT, FF>), grid, dim3(threads), 0, st, (const TT *)logits, label, loss_pix, pix_lse2, correct, C, h, \
+                       w, nband, ignore_index)
     if (dtype == SD_F32) {
-        if (F == 2) SD_CE_FWD(float, 2, 2, 2);
-        else if (F == 4) SD_CE_FWD(float, 4, 4, 2);
-        else SD_CE_FWD(float, 8, 2, 1);
+        if (F == 2) SD_CE_FWD(float, 2);
+        else if (F == 4) SD_CE_FWD(float, 4);
+        else SD_CE_FWD(float, 8);
     } else {
-        if (F == 2) SD_CE_FWD(sd::bf16_t, 2, 2, 2);
-        else if (F == 4) SD_CE_FWD(sd::bf16_t, 4, 4, 2);
-        else SD_CE_FWD(sd::bf16_t, 8, 2, 1);
+        if (F == 2) SD_CE_FWD(sd::bf16_t, 2);
+        else if (F == 4) SD_CE_FWD(sd::bf16_t, 4);
+        else SD_CE_FWD(sd::bf16_t, 8);
     }
 #undef SD_CE_FWD
     return (int)hipGetLastError();
