@@ -231,8 +231,8 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--graph', choices=['auto', 'on', 'hybrid', 'off'], default='auto',
-                    help='on: capture the whole forward+backward into one hipGraph; hybrid: capture only the collective-free pieces '
-                         '(teacher forward, student backbone fwd/bwd) -- safe with SyncBN over RCCL; auto: on for 1 GPU, hybrid otherwise')
+                    help='on: capture the whole forward+backward as hipGraphs (cut at the SyncBN collectives when ranks > 1); hybrid: '
+                         'capture only the teacher forward and the student backbone fwd/bwd; auto: on, falling back to hybrid')
     args = ap.parse_args()
 
     from segdistill_amd.config import Config
@@ -262,10 +262,14 @@ def main():
     n_eager_warm = max(1, args.warmup // 2)
     for _ in range(n_eager_warm):            # eager warm-up first (MIOpen find, hipBLASLt heuristics, allocator)
         trainer.step(data.next())
-    mode = args.graph if args.graph != 'auto' else ('on' if world == 1 and not dist.is_initialized() else 'hybrid')
+    # auto: the whole step as hipGraphs at any world size (with ranks > 1 the capture is cut at the SyncBN collectives,
+    # engine/segments.py); a capture that fails degrades to the hybrid mode, then to eager
+    mode = args.graph if args.graph != 'auto' else 'on'
     if mode == 'on':
         graphed = 'full' if trainer.enable_graph(data.next()) else False
-    elif mode == 'hybrid':
+        if not graphed and args.graph == 'auto':
+            mode = 'hybrid'
+    if mode == 'hybrid':
         graphed = 'hybrid' if trainer.enable_hybrid_graph(data.next()) else False
     for _ in range(args.warmup - n_eager_warm):
         trainer.step(data.next())
@@ -286,7 +290,9 @@ def main():
                        if 'cfg2' in os.path.basename(args.config) else os.path.basename(args.config),
                        'config_file': os.path.relpath(args.config, ROOT), 'per_gpu_batch': B, 'global_batch': B * world,
                        'parallelism': f'dp{world}', 'kd_path': args.kd_path, 'hip_graph': graphed, 'weights': 'random-init (no checkpoints offline)',
-                       'grad_allreduce_bytes': trainer.reducer.nbytes},
+                       'grad_allreduce_bytes': trainer.reducer.nbytes,
+                       'graph_segments': (len([g for g in trainer._seg.items if isinstance(g, torch.cuda.CUDAGraph)])
+                                          if graphed == 'full' else None)},
             'final_log_vars': {k: round(v, 5) for k, v in logs.items()},
         }
         if not args.no_roofline:

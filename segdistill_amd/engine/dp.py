@@ -105,19 +105,30 @@ class DataParallelReducer:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, src=0)
 
-    def all_reduce(self):
-        if not self.collective:
-            self.match_layouts()
-            return
+    def pack(self):
+        """Gradients -> the flat buffer (one multi-tensor copy), pre-scaled by 1/world.  Device work only and no host decision
+        that depends on values: a trainer that captures the step records it at the end of the backward graph, reading
+        the capture's static gradient tensors."""
         grads, views = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()
-            else:
+            elif p.grad is not v:
                 grads.append(p.grad)
                 views.append(v)
-        torch._foreach_copy_(views, grads)
+        if grads:
+            torch._foreach_copy_(views, grads)
         self.flat.div_(self.world)
+
+    def exchange(self):
+        """ONE all-reduce of the packed buffer; `.grad` then points at its views."""
         dist.all_reduce(self.flat)
         for p, v in zip(self.params, self.views):
             p.grad = v
+
+    def all_reduce(self):
+        if not self.collective:
+            self.match_layouts()
+            return
+        self.pack()
+        self.exchange()

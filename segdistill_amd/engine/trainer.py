@@ -7,6 +7,7 @@ import contextlib
 
 import torch
 
+from . import segments
 from .dp import DataParallelReducer
 from .optim import PolyLR, build_optimizer
 
@@ -75,7 +76,9 @@ class KDTrainer:
     # about as much as the GPU work itself.  Forward + backward are therefore captured ONCE into a hipGraph (static
     # input buffers; the teacher's side stream forks/joins inside the capture) and replayed; everything that changes
     # per iteration reaches the kernels as data (alpha scalar, permutation table -- distillation/losses.py), the
-    # gradient all-reduce and the fused optimizer step stay outside the graph.
+    # gradient all-reduce and the fused optimizer step stay outside the graph.  With more than one rank the student's
+    # SyncBatchNorm exchanges statistics mid-forward and mid-backward: the capture is CUT there (engine/segments.py) and
+    # the step becomes a chain graph | all_gather | graph | all_reduce | graph -- no RCCL call is ever recorded.
     def enable_graph(self, example_batch):
         """Capture the step for batches shaped like `example_batch` as TWO graphs: the frozen teacher's forward (side
         stream; replayed one iteration AHEAD when the next batch is known, so it overlaps the current backward) and the
@@ -91,6 +94,8 @@ class KDTrainer:
             if hasattr(m, 'distillation_loss'):
                 m.distillation_loss.set_graph_safe(True)
             m.train()
+            self._seg = segments.SegmentRecorder()
+            segments.attach(m, self._seg)   # synchronised norms (world > 1) become cut points of the capture
             cnt0 = getattr(m, 'cnt', 0)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -127,14 +132,24 @@ class KDTrainer:
                 self._primed = None
             m.external_step = True
             self.reducer.zero_grad()        # .grad = None: the captured backward creates the (static) gradient tensors
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with self._seg:
                 self._graph_out = self._fwd_bwd(self._static)
+                if self.reducer.collective:
+                    # the pack into the flat all-reduce buffer is recorded too: it reads the capture's STATIC gradient tensors
+                    # (after the first exchange `.grad` points at the flat views, which a replay does not write)
+                    self.reducer.pack()
+            self._graph_packs = self.reducer.collective
+            self._graph = self._seg         # .replay(): the graphs in capture order, the collectives between them
+            segments.attach(m, None)
             torch.cuda.synchronize()
             return True
         except Exception as e:  # noqa: BLE001 -- any capture problem must degrade to eager, not kill the run
             warnings.warn(f'hipGraph capture failed ({type(e).__name__}: {e}); continuing in eager mode')
             self._graph = None
+            self._seg = None
+            segments.attach(m, None)
+            if hasattr(m, 'cnt') and 'cnt0' in locals():
+                m.cnt = cnt0
             m.external_step = False
             if hasattr(m, '_taps_override'):
                 m._taps_override = None
@@ -213,6 +228,8 @@ class KDTrainer:
         with (self._autocast() if batch['img'].is_cuda else contextlib.nullcontext()):
             out = self.model.train_step(batch, self.optimizer)
         out['loss'].backward()
+        if getattr(self, '_seg', None) is not None:
+            self._seg.finish_backward()     # chained SyncBatchNorm layers: exchange, then the backward in front of them
         return out
 
     def _replay_teacher(self, img):
@@ -270,7 +287,10 @@ class KDTrainer:
             if next_batch is not None and hasattr(self.model, 'prefetch_teacher'):
                 self.model.prefetch_teacher(next_batch['img'])
             out['loss'].backward()
-        self.reducer.all_reduce()
+        if getattr(self, '_graph', None) is not None and self._graph_packs:
+            self.reducer.exchange()         # packed by the replayed graph
+        else:
+            self.reducer.all_reduce()
         self.optimizer.step()
         self.iter += 1
         self.last_log_vars = out['log_vars']
@@ -312,9 +332,15 @@ class KDTrainer:
         self.load_state_dict(torch.load(path, map_location=map_location, weights_only=False))
 
     def log_values(self):
-        """Host copies of the most recent log variables (one device->host sync)."""
+        """Host copies of the most recent log variables, averaged over the ranks: one packed all-reduce + one device->host
+        sync.  COLLECTIVE: every rank must call it at the same iterations (the model defers the per-step log reduction of
+        the reference, base.py:204-207, to this point)."""
         if self.last_log_vars is None:
             return {}
         names = list(self.last_log_vars)
-        vals = torch.stack([torch.as_tensor(self.last_log_vars[n]).float().reshape(()) for n in names]).tolist()
-        return dict(zip(names, vals))
+        packed = torch.stack([torch.as_tensor(self.last_log_vars[n]).float().reshape(()) for n in names])
+        if self.reducer.world > 1 and getattr(self.model, 'defer_log_sync', False):
+            import torch.distributed as dist
+            packed = packed.to(self.reducer.flat.device) / self.reducer.world
+            dist.all_reduce(packed)
+        return dict(zip(names, packed.tolist()))

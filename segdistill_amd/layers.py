@@ -11,8 +11,8 @@ so that reference checkpoints' state-dict keys line up:
 """
 from __future__ import annotations
 
+import os
 import warnings
-
 import weakref
 
 import torch
@@ -22,13 +22,32 @@ import torch.nn.functional as F
 
 
 def _want_sync_bn():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and torch.cuda.is_available()
+    """A multi-rank GPU process group exists.  SEGDISTILL_FORCE_SYNCBN=1 also builds the synchronised layer for a ONE-rank
+    group, so that its RCCL collectives (and the segmented graph capture around them) can be exercised on a one-GPU box."""
+    if not (dist.is_available() and dist.is_initialized() and torch.cuda.is_available()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('SEGDISTILL_FORCE_SYNCBN') == '1'
+
+
+class ChainedSyncBatchNorm(nn.SyncBatchNorm):
+    """torch.nn.SyncBatchNorm (same parameters, buffers, state-dict keys, arithmetic).  While a trainer records a
+    SEGMENTED hipGraph step it points ``_segments`` at its recorder and the training-mode forward goes through
+    ``SegmentRecorder.sync_batch_norm``: the same ATen sequence with the two collectives exposed as cut points between
+    graphs (engine/segments.py).  Otherwise this is exactly the parent class."""
+
+    _segments = None
+
+    def forward(self, x):
+        rec = self._segments
+        if rec is None or not self.training or not x.is_cuda:
+            return super().forward(x)
+        return rec.sync_batch_norm(self, x)
 
 
 def build_norm_layer(cfg, num_features, postfix=''):
     """``cfg``: dict(type='BN'|'SyncBN'|'GN'|'LN', requires_grad=True, eps=..., ...).
 
-    'SyncBN' builds torch.nn.SyncBatchNorm when a multi-rank GPU process group exists and
+    'SyncBN' builds a torch.nn.SyncBatchNorm (ChainedSyncBatchNorm) when a multi-rank GPU process group exists and
     plain BatchNorm2d otherwise (identical math on one rank, identical state-dict keys).
     """
     if not isinstance(cfg, dict) or 'type' not in cfg:
@@ -41,7 +60,7 @@ def build_norm_layer(cfg, num_features, postfix=''):
         abbr, layer = 'bn', nn.BatchNorm2d(num_features, **opts)
     elif kind == 'SyncBN':
         abbr = 'bn'
-        layer = nn.SyncBatchNorm(num_features, **opts) if _want_sync_bn() else nn.BatchNorm2d(num_features, **opts)
+        layer = ChainedSyncBatchNorm(num_features, **opts) if _want_sync_bn() else nn.BatchNorm2d(num_features, **opts)
     elif kind == 'GN':
         abbr, layer = 'gn', nn.GroupNorm(num_channels=num_features, **opts)
     elif kind == 'LN':

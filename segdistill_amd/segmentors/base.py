@@ -7,7 +7,7 @@ Counterpart of reference mmseg/models/segmentors/base.py (forward :113-126, trai
 MI355X difference: the reference all-reduces and ``.item()``s every log variable separately
 (4-6 NCCL calls + 4-6 host syncs per step, :204-207).  Here all log scalars are stacked into
 ONE tensor, reduced with ONE RCCL all-reduce and copied to the host with ONE sync; with
-``defer_log_sync`` the host copy is skipped entirely except on logging iterations.
+``defer_log_sync`` both the all-reduce and the host copy happen only on logging iterations.
 """
 from __future__ import annotations
 
@@ -23,7 +23,10 @@ def parse_losses(losses, want_host_values=True):
     """-> (loss tensor, OrderedDict name -> float | 0-dim tensor).
 
     mean of every entry; ``loss`` = sum of the entries whose key contains 'loss'
-    (so acc_seg is excluded and the KD keys are included)."""
+    (so acc_seg is excluded and the KD keys are included).  With ``want_host_values=False`` (``defer_log_sync``) the
+    returned 0-dim tensors are this RANK's values: nobody reads them until a log line is due, so their cross-rank mean
+    is taken there (``KDTrainer.log_values`` -- one collective per log interval instead of one per step, and none
+    inside a captured step)."""
     log_vars = OrderedDict()
     for name, value in losses.items():
         if isinstance(value, torch.Tensor):
@@ -36,7 +39,7 @@ def parse_losses(losses, want_host_values=True):
     log_vars['loss'] = loss
     names = list(log_vars)
     packed = torch.stack([log_vars[n].detach().float().reshape(()) for n in names])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if want_host_values and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         packed = packed / dist.get_world_size()
         dist.all_reduce(packed)
     if want_host_values:

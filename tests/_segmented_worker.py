@@ -1,0 +1,92 @@
+"""Worker of tests/test_segmented_graph_gpu.py: one rank of a (possibly one-rank) process group on cuda:0.  Trains the same
+tiny SegFormer KD model twice from identical weights -- eagerly with torch's SyncBatchNorm path, and through the SEGMENTED
+hipGraph step (engine/segments.py) -- and prints one JSON line with what the test compares."""
+import copy
+import json
+import os
+import sys
+import warnings
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def main():
+    import segdistill_amd
+    from segdistill_amd.builder import build_segmentor
+    from segdistill_amd.engine import KDTrainer, SyntheticADE, init_distributed
+    from segdistill_amd.layers import ChainedSyncBatchNorm
+    from segdistill_amd.segmentors import sd_module
+    rank, local, world = init_distributed()
+    torch.cuda.set_device(0)
+    segdistill_amd.register_all()
+    norm = dict(type='SyncBN', requires_grad=True)
+
+    def seg(v, ch, e):
+        return dict(type='EncoderDecoder', pretrained=None, backbone=dict(type=f'mit_{v}', style='pytorch'),
+                    decode_head=dict(type='SegFormerHead', in_channels=ch, in_index=[0, 1, 2, 3], feature_strides=[4, 8, 16, 32], channels=128,
+                                     dropout_ratio=1e-12, num_classes=150, norm_cfg=norm, align_corners=False, decoder_params=dict(embed_dim=e),
+                                     loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)))
+    bil = dict(mode='bilinear', align_corners=False)
+    cfg = dict(type='SDModule', cfg_s=seg('b0', [32, 64, 160, 256], 256), cfg_t=seg('b0', [32, 64, 160, 256], 256),
+               distillation=[dict(student_layer='decode_head.linear_pred', teacher_layer='decode_head.linear_pred', loss_name='KLDLoss',
+                                  loss_config=dict(alpha=3, tau=4, resize_config=bil, shuffle_config={'interval': 3},
+                                                   transform_config={'loss_type': 'channel', 'group_size': 8}))],
+               t_pretrain=None, train_cfg=dict(), test_cfg=dict(mode='whole'))
+    sd_module.SYNTHETIC_WEIGHTS_OK = True
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        torch.manual_seed(0)
+        ref = build_segmentor(cfg)
+    ref.student.backbone.reset_drop_path(0.)
+    ref = ref.cuda()
+    gra = copy.deepcopy(ref)
+    bn_e, bn_g = ref.student.decode_head.linear_fuse.norm, gra.student.decode_head.linear_fuse.norm
+    out = {'rank': rank, 'world': world, 'chained': isinstance(bn_g, ChainedSyncBatchNorm)}
+    opt = dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+    t_e = KDTrainer(ref, opt, dict(policy='poly', power=1.0, min_lr=0.0, by_epoch=False), world=world)
+    t_g = KDTrainer(gra, opt, dict(policy='poly', power=1.0, min_lr=0.0, by_epoch=False), world=world)
+    data_e = SyntheticADE(2, size=(128, 128), device='cuda:0', pool=3, seed=1, rank=rank)
+    data_g = SyntheticADE(2, size=(128, 128), device='cuda:0', pool=3, seed=1, rank=rank)
+    example = dict(img=data_g._pool[0][0], img_metas=None, gt_semantic_seg=data_g._pool[0][1])
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        ok = t_g.enable_graph(example)
+    out['graph'] = bool(ok)
+    out['warnings'] = [str(w.message)[:300] for w in caught if 'capture failed' in str(w.message)]
+    if ok:
+        out['graphs'] = len([g for g in t_g._seg.items if isinstance(g, torch.cuda.CUDAGraph)])
+        out['cuts'] = t_g._seg.cuts
+    out['cnt_after_capture'] = gra.cnt
+    out['tracked_after_capture'] = int(bn_g.num_batches_tracked) - int(bn_e.num_batches_tracked)
+    bn_g.num_batches_tracked.copy_(bn_e.num_batches_tracked)   # the capture's warm-up passes advanced the running statistics
+    bn_g.running_mean.copy_(bn_e.running_mean)
+    bn_g.running_var.copy_(bn_e.running_var)
+    steps = []
+    cur = data_g.next()
+    for it in range(5):
+        torch.manual_seed(100 + it)
+        t_e.step(data_e.next())
+        torch.manual_seed(100 + it)
+        nxt = data_g.next()
+        t_g.step(cur, nxt)
+        cur = nxt
+        steps.append((t_e.log_values(), t_g.log_values()))
+    out['steps'] = steps
+    num = sum(float((a - b).pow(2).sum()) for a, b in zip(ref.student.parameters(), gra.student.parameters()))
+    den = sum(float(a.pow(2).sum()) for a in ref.student.parameters())
+    out['param_rel_l2'] = (num / den) ** 0.5
+    out['running_mean_diff'] = float((bn_e.running_mean - bn_g.running_mean).abs().max())
+    out['running_var_rel'] = float(((bn_e.running_var - bn_g.running_var).abs() / bn_e.running_var.abs().clamp_min(1e-6)).max())
+    out['tracked'] = [int(bn_e.num_batches_tracked), int(bn_g.num_batches_tracked)]
+    out['digest'] = float(sum(p.detach().double().sum() for p in gra.student.parameters()))
+    print('RESULT ' + json.dumps(out), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,65 @@
+"""The whole-step hipGraph capture with MORE THAN ONE RANK (engine/segments.py): the capture is cut at the student's
+SyncBatchNorm collectives and replayed as graph | all_gather | graph | all_reduce | graph.
+
+* two ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one device): the segmented step must train like
+  the eager step that uses torch's own SyncBatchNorm, on both ranks, and keep the replicas identical;
+* one rank over RCCL with the synchronised layer forced on: the same chain with the real RCCL collectives issued
+  between graph replays."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, 'tests', '_segmented_worker.py')
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _results(res):
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    return [json.loads(ln[len('RESULT '):]) for ln in res.stdout.splitlines() if ln.startswith('RESULT ')]
+
+
+def _check(r):
+    assert r['chained'] and r['graph'], r.get('warnings')
+    assert r['graphs'] == 3 and r['cuts'] == 2          # forward | statistics | rest of forward + backward | dy sums | backward
+    assert r['cnt_after_capture'] == 0
+    for it, (ve, vg) in enumerate(r['steps']):
+        assert list(ve) == list(vg)
+        for k in ve:
+            tol = 100.0 * 8 / (2 * 128 * 128) if 'acc' in k else 3e-4 * max(1.0, abs(ve[k]))
+            assert vg[k] == pytest.approx(ve[k], abs=tol), (it, k, ve[k], vg[k])
+    assert r['param_rel_l2'] < 3e-4
+    assert r['running_mean_diff'] < 1e-4 and r['running_var_rel'] < 1e-3
+    assert r['tracked'][0] == r['tracked'][1]
+
+
+def test_segmented_graph_two_ranks_gloo():
+    env = dict(os.environ, SEGDISTILL_DIST_BACKEND='gloo', SEGDISTILL_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), WORKER]
+    out = _results(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
+    assert sorted(r['rank'] for r in out) == [0, 1]
+    for r in out:
+        assert r['world'] == 2
+        _check(r)
+    assert out[0]['digest'] == out[1]['digest']          # replicas stay identical
+    assert out[0]['steps'] == out[1]['steps']            # log values are rank means
+
+
+def test_segmented_graph_one_rank_rccl():
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY='0', SEGDISTILL_FORCE_COLLECTIVES='1', SEGDISTILL_FORCE_SYNCBN='1')
+    env.pop('SEGDISTILL_DIST_BACKEND', None)
+    out = _results(subprocess.run([sys.executable, WORKER], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
+    assert len(out) == 1 and out[0]['world'] == 1
+    _check(out[0])

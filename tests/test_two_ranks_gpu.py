@@ -24,6 +24,6 @@ def test_bench_two_ranks_on_one_gpu():
     assert len(lines) == 1, res.stdout[-2000:]          # rank 0 prints exactly one JSON line
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 2 and d['config']['parallelism'] == 'dp2'
-    assert d['config']['hip_graph'] == 'hybrid' and d['scaling'] == 'weak' and d['value'] > 0
+    assert d['config']['hip_graph'] == 'full' and d['config']['graph_segments'] == 3 and d['scaling'] == 'weak' and d['value'] > 0
     assert all(v == v and abs(v) < 1e6 for v in d['final_log_vars'].values())
     assert 'cpu_baseline' not in d                       # N=1 only

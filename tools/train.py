@@ -90,14 +90,15 @@ def main():
     work = args.work_dir or os.path.join(ROOT, 'work_dirs', os.path.splitext(os.path.basename(args.config))[0])
     if rank == 0:
         os.makedirs(work, exist_ok=True)
-    mode = args.graph if args.graph != 'auto' else ('on' if world == 1 else 'hybrid')
+    mode = args.graph if args.graph != 'auto' else 'on'
     warm = 0
     t0 = time.perf_counter()
     while trainer.iter < n_iters:
         trainer.step(data.next())
         warm += 1
         if warm == 3 and device.type == 'cuda' and mode != 'off':
-            (trainer.enable_graph if mode == 'on' else trainer.enable_hybrid_graph)(data.next())
+            if not (mode == 'on' and trainer.enable_graph(data.next())):
+                trainer.enable_hybrid_graph(data.next())
         it = trainer.iter
         if it % log_every == 0 or it == n_iters:
             vals = trainer.log_values()  # the only device->host sync
