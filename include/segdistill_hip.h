@@ -340,6 +340,44 @@ int sd_upsum_affine_fwd(const void *z1, const void *z2, const void *z3, const vo
 
 int sd_upsum_bwd(const void *dy, void *dz, int dtype, int B, int h, int w, int E, int F, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Training-mode BatchNorm over token-major activations [rows][C] (C % 4 == 0, C <= 1024) with the ReLU and the channel
+ * dropout that follow it fused in.  Replaces the `linear_fuse` tail of the SegFormer head -- (Sync)BatchNorm -> ReLU
+ * (segformer_head.py:66-71,93-94) -> Dropout2d (decode_head.py:210-215) -- and its autograd; the statistics and the
+ * backward sums are separate entry points because with more than one rank a collective sits behind each of them
+ * (torch.nn.SyncBatchNorm's all-gather of mean / invstd / count and all-reduce of the dy sums).
+ *   sd_bn_stats            mean[C], invstd[C] = 1/sqrt(biased var + eps) of THIS rank's rows; when running_mean / running_var
+ *                          are given they are updated in place (momentum; unbiased variance) -- the single-rank case.
+ *   sd_bn_act_fwd          y = act((x - mean) * invstd * weight + bias) * drop_scale[row / rows_per_image][c]
+ *                          (relu = 0: act = identity; weight / bias / drop_scale may be NULL: 1 / 0 / 1).
+ *   sd_bn_act_bwd_reduce   g = dy * drop_scale * [pre-activation > 0];  sum_dy[c] = sum_rows g,
+ *                          sum_dy_xmu[c] = sum_rows g * (x - mean)       (grad_bias = sum_dy, grad_weight = sum_dy_xmu * invstd)
+ *   sd_bn_act_bwd_elemt    dx = (g - sum_dy * inv_count - (x - mean) * invstd^2 * sum_dy_xmu * inv_count) * invstd * weight,
+ *                          inv_count = 1 / (rows summed over all ranks) -- as a host value or, when the total is only known on
+ *                          the device (ranks with unequal batches), through inv_count_dev; sum_dy / sum_dy_xmu summed over all ranks.
+ * Per-workgroup partials in `workspace` (sd_bn_workspace_bytes), combined in fp64: deterministic, no float atomics.
+ */
+int sd_bn_supported(int C);
+size_t sd_bn_workspace_bytes(long rows, int C);
+
+int sd_bn_stats(const void *x, int dtype, long rows, int C, float eps, float *mean, float *invstd,
+                float *running_mean /* or NULL */, float *running_var /* or NULL */, float momentum,
+                void *workspace, size_t workspace_bytes, void *stream);
+
+int sd_bn_act_fwd(const void *x, const float *mean, const float *invstd, const float *weight, const float *bias,
+                  const float *drop_scale, long rows_per_image, int relu, void *y, int dtype, long rows, int C, void *stream);
+
+int sd_bn_act_bwd_reduce(const void *x, const void *dy, const float *mean, const float *invstd, const float *weight,
+                         const float *bias, const float *drop_scale, long rows_per_image, int relu,
+                         float *sum_dy, float *sum_dy_xmu, int dtype, long rows, int C,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+int sd_bn_act_bwd_elemt(const void *x, const void *dy, const float *mean, const float *invstd, const float *weight,
+                        const float *bias, const float *drop_scale, long rows_per_image, int relu,
+                        const float *sum_dy, const float *sum_dy_xmu, float inv_count,
+                        const float *inv_count_dev /* or NULL; when given it replaces inv_count */, void *dx,
+                        int dtype, long rows, int C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

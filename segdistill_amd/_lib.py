@@ -73,6 +73,12 @@ SIGNATURES = {
     'sd_upsum_fwd': (_i, [_vp] * 6 + [_i] * 8 + [_vp]),
     'sd_upsum_affine_fwd': (_i, [_vp] * 7 + [_i] + [_vp] + [_i] * 8 + [_vp]),
     'sd_upsum_bwd': (_i, [_vp, _vp] + [_i] * 6 + [_vp]),
+    'sd_bn_supported': (_i, [_i]),
+    'sd_bn_workspace_bytes': (_sz, [C.c_long, _i]),
+    'sd_bn_stats': (_i, [_vp, _i, C.c_long, _i, _f, _vp, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
+    'sd_bn_act_fwd': (_i, [_vp] * 6 + [C.c_long, _i, _vp, _i, C.c_long, _i, _vp]),
+    'sd_bn_act_bwd_reduce': (_i, [_vp] * 7 + [C.c_long, _i, _vp, _vp, _i, C.c_long, _i, _vp, _sz, _vp]),
+    'sd_bn_act_bwd_elemt': (_i, [_vp] * 7 + [C.c_long, _i, _vp, _vp, _f, _vp, _vp, _i, C.c_long, _i, _vp]),
     'sd_ce_up_supported': (_i, [_i, _i, _i, _i]),
     'sd_ce_up_fwd': (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     'sd_ce_up_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp] + [_i] * 8 + [_vp]),

@@ -132,9 +132,35 @@ class SegFormerHead(BaseDecodeHead):
                 and isinstance(fuse.activate, nn.ReLU) and not (norm._forward_hooks or norm._forward_pre_hooks or fuse.activate._forward_hooks
                                                                  or fuse.activate._forward_pre_hooks))
 
+    def _fused_tail(self, y):
+        """Training-mode (Sync)BatchNorm -> ReLU -> Dropout2d of `linear_fuse` as the four HIP passes of csrc/batchnorm.hip
+        (segdistill_amd/batchnorm.py) on the token-major view of y; None when the generic modules must run (hooks, eval mode,
+        unsupported layout)."""
+        from .. import batchnorm as hip_bn
+        fuse, drop = self.linear_fuse, self.dropout
+        if not (self.training and fuse.with_norm and fuse.with_activation and isinstance(fuse.activate, nn.ReLU) and y.is_cuda and y.dim() == 4
+                and y.is_contiguous(memory_format=torch.channels_last)):
+            return None
+        mods = (fuse, fuse.activate) + ((drop,) if drop is not None else ())
+        if any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in mods):
+            return None
+        if drop is not None and not (isinstance(drop, nn.Dropout2d) and 0.0 <= drop.p < 1.0):
+            return None
+        b, e, h, w = y.shape
+        tokens = tokens_of(y)
+        if not hip_bn.supported(tokens, fuse.norm):
+            return None
+        scale = hip_bn.channel_dropout_scale(tokens, drop.p) if (drop is not None and drop.training and drop.p > 0.0) else None
+        out = hip_bn.norm_act(tokens, fuse.norm, relu=True, drop=scale)
+        return out.reshape(b, h, w, e).permute(0, 3, 1, 2)
+
     def finish(self, y, normed=False):
         """SyncBN -> ReLU -> dropout -> linear_pred on the summed branch maps (the part of the head that may communicate)."""
         fuse = self.linear_fuse
+        if not normed:
+            fast = self._fused_tail(y)
+            if fast is not None:
+                return self._predict(fast)
         if fuse.with_norm and not normed:
             y = fuse.norm(y)
         if fuse.with_activation and not normed:

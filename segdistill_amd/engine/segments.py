@@ -23,36 +23,50 @@ torch SyncBatchNorm step agree to rounding.
 from __future__ import annotations
 
 import gc
+import time
 
 import torch
 import torch.distributed as dist
 
+def quiesce_collectives():
+    """Call before a hipGraph capture begins.  The process group's watchdog thread polls the completion events of outstanding
+    collectives (hipEventQuery, every ~100 ms); HIP refuses that call from ANY thread while a stream captures in the default
+    `global` mode (hipErrorStreamCaptureUnsupported) and the watchdog then takes the process down.  Drain the device and give
+    the watchdog time to retire what has completed; captures opened by this package additionally use the `thread_local` mode,
+    under which other threads are not restricted."""
+    torch.cuda.synchronize()
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
+        time.sleep(0.35)
+
+
+CAPTURE_MODE = 'thread_local'
 MAX_CHAINED_NORMS = 8   # more cuts than this (ResNet students: 28 SyncBN layers) and the hybrid mode is the better trade
 
 
 class _Record:
-    __slots__ = ('mod', 'x', 'xd', 'mean', 'invstd', 'counts', 'dy', 'red')
+    """One chained norm of the step: x = its input inside the upstream autograd graph; finish(dy) -> dx (or None), the rest
+    of the layer's backward including its collective, run by SegmentRecorder.finish_backward on the host thread."""
+    __slots__ = ('x', 'dy', 'finish')
 
-    def __init__(self, mod, x, xd, mean, invstd, counts):
-        self.mod, self.x, self.xd, self.mean, self.invstd, self.counts = mod, x, xd, mean, invstd, counts
-        self.dy = None
-        self.red = None
+    def __init__(self, x, finish=None):
+        self.x, self.dy, self.finish = x, None, finish
 
 
-class _ChainedNormApply(torch.autograd.Function):
-    """y = (xd - mean) * invstd * w + b with the statistics as constants; the backward only COLLECTS dy (the statistics'
-    share of the input gradient needs an all-reduce first and is added by SegmentRecorder.finish_backward)."""
+class _CollectGrad(torch.autograd.Function):
+    """Runs `compute()` -- a layer's forward on a DETACHED input, cuts included -- outside autograd and returns its result; the
+    backward only COLLECTS the gradient (the layer's own backward needs an all-reduce first and is run on the host thread by
+    SegmentRecorder.finish_backward).  `anchor` is any tensor that requires grad, so that the output does."""
 
     @staticmethod
-    def forward(ctx, xd, weight, bias, mean, invstd, eps, rec):
+    def forward(ctx, anchor, rec, compute):
         ctx.rec = rec
-        return torch.batch_norm_elemt(xd, weight, bias, mean, invstd, eps)
+        return compute()
 
     @staticmethod
     def backward(ctx, dy):
         rec = ctx.rec
         rec.dy = dy if rec.dy is None else rec.dy + dy
-        return None, None, None, None, None, None, None
+        return None, None, None
 
 
 def _channels_first_dense(t):
@@ -69,12 +83,13 @@ class SegmentRecorder:
         self._graph = None
         self._pool = None
         self._stream_ctx = None
+        self._coll_stream = None
         self.cuts = 0
 
     # ---- capture / replay ---------------------------------------------------------------------------------------------
     def _begin_graph(self):
         self._graph = torch.cuda.CUDAGraph()
-        self._graph.capture_begin(pool=self._pool)
+        self._graph.capture_begin(pool=self._pool, capture_error_mode=CAPTURE_MODE)
 
     def _end_graph(self):
         self._graph.capture_end()
@@ -82,11 +97,12 @@ class SegmentRecorder:
         self._graph = None
 
     def __enter__(self):
-        torch.cuda.synchronize()
+        quiesce_collectives()
         gc.collect()
         torch.cuda.empty_cache()
         self.items, self.records, self.cuts = [], [], 0
         self._pool = torch.cuda.graph_pool_handle()
+        self._coll_stream = torch.cuda.Stream()
         self._stream_ctx = torch.cuda.stream(torch.cuda.Stream())
         self._stream_ctx.__enter__()
         self.capturing = True
@@ -112,8 +128,14 @@ class SegmentRecorder:
             fn()
             return
         self._end_graph()
-        fn()
-        torch.cuda.synchronize()     # nothing of the collective is in flight (or being polled) when the next capture opens
+        # At capture time the collective runs on a stream that NEVER captures, bracketed by device synchronisations (its operands are
+        # not meaningful yet -- the graph in front of it was recorded, not run -- only its completion matters).  Issued on the
+        # capture stream itself, its completion event would sit on a stream that is capturing again a moment later, and the process
+        # group's watchdog thread, polling that event, dies with hipErrorCapturedEvent.
+        torch.cuda.synchronize()
+        with torch.cuda.stream(self._coll_stream):
+            fn()
+        quiesce_collectives()
         self.items.append(fn)
         self.cuts += 1
         self._begin_graph()
@@ -135,8 +157,10 @@ class SegmentRecorder:
         group = mod.process_group if mod.process_group is not None else dist.group.WORLD
         world = dist.get_world_size(group)
         C = x.shape[1]
-        xd = _channels_first_dense(x.detach()).requires_grad_(x.requires_grad)
-        with torch.no_grad():     # the statistics are constants of _ChainedNormApply; their gradient share is added in finish_backward
+        xd = _channels_first_dense(x.detach())
+        st = {}
+
+        def compute():
             if mod.track_running_stats and mod.num_batches_tracked is not None:
                 mod.num_batches_tracked.add_(1)
             mean_l, invstd_l = torch.batch_norm_stats(xd, mod.eps)
@@ -151,46 +175,80 @@ class SegmentRecorder:
             counts = count_all.reshape(-1)
             running_mean = mod.running_mean if mod.track_running_stats else None
             running_var = mod.running_var if mod.track_running_stats else None
-            mean, invstd = torch.batch_norm_gather_stats_with_counts(xd, mean_all, invstd_all, running_mean, running_var,
-                                                                     mod.momentum, mod.eps, counts)
-        rec = _Record(mod, x, xd, mean, invstd, counts.to(torch.int32))
-        self.records.append(rec)
-        return _ChainedNormApply.apply(xd, mod.weight, mod.bias, mean, invstd, mod.eps, rec)
+            st['mean'], st['invstd'] = torch.batch_norm_gather_stats_with_counts(xd, mean_all, invstd_all, running_mean, running_var,
+                                                                                 mod.momentum, mod.eps, counts)
+            st['counts'] = counts.to(torch.int32)
+            return torch.batch_norm_elemt(xd, mod.weight, mod.bias, st['mean'], st['invstd'], mod.eps)
 
-    def finish_backward(self):
-        """After the backward from the loss: per chained norm, latest first -- reduce dy, exchange, input gradient, and
-        continue the backward into the part of the network in front of the norm."""
-        recs, self.records = self.records, []
-        with torch.no_grad():
-            self._finish(recs)
-
-    def _finish(self, recs):
-        for i in range(len(recs) - 1, -1, -1):
-            r = recs[i]
-            if r.dy is None:
-                continue
-            mod = r.mod
-            group = mod.process_group if mod.process_group is not None else dist.group.WORLD
-            dy = _channels_first_dense(r.dy)
+        def finish(dy, need_dx):
+            mean, invstd = st['mean'], st['invstd']
+            dy = _channels_first_dense(dy)
             w = mod.weight
             need_w = w is not None and w.requires_grad
             need_b = mod.bias is not None and mod.bias.requires_grad
-            sum_dy, sum_dy_xmu, gw, gb = torch.batch_norm_backward_reduce(dy, r.xd, r.mean, r.invstd, w, True, need_w, need_b)
+            sum_dy, sum_dy_xmu, gw, gb = torch.batch_norm_backward_reduce(dy, xd, mean, invstd, w, True, need_w, need_b)
             if need_w:
                 w.grad = gw if w.grad is None else w.grad + gw
             if need_b:
                 mod.bias.grad = gb if mod.bias.grad is None else mod.bias.grad + gb
-            if not r.x.requires_grad:
-                continue
+            if not need_dx:
+                return None
             red = torch.cat([sum_dy, sum_dy_xmu])
-            self.cut(lambda red=red, group=group: dist.all_reduce(red, group=group))
-            C = sum_dy.numel()
+            self.cut(lambda: dist.all_reduce(red, group=group))
             sum_dy, sum_dy_xmu = torch.split(red, C)
-            if w is not None and w.dtype != r.mean.dtype:
-                w = w.to(r.mean.dtype)
-            dx = torch.batch_norm_backward_elemt(dy, r.xd, r.mean, r.invstd, w, sum_dy, sum_dy_xmu, r.counts)
-            # an earlier record may share upstream nodes with this one: keep the graph until the last walk
-            torch.autograd.backward(r.x, dx, retain_graph=any(q.dy is not None or q.x.requires_grad for q in recs[:i]))
+            if w is not None and w.dtype != mean.dtype:
+                w = w.to(mean.dtype)
+            return torch.batch_norm_backward_elemt(dy, xd, mean, invstd, w, sum_dy, sum_dy_xmu, st['counts'])
+
+        rec = _Record(x, finish)
+        self.records.append(rec)
+        return _CollectGrad.apply(self._anchor(x, mod), rec, compute)
+
+    @staticmethod
+    def _anchor(x, mod):
+        """A fresh leaf that requires grad, so that _CollectGrad's output does.  Deliberately NOT x: an edge to x's graph would
+        let the backward from the loss walk into (and free) the upstream nodes that finish_backward has yet to run."""
+        return torch.empty(0, device=x.device, requires_grad=True)
+
+    def fused_norm_act(self, mod, tokens, relu, drop):
+        """The HIP form (segdistill_amd/batchnorm.py): BatchNorm + ReLU + channel dropout on tokens [B, N, C], its collectives
+        as cut points.  Used by the SegFormer head for its `linear_fuse` tail."""
+        from .. import batchnorm as hip_bn
+        if len(self.records) >= MAX_CHAINED_NORMS:
+            raise RuntimeError(f'more than {MAX_CHAINED_NORMS} synchronised norms in one step: use the hybrid graph mode')
+        xd = tokens.detach()
+        st = {}
+
+        def compute():
+            y, st['sv'] = hip_bn.forward_pieces(xd, mod, relu, drop, cut=self.cut)
+            return y
+
+        def finish(dy, need_dx):
+            dx, gw, gb = hip_bn.backward_pieces(st['sv'], dy, need_dx=need_dx, cut=self.cut)
+            if mod.weight.requires_grad:
+                mod.weight.grad = gw if mod.weight.grad is None else mod.weight.grad + gw
+            if mod.bias.requires_grad:
+                mod.bias.grad = gb if mod.bias.grad is None else mod.bias.grad + gb
+            return dx
+
+        rec = _Record(tokens, finish)
+        self.records.append(rec)
+        return _CollectGrad.apply(self._anchor(tokens, mod), rec, compute)
+
+    def finish_backward(self):
+        """After the backward from the loss: per chained norm, latest first -- the layer's own backward (dy sums, exchange,
+        input gradient), then the backward continues into the part of the network in front of the norm."""
+        recs, self.records = self.records, []
+        with torch.no_grad():
+            for i in range(len(recs) - 1, -1, -1):
+                r = recs[i]
+                if r.dy is None:
+                    continue
+                dx = r.finish(r.dy, r.x.requires_grad)
+                r.dy = r.finish = None
+                if dx is not None:
+                    # an earlier record may share upstream nodes with this one: keep the graph until the last walk
+                    torch.autograd.backward(r.x, dx, retain_graph=i > 0)
 
 
 def attach(model, recorder):

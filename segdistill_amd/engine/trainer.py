@@ -115,7 +115,8 @@ class KDTrainer:
                 m._prefetched = None
                 m.extractor.teacher_features.clear()
                 gt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gt, stream=ts):
+                segments.quiesce_collectives()      # the warm-up passes may have left collectives for the watchdog to retire
+                with torch.cuda.graph(gt, stream=ts, capture_error_mode=segments.CAPTURE_MODE):
                     m._teacher_forward(self._t_img, None, None)
                 self._t_out = dict(m.extractor.teacher_features)
                 m.extractor.clear()
@@ -185,6 +186,7 @@ class KDTrainer:
             # (1) student backbone: forward + backward graphs, replayed from inside eager autograd
             wrapper = _TupleOut(m.student.backbone)
             wrapper.train()
+            segments.quiesce_collectives()          # earlier eager steps may have left collectives for the watchdog to retire
             with self._autocast(cache_enabled=False):   # graphed callables must not share autocast's weight-cast cache
                 torch.cuda.make_graphed_callables(wrapper, (h_img,), num_warmup_iters=2)
             object.__setattr__(m.student, '_graphed_backbone', wrapper)   # not registered as a sub-module (state dict unchanged)
@@ -199,7 +201,7 @@ class KDTrainer:
             torch.cuda.synchronize()
             m.extractor.teacher_features.clear()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode=segments.CAPTURE_MODE):
                 m._teacher_forward(h_img, None, None)
             outs = dict(m.extractor.teacher_features)
             m.extractor.clear()

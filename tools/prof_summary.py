@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--skip', type=int, default=5)
     ap.add_argument('--top', type=int, default=40)
     ap.add_argument('--out', default=None)
+    ap.add_argument('--gaps', type=int, default=0, help='also list the N idle-gap sites with the largest total (kernel before -> kernel after)')
     a = ap.parse_args()
     files = glob.glob(os.path.join(a.dir, '**', '*kernel_trace.csv'), recursive=True)
     if not files:
@@ -58,6 +59,7 @@ def main():
             busy += e - s
     # union of the kernel intervals (at least one kernel resident) and the idle gaps between them
     union, cur_s, cur_e, gaps = 0, None, None, []
+    sites, last_name = defaultdict(lambda: [0, 0]), None
     for s, e, n in rows:
         if not (t0 <= s < t1):
             continue
@@ -65,9 +67,13 @@ def main():
             if cur_e is not None:
                 union += cur_e - cur_s
                 gaps.append(s - cur_e)
-            cur_s, cur_e = s, e
+                site = sites[(short(last_name)[:44], short(n)[:44])]
+                site[0] += s - cur_e
+                site[1] += 1
+            cur_s, cur_e, last_name = s, e, n
         else:
-            cur_e = max(cur_e, e)
+            if e > cur_e:
+                cur_e, last_name = e, n
     if cur_e is not None:
         union += cur_e - cur_s
     gaps.sort()
@@ -79,6 +85,10 @@ def main():
              f'{"kernel":92s} {"ms/step":>9s} {"%busy":>7s} {"calls/step":>10s} {"avg us":>9s}']
     for k, (ns, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:a.top]:
         lines.append(f'{k:92s} {ns / nsteps / 1e6:9.3f} {100 * ns / busy:7.2f} {c / nsteps:10.1f} {ns / c / 1e3:9.1f}')
+    if a.gaps:
+        lines.append(f'# idle-gap sites (kernel that ended last -> kernel that started next), by total idle time')
+        for (ka, kb), (ns, c) in sorted(sites.items(), key=lambda kv: -kv[1][0])[:a.gaps]:
+            lines.append(f'#   {ka:44s} -> {kb:44s} {ns / nsteps / 1e3:8.1f} us/step  {c / nsteps:5.1f}/step  avg {ns / c / 1e3:7.1f} us')
     text = '\n'.join(lines)
     print(text)
     if a.out:
