@@ -57,8 +57,15 @@ class _TokenLinear(torch.autograd.Function):
             dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
             T, M, N = x2.shape[0], weight.shape[0], weight.shape[1]
             L = _lib.lib()
+            direct = bool(L.sd_linear_wgrad_fuses_bias_dtype(_DT[x.dtype], T, M, N))
+            if not direct and x.dtype == torch.float32:
+                # fewer than 8192 tokens or a weight of more than 16 64x64 regions: no longer tall-skinny, and the library's GEMM beats
+                # the generic split-K kernel 2-2.7x there (tools/wgrad_bench.py: T=8192 640x160 51 vs 107 us, T=4096 512x256 26 vs 67 us)
+                dw = (dyc.t() @ x2).to(ctx.w_dtype)
+                db = dy2.sum(0, dtype=torch.float32).to(ctx.w_dtype) if want_db else None
+                return dx, dw, db
             dw32 = torch.empty(M, N, dtype=torch.float32, device=x.device)
-            fuse_b = want_db and bool(L.sd_linear_wgrad_fuses_bias_dtype(_DT[x.dtype], T, M, N))
+            fuse_b = want_db and direct
             db32 = torch.empty(M, dtype=torch.float32, device=x.device) if fuse_b else None
             wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
             ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
