@@ -364,11 +364,90 @@ int align_bwd_weight(const void *dY, const void *X, float *dW, float *db, void *
 // of token t+1 for lanes 32-63), so no LDS staging / barriers are needed at all.  Each wave owns one 64x64 output
 // region (2x2 accumulators); a workgroup covers up to four regions, and when the problem has fewer than four the
 // spare waves split the token range instead (more slabs).  slab index = blockIdx.x * ksubs + ksub.
+// Branch-free inner loop: TM / TN = number of 32-blocks of the region that exist (1 or 2; wave-uniform, compile-time here), column
+// indices are CLAMPED into the matrix and the values of lanes beyond it zeroed by a select, the token range is walked in full steps
+// of 2*U tokens (no predicate at all) plus one clamped + masked tail step.  All loads of a step are plain back-to-back
+// global_load_dword instructions, and the loads of step i+1 are issued before the MFMAs of step i (two register sets): the grid
+// holds about one wave per SIMD (more waves = more slabs to combine), so nothing else hides the HBM latency.
+template <int TM, int TN, int U>
+struct WgradFrag {
+    float a[TM][U], b[TN][U];
+};
+
+template <typename T, int TM, int TN, int U, bool TAIL>
+__device__ __forceinline__ void wgrad_load(WgradFrag<TM, TN, U> &f, const T *__restrict__ dY, const T *__restrict__ X, long t0, int kh,
+                                           long k_end, int M, int N, const int (&ca)[2], const int (&cb)[2], const bool (&am)[2],
+                                           const bool (&bn)[2]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        long t = t0 + 2 * u + kh;
+        bool in = true;
+        if (TAIL) {
+            in = t < k_end;
+            t = in ? t : k_end - 1;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float v = ld1<T>(dY + t * M + ca[i]);
+            f.a[i][u] = (in && am[i]) ? v : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float v = ld1<T>(X + t * N + cb[j]);
+            f.b[j][u] = (in && bn[j]) ? v : 0.f;
+        }
+    }
+}
+
+template <int TM, int TN, int U>
+__device__ __forceinline__ void wgrad_multiply(const WgradFrag<TM, TN, U> &f, f32x16 (&acc)[2][2], bool do_bias, float (&bs)[2]) {
+    if (do_bias) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) bs[i] += f.a[i][u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][u], f.b[j][u], acc[i][j], 0, 0, 0);
+}
+
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void wgrad_walk(const T *__restrict__ dY, const T *__restrict__ X, long k_begin, long k_end, int kh, int M, int N,
+                                           const int (&ca)[2], const int (&cb)[2], const bool (&am)[2], const bool (&bn)[2],
+                                           f32x16 (&acc)[2][2], bool do_bias, float (&bs)[2]) {
+    constexpr int U = 8;   // token pairs per step: up to 32 dword loads in flight per lane and register set
+    WgradFrag<TM, TN, U> fa, fb;
+    const long full_end = k_begin + (k_end - k_begin) / (2 * U) * (2 * U);
+    long t0 = k_begin;
+    if (t0 < full_end) {
+        wgrad_load<T, TM, TN, U, false>(fa, dY, X, t0, kh, k_end, M, N, ca, cb, am, bn);
+        while (true) {
+            const long t1 = t0 + 2 * U;
+            if (t1 >= full_end) { wgrad_multiply<TM, TN, U>(fa, acc, do_bias, bs); break; }
+            wgrad_load<T, TM, TN, U, false>(fb, dY, X, t1, kh, k_end, M, N, ca, cb, am, bn);
+            wgrad_multiply<TM, TN, U>(fa, acc, do_bias, bs);
+            const long t2 = t1 + 2 * U;
+            if (t2 >= full_end) { wgrad_multiply<TM, TN, U>(fb, acc, do_bias, bs); break; }
+            wgrad_load<T, TM, TN, U, false>(fa, dY, X, t2, kh, k_end, M, N, ca, cb, am, bn);
+            wgrad_multiply<TM, TN, U>(fb, acc, do_bias, bs);
+            t0 = t2;
+        }
+    }
+    if (full_end < k_end) {
+        wgrad_load<T, TM, TN, U, true>(fa, dY, X, full_end, kh, k_end, M, N, ca, cb, am, bn);
+        wgrad_multiply<TM, TN, U>(fa, acc, do_bias, bs);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void linear_wgrad_direct(const T *__restrict__ dY, const T *__restrict__ X, float *__restrict__ slabs, int M,
                                                             int N, long Tn, int klen, int regions_m, int regions_n, int regions_per_wg,
                                                             int with_bias) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform values stay scalar
     const int r = lane & 31, kh = lane >> 5;
     const int ksubs = 4 / regions_per_wg;
     const int region = blockIdx.y * regions_per_wg + wave % regions_per_wg;
@@ -377,7 +456,9 @@ __global__ __launch_bounds__(256) void linear_wgrad_direct(const T *__restrict__
     const int m0 = (region / regions_n) * 64, n0 = (region % regions_n) * 64;
     const long k_begin = (long)blockIdx.x * klen + (long)ksub * (klen / ksubs);
     const long k_end = min(Tn, ksub == ksubs - 1 ? (long)(blockIdx.x + 1) * klen : k_begin + klen / ksubs);
-    const bool am0 = m0 + r < M, am1 = m0 + 32 + r < M, bn0 = n0 + r < N, bn1 = n0 + 32 + r < N;
+    const bool am[2] = {m0 + r < M, m0 + 32 + r < M}, bn[2] = {n0 + r < N, n0 + 32 + r < N};
+    const bool am0 = am[0], am1 = am[1];
+    const int ca[2] = {min(m0 + r, M - 1), min(m0 + 32 + r, M - 1)}, cb[2] = {min(n0 + r, N - 1), min(n0 + 32 + r, N - 1)};
     const bool tm1 = m0 + 32 < M, tn1 = n0 + 32 < N;  // wave-uniform: does the second 32-block exist at all
     f32x16 acc[2][2];
 #pragma unroll
@@ -386,34 +467,16 @@ __global__ __launch_bounds__(256) void linear_wgrad_direct(const T *__restrict__
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    constexpr int U = 8;  // token pairs per unrolled step: up to 32 dword loads in flight per lane
     // bias gradient = column sums of dY: the A operands ARE dY, so the waves of the first n-region add them up on the side
     const bool do_bias = with_bias && (region % regions_n) == 0;
-    float bs0 = 0.f, bs1 = 0.f;
-    for (long t0 = k_begin; t0 < k_end; t0 += 2 * U) {
-        float a0[U], a1[U], b0[U], b1[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const long t = t0 + 2 * u + kh;
-            const bool in = t < k_end;
-            const T *pa = dY + t * M + m0 + r, *pb = X + t * N + n0 + r;
-            a0[u] = (in && am0) ? ld1<T>(pa) : 0.f;
-            a1[u] = (in && am1) ? ld1<T>(pa + 32) : 0.f;
-            b0[u] = (in && bn0) ? ld1<T>(pb) : 0.f;
-            b1[u] = (in && bn1) ? ld1<T>(pb + 32) : 0.f;
-        }
-        if (do_bias) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) { bs0 += a0[u]; bs1 += a1[u]; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
-            if (tn1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
-            if (tm1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
-            if (tm1 && tn1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
-        }
+    float bs[2] = {0.f, 0.f};
+    if (k_begin < k_end) {
+        if (tm1 && tn1) wgrad_walk<T, 2, 2>(dY, X, k_begin, k_end, kh, M, N, ca, cb, am, bn, acc, do_bias, bs);
+        else if (tm1) wgrad_walk<T, 2, 1>(dY, X, k_begin, k_end, kh, M, N, ca, cb, am, bn, acc, do_bias, bs);
+        else if (tn1) wgrad_walk<T, 1, 2>(dY, X, k_begin, k_end, kh, M, N, ca, cb, am, bn, acc, do_bias, bs);
+        else wgrad_walk<T, 1, 1>(dY, X, k_begin, k_end, kh, M, N, ca, cb, am, bn, acc, do_bias, bs);
     }
+    float bs0 = bs[0], bs1 = bs[1];
     const long slab_elems = (long)M * N + (with_bias ? M : 0);   // a slab = the M x N partial, then (optionally) M bias partials
     float *C = slabs + ((long)blockIdx.x * ksubs + ksub) * slab_elems;
 #pragma unroll
