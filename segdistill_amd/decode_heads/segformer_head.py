@@ -189,7 +189,12 @@ class SegFormerHead(BaseDecodeHead):
         # 131072 tokens -- then runs on the split-K kernel instead of a 20-workgroup library GEMM (0.39 ms at config 2);
         # (b) ROCm 7.0 hipBLASLt's bf16 kernel for the batched W x tokens^T form (E=768, HW=16384) reads out of bounds
         # (tools/gemm_fault_probe.py reproduces the GPU memory fault).
-        out = token_linear(tokens, w2d, pred.bias).transpose(1, 2).contiguous()
+        if not torch.is_grad_enabled() and tokens.dtype == torch.float32 and not torch.is_autocast_enabled() and pred.bias is not None:
+            # frozen network in fp32 (the teacher): W x tokens^T lands in contiguous NCHW planes directly -- no weight gradient to
+            # care about, the faulty kernel is a bf16 one -- and the 79 MB transpose copy of the [8,16384,150] logits is saved
+            out = torch.baddbmm(pred.bias.view(1, -1, 1), w2d.unsqueeze(0).expand(b, -1, -1), tokens.transpose(1, 2))
+        else:
+            out = token_linear(tokens, w2d, pred.bias).transpose(1, 2).contiguous()
         out = out.view(b, pred.out_channels, h, w)
         for hook in pred._forward_hooks.values():
             r = hook(pred, (fused,), out)
