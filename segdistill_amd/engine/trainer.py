@@ -183,13 +183,19 @@ class KDTrainer:
                 torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
             except AttributeError:
                 pass
-            # (1) student backbone: forward + backward graphs, replayed from inside eager autograd
-            wrapper = _TupleOut(m.student.backbone)
-            wrapper.train()
+            # (1) student backbone: forward + backward graphs, replayed from inside eager autograd -- unless it holds synchronised
+            # norms (ResNet students with ranks > 1): their collectives must not be recorded (over gloo the attempt invalidates
+            # the capture and leaves the HIP runtime unusable), so such a backbone stays eager and only the teacher is graphed
+            import torch.distributed as dist
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            sync_norms = multi and any(isinstance(mod, torch.nn.SyncBatchNorm) for mod in m.student.backbone.modules())
             segments.quiesce_collectives()          # earlier eager steps may have left collectives for the watchdog to retire
-            with self._autocast(cache_enabled=False):   # graphed callables must not share autocast's weight-cast cache
-                torch.cuda.make_graphed_callables(wrapper, (h_img,), num_warmup_iters=2)
-            object.__setattr__(m.student, '_graphed_backbone', wrapper)   # not registered as a sub-module (state dict unchanged)
+            if not sync_norms:
+                wrapper = _TupleOut(m.student.backbone)
+                wrapper.train()
+                with self._autocast(cache_enabled=False):   # graphed callables must not share autocast's weight-cast cache
+                    torch.cuda.make_graphed_callables(wrapper, (h_img,), num_warmup_iters=2)
+                object.__setattr__(m.student, '_graphed_backbone', wrapper)   # not registered as a sub-module (state dict unchanged)
             # (2) teacher: forward-only graph on the side stream; its tapped features are static outputs
             side = m._side_stream or torch.cuda.Stream(device=img.device)
             m._side_stream = side

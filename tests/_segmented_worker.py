@@ -13,6 +13,59 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
+def pspnet_main():
+    """A ResNet student (SyncBN throughout) with ranks > 1: the segmented capture must decline BEFORE touching the device state, the
+    hybrid mode must leave the backbone eager (its collectives cannot be recorded) and still graph the teacher, and training goes on."""
+    import segdistill_amd
+    from segdistill_amd.builder import build_segmentor
+    from segdistill_amd.engine import KDTrainer, SyntheticADE, init_distributed
+    from segdistill_amd.segmentors import sd_module
+    rank, local, world = init_distributed()
+    torch.cuda.set_device(0)
+    segdistill_amd.register_all()
+    norm = dict(type='SyncBN', requires_grad=True)
+
+    def seg(depth):
+        ch = 512 if depth == 18 else 2048
+        return dict(type='EncoderDecoder', pretrained=None,
+                    backbone=dict(type='ResNetV1c', depth=depth, num_stages=4, out_indices=(0, 1, 2, 3), dilations=(1, 1, 2, 4), strides=(1, 2, 1, 1),
+                                  norm_cfg=norm, norm_eval=False, style='pytorch', contract_dilation=True),
+                    decode_head=dict(type='PSPHead', in_channels=ch, in_index=3, channels=64, pool_scales=(1, 2, 3, 6), dropout_ratio=0.1,
+                                     num_classes=150, norm_cfg=norm, align_corners=False,
+                                     loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)))
+    cfg = dict(type='SDModule', cfg_s=seg(18), cfg_t=seg(18),
+               distillation=[dict(student_layer='decode_head.conv_seg', teacher_layer='decode_head.conv_seg', loss_name='CDLoss', loss_config={})],
+               t_pretrain=None, train_cfg=dict(), test_cfg=dict(mode='whole'))
+    sd_module.SYNTHETIC_WEIGHTS_OK = True
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        torch.manual_seed(0)
+        model = build_segmentor(cfg).cuda()
+    tr = KDTrainer(model, dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01), None, world=world)
+    data = SyntheticADE(2, size=(128, 128), device='cuda:0', pool=2, seed=1, rank=rank)
+    out = {'rank': rank, 'world': world, 'mode': 'pspnet'}
+    tr.step(data.next())
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        out['full'] = bool(tr.enable_graph(data.next()))
+        out['hybrid'] = bool(tr.enable_hybrid_graph(data.next()))
+    out['warnings'] = [str(w.message)[:200] for w in caught if 'capture failed' in str(w.message)]
+    out['backbone_graphed'] = getattr(model.student, '_graphed_backbone', None) is not None
+    out['teacher_graphed'] = model._graphed_teacher is not None
+    vals = []
+    cur = data.next()
+    for _ in range(3):
+        nxt = data.next()
+        tr.step(cur, nxt)
+        cur = nxt
+        vals.append(tr.log_values())
+    out['steps'] = vals
+    out['digest'] = float(sum(p.detach().double().sum() for p in model.student.parameters()))
+    print('RESULT ' + json.dumps(out), flush=True)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
 def main():
     import segdistill_amd
     from segdistill_amd.builder import build_segmentor
@@ -89,4 +142,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    pspnet_main() if (len(sys.argv) > 1 and sys.argv[1] == 'pspnet') else main()

@@ -63,3 +63,19 @@ def test_segmented_graph_one_rank_rccl():
     out = _results(subprocess.run([sys.executable, WORKER], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
     assert len(out) == 1 and out[0]['world'] == 1
     _check(out[0])
+
+
+def test_resnet_student_two_ranks_falls_back_cleanly():
+    """28 SyncBN layers in the student: the segmented capture declines (before any capture starts), the hybrid mode graphs the teacher
+    only -- no collective is ever recorded -- and both ranks keep training in step."""
+    import math
+    env = dict(os.environ, SEGDISTILL_DIST_BACKEND='gloo', SEGDISTILL_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), WORKER, 'pspnet']
+    out = _results(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
+    assert sorted(r['rank'] for r in out) == [0, 1]
+    for r in out:
+        assert r['full'] is False and any('synchronised norms' in w for w in r['warnings'])
+        assert r['hybrid'] is True and r['teacher_graphed'] and not r['backbone_graphed']
+        assert all(math.isfinite(v) for step in r['steps'] for v in step.values())
+    assert out[0]['digest'] == out[1]['digest'] and out[0]['steps'] == out[1]['steps']

@@ -13,17 +13,20 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize('config,batch,mode,segments', [
+    ('cfg2_segformer_b2_b0_cgd.py', 1, 'full', 3),        # one SyncBN in the student: whole step replayed, cut at its two collectives
+])
+def test_bench_two_ranks_on_one_gpu(config, batch, mode, segments):
     env = dict(os.environ, SEGDISTILL_DIST_BACKEND='gloo', SEGDISTILL_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29547', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '4', '--batch', '1',
-           '--no-roofline']
+           '--master-port', '29547', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '4', '--batch', str(batch),
+           '--no-roofline', '--config', os.path.join(ROOT, 'configs', 'kd', config)]
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, res.stdout[-2000:]          # rank 0 prints exactly one JSON line
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 2 and d['config']['parallelism'] == 'dp2'
-    assert d['config']['hip_graph'] == 'full' and d['config']['graph_segments'] == 3 and d['scaling'] == 'weak' and d['value'] > 0
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 2 * batch and d['config']['parallelism'] == 'dp2'
+    assert d['config']['hip_graph'] == mode and d['config']['graph_segments'] == segments and d['scaling'] == 'weak' and d['value'] > 0
     assert all(v == v and abs(v) < 1e6 for v in d['final_log_vars'].values())
     assert 'cpu_baseline' not in d                       # N=1 only
