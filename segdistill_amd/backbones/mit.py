@@ -173,6 +173,11 @@ class EncoderBlock(nn.Module):
         return any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in mods)
 
     def _scale(self, x):
+        """Stochastic-depth factor [B] of the next residual branch (None = identity): a row of the table the encoder drew for the
+        whole forward (MixVisionTransformer._draw_drop_path) when there is one, else an own draw."""
+        pending = getattr(self, '_dp_pending', None)
+        if pending:
+            return pending.pop(0)
         return self.drop_path.sample_scale(x) if isinstance(self.drop_path, DropPath) else None
 
 
@@ -248,8 +253,31 @@ class MixVisionTransformer(nn.Module):
                     blk.drop_path.drop_prob = rates[cursor + i]
             cursor += self.depths[s]
 
+    def _draw_drop_path(self, x):
+        """All stochastic-depth factors of one forward with TWO kernels (one Bernoulli over a [2*blocks, B] table of keep
+        probabilities, one division) instead of two per residual branch (28 tiny launches for B0): each block gets two rows, one
+        per branch, drawn independently as the reference's two `self.drop_path(...)` calls are (mix_transformer.py:150-151)."""
+        blocks = [b for s in range(1, 5) for b in getattr(self, f'block{s}')]
+        for b in blocks:
+            b._dp_pending = None
+        if not (self.training and x.is_cuda):
+            return
+        active = [b for b in blocks if isinstance(b.drop_path, DropPath) and b.drop_path.drop_prob > 0.]
+        if not active:
+            return
+        probs = tuple(1.0 - b.drop_path.drop_prob for b in active for _ in range(2))
+        cache = getattr(self, '_dp_keep', None)
+        if cache is None or cache[0] != (probs, x.device):
+            cache = ((probs, x.device), torch.tensor(probs, dtype=torch.float32, device=x.device).unsqueeze(1))
+            object.__setattr__(self, '_dp_keep', cache)
+        keep = cache[1]
+        table = torch.bernoulli(keep.expand(-1, x.shape[0])).div_(keep)
+        for i, b in enumerate(active):
+            b._dp_pending = [table[2 * i], table[2 * i + 1]]
+
     def forward_features(self, x):
         feats = []
+        self._draw_drop_path(x)
         for s in range(1, 5):
             x, hw = getattr(self, f'patch_embed{s}')(x)
             x = _run_stage(x, hw, list(getattr(self, f'block{s}')), getattr(self, f'norm{s}'))

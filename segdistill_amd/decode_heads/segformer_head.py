@@ -68,8 +68,11 @@ class SegFormerHead(BaseDecodeHead):
         e = w.shape[0]
         fold = (not self.training) and not any(m._forward_hooks or m.proj._forward_hooks for _, m in self._branches(feats))
         zs, sizes = [], []
+        # the four [E, E] input-channel blocks as ONE unbind of a strided view: no copy forward, and the backward stacks the four block
+        # gradients with one kernel (per-block slicing made autograd zero-fill and add four full-size [E, 4E] gradients)
+        w_blocks = w.reshape(e, 4, e).transpose(0, 1).unbind(0) if w.shape[1] == 4 * e else None
         for i, (feat, mlp) in enumerate(self._branches(feats)):
-            wi = w[:, i * e:(i + 1) * e, 0, 0]                      # [E, E]
+            wi = w_blocks[i] if w_blocks is not None else w[:, i * e:(i + 1) * e, 0, 0]   # [E, E], rows strided by 4E
             tokens = tokens_of(feat)                                  # [B, hw, Cin] (a view for channels-last features)
             if fold:
                 # W_i P_i and W_i b_i: four small products per call -- cached while both parameters are frozen (the teacher)
