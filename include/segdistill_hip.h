@@ -378,6 +378,30 @@ int sd_bn_act_bwd_elemt(const void *x, const void *dy, const float *mean, const 
                         const float *inv_count_dev /* or NULL; when given it replaces inv_count */, void *dx,
                         int dtype, long rows, int C, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Deferred combination of partial slabs.  The parameter-gradient kernels (sd_layernorm_bwd / sd_add_layernorm_bwd with
+ * dgamma == dbeta == NULL, sd_linear_wgrad_partials) leave their per-workgroup partials in the caller's workspace instead
+ * of launching their own combine pass; nothing reads a parameter gradient before the optimizer, so the caller collects the
+ * jobs of a whole backward and combines them in ONE launch per 24 jobs:  out[i] = sum_{s < nslabs} partials[s*n + i].
+ * `jobs` is a HOST array (its contents travel as kernel arguments: nothing is copied, safe under hipGraph capture).
+ *   sd_layernorm_bwd_blocks(rows, C)           slabs the LayerNorm backward leaves: partials [nblk][2][C] (dgamma row, dbeta row)
+ *   sd_linear_wgrad_slabs(dtype, T, M, N)      slabs of the tall-skinny weight-gradient plan (0: the shape does not take that plan);
+ *                                              a slab is M*N floats, followed by M bias partials when with_bias != 0
+ */
+typedef struct sd_reduce_job {
+    const float *partials;
+    float *out;
+    long n;
+    int nslabs;
+    int reserved;
+} sd_reduce_job;
+
+int sd_multi_slab_reduce(const sd_reduce_job *jobs, int njobs, void *stream);
+int sd_layernorm_bwd_blocks(long rows, int C);
+int sd_linear_wgrad_slabs(int dtype, long tokens, int out_features, int in_features);
+int sd_linear_wgrad_partials(const void *dY, const void *X, int dtype, long tokens, int out_features, int in_features,
+                             int with_bias, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

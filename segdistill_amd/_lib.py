@@ -73,6 +73,10 @@ SIGNATURES = {
     'sd_upsum_fwd': (_i, [_vp] * 6 + [_i] * 8 + [_vp]),
     'sd_upsum_affine_fwd': (_i, [_vp] * 7 + [_i] + [_vp] + [_i] * 8 + [_vp]),
     'sd_upsum_bwd': (_i, [_vp, _vp] + [_i] * 6 + [_vp]),
+    'sd_multi_slab_reduce': (_i, [_vp, _i, _vp]),
+    'sd_layernorm_bwd_blocks': (_i, [C.c_long, _i]),
+    'sd_linear_wgrad_slabs': (_i, [_i, C.c_long, _i, _i]),
+    'sd_linear_wgrad_partials': (_i, [_vp, _vp, _i, C.c_long, _i, _i, _i, _vp, _sz, _vp]),
     'sd_bn_supported': (_i, [_i]),
     'sd_bn_workspace_bytes': (_sz, [C.c_long, _i]),
     'sd_bn_stats': (_i, [_vp, _i, C.c_long, _i, _f, _vp, _vp, _vp, _vp, _f, _vp, _sz, _vp]),

@@ -653,6 +653,35 @@ int sd_linear_wgrad_fuses_bias_dtype(int dtype, long tokens, int out_features, i
     return sd::linear_wgrad_plan(tokens, out_features, in_features, dtype == SD_BF16).direct ? 1 : 0;
 }
 
+int sd_linear_wgrad_slabs(int dtype, long tokens, int out_features, int in_features) {
+    if (tokens <= 0 || out_features <= 0 || in_features <= 0 || (dtype != SD_F32 && dtype != SD_BF16)) return 0;
+    const sd::WgradPlan p = sd::linear_wgrad_plan(tokens, out_features, in_features, dtype == SD_BF16);
+    return p.direct ? p.nslabs : 0;
+}
+
+int sd_linear_wgrad_partials(const void *dY, const void *X, int dtype, long tokens, int out_features, int in_features, int with_bias,
+                             void *workspace, size_t workspace_bytes, void *stream) {
+    if (!dY || !X || !workspace) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (tokens <= 0 || out_features <= 0 || in_features <= 0) return SD_E_SHAPE;
+    const int M = out_features, N = in_features;
+    const sd::WgradPlan p = sd::linear_wgrad_plan(tokens, M, N, dtype == SD_BF16);
+    if (!p.direct) return SD_E_UNSUPPORTED;
+    const long slab = (long)M * N + (with_bias ? M : 0);
+    if (workspace_bytes < (size_t)p.nslabs * slab * sizeof(float) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return SD_E_WORKSPACE;
+    const int regions = p.regions_m * p.regions_n;
+    dim3 grid(p.nsplit, (regions + p.regions_per_wg - 1) / p.regions_per_wg);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *slabs = static_cast<float *>(workspace);
+    if (dtype == SD_F32)
+        hipLaunchKernelGGL((sd::linear_wgrad_direct<float>), grid, dim3(256), 0, st, (const float *)dY, (const float *)X, slabs, M, N, tokens,
+                           p.klen, p.regions_m, p.regions_n, p.regions_per_wg, with_bias ? 1 : 0);
+    else
+        hipLaunchKernelGGL((sd::linear_wgrad_direct<sd::bf16_t>), grid, dim3(256), 0, st, (const sd::bf16_t *)dY, (const sd::bf16_t *)X, slabs,
+                           M, N, tokens, p.klen, p.regions_m, p.regions_n, p.regions_per_wg, with_bias ? 1 : 0);
+    return (int)hipGetLastError();
+}
+
 int sd_linear_wgrad_fuses_bias(long tokens, int out_features, int in_features) {
     if (tokens <= 0 || out_features <= 0 || in_features <= 0) return 0;
     return sd::linear_wgrad_plan(tokens, out_features, in_features).direct ? 1 : 0;

@@ -264,7 +264,8 @@ int ln_bwd_launch(const void *x, const void *dy, const float *gamma, const float
                        (const T *)dres, row_scale, rows_per_sample, (T *)dx, (T *)dr, part, rows, C)
     SD_LN_DISPATCH(SD_CALL);
 #undef SD_CALL
-    hipLaunchKernelGGL(ln_param_reduce, dim3((2 * C + 15) / 16), dim3(256), 0, st, part, dgamma, dbeta, nblk, C);
+    // dgamma == dbeta == NULL: the partials [nblk][2][C] stay in the workspace for a deferred combine (sd_multi_slab_reduce)
+    if (dgamma || dbeta) hipLaunchKernelGGL(ln_param_reduce, dim3((2 * C + 15) / 16), dim3(256), 0, st, part, dgamma, dbeta, nblk, C);
     return (int)hipGetLastError();
 }
 
@@ -283,6 +284,11 @@ int check_ln(const void *a, const void *b, int dtype, long rows, int C) {
 extern "C" {
 
 int sd_layernorm_supported(int C) { return (C > 0 && C % 4 == 0 && C <= 1024) ? 1 : 0; }
+
+int sd_layernorm_bwd_blocks(long rows, int C) {
+    if (rows <= 0 || C <= 0 || C % 4) return 0;
+    return sd::ln_bwd_blocks(rows, sd::ln_plan(C).G);
+}
 
 size_t sd_layernorm_workspace_bytes(long rows, int C) {
     if (rows <= 0 || C <= 0 || C % 4) return 0;
@@ -318,7 +324,7 @@ int sd_layernorm_bwd(const void *x, const void *dy, const float *gamma, const fl
                      float *dbeta, int dtype, long rows, int C, void *workspace, size_t workspace_bytes, void *stream) {
     int rc = sd::check_ln(x, dy, dtype, rows, C);
     if (rc) return rc;
-    if (!gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return SD_E_NULL;
+    if (!gamma || !mean || !rstd || !dx || !workspace || (!dgamma != !dbeta)) return SD_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == SD_F32)
         return sd::ln_bwd_launch<float>(x, dy, gamma, mean, rstd, nullptr, nullptr, 1, dx, nullptr, dgamma, dbeta, workspace, workspace_bytes,
@@ -332,7 +338,7 @@ int sd_add_layernorm_bwd(const void *xsum, const void *dy, const float *gamma, c
                          int C, void *workspace, size_t workspace_bytes, void *stream) {
     int rc = sd::check_ln(xsum, dy, dtype, rows, C);
     if (rc) return rc;
-    if (!gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace) return SD_E_NULL;
+    if (!gamma || !mean || !rstd || !dx || !workspace || (!dgamma != !dbeta)) return SD_E_NULL;
     if ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dres) | reinterpret_cast<uintptr_t>(dr)) & 15) return SD_E_ALIGN;
     if (row_scale && (rows_per_sample <= 0 || rows % rows_per_sample)) return SD_E_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -197,7 +197,7 @@ class SegFormerHead(BaseDecodeHead):
             # care about, the faulty kernel is a bf16 one -- and the 79 MB transpose copy of the [8,16384,150] logits is saved
             out = torch.baddbmm(pred.bias.view(1, -1, 1), w2d.unsqueeze(0).expand(b, -1, -1), tokens.transpose(1, 2))
         else:
-            out = token_linear(tokens, w2d, pred.bias).transpose(1, 2).contiguous()
+            out = token_linear(tokens, w2d, pred.bias, defer_ok=True).transpose(1, 2).contiguous()   # w2d: a view of the leaf weight
         out = out.view(b, pred.out_channels, h, w)
         for hook in pred._forward_hooks.values():
             r = hook(pred, (fused,), out)

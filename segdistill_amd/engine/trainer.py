@@ -7,6 +7,7 @@ import contextlib
 
 import torch
 
+from .. import deferred
 from . import segments
 from .dp import DataParallelReducer
 from .optim import PolyLR, build_optimizer
@@ -235,10 +236,15 @@ class KDTrainer:
     def _fwd_bwd(self, batch):
         with (self._autocast() if batch['img'].is_cuda else contextlib.nullcontext()):
             out = self.model.train_step(batch, self.optimizer)
-        out['loss'].backward()
-        if getattr(self, '_seg', None) is not None:
-            self._seg.finish_backward()     # chained SyncBatchNorm layers: exchange, then the backward in front of them
+        self._backward(out['loss'])
         return out
+
+    def _backward(self, loss):
+        """loss.backward() with the parameter-gradient combines of the HIP ops deferred to ONE launch at its end (deferred.py)."""
+        with (deferred.scope() if loss.is_cuda else contextlib.nullcontext()):
+            loss.backward()
+            if getattr(self, '_seg', None) is not None:
+                self._seg.finish_backward()     # chained SyncBatchNorm layers: exchange, then the backward in front of them
 
     def _replay_teacher(self, img):
         """side stream: copy the image into the teacher graph's input and replay it; returns the completion event."""
@@ -294,7 +300,7 @@ class KDTrainer:
                 out = self.model.train_step(batch, self.optimizer)
             if next_batch is not None and hasattr(self.model, 'prefetch_teacher'):
                 self.model.prefetch_teacher(next_batch['img'])
-            out['loss'].backward()
+            self._backward(out['loss'])
         if getattr(self, '_graph', None) is not None and self._graph_packs:
             self.reducer.exchange()         # packed by the replayed graph
         else:

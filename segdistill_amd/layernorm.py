@@ -6,8 +6,14 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, deferred
 from .ops import _DT, _stream_ptr
+
+
+def _defer(param_dtype):
+    """Leave the dgamma / dbeta partials to the enclosing deferred scope?  Only when the fp32 results go to the parameters as they
+    are (a dtype cast would read them before they exist)."""
+    return deferred.enabled() and param_dtype == torch.float32
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -35,14 +41,17 @@ class _LayerNormFn(torch.autograd.Function):
         rows = x.numel() // C
         L = _lib.lib()
         dx = torch.empty_like(x)
-        dg = torch.empty(C, dtype=torch.float32, device=x.device)
-        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        dgb = torch.empty(2, C, dtype=torch.float32, device=x.device)   # [dgamma; dbeta]
         wsb = L.sd_layernorm_workspace_bytes(rows, C)
         ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-        rc = L.sd_layernorm_bwd(x.data_ptr(), dy.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(),
-                                db.data_ptr(), _DT[x.dtype], rows, C, ws.data_ptr(), wsb, _stream_ptr())
+        later = _defer(ctx.pdtype)
+        rc = L.sd_layernorm_bwd(x.data_ptr(), dy.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                None if later else dgb[0].data_ptr(), None if later else dgb[1].data_ptr(), _DT[x.dtype], rows, C, ws.data_ptr(),
+                                wsb, _stream_ptr())
         _lib.check(rc, 'sd_layernorm_bwd')
-        return dx, dg.to(ctx.pdtype), db.to(ctx.pdtype), None
+        if later:
+            deferred.add(ws, dgb, 2 * C, L.sd_layernorm_bwd_blocks(rows, C))
+        return dx, dgb[0].to(ctx.pdtype), dgb[1].to(ctx.pdtype), None
 
 
 class HipLayerNorm(nn.LayerNorm):
@@ -92,16 +101,18 @@ class _AddLayerNormFn(torch.autograd.Function):
         dres = None if g_xsum is None else g_xsum.contiguous()
         dx = torch.empty_like(xsum)
         dr = None if sc is None else torch.empty_like(xsum)
-        dg = torch.empty(C, dtype=torch.float32, device=xsum.device)
-        db = torch.empty(C, dtype=torch.float32, device=xsum.device)
+        dgb = torch.empty(2, C, dtype=torch.float32, device=xsum.device)   # [dgamma; dbeta]
         wsb = L.sd_layernorm_workspace_bytes(rows, C)
         ws = torch.empty(wsb, dtype=torch.uint8, device=xsum.device)
+        later = _defer(ctx.pdtype)
         rc = L.sd_add_layernorm_bwd(xsum.data_ptr(), dy.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                     None if dres is None else dres.data_ptr(), None if sc is None else sc.data_ptr(), ctx.rps, dx.data_ptr(),
-                                    None if dr is None else dr.data_ptr(), dg.data_ptr(), db.data_ptr(), _DT[xsum.dtype], rows, C, ws.data_ptr(),
-                                    wsb, _stream_ptr())
+                                    None if dr is None else dr.data_ptr(), None if later else dgb[0].data_ptr(),
+                                    None if later else dgb[1].data_ptr(), _DT[xsum.dtype], rows, C, ws.data_ptr(), wsb, _stream_ptr())
         _lib.check(rc, 'sd_add_layernorm_bwd')
-        return dx, (dx if dr is None else dr), None, dg.to(ctx.pdtype), db.to(ctx.pdtype), None
+        if later:
+            deferred.add(ws, dgb, 2 * C, L.sd_layernorm_bwd_blocks(rows, C))
+        return dx, (dx if dr is None else dr), None, dgb[0].to(ctx.pdtype), dgb[1].to(ctx.pdtype), None
 
 
 def add_layernorm_supported(x, res, norm):

@@ -9,7 +9,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, deferred
 from .ops import _DT, _stream_ptr
 
 MIN_TOKENS = 4096  # below this the library GEMM is fine
@@ -25,7 +25,8 @@ class _TokenLinear(torch.autograd.Function):
     the bytes, and dW / dbias are produced in fp32 for the fp32 master parameters."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, defer_ok=False):
+        ctx.defer_ok = defer_ok
         if torch.is_autocast_enabled():
             dt = torch.get_autocast_dtype('cuda')
             with torch.autocast('cuda', enabled=False):
@@ -63,9 +64,25 @@ class _TokenLinear(torch.autograd.Function):
                 # the generic split-K kernel 2-2.7x there (tools/wgrad_bench.py: T=8192 640x160 51 vs 107 us, T=4096 512x256 26 vs 67 us)
                 dw = (dyc.t() @ x2).to(ctx.w_dtype)
                 db = dy2.sum(0, dtype=torch.float32).to(ctx.w_dtype) if want_db else None
-                return dx, dw, db
-            dw32 = torch.empty(M, N, dtype=torch.float32, device=x.device)
+                return dx, dw, db, None
             fuse_b = want_db and direct
+            if direct and ctx.defer_ok and deferred.enabled() and ctx.w_dtype == torch.float32:
+                # tall-skinny plan inside a deferred scope, gradients going straight to fp32 leaf parameters: leave the split-K slabs
+                # in the workspace, the scope's exit combines them together with everybody else's (segdistill_amd/deferred.py)
+                slab = M * N + (M if fuse_b else 0)
+                buf = torch.empty(slab, dtype=torch.float32, device=x.device)
+                wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
+                ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+                _lib.check(L.sd_linear_wgrad_partials(dyc.data_ptr(), x2.data_ptr(), _DT[x.dtype], T, M, N, int(fuse_b), ws.data_ptr(), wsb,
+                                                      _stream_ptr()), 'sd_linear_wgrad_partials')
+                deferred.add(ws, buf, slab, L.sd_linear_wgrad_slabs(_DT[x.dtype], T, M, N))
+                dw = buf[:M * N].view(M, N)
+                if fuse_b:
+                    db = buf[M * N:]
+                elif want_db:
+                    db = dy2.sum(0, dtype=torch.float32).to(ctx.w_dtype)
+                return dx, dw, db, None
+            dw32 = torch.empty(M, N, dtype=torch.float32, device=x.device)
             db32 = torch.empty(M, dtype=torch.float32, device=x.device) if fuse_b else None
             wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
             ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
@@ -76,16 +93,18 @@ class _TokenLinear(torch.autograd.Function):
                 db = db32.to(ctx.w_dtype)
         if want_db and db is None:
             db = dy2.sum(0, dtype=torch.float32).to(ctx.w_dtype)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
-def token_linear(x, weight, bias=None):
-    """F.linear with the HIP weight-gradient kernel when it pays (GPU, fp32/bf16 storage, many tokens, training)."""
+def token_linear(x, weight, bias=None, defer_ok=False):
+    """F.linear with the HIP weight-gradient kernel when it pays (GPU, fp32/bf16 storage, many tokens, training).
+    defer_ok: weight and bias are LEAF parameters whose gradients nothing reads before the optimizer, so inside a
+    ``deferred.scope()`` the split-K slabs may be combined at the scope's end."""
     amp = torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
     use = (x.is_cuda and x.dtype in _DT and (x.dtype == weight.dtype or amp) and weight.requires_grad and torch.is_grad_enabled()
            and (amp or not torch.is_autocast_enabled()) and x.numel() // x.shape[-1] >= MIN_TOKENS)
     if use:
-        return _TokenLinear.apply(x, weight, bias)
+        return _TokenLinear.apply(x, weight, bias, defer_ok)
     return F.linear(x, weight, bias)
 
 
@@ -93,7 +112,7 @@ def call_linear(module, x):
     """Apply an nn.Linear through token_linear unless somebody hooked the module (taps must see a module call)."""
     if module._forward_hooks or module._forward_pre_hooks:
         return module(x)
-    return token_linear(x, module.weight, module.bias)
+    return token_linear(x, module.weight, module.bias, defer_ok=True)
 
 
 class _LongKLinear(torch.autograd.Function):

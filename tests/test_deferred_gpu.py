@@ -1,0 +1,81 @@
+"""Deferred combination of parameter-gradient partials (csrc/reduce.hip, segdistill_amd/deferred.py): the batched kernel against
+torch sums, and a MiT-B0 + SegFormer-head backward inside a deferred scope against the same backward with immediate combines."""
+import copy
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_multi_slab_reduce_matches_sums():
+    from segdistill_amd import _lib, deferred
+    torch.manual_seed(0)
+    dev = 'cuda:0'
+    shapes = [(1, 1), (3, 64), (16, 65), (17, 4096), (256, 512), (5, 65792), (64, 100)] * 5      # 35 jobs: two launches (24 + 11)
+    parts = [torch.randn(ns, n, device=dev) for ns, n in shapes]
+    outs = [torch.full((n,), float('nan'), device=dev) for _, n in shapes]
+    with deferred.scope():
+        assert deferred.enabled()
+        for p, o, (ns, n) in zip(parts, outs, shapes):
+            deferred.add(p, o, n, ns)
+        with deferred.scope():                     # nested scopes join the outer one
+            pass
+        assert all(torch.isnan(o).all() for o in outs)    # nothing is combined before the scope ends
+    assert not deferred.enabled()
+    for p, o in zip(parts, outs):
+        assert torch.allclose(o, p.double().sum(0).float(), rtol=1e-5, atol=1e-4)
+    L = _lib.lib()
+    assert L.sd_multi_slab_reduce(None, 0, None) == 0
+    assert L.sd_multi_slab_reduce(None, 3, None) != 0
+    bad = (deferred._Job * 1)()
+    bad[0].partials, bad[0].out, bad[0].n, bad[0].nslabs = parts[0].data_ptr(), outs[0].data_ptr(), 0, 1
+    assert L.sd_multi_slab_reduce(C.cast(bad, C.c_void_p), 1, None) != 0
+
+
+def _student():
+    import segdistill_amd
+    from segdistill_amd.builder import build_segmentor
+    segdistill_amd.register_all()
+    torch.manual_seed(1)
+    cfg = dict(type='EncoderDecoder', pretrained=None, backbone=dict(type='mit_b0', style='pytorch'),
+               decode_head=dict(type='SegFormerHead', in_channels=[32, 64, 160, 256], in_index=[0, 1, 2, 3], feature_strides=[4, 8, 16, 32], channels=128,
+                                dropout_ratio=0.1, num_classes=150, norm_cfg=dict(type='SyncBN', requires_grad=True), align_corners=False,
+                                decoder_params=dict(embed_dim=256), loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)))
+    m = build_segmentor(cfg).cuda().train()
+    m.backbone.reset_drop_path(0.)
+    m.decode_head.dropout.p = 0.0
+    return m
+
+
+def test_backward_in_deferred_scope_matches_immediate():
+    from segdistill_amd import deferred
+    a = _student()
+    b = copy.deepcopy(a)
+    img = torch.randn(2, 3, 512, 512, device='cuda:0')      # 32768 tokens at stage 1: the tall-skinny weight-gradient plan is taken
+    gt = torch.randint(0, 150, (2, 1, 512, 512), device='cuda:0')
+    la = a(img, None, return_loss=True, gt_semantic_seg=gt)['decode.loss_seg'].mean()
+    lb = b(img, None, return_loss=True, gt_semantic_seg=gt)['decode.loss_seg'].mean()
+    la.backward()
+    counted = {}
+    orig = deferred.add
+
+    def spy(*args):
+        counted['n'] = counted.get('n', 0) + 1
+        return orig(*args)
+    deferred.add = spy
+    try:
+        with deferred.scope():
+            lb.backward()
+    finally:
+        deferred.add = orig
+    assert counted.get('n', 0) >= 30                        # LayerNorm layers + tall-skinny Linear weight gradients registered jobs
+    assert float(la) == pytest.approx(float(lb), rel=1e-6)
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pa.grad is None:
+            assert pb.grad is None, n
+            continue
+        assert pb.grad is not None and pb.grad.shape == pa.grad.shape, n
+        err = float((pa.grad - pb.grad).norm())
+        assert err <= 1e-5 * float(pa.grad.norm()) + 1e-7, (n, err, float(pa.grad.norm()))
