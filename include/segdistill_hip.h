@@ -228,24 +228,31 @@ int sd_linear_longk_fwd(const void *X, const float *W, const float *bias /* or N
  * Depth-wise 3x3 convolution (stride 1, zero pad 1) on TOKEN-MAJOR activations [B, H*W, C]: the
  * DWConv inside every MiT Mix-FFN (mix_transformer.py:376-387: transpose to NCHW ->
  * nn.Conv2d(dim, dim, 3, 1, 1, groups=dim) -> flatten/transpose back; called from Mlp.forward :48-55).
- * Replaces those two transposes plus the grouped conv and its two backward convs.  Weights are passed
- * tap-major [9][C] fp32 (k = 3*ky + kx; the binding transposes Conv2d's [C,1,3,3]); C % 4 == 0
- * (fp32) / C % 8 == 0 (bf16), 16-byte aligned pointers.
+ * Replaces those two transposes plus the grouped conv and its two backward convs.  Weights are passed, and
+ * weight gradients returned, in nn.Conv2d's own layout [C][9] fp32 (= [C,1,3,3] contiguous, k = 3*ky + kx):
+ * no transpose on either side of the boundary; C % 4 == 0 (fp32) / C % 8 == 0 (bf16), 16-byte aligned pointers.
+ * sd_dwconv3x3_bwd_weight with dw == NULL leaves its partials [slabs][9*C + C] (weight gradient in conv layout,
+ * then the C bias sums) in the workspace for sd_multi_slab_reduce; slabs = sd_dwconv3x3_wgrad_slabs(...).
  */
 size_t sd_dwconv3x3_workspace_bytes(int dtype, int B, int H, int W, int C);
+int sd_dwconv3x3_wgrad_slabs(int dtype, int B, int H, int W, int C);
 
-int sd_dwconv3x3_fwd(const void *x, const float *w_tap_major, const float *bias /* or NULL */, void *y,
+int sd_dwconv3x3_fwd(const void *x, const float *w, const float *bias /* or NULL */, void *y,
                      int dtype, int B, int H, int W, int C, void *stream);
 
 /* inference-only: y = GELU(dwconv(x) + bias) (exact erf GELU), i.e. DWConv followed by the Mix-FFN activation
  * (mix_transformer.py:50-51) in one pass; used for the frozen teacher, which never needs the pre-activation */
-int sd_dwconv3x3_gelu_fwd(const void *x, const float *w_tap_major, const float *bias /* or NULL */, void *y,
+int sd_dwconv3x3_gelu_fwd(const void *x, const float *w, const float *bias /* or NULL */, void *y,
                           int dtype, int B, int H, int W, int C, void *stream);
 
-int sd_dwconv3x3_bwd_data(const void *dy, const float *w_tap_major, void *dx,
+/* training form of the same: also keeps the pre-activation y_pre = dwconv(x) + bias, which the GELU backward needs */
+int sd_dwconv3x3_gelu_fwd_train(const void *x, const float *w, const float *bias /* or NULL */, void *y_pre, void *y,
+                                int dtype, int B, int H, int W, int C, void *stream);
+
+int sd_dwconv3x3_bwd_data(const void *dy, const float *w, void *dx,
                           int dtype, int B, int H, int W, int C, void *stream);
 
-int sd_dwconv3x3_bwd_weight(const void *x, const void *dy, float *dw_tap_major, float *dbias /* or NULL */,
+int sd_dwconv3x3_bwd_weight(const void *x, const void *dy, float *dw /* [C][9], or NULL: partials only */, float *dbias /* or NULL */,
                             int dtype, int B, int H, int W, int C,
                             void *workspace, size_t workspace_bytes, void *stream);
 

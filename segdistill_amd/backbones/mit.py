@@ -81,6 +81,9 @@ class MixFFN(nn.Module):
                 and hip_dw.supported(h, conv.weight)
                 and not (self.dwconv._forward_hooks or conv._forward_hooks or self.act._forward_hooks)):
             h = hip_dw.dwconv3x3_gelu_tokens_inference(h, conv.weight, conv.bias, hw[0], hw[1])   # frozen-teacher path
+        elif (isinstance(self.act, nn.GELU) and getattr(self.act, 'approximate', 'none') == 'none' and hip_dw.supported(h, conv.weight)
+              and not (self.dwconv._forward_hooks or conv._forward_hooks or self.act._forward_hooks)):
+            h = hip_dw.dwconv3x3_gelu_tokens(h, conv.weight, conv.bias, hw[0], hw[1])             # training: conv + GELU in one pass
         else:
             h = self.act(self.dwconv(h, hw))
         return self.drop(call_linear(self.fc2, self.drop(h)))

@@ -15,7 +15,9 @@
 //   bwd-data dx        = same kernel on dy with the taps mirrored (k -> 8-k), no bias
 //   bwd-wgt  dw[k][c]  = sum_{b,p} dy[b,p,c] * x[b,p+off(k),c] ;  db[c] = sum dy
 //            (per-workgroup partials in a workspace, then a deterministic second pass; no float atomics)
-// Weights are passed TAP-MAJOR [9][C] fp32 (the binding transposes nn.Conv2d's [C,1,3,3], 36 B/channel).
+// Weights are passed, and weight gradients returned, in nn.Conv2d's OWN layout [C][9] fp32 (= [C,1,3,3] contiguous, k = 3*ky+kx): a
+// lane's N channels are 9N consecutive floats, and the binding needs no transpose copy in either direction (it used to launch one per
+// block and pass -- 16 tiny kernels per step of Segformer-B0).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -63,8 +65,10 @@ template <int N>
 __device__ __forceinline__ void load_w(const float *__restrict__ w, int C, int c, int k, float (&o)[N]) {
 #pragma unroll
     for (int i = 0; i < N; i += 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)k * C + c + i);
-        o[i] = v.x; o[i + 1] = v.y; o[i + 2] = v.z; o[i + 3] = v.w;
+        o[i] = w[(size_t)(c + i) * 9 + k];          // conv layout [C][9]: 36 consecutive bytes per channel, L1/K$-resident
+        o[i + 1] = w[(size_t)(c + i + 1) * 9 + k];
+        o[i + 2] = w[(size_t)(c + i + 2) * 9 + k];
+        o[i + 3] = w[(size_t)(c + i + 3) * 9 + k];
     }
 }
 
@@ -75,7 +79,7 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + er
 
 template <typename T, bool FLIP, bool BIAS, bool GELU = false>
 __global__ __launch_bounds__(256) void dw3x3_fwd(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                                                  T *__restrict__ y, int H, int W, int C) {
+                                                  T *__restrict__ y, int H, int W, int C, T *__restrict__ y_pre = nullptr) {
     constexpr int N = CV<T>::N;
     const int cv = C / N;
     // XCD-aware work order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in linear-id order, and a
@@ -135,7 +139,12 @@ __global__ __launch_bounds__(256) void dw3x3_fwd(const T *__restrict__ x, const 
                 for (int i = 0; i < N; ++i) acc[p][i] = fmaf(wv[i], col[p + kx][i], acc[p][i]);
         }
     }
-    if constexpr (GELU) {  // inference-only epilogue: the frozen teacher never needs the pre-activation
+    if constexpr (GELU) {  // epilogue GELU; the frozen teacher never needs the pre-activation, training keeps it in y_pre for the backward
+        if (y_pre) {
+#pragma unroll
+            for (int p = 0; p < kStrip; ++p)
+                if (x0 + p < W) CV<T>::store(y_pre + (img + (size_t)yy * W + x0 + p) * C + c, acc[p]);
+        }
 #pragma unroll
         for (int p = 0; p < kStrip; ++p)
 #pragma unroll
@@ -238,11 +247,12 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_partials(const T *__restrict_
         for (int r = 0; r < RY; ++r) s += red[r * 10 * LC + e];
         const int k = e / LC, col = e - k * LC;
         const int cc = bx * LC + col;
-        if (cc < C) part[((size_t)by * 10 + k) * C + cc] = s;
+        if (cc < C) part[(size_t)by * 10 * C + (k < 9 ? cc * 9 + k : 9 * C + cc)] = s;
     }
 }
 
-// out[k][c] = sum_p part[p][k][c].  grid: ceil(10*C / 64); block 256 = 4 partial-groups x 64 outputs.
+// out[o] = sum_p part[p][o], o < 10*C (9*C weight-gradient entries in conv layout, then C bias sums).  grid: ceil(10*C / 64);
+// block 256 = 4 partial-groups x 64 outputs.
 __global__ __launch_bounds__(256) void dw3x3_wgrad_reduce(const float *__restrict__ part, float *__restrict__ dw, float *__restrict__ db,
                                                            int nparts, int C) {
     __shared__ float red[4][64];
@@ -291,12 +301,12 @@ int check_dw(const void *a, const void *b, int dtype, int B, int H, int W, int C
 
 template <typename T>
 int fwd_launch(const void *x, const float *w, const float *bias, void *y, int B, int H, int W, int C, bool flip, hipStream_t st,
-               bool gelu = false) {
+               bool gelu = false, void *y_pre = nullptr) {
     const int cv = C / CV<T>::N;
     const int spr = (W + kStrip - 1) / kStrip;
     dim3 grid((spr * cv + 255) / 256, B * H);
-    if (gelu && bias) hipLaunchKernelGGL((dw3x3_fwd<T, false, true, true>), grid, dim3(256), 0, st, (const T *)x, w, bias, (T *)y, H, W, C);
-    else if (gelu) hipLaunchKernelGGL((dw3x3_fwd<T, false, false, true>), grid, dim3(256), 0, st, (const T *)x, w, nullptr, (T *)y, H, W, C);
+    if (gelu && bias) hipLaunchKernelGGL((dw3x3_fwd<T, false, true, true>), grid, dim3(256), 0, st, (const T *)x, w, bias, (T *)y, H, W, C, (T *)y_pre);
+    else if (gelu) hipLaunchKernelGGL((dw3x3_fwd<T, false, false, true>), grid, dim3(256), 0, st, (const T *)x, w, nullptr, (T *)y, H, W, C, (T *)y_pre);
     else if (flip) hipLaunchKernelGGL((dw3x3_fwd<T, true, false>), grid, dim3(256), 0, st, (const T *)x, w, nullptr, (T *)y, H, W, C);
     else if (bias) hipLaunchKernelGGL((dw3x3_fwd<T, false, true>), grid, dim3(256), 0, st, (const T *)x, w, bias, (T *)y, H, W, C);
     else hipLaunchKernelGGL((dw3x3_fwd<T, false, false>), grid, dim3(256), 0, st, (const T *)x, w, nullptr, (T *)y, H, W, C);
@@ -320,7 +330,8 @@ int wgrad_launch(const void *x, const void *dy, float *dw, float *db, void *ws, 
     }
     hipLaunchKernelGGL((dw3x3_wgrad_partials<T>), dim3(q.gx, q.gy), dim3(256), q.lds, st, (const T *)x, (const T *)dy, part, q.nsegs,
                        q.nseg, kSeg, H, W, C, q.LX, q.RY);
-    hipLaunchKernelGGL(dw3x3_wgrad_reduce, dim3((10 * C + 63) / 64), dim3(256), 0, st, part, dw, db, q.gy, C);
+    // dw == NULL: the partials [gy][10*C] stay in the workspace for a deferred combine (sd_multi_slab_reduce; gy = sd_dwconv3x3_wgrad_slabs)
+    if (dw) hipLaunchKernelGGL(dw3x3_wgrad_reduce, dim3((10 * C + 63) / 64), dim3(256), 0, st, part, dw, db, q.gy, C);
     return (int)hipGetLastError();
 }
 
@@ -329,49 +340,65 @@ int wgrad_launch(const void *x, const void *dy, float *dw, float *db, void *ws, 
 
 extern "C" {
 
+int sd_dwconv3x3_wgrad_slabs(int dtype, int B, int H, int W, int C) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    return dtype == SD_F32 ? sd::wgrad_geo<float>(B, H, W, C).gy : sd::wgrad_geo<sd::bf16_t>(B, H, W, C).gy;
+}
+
 size_t sd_dwconv3x3_workspace_bytes(int dtype, int B, int H, int W, int C) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
     const int gy = dtype == SD_F32 ? sd::wgrad_geo<float>(B, H, W, C).gy : sd::wgrad_geo<sd::bf16_t>(B, H, W, C).gy;
     return (size_t)gy * 10 * C * sizeof(float) + 16;
 }
 
-int sd_dwconv3x3_fwd(const void *x, const float *w_tap_major, const float *bias, void *y, int dtype, int B, int H, int W, int C,
+int sd_dwconv3x3_fwd(const void *x, const float *w, const float *bias, void *y, int dtype, int B, int H, int W, int C,
                      void *stream) {
     int rc = sd::check_dw(x, y, dtype, B, H, W, C);
     if (rc) return rc;
-    if (!w_tap_major) return SD_E_NULL;
+    if (!w) return SD_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == SD_F32) return sd::fwd_launch<float>(x, w_tap_major, bias, y, B, H, W, C, false, st);
-    return sd::fwd_launch<sd::bf16_t>(x, w_tap_major, bias, y, B, H, W, C, false, st);
+    if (dtype == SD_F32) return sd::fwd_launch<float>(x, w, bias, y, B, H, W, C, false, st);
+    return sd::fwd_launch<sd::bf16_t>(x, w, bias, y, B, H, W, C, false, st);
 }
 
-int sd_dwconv3x3_gelu_fwd(const void *x, const float *w_tap_major, const float *bias, void *y, int dtype, int B, int H, int W, int C,
+int sd_dwconv3x3_gelu_fwd(const void *x, const float *w, const float *bias, void *y, int dtype, int B, int H, int W, int C,
                           void *stream) {
     int rc = sd::check_dw(x, y, dtype, B, H, W, C);
     if (rc) return rc;
-    if (!w_tap_major) return SD_E_NULL;
+    if (!w) return SD_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == SD_F32) return sd::fwd_launch<float>(x, w_tap_major, bias, y, B, H, W, C, false, st, true);
-    return sd::fwd_launch<sd::bf16_t>(x, w_tap_major, bias, y, B, H, W, C, false, st, true);
+    if (dtype == SD_F32) return sd::fwd_launch<float>(x, w, bias, y, B, H, W, C, false, st, true);
+    return sd::fwd_launch<sd::bf16_t>(x, w, bias, y, B, H, W, C, false, st, true);
 }
 
-int sd_dwconv3x3_bwd_data(const void *dy, const float *w_tap_major, void *dx, int dtype, int B, int H, int W, int C, void *stream) {
+int sd_dwconv3x3_gelu_fwd_train(const void *x, const float *w, const float *bias, void *y_pre, void *y, int dtype, int B, int H, int W,
+                                int C, void *stream) {
+    int rc = sd::check_dw(x, y, dtype, B, H, W, C);
+    if (rc) return rc;
+    if (!w || !y_pre) return SD_E_NULL;
+    if (reinterpret_cast<uintptr_t>(y_pre) & 15) return SD_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32) return sd::fwd_launch<float>(x, w, bias, y, B, H, W, C, false, st, true, y_pre);
+    return sd::fwd_launch<sd::bf16_t>(x, w, bias, y, B, H, W, C, false, st, true, y_pre);
+}
+
+int sd_dwconv3x3_bwd_data(const void *dy, const float *w, void *dx, int dtype, int B, int H, int W, int C, void *stream) {
     int rc = sd::check_dw(dy, dx, dtype, B, H, W, C);
     if (rc) return rc;
-    if (!w_tap_major) return SD_E_NULL;
+    if (!w) return SD_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == SD_F32) return sd::fwd_launch<float>(dy, w_tap_major, nullptr, dx, B, H, W, C, true, st);
-    return sd::fwd_launch<sd::bf16_t>(dy, w_tap_major, nullptr, dx, B, H, W, C, true, st);
+    if (dtype == SD_F32) return sd::fwd_launch<float>(dy, w, nullptr, dx, B, H, W, C, true, st);
+    return sd::fwd_launch<sd::bf16_t>(dy, w, nullptr, dx, B, H, W, C, true, st);
 }
 
-int sd_dwconv3x3_bwd_weight(const void *x, const void *dy, float *dw_tap_major, float *dbias, int dtype, int B, int H, int W, int C,
+int sd_dwconv3x3_bwd_weight(const void *x, const void *dy, float *dw, float *dbias, int dtype, int B, int H, int W, int C,
                             void *workspace, size_t workspace_bytes, void *stream) {
     int rc = sd::check_dw(x, dy, dtype, B, H, W, C);
     if (rc) return rc;
-    if (!dw_tap_major || !workspace) return SD_E_NULL;
+    if (!workspace) return SD_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == SD_F32) return sd::wgrad_launch<float>(x, dy, dw_tap_major, dbias, workspace, workspace_bytes, B, H, W, C, st);
-    return sd::wgrad_launch<sd::bf16_t>(x, dy, dw_tap_major, dbias, workspace, workspace_bytes, B, H, W, C, st);
+    if (dtype == SD_F32) return sd::wgrad_launch<float>(x, dy, dw, dbias, workspace, workspace_bytes, B, H, W, C, st);
+    return sd::wgrad_launch<sd::bf16_t>(x, dy, dw, dbias, workspace, workspace_bytes, B, H, W, C, st);
 }
 
 }  // extern "C"

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib
+from . import _lib, deferred
 from .layers import frozen_derived
 from .ops import _DT, _stream_ptr
 
@@ -12,26 +12,35 @@ class _DWConv3x3Tokens(torch.autograd.Function):
     """tokens [B, H*W, C] -> [B, H*W, C]; weight is nn.Conv2d(C, C, 3, 1, 1, groups=C).weight ([C,1,3,3]), bias [C]."""
 
     @staticmethod
-    def forward(ctx, tokens, weight, bias, H, W):
+    def forward(ctx, tokens, weight, bias, H, W, gelu=False):
         x = tokens.contiguous()
         B, N, C = x.shape
         assert N == H * W
-        w_t = weight.detach().reshape(C, 9).t().contiguous().float()  # tap-major [9][C]
+        w_t = weight.detach().reshape(C, 9).float().contiguous()  # nn.Conv2d's own [C][9] layout: a view for an fp32 parameter
         b = None if bias is None else bias.detach().contiguous().float()
         y = torch.empty_like(x)
-        rc = _lib.lib().sd_dwconv3x3_fwd(x.data_ptr(), w_t.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), _DT[x.dtype], B, H,
-                                         W, C, _stream_ptr())
-        _lib.check(rc, 'sd_dwconv3x3_fwd')
-        ctx.save_for_backward(x, w_t)
+        if gelu:   # Mix-FFN: the exact-erf GELU that follows the conv in the same pass; the pre-activation is kept for its backward
+            pre = torch.empty_like(x)
+            rc = _lib.lib().sd_dwconv3x3_gelu_fwd_train(x.data_ptr(), w_t.data_ptr(), None if b is None else b.data_ptr(), pre.data_ptr(),
+                                                        y.data_ptr(), _DT[x.dtype], B, H, W, C, _stream_ptr())
+            _lib.check(rc, 'sd_dwconv3x3_gelu_fwd_train')
+            ctx.save_for_backward(x, w_t, pre)
+        else:
+            rc = _lib.lib().sd_dwconv3x3_fwd(x.data_ptr(), w_t.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), _DT[x.dtype], B, H,
+                                             W, C, _stream_ptr())
+            _lib.check(rc, 'sd_dwconv3x3_fwd')
+            ctx.save_for_backward(x, w_t)
         ctx.geom = (H, W, bias is not None, weight.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w_t = ctx.saved_tensors
+        x, w_t = ctx.saved_tensors[:2]
         H, W, has_bias, wdtype = ctx.geom
         B, N, C = x.shape
         dy = dy.contiguous()
+        if len(ctx.saved_tensors) == 3:
+            dy = torch.ops.aten.gelu_backward(dy, ctx.saved_tensors[2], approximate='none')
         L = _lib.lib()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -39,15 +48,19 @@ class _DWConv3x3Tokens(torch.autograd.Function):
             _lib.check(L.sd_dwconv3x3_bwd_data(dy.data_ptr(), w_t.data_ptr(), dx.data_ptr(), _DT[x.dtype], B, H, W, C, _stream_ptr()),
                        'sd_dwconv3x3_bwd_data')
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw_t = torch.empty(9, C, dtype=torch.float32, device=x.device)
-            dbv = torch.empty(C, dtype=torch.float32, device=x.device) if has_bias else None
+            # one buffer [9*C + C]: the weight gradient in the parameter's own [C,1,3,3] layout, then the bias gradient
+            buf = torch.empty(10 * C, dtype=torch.float32, device=x.device)
             wsb = L.sd_dwconv3x3_workspace_bytes(_DT[x.dtype], B, H, W, C)
             ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-            _lib.check(L.sd_dwconv3x3_bwd_weight(x.data_ptr(), dy.data_ptr(), dw_t.data_ptr(), None if dbv is None else dbv.data_ptr(),
-                                                 _DT[x.dtype], B, H, W, C, ws.data_ptr(), wsb, _stream_ptr()), 'sd_dwconv3x3_bwd_weight')
-            dw = dw_t.t().reshape(C, 1, 3, 3).to(wdtype)
-            db = None if dbv is None else dbv.to(wdtype)
-        return dx, dw, db, None, None
+            later = deferred.enabled() and wdtype == torch.float32     # fp32 leaf parameters: combine at the end of the backward
+            _lib.check(L.sd_dwconv3x3_bwd_weight(x.data_ptr(), dy.data_ptr(), None if later else buf.data_ptr(),
+                                                 None if later else buf[9 * C:].data_ptr(), _DT[x.dtype], B, H, W, C, ws.data_ptr(), wsb,
+                                                 _stream_ptr()), 'sd_dwconv3x3_bwd_weight')
+            if later:
+                deferred.add(ws, buf, 10 * C, L.sd_dwconv3x3_wgrad_slabs(_DT[x.dtype], B, H, W, C))
+            dw = buf[:9 * C].view(C, 1, 3, 3).to(wdtype)
+            db = buf[9 * C:].to(wdtype) if has_bias else None
+        return dx, dw, db, None, None, None
 
 
 def supported(tokens, weight):
@@ -63,11 +76,17 @@ def dwconv3x3_tokens(tokens, weight, bias, H, W):
     return _DWConv3x3Tokens.apply(tokens, weight, bias, H, W)
 
 
+def dwconv3x3_gelu_tokens(tokens, weight, bias, H, W):
+    """GELU(dwconv(tokens) + bias), exact erf form, with autograd: the training counterpart of the inference kernel below."""
+    return _DWConv3x3Tokens.apply(tokens, weight, bias, H, W, True)
+
+
 def dwconv3x3_gelu_tokens_inference(tokens, weight, bias, H, W):
     """GELU(dwconv(tokens) + bias) in one kernel; no autograd (frozen-teacher path)."""
     x = tokens.contiguous()
     B, N, C = x.shape
-    w_t = frozen_derived(weight, 'dw_taps', lambda: weight.detach().reshape(C, 9).t().contiguous().float())
+    w_t = (weight.detach().reshape(C, 9) if weight.dtype == torch.float32 and weight.is_contiguous()
+           else frozen_derived(weight, 'dw_taps', lambda: weight.detach().reshape(C, 9).float().contiguous()))
     b = None if bias is None else bias.detach().contiguous().float()
     y = torch.empty_like(x)
     rc = _lib.lib().sd_dwconv3x3_gelu_fwd(x.data_ptr(), w_t.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), _DT[x.dtype], B, H, W,

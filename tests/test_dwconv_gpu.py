@@ -80,3 +80,34 @@ def test_dwconv_gelu_inference_kernel():
     ref = F.gelu(F.conv2d(x.double().transpose(1, 2).reshape(B, C, H, W), w.double(), b.double(), padding=1, groups=C)).flatten(2).transpose(1, 2)
     y = dwconv3x3_gelu_tokens_inference(x.cuda(), w.cuda(), b.cuda(), H, W)
     assert _err(y, ref) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('deferred_scope', [False, True])
+def test_dwconv_gelu_training_form(dtype, deferred_scope):
+    """conv + exact GELU in one pass with autograd (the Mix-FFN of the student), immediate and deferred weight-gradient combine."""
+    import contextlib
+    from segdistill_amd import deferred
+    from segdistill_amd.dwconv import dwconv3x3_gelu_tokens
+    B, H, W, C = 2, 33, 18, 64
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, H * W, C, generator=g).to(dtype)
+    w = torch.randn(C, 1, 3, 3, generator=g) / 3
+    b = torch.randn(C, generator=g)
+    dy = torch.randn(B, H * W, C, generator=g).to(dtype)
+    x64 = x.double().requires_grad_(True)
+    w64, b64 = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    y_ref = F.gelu(F.conv2d(x64.transpose(1, 2).reshape(B, C, H, W), w64, b64, padding=1, groups=C)).flatten(2).transpose(1, 2)
+    y_ref.backward(dy.double())
+    dev = torch.device('cuda:0')
+    xg = x.to(dev).requires_grad_(True)
+    wg, bg = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = dwconv3x3_gelu_tokens(xg, wg, bg, H, W)
+    with (deferred.scope() if deferred_scope else contextlib.nullcontext()):
+        y.backward(dy.to(dev))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert _err(y, y_ref) < tol
+    assert _err(xg.grad, x64.grad) < tol
+    assert wg.grad.shape == (C, 1, 3, 3) and wg.grad.is_contiguous()
+    assert _err(wg.grad, w64.grad) < (2e-5 if dtype == torch.float32 else 2e-2)
+    assert _err(bg.grad, b64.grad) < (2e-5 if dtype == torch.float32 else 2e-2)
