@@ -404,6 +404,11 @@ typedef struct sd_reduce_job {
 } sd_reduce_job;
 
 int sd_multi_slab_reduce(const sd_reduce_job *jobs, int njobs, void *stream);
+
+/* Column sums of a token-major matrix x [rows][C] (C % 4 == 0): the bias gradient of a Linear / 1x1 conv, db = sum_t dY[t].
+ * Leaves partials [sd_colsum_blocks(rows, C)][C] for sd_multi_slab_reduce (n = C). */
+int sd_colsum_blocks(long rows, int C);
+int sd_colsum_partials(const void *x, int dtype, long rows, int C, float *partials, size_t partials_bytes, void *stream);
 int sd_layernorm_bwd_blocks(long rows, int C);
 int sd_linear_wgrad_slabs(int dtype, long tokens, int out_features, int in_features);
 int sd_linear_wgrad_partials(const void *dY, const void *X, int dtype, long tokens, int out_features, int in_features,

