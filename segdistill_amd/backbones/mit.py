@@ -108,6 +108,10 @@ class SRAttention(nn.Module):
         if sr_ratio > 1:
             self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
             self.norm = HipLayerNorm(dim)
+            # kept in channels-last STORAGE (same shape / values / state-dict entry, like the patch-embed filters): the (ky, kx, cin)-ordered
+            # matrix _spatial_reduce multiplies with is then a VIEW of the parameter -- no re-layout copy forward, none for its gradient
+            if os.environ.get('SEGDISTILL_CL_WEIGHTS', '1') == '1':
+                self.sr.weight.data = self.sr.weight.data.contiguous(memory_format=torch.channels_last)
 
     def _spatial_reduce(self, x, hw):
         """The SR conv has kernel == stride == r, i.e. it is a Linear over non-overlapping r x r patches.  On token-major
@@ -120,6 +124,9 @@ class SRAttention(nn.Module):
             return conv(x.transpose(1, 2).reshape(b, c, H, W)).flatten(2).transpose(1, 2)
         patches = x.reshape(b, H // r, r, W // r, r, c).permute(0, 1, 3, 2, 4, 5).reshape(b, (H // r) * (W // r), r * r * c)
         # (ky, kx, cin) order to match the patches; the re-layout is cached for a frozen network
+        if conv.weight.is_contiguous(memory_format=torch.channels_last):
+            w2 = conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c)     # a view: the storage already has this order
+            return longk_linear(patches, w2, conv.bias, weight_is_view=True)
         w2 = frozen_derived(conv.weight, 'sr_patch', lambda: conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c).contiguous())
         return longk_linear(patches, w2, conv.bias)
 

@@ -150,11 +150,12 @@ class _LongKLinear(torch.autograd.Function):
         return dx, dw, db
 
 
-def longk_linear(x, weight, bias=None):
+def longk_linear(x, weight, bias=None, weight_is_view=False):
     """F.linear for in_features >= 1024 with few rows/outputs on the GPU (fp32 weights); otherwise F.linear."""
     rows = x.numel() // x.shape[-1]
     if (_LONGK_ENABLED and x.is_cuda and x.dtype in _DT and weight.dtype == torch.float32 and x.shape[-1] >= 1024 and weight.shape[0] <= 512 and rows <= 16384
             and not torch.is_autocast_enabled()):
         return _LongKLinear.apply(x, weight, bias)
-    # `weight` is the caller's re-laid-out copy of a conv filter (its gradient is read by the copy's backward at once); the bias is the leaf
-    return token_linear(x, weight, bias, defer_ok=False, defer_bias_ok=True)
+    # `weight` is a view of the conv filter (channels-last storage) or the caller's re-laid-out copy of it: the gradient of a copy is read
+    # by the copy's backward at once, so only a view may be deferred; the bias is the leaf itself
+    return token_linear(x, weight, bias, defer_ok=weight_is_view, defer_bias_ok=True)
