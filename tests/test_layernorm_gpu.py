@@ -123,5 +123,5 @@ def test_fused_stage_loop_equals_block_by_block():
         h.remove()
     for a, b2 in zip(outs, outs2):
         assert _err(a, b2) < 1e-5
-    for n, p in net.named_parameters():
-        assert _err(g_fused[n], p.grad) < 2e-4, n
+    bad = [(n, _err(g_fused[n], p.grad)) for n, p in net.named_parameters() if not _err(g_fused[n], p.grad) < 2e-4]
+    assert not bad, bad[:12]
