@@ -407,7 +407,17 @@ int sd_multi_slab_reduce(const sd_reduce_job *jobs, int njobs, void *stream);
 
 /* Column sums of a token-major matrix x [rows][C] (C % 4 == 0): the bias gradient of a Linear / 1x1 conv, db = sum_t dY[t].
  * Leaves partials [sd_colsum_blocks(rows, C)][C] for sd_multi_slab_reduce (n = C). */
+typedef struct sd_colsum_job {
+    const void *x;        /* [rows][C], all jobs of one call in the same dtype */
+    float *partials;      /* [sd_colsum_blocks(rows, C)][C] */
+    long rows;
+    int C;
+    int reserved;
+} sd_colsum_job;
+
 int sd_colsum_blocks(long rows, int C);
+/* the partials of MANY matrices in one launch per 24 jobs (host array, by-value kernel arguments like sd_multi_slab_reduce) */
+int sd_multi_colsum_partials(const sd_colsum_job *jobs, int njobs, int dtype, void *stream);
 int sd_colsum_partials(const void *x, int dtype, long rows, int C, float *partials, size_t partials_bytes, void *stream);
 int sd_layernorm_bwd_blocks(long rows, int C);
 int sd_linear_wgrad_slabs(int dtype, long tokens, int out_features, int in_features);

@@ -77,6 +77,7 @@ SIGNATURES = {
     'sd_upsum_bwd': (_i, [_vp, _vp] + [_i] * 6 + [_vp]),
     'sd_multi_slab_reduce': (_i, [_vp, _i, _vp]),
     'sd_colsum_blocks': (_i, [C.c_long, _i]),
+    'sd_multi_colsum_partials': (_i, [_vp, _i, _i, _vp]),
     'sd_colsum_partials': (_i, [_vp, _i, C.c_long, _i, _vp, _sz, _vp]),
     'sd_layernorm_bwd_blocks': (_i, [C.c_long, _i]),
     'sd_linear_wgrad_slabs': (_i, [_i, C.c_long, _i, _i]),

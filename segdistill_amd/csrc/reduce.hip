@@ -95,6 +95,53 @@ __global__ __launch_bounds__(256) void colsum_partials(const T *__restrict__ x, 
     }
 }
 
+// The same for MANY matrices in one launch (the deferred form: the binding keeps the dY tensors of a backward alive and sums their
+// columns at its end, so that the per-layer launches leave the critical chain).  Table by value, like JobTable.
+struct ColsumTable {
+    const void *x[kMaxJobs];
+    float *part[kMaxJobs];
+    long rows[kMaxJobs];
+    int C[kMaxJobs];
+    int cg[kMaxJobs];
+    int blk_begin[kMaxJobs + 1];
+    int njobs;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void multi_colsum_partials(const ColsumTable t) {
+    extern __shared__ float red[];   // [rpb][C] of the widest job
+    int j = 0;
+    while (j + 1 < t.njobs && (int)blockIdx.x >= t.blk_begin[j + 1]) ++j;   // wave-uniform
+    const T *__restrict__ x = static_cast<const T *>(t.x[j]);
+    float *__restrict__ part = t.part[j];
+    const long rows = t.rows[j];
+    const int C = t.C[j], cg = t.cg[j];
+    const int blk = (int)blockIdx.x - t.blk_begin[j], nblk = t.blk_begin[j + 1] - t.blk_begin[j];
+    const int j0 = threadIdx.x & (cg - 1), rg = threadIdx.x / cg, rpb = 256 / cg, cv = C / 4;
+    const long stride = (long)nblk * rpb;
+    for (int jj = j0; jj < cv; jj += cg) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), u = make_float4(0.f, 0.f, 0.f, 0.f);
+        long row = (long)blk * rpb + rg;
+        for (; row + stride < rows; row += 2 * stride) {
+            const float4 a = CS<T>::load(x + row * C + 4 * jj), b = CS<T>::load(x + (row + stride) * C + 4 * jj);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            u.x += b.x; u.y += b.y; u.z += b.z; u.w += b.w;
+        }
+        if (row < rows) {
+            const float4 a = CS<T>::load(x + row * C + 4 * jj);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        float *r = red + (size_t)rg * C + 4 * jj;
+        r[0] = s.x + u.x; r[1] = s.y + u.y; r[2] = s.z + u.z; r[3] = s.w + u.w;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C; e += 256) {
+        float v = 0.f;
+        for (int r = 0; r < rpb; ++r) v += red[(size_t)r * C + e];
+        part[(size_t)blk * C + e] = v;
+    }
+}
+
 int colsum_cg(int C) {
     int p = 1;
     while (p < C / 4 && p < 256) p <<= 1;
@@ -115,6 +162,43 @@ extern "C" {
 int sd_colsum_blocks(long rows, int C) {
     if (rows <= 0 || C <= 0 || C % 4) return 0;
     return sd::colsum_blocks(rows, C);
+}
+
+int sd_multi_colsum_partials(const sd_colsum_job *jobs, int njobs, int dtype, void *stream) {
+    if (njobs < 0) return SD_E_SHAPE;
+    if (njobs == 0) return SD_OK;
+    if (!jobs) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int base = 0; base < njobs; base += sd::kMaxJobs) {
+        sd::ColsumTable t{};
+        const int cnt = njobs - base < sd::kMaxJobs ? njobs - base : sd::kMaxJobs;
+        long blocks = 0;
+        size_t lds = 0;
+        for (int k = 0; k < cnt; ++k) {
+            const sd_colsum_job &q = jobs[base + k];
+            if (!q.x || !q.partials) return SD_E_NULL;
+            if (q.rows <= 0 || q.C <= 0) return SD_E_SHAPE;
+            if (q.C % 4 || q.C > 8192) return SD_E_UNSUPPORTED;
+            if (reinterpret_cast<uintptr_t>(q.x) & (dtype == SD_F32 ? 15 : 7)) return SD_E_ALIGN;
+            const int cg = sd::colsum_cg(q.C);
+            const size_t need = (size_t)(256 / cg) * q.C * sizeof(float);
+            if (need > 64 * 1024) return SD_E_UNSUPPORTED;
+            lds = need > lds ? need : lds;
+            t.x[k] = q.x;
+            t.part[k] = q.partials;
+            t.rows[k] = q.rows;
+            t.C[k] = q.C;
+            t.cg[k] = cg;
+            t.blk_begin[k] = (int)blocks;
+            blocks += sd::colsum_blocks(q.rows, q.C);      // partials: [sd_colsum_blocks(rows, C)][C]
+        }
+        t.blk_begin[cnt] = (int)blocks;
+        t.njobs = cnt;
+        if (dtype == SD_F32) hipLaunchKernelGGL(sd::multi_colsum_partials<float>, dim3((unsigned)blocks), dim3(256), lds, st, t);
+        else hipLaunchKernelGGL(sd::multi_colsum_partials<sd::bf16_t>, dim3((unsigned)blocks), dim3(256), lds, st, t);
+    }
+    return (int)hipGetLastError();
 }
 
 int sd_colsum_partials(const void *x, int dtype, long rows, int C, float *partials, size_t partials_bytes, void *stream) {

@@ -16,6 +16,11 @@ from . import _lib
 from .ops import _DT, _stream_ptr
 
 _jobs = None   # None: not deferring.  list of (partials tensor, out tensor, n, nslabs) -- the tensors are held until the flush
+_colsums = []  # column sums whose PARTIALS are deferred as well: (x2d, partials, out, rows, C, nblk), x2d kept alive until the flush
+
+
+class _ColsumJob(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('partials', C.c_void_p), ('rows', C.c_long), ('C', C.c_int), ('reserved', C.c_int)]
 
 
 class _Job(C.Structure):
@@ -33,7 +38,17 @@ def add(partials, out, n, nslabs):
 
 
 def flush():
-    global _jobs
+    global _jobs, _colsums
+    if _colsums:
+        pend, _colsums = _colsums, []
+        for dt in {p[0].dtype for p in pend}:          # one batched partials launch per storage type
+            group = [p for p in pend if p[0].dtype == dt]
+            arr = (_ColsumJob * len(group))()
+            for k, (x, part, out, rows, Cc, nblk) in enumerate(group):
+                arr[k].x, arr[k].partials, arr[k].rows, arr[k].C = x.data_ptr(), part.data_ptr(), rows, Cc
+            _lib.check(_lib.lib().sd_multi_colsum_partials(C.cast(arr, C.c_void_p), len(group), _DT[dt], _stream_ptr()), 'sd_multi_colsum_partials')
+        for (x, part, out, rows, Cc, nblk) in pend:
+            _jobs.append((part, out, Cc, nblk))
     if not _jobs:
         return
     jobs, _jobs = _jobs, []
@@ -57,6 +72,7 @@ def scope():
         flush()
     finally:
         _jobs = None
+        _colsums.clear()
 
 
 def column_sum(x2d, defer_ok=True):
@@ -70,15 +86,16 @@ def column_sum(x2d, defer_ok=True):
     nblk = L.sd_colsum_blocks(rows, Cc)
     part = torch.empty(nblk, Cc, dtype=torch.float32, device=x2d.device)
     out = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
-    _lib.check(L.sd_colsum_partials(x2d.data_ptr(), _DT[x2d.dtype], rows, Cc, part.data_ptr(), part.numel() * 4, _stream_ptr()), 'sd_colsum_partials')
     if enabled() and defer_ok:
-        add(part, out, Cc, nblk)
+        # nothing at all is launched now: the matrix is kept alive and its columns are summed, together with everybody else's, when the
+        # scope ends (one partials launch + the shared combine) -- the per-layer launch leaves the backward's critical chain
+        _colsums.append((x2d, part, out, rows, Cc, nblk))
         # hand out a VIEW: autograd's AccumulateGrad keeps ("steals") a gradient tensor only if nobody else references that tensor
         # object, and clones it otherwise -- a clone taken before the flush would freeze the not-yet-written values.  The job list holds
         # `out`; a view is its own tensor object on the same storage.  (Every deferring op returns views of its job's buffer.)
         return out.view(Cc)
-    else:
-        job = (_Job * 1)()
-        job[0].partials, job[0].out, job[0].n, job[0].nslabs = part.data_ptr(), out.data_ptr(), Cc, nblk
-        _lib.check(L.sd_multi_slab_reduce(C.cast(job, C.c_void_p), 1, _stream_ptr()), 'sd_multi_slab_reduce')
+    _lib.check(L.sd_colsum_partials(x2d.data_ptr(), _DT[x2d.dtype], rows, Cc, part.data_ptr(), part.numel() * 4, _stream_ptr()), 'sd_colsum_partials')
+    job = (_Job * 1)()
+    job[0].partials, job[0].out, job[0].n, job[0].nslabs = part.data_ptr(), out.data_ptr(), Cc, nblk
+    _lib.check(L.sd_multi_slab_reduce(C.cast(job, C.c_void_p), 1, _stream_ptr()), 'sd_multi_slab_reduce')
     return out
