@@ -53,11 +53,15 @@ class _DWConv3x3Tokens(torch.autograd.Function):
             wsb = L.sd_dwconv3x3_workspace_bytes(_DT[x.dtype], B, H, W, C)
             ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
             later = deferred.enabled() and wdtype == torch.float32     # fp32 leaf parameters: combine at the end of the backward
-            _lib.check(L.sd_dwconv3x3_bwd_weight(x.data_ptr(), dy.data_ptr(), None if later else buf.data_ptr(),
-                                                 None if later else buf[9 * C:].data_ptr(), _DT[x.dtype], B, H, W, C, ws.data_ptr(), wsb,
-                                                 _stream_ptr()), 'sd_dwconv3x3_bwd_weight')
-            if later:
+            def launch():
+                _lib.check(L.sd_dwconv3x3_bwd_weight(x.data_ptr(), dy.data_ptr(), None if later else buf.data_ptr(),
+                                                     None if later else buf[9 * C:].data_ptr(), _DT[x.dtype], B, H, W, C, ws.data_ptr(), wsb,
+                                                     _stream_ptr()), 'sd_dwconv3x3_bwd_weight')
+            if later:   # partials only, off the critical chain: side stream, combined when the scope ends
+                deferred.side_launch(launch, x, dy, ws)
                 deferred.add(ws, buf, 10 * C, L.sd_dwconv3x3_wgrad_slabs(_DT[x.dtype], B, H, W, C))
+            else:
+                launch()
             dw = buf[:9 * C].view(C, 1, 3, 3).to(wdtype)
             db = buf[9 * C:].to(wdtype) if has_bias else None
         return dx, dw, db, None, None, None

@@ -124,6 +124,8 @@ class SegmentRecorder:
     def cut(self, fn):
         """Run `fn` (a collective on static buffers) NOW; while capturing, end the current graph in front of it and open
         the next one behind it, and remember `fn` for the replays."""
+        from .. import deferred
+        deferred.join()          # weight-gradient kernels forked to the side stream: a graph may only end with every stream joined
         if not self.capturing:
             fn()
             return

@@ -74,8 +74,9 @@ class _TokenLinear(torch.autograd.Function):
                 buf = torch.empty(slab, dtype=torch.float32, device=x.device)
                 wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
                 ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-                _lib.check(L.sd_linear_wgrad_partials(dyc.data_ptr(), x2.data_ptr(), _DT[x.dtype], T, M, N, int(fuse_b), ws.data_ptr(), wsb,
-                                                      _stream_ptr()), 'sd_linear_wgrad_partials')
+                deferred.side_launch(lambda: _lib.check(L.sd_linear_wgrad_partials(dyc.data_ptr(), x2.data_ptr(), _DT[x.dtype], T, M, N, int(fuse_b),
+                                                                                    ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_wgrad_partials'),
+                                     dyc, x2, ws)
                 deferred.add(ws, buf, slab, L.sd_linear_wgrad_slabs(_DT[x.dtype], T, M, N))
                 dw = buf[:M * N].view(M, N)
                 if fuse_b:
