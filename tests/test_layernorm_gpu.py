@@ -113,15 +113,19 @@ def test_fused_stage_loop_equals_block_by_block():
     finally:
         layernorm._AddLayerNormFn.apply = real
     assert len(calls) == 2 * sum(net.depths)          # every residual add of every block went through the fused kernel
-    sum(o.float().pow(2).mean() for o in outs).backward()
+    # A loss WITH a gradient: sum of mean(o^2) would not do -- the stage outputs are LayerNorm outputs with gamma = 1, beta = 0, whose mean
+    # square is 1 whatever the input, so every gradient would be rounding noise and the comparison below would hold only while the library
+    # GEMMs happen to round identically in both passes (they stop doing so once earlier tests have given hipBLASLt a workspace).
+    probes = [torch.randn_like(o) for o in outs]
+    sum((o.float() * w).mean() for o, w in zip(outs, probes)).backward()
     g_fused = {n: p.grad.clone() for n, p in net.named_parameters()}
     net.zero_grad(set_to_none=True)
     handles = [blk.register_forward_hook(lambda m, i, o: None) for s in range(1, 5) for blk in getattr(net, f'block{s}')]
     outs2 = net(img)
-    sum(o.float().pow(2).mean() for o in outs2).backward()
+    sum((o.float() * w).mean() for o, w in zip(outs2, probes)).backward()
     for h in handles:
         h.remove()
     for a, b2 in zip(outs, outs2):
         assert _err(a, b2) < 1e-5
     bad = [(n, _err(g_fused[n], p.grad)) for n, p in net.named_parameters() if not _err(g_fused[n], p.grad) < 2e-4]
-    assert not bad, bad[:12]
+    assert not bad, (len(bad), bad[:12])
