@@ -61,7 +61,8 @@ def pspnet_main():
         vals.append(tr.log_values())
     out['steps'] = vals
     out['digest'] = float(sum(p.detach().double().sum() for p in model.student.parameters()))
-    print('RESULT ' + json.dumps(out), flush=True)
+    sys.stdout.write('RESULT ' + json.dumps(out) + '\n')     # one write call per record (two ranks share the pipe)
+    sys.stdout.flush()
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -135,7 +136,8 @@ def main():
     out['running_var_rel'] = float(((bn_e.running_var - bn_g.running_var).abs() / bn_e.running_var.abs().clamp_min(1e-6)).max())
     out['tracked'] = [int(bn_e.num_batches_tracked), int(bn_g.num_batches_tracked)]
     out['digest'] = float(sum(p.detach().double().sum() for p in gra.student.parameters()))
-    print('RESULT ' + json.dumps(out), flush=True)
+    sys.stdout.write('RESULT ' + json.dumps(out) + '\n')     # one write call per record (two ranks share the pipe)
+    sys.stdout.flush()
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -25,8 +25,16 @@ def _free_port():
 
 
 def _results(res):
+    """The workers' `RESULT {json}` records; two ranks share one pipe, so a record may be followed by the other rank's on the same line."""
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    return [json.loads(ln[len('RESULT '):]) for ln in res.stdout.splitlines() if ln.startswith('RESULT ')]
+    out, dec, pos = [], json.JSONDecoder(), 0
+    while True:
+        pos = res.stdout.find('RESULT ', pos)
+        if pos < 0:
+            return out
+        obj, end = dec.raw_decode(res.stdout, pos + len('RESULT '))
+        out.append(obj)
+        pos = end
 
 
 def _check(r):
