@@ -424,3 +424,44 @@ def test_frozen_derived_cache():
         other.add_(1)
     e = frozen_derived(w, 'u', lambda: (w.detach()[:, 0] * other).clone(), other)
     assert not torch.equal(d, e)                         # a dependency changed
+
+
+def test_deferred_scope_and_column_sum_host_behaviour():
+    """deferred.py without a GPU: scopes nest and always close, nothing is deferred outside a scope, CPU tensors take the ATen sum."""
+    from segdistill_amd import deferred
+    assert not deferred.enabled()
+    x = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    assert torch.equal(deferred.column_sum(x), x.sum(0))
+    with deferred.scope():
+        assert deferred.enabled()
+        with deferred.scope():                      # a nested scope joins the outer one
+            assert deferred.enabled()
+        assert deferred.enabled()
+        assert torch.equal(deferred.column_sum(x), x.sum(0))      # CPU input: summed at once even inside a scope
+    assert not deferred.enabled()
+    with pytest.raises(ValueError):
+        with deferred.scope():
+            raise ValueError('boom')
+    assert not deferred.enabled()                   # an exception inside the scope still closes it
+
+
+def test_chained_sync_batchnorm_is_a_plain_syncbn_outside_a_recording():
+    """layers.ChainedSyncBatchNorm: torch.nn.SyncBatchNorm's parameters / buffers / state-dict keys; SegmentRecorder.cut just runs the
+    collective when nothing is being captured; build_norm_layer gives BatchNorm2d without a multi-rank GPU group."""
+    from segdistill_amd.engine import segments
+    from segdistill_amd.layers import ChainedSyncBatchNorm, build_norm_layer
+    bn, ref = ChainedSyncBatchNorm(8), torch.nn.BatchNorm2d(8)
+    assert isinstance(bn, torch.nn.SyncBatchNorm) and bn._segments is None
+    assert list(bn.state_dict()) == list(ref.state_dict())
+    bn.eval()
+    x = torch.randn(2, 8, 3, 3)
+    assert torch.allclose(bn(x), ref.eval()(x))     # eval mode / CPU: the parent's forward
+    name, layer = build_norm_layer(dict(type='SyncBN', requires_grad=True), 8)
+    assert name == 'bn' and type(layer) is torch.nn.BatchNorm2d
+    rec = segments.SegmentRecorder()
+    ran = []
+    rec.cut(lambda: ran.append(1))
+    assert ran == [1] and rec.items == [] and rec.cuts == 0
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 1), bn, ChainedSyncBatchNorm(8))
+    assert segments.attach(net, rec) == 2 and bn._segments is rec
+    assert segments.attach(net, None) == 2 and bn._segments is None
