@@ -16,9 +16,11 @@ Cutting the BACKWARD on the host thread needs the autograd graph cut as well (th
 worker thread, from which a capture cannot be ended): ``ChainedSyncBatchNorm`` (layers.py) normalises a DETACHED copy of
 its input and leaves a record here; after ``loss.backward()`` the trainer calls ``finish_backward()``, which walks the
 records in reverse creation order: reduce dy -> CUT -> all-reduce -> input gradient -> ``x.backward(dx)`` into the
-upstream part of the autograd graph.  The arithmetic is torch.nn.SyncBatchNorm's own ATen sequence
-(batch_norm_stats / gather_stats_with_counts / elemt / backward_reduce / backward_elemt), so a chained step and a plain
-torch SyncBatchNorm step agree to rounding.
+upstream part of the autograd graph.  Two forms of the layer exist: the SegFormer head's ``linear_fuse`` tail goes through
+``fused_norm_act`` (the HIP passes of csrc/batchnorm.hip: BatchNorm + ReLU + channel dropout, segdistill_amd/batchnorm.py);
+any other 4-D input goes through ``sync_batch_norm``, torch.nn.SyncBatchNorm's own ATen sequence (batch_norm_stats /
+gather_stats_with_counts / elemt / backward_reduce / backward_elemt).  Both combine the ranks' statistics with
+torch.batch_norm_gather_stats_with_counts, so a chained step and a plain torch SyncBatchNorm step agree to rounding.
 """
 from __future__ import annotations
 
