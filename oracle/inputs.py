@@ -61,6 +61,51 @@ def fill_state_dict_(module, salt=0):
     return module
 
 
+def splitmix_uniform(n, seed):
+    """n reproducible uniforms in [0, 1): the splitmix64 finaliser applied to the counter seed+i.  Integer arithmetic only
+    (wrap-around uint64), so every platform produces the same bits -- unlike a sine-based hash, whose last-ulp differences
+    would be amplified into different values."""
+    z = (np.arange(n, dtype=np.uint64) + np.uint64(seed % (1 << 64))) * np.uint64(0x9E3779B97F4A7C15)
+    z ^= z >> np.uint64(30)
+    z *= np.uint64(0xBF58476D1CE4E5B9)
+    z ^= z >> np.uint64(27)
+    z *= np.uint64(0x94D049BB133111EB)
+    z ^= z >> np.uint64(31)
+    return (z >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+
+
+def fill_state_dict_hashed_(module, salt=0, gain=1.4):
+    """Like fill_state_dict_, with decorrelated (hash-uniform) values: matrices / filters ~ U(-a, a), a = sqrt(3) gain / sqrt(fan_in)
+    (unit-gain He-like variance).  The smooth sine weights of fill_state_dict_ give strongly correlated features, tiny batch
+    variances and gradients that the reference's OWN fp32 run reproduces only to 1-90 %; with these the reference's fp32 run
+    agrees with its fp64 run to ~1e-5 on every probe (recorded per value as '@fp32dev'), so fp32 consumers can hold 1e-3."""
+    import zlib
+
+    import torch
+    sd = module.state_dict()
+    with torch.no_grad():
+        for name, t in sd.items():
+            if not torch.is_floating_point(t):
+                continue
+            n = t.numel()
+            u = 2.0 * splitmix_uniform(n, (zlib.crc32(name.encode()) + 7919 * salt) * 1000003) - 1.0
+            if name.endswith('running_var'):
+                v = 1.0 + 0.2 * u * u
+            elif name.endswith('running_mean'):
+                v = 0.1 * u
+            elif t.dim() <= 1 and name.endswith('weight'):
+                v = 1.0 + 0.1 * u
+            elif t.dim() <= 1:
+                v = 0.05 * u
+            elif 'relative_position_bias_table' in name or 'absolute_pos_embed' in name:
+                v = 0.2 * u
+            else:
+                fan_in = n // t.shape[0]
+                v = u * (3 ** 0.5) * gain / max(fan_in, 1) ** 0.5
+            t.copy_(torch.from_numpy(v.reshape(tuple(t.shape))).to(t.dtype))
+    return module
+
+
 def wavy_image(shape=(2, 3, 64, 64)):
     """Synthetic normalised image batch (float32) and a label map with some 255 (ignore) pixels."""
     n = int(np.prod(shape))
