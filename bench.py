@@ -218,6 +218,28 @@ def cpu_baseline_leg(cfg, batch=2, budget_s=25.0, max_threads=32):
             's_per_step': round(dt / timed, 3)}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with no torchrun environment: THIS process becomes the launcher (the reference's
+    tools/dist_train.sh:8 is `python -m torch.distributed.launch --nproc_per_node=$GPUS ... train.py`).  It has not touched the GPU
+    (importing torch does not initialise HIP; nothing below does either), starts `torch.distributed.run` with one rank per GPU as a
+    CHILD process -- never an exec --, relays its output (rank 0's JSON line) and exits with its status."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env['SEGDISTILL_BENCH_SPAWNED'] = '1'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print(f'[bench] launching {n} ranks: {" ".join(cmd[1:9])} bench.py ...', file=sys.stderr)
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -234,12 +256,14 @@ def main():
                     help='on: capture the whole forward+backward as hipGraphs (cut at the SyncBN collectives when ranks > 1); hybrid: '
                          'capture only the teacher forward and the student backbone fwd/bwd; auto: on, falling back to hybrid')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     from segdistill_amd.config import Config
     from segdistill_amd.engine import KDTrainer, SyntheticADE, init_distributed
     rank, local, world = init_distributed()
-    if world != args.gpus and rank == 0:
-        print(f'[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f'[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)')
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
@@ -279,6 +303,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     logs = trainer.log_values()
+    # how many ranks really took part: an all-reduce of ones over the process group the gradients went through
+    ranks_seen, backend = 1, None
+    if dist.is_initialized():
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        ranks_seen, backend = int(ones.item()), dist.get_backend()
+        assert ranks_seen == dist.get_world_size() == world
+    try:
+        rccl_version = '.'.join(str(v) for v in torch.cuda.nccl.version()) if backend == 'nccl' else None
+    except Exception:  # noqa: BLE001
+        rccl_version = None
 
     if rank == 0:
         line = {
@@ -290,7 +325,8 @@ def main():
                        if 'cfg2' in os.path.basename(args.config) else os.path.basename(args.config),
                        'config_file': os.path.relpath(args.config, ROOT), 'per_gpu_batch': B, 'global_batch': B * world,
                        'parallelism': f'dp{world}', 'kd_path': args.kd_path, 'hip_graph': graphed, 'weights': 'random-init (no checkpoints offline)',
-                       'grad_allreduce_bytes': trainer.reducer.nbytes,
+                       'grad_allreduce_bytes': trainer.reducer.nbytes, 'rccl_ranks': ranks_seen, 'dist_backend': backend, 'rccl_version': rccl_version,
+                       'cpu_baseline_batch': 2,
                        'graph_segments': (len([g for g in trainer._seg.items if isinstance(g, torch.cuda.CUDAGraph)])
                                           if graphed == 'full' else None)},
             'final_log_vars': {k: round(v, 5) for k, v in logs.items()},

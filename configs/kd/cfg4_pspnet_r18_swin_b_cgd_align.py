@@ -1,7 +1,8 @@
 # BASELINE config 4: PSPNet-R18 student <- Swin-B UPerNet teacher, CGD on decoder features through a trainable 1x1
 # align conv 128 -> 512 (MFMA kernel); student decode_head.bottleneck [B,128,64,64] vs teacher decode_head.fpn_bottleneck
-# [B,512,128,128]; both resized to the label size is wasteful, so the softmax runs at the teacher's 128x128 (resize x2 of the
-# aligned student feature is fused into the kernel); group_size 16 (512 % 16 == 0, no padding).  bs 32 = 8 per GPU x 4 GPUs.
+# [B,512,128,128]; both resized to the label size is wasteful, so the softmax runs at the teacher's 128x128
+# (resize_config target='teacher': the aligned student feature is resized x2 and the criterion reads both at 128x128);
+# group_size 16 (512 % 16 == 0, no padding).  bs 32 = 8 per GPU x 4 GPUs.
 _base_ = ['../_base_/synthetic_ade20k.py', '../_base_/default_runtime.py', '../_base_/schedule_160k_adamw.py']
 norm_cfg = dict(type='SyncBN', requires_grad=True)
 

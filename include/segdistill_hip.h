@@ -10,8 +10,12 @@
  *
  * Contract:
  *  - plain C types only; device pointers are raw addresses owned by the caller
- *    (torch tensors in practice); the library allocates nothing persistent and
- *    keeps no global state;
+ *    (torch tensors in practice); the library allocates nothing persistent.  Its
+ *    only process-wide state are the benchmarking tunables below (sd_set_tunable):
+ *    they change launch geometry AND the answers of the *_workspace_bytes()
+ *    queries, so a tunable must not be changed between sizing a workspace and
+ *    the launch that uses it (the launch then fails cleanly with SD_E_WORKSPACE);
+ *    production code never sets them;
  *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*;
  *    NULL = the default stream) and never synchronises the host;
  *  - return value: 0 = ok, <0 = argument error (SD_E_*), >0 = a hipError_t;
@@ -55,7 +59,8 @@ enum {
 int sd_abi_version(void);
 const char *sd_error_string(int code);
 
-/* Tunables (process-wide, for benchmarking only; defaults are the shipped values).
+/* Tunables (process-wide, NOT thread-safe, for benchmarking only; defaults are the shipped values; see the contract above:
+ * set them before sizing workspaces, never between a *_workspace_bytes() call and its launch).
  * keys: "cgd_fwd_chunk_iters" / "cgd_bwd_chunk_iters" (rounds of 4 x 16-byte loads per
  *       operand per lane per workgroup), "cgd_bwd_nt_store" (0|1), "cgd_bwd_unroll" (2|4|8),
  *       "cgd_up_band_rows" (tap rows per workgroup of the fused-upsample kernels). */

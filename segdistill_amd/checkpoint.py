@@ -12,7 +12,7 @@ import torch
 
 def _state_dict_of(obj):
     if isinstance(obj, dict):
-        for k in ('state_dict', 'model'):
+        for k in ('state_dict', 'model', 'student'):
             if k in obj and isinstance(obj[k], dict):
                 return obj[k]
     return obj
@@ -27,6 +27,11 @@ def load_checkpoint(module, path, strict=False, prefix=None, map_location='cpu')
     if prefix:
         sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     sd = adapt_public_state_dict(module, dict(sd))
+    own = module.state_dict()
+    if own and sd and not any(k in own for k in sd):
+        # strict=False would "succeed" while loading nothing at all (e.g. a whole-SDModule file given without prefix='student.')
+        raise KeyError(f'{path}: none of its {len(sd)} keys (e.g. {sorted(sd)[0]!r}) names a parameter of {type(module).__name__} '
+                       f'(e.g. {next(iter(own))!r}); wrong checkpoint or missing `prefix`')
     result = module.load_state_dict(sd, strict=strict)
     return result
 

@@ -249,33 +249,15 @@ class ATLoss(nn.Module):
 class IFVDLoss(nn.Module):
     """Intra-class feature variation distillation (reference :199-238): cosine similarity of
     every pixel to its class centre, matched between student and teacher (x10 MSE), plus the
-    class-softmax KL.  The reference's 150-pass mask loop (:226-230) is one segmented mean
-    (index_add over class ids) here."""
+    class-softmax KL.  The reference's 150-pass mask loop (:226-230) is one segmented mean over
+    class-sorted pixels (csrc/ifvd.hip).  GPU only, like every criterion of this module."""
 
-    @staticmethod
-    def _centres(feat, label, n_cls):
-        b, c, h, w = feat.shape
-        lab = label.reshape(b, h * w)
-        valid = (lab >= 0) & (lab < n_cls) & (lab == lab.floor())
-        idx = torch.where(valid, lab, torch.zeros_like(lab)).long()
-        flat = feat.reshape(b, c, h * w)
-        one = valid.to(feat.dtype)
-        sums = feat.new_zeros(b, c, n_cls).scatter_add_(2, idx.unsqueeze(1).expand(b, c, h * w), flat * one.unsqueeze(1))
-        cnt = feat.new_zeros(b, n_cls).scatter_add_(1, idx, one)
-        mean = sums / (cnt.unsqueeze(1) + 1e-6)
-        centre = torch.gather(mean, 2, idx.unsqueeze(1).expand(b, c, h * w))
-        centre = torch.where(valid.unsqueeze(1), centre, flat)  # pixels of no class keep their own feature
-        return centre.reshape(b, c, h, w)
 
     def forward(self, preds_S, preds_T, target, step):
         feat_T = _bilinear(preds_T, preds_S.shape[2:])
         n_cls = feat_T.shape[1]
         pd = ops.pix_kl(preds_S, feat_T, tau=1.0, alpha=1.0)
         lab = F.interpolate(target.float(), size=preds_S.shape[2:], mode='nearest')
-        if preds_S.is_cuda:
-            # csrc/ifvd.hip: class means as sorted-run gathers, cosine pass, gradient through the centres -- no mask loop, no atomics
-            cls = torch.where((lab >= 0) & (lab < n_cls) & (lab == lab.floor()), lab, torch.full_like(lab, -1.)).to(torch.int32)
-            return ops.ifvd_term(preds_S, feat_T.detach(), cls, n_cls) + pd
-        sim_s = F.cosine_similarity(preds_S, self._centres(preds_S, lab, n_cls), dim=1)
-        sim_t = F.cosine_similarity(feat_T, self._centres(feat_T, lab, n_cls), dim=1)
-        return 10 * F.mse_loss(sim_s, sim_t) + pd
+        # csrc/ifvd.hip: class means as sorted-run gathers, cosine pass, gradient through the centres -- no mask loop, no atomics
+        cls = torch.where((lab >= 0) & (lab < n_cls) & (lab == lab.floor()), lab, torch.full_like(lab, -1.)).to(torch.int32)
+        return ops.ifvd_term(preds_S, feat_T.detach(), cls, n_cls) + pd

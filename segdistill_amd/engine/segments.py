@@ -239,9 +239,10 @@ class SegmentRecorder:
         self.records.append(rec)
         return _CollectGrad.apply(self._anchor(tokens, mod), rec, compute)
 
-    def finish_backward(self):
+    def finish_backward(self, walk=None):
         """After the backward from the loss: per chained norm, latest first -- the layer's own backward (dy sums, exchange,
-        input gradient), then the backward continues into the part of the network in front of the norm."""
+        input gradient), then the backward continues into the part of the network in front of the norm.  `walk(fn)`, when given,
+        runs each of those further autograd walks (the trainer isolates them: engine/trainer.py:_isolated_walk)."""
         recs, self.records = self.records, []
         with torch.no_grad():
             for i in range(len(recs) - 1, -1, -1):
@@ -252,7 +253,9 @@ class SegmentRecorder:
                 r.dy = r.finish = None
                 if dx is not None:
                     # an earlier record may share upstream nodes with this one: keep the graph until the last walk
-                    torch.autograd.backward(r.x, dx, retain_graph=i > 0)
+                    def go(x=r.x, dx=dx, keep=i > 0):
+                        torch.autograd.backward(x, dx, retain_graph=keep)
+                    go() if walk is None else walk(go)
 
 
 def attach(model, recorder):

@@ -58,10 +58,15 @@ class KDTrainer:
         self.optimizer = build_optimizer(model, optimizer_cfg)
         self.reducer = DataParallelReducer([p for g in self.optimizer.param_groups for p in g['params']], world=world)
         self.reducer.broadcast_parameters(model)
-        lr_cfg = dict(lr_cfg or {})
-        lr_cfg.pop('policy', None)
-        lr_cfg.pop('by_epoch', None)
-        self.sched = PolyLR(self.optimizer, max_iters=max_iters, **lr_cfg) if lr_cfg is not None else None
+        if lr_cfg is None:
+            self.sched = None                       # constant learning rate
+        else:
+            lr_cfg = dict(lr_cfg)
+            policy = lr_cfg.pop('policy', 'poly')
+            if policy != 'poly':
+                raise NotImplementedError(f"lr_config policy {policy!r}: every KD config of the reference uses 'poly' (schedule_160k_adamw.py)")
+            lr_cfg.pop('by_epoch', None)
+            self.sched = PolyLR(self.optimizer, max_iters=max_iters, **lr_cfg)
         self.iter = 0
         self.log_interval = log_interval
         self.last_log_vars = None
@@ -98,6 +103,7 @@ class KDTrainer:
             self._seg = segments.SegmentRecorder()
             segments.attach(m, self._seg)   # synchronised norms (world > 1) become cut points of the capture
             cnt0 = getattr(m, 'cnt', 0)
+            buffers0 = self._snapshot_buffers()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):   # warm-up on a non-default stream, as graph capture requires
@@ -107,7 +113,8 @@ class KDTrainer:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             if hasattr(m, 'cnt'):
-                m.cnt = cnt0                # the warm-up passes do not count as training iterations
+                m.cnt = cnt0                # the warm-up passes do not count as training iterations ...
+            self._restore_buffers(buffers0)  # ... and must not advance the student's BatchNorm running statistics either
             if has_kd:
                 # (1) teacher graph on the model's side stream; its tapped features are static outputs
                 ts = m._side_stream or torch.cuda.Stream(device=example_batch['img'].device)
@@ -178,6 +185,7 @@ class KDTrainer:
                 raise RuntimeError('a student tap lives inside the backbone: its hook would not fire during graph replay')
             m.train()
             cnt0 = m.cnt
+            buffers0 = self._snapshot_buffers()     # make_graphed_callables' warm-up iterations run the backbone in training mode
             h_img = img.clone()
             # graphed backward nodes run on the capture side stream while AccumulateGrad lives on the main one: benign here
             try:
@@ -219,6 +227,7 @@ class KDTrainer:
             m.extractor.teacher_features.clear()
             m.cnt = cnt0
             torch.cuda.synchronize()
+            self._restore_buffers(buffers0)
             return True
         except Exception as e:  # noqa: BLE001
             warnings.warn(f'hybrid hipGraph capture failed ({type(e).__name__}: {e}); continuing in eager mode')
@@ -227,6 +236,17 @@ class KDTrainer:
                 object.__setattr__(m.student, '_graphed_backbone', None)
             torch.cuda.synchronize()
             return False
+
+    def _trainable_net(self):
+        return self.model.student if hasattr(self.model, 'student') else self.model
+
+    def _snapshot_buffers(self):
+        return [b.detach().clone() for b in self._trainable_net().buffers()]
+
+    def _restore_buffers(self, saved):
+        with torch.no_grad():
+            for b, b0 in zip(self._trainable_net().buffers(), saved):
+                b.copy_(b0)
 
     def _autocast(self, cache_enabled=True):
         if self.bf16 and torch.cuda.is_available():
@@ -240,11 +260,34 @@ class KDTrainer:
         return out
 
     def _backward(self, loss):
-        """loss.backward() with the parameter-gradient combines of the HIP ops deferred to ONE launch at its end (deferred.py)."""
-        with (deferred.scope() if loss.is_cuda else contextlib.nullcontext()):
+        """loss.backward() with the parameter-gradient combines of the HIP ops deferred to ONE launch at its end (deferred.py).
+
+        A deferred gradient is a view of a buffer that is only WRITTEN when its scope ends, so inside one scope no parameter may
+        receive two gradients (AccumulateGrad would add the second into the unwritten first).  With chained SyncBatchNorm layers the
+        backward is several autograd walks -- from the loss to the norms, then from each norm's input further up (segments.py) -- and a
+        KD tap upstream of a norm (config 5 taps decode_head.linear_c1..4, in front of linear_fuse's norm) puts the same parameters
+        into two walks.  Every walk therefore gets its own scope and starts from `.grad = None`; gradients of earlier walks are set
+        aside and added back (one multi-tensor add, and only for parameters that really were reached twice)."""
+        cuda = loss.is_cuda
+        with (deferred.scope() if cuda else contextlib.nullcontext()):
             loss.backward()
-            if getattr(self, '_seg', None) is not None:
-                self._seg.finish_backward()     # chained SyncBatchNorm layers: exchange, then the backward in front of them
+        seg = getattr(self, '_seg', None)
+        if seg is not None and seg.records:
+            seg.finish_backward(walk=self._isolated_walk if cuda else None)
+
+    def _isolated_walk(self, fn):
+        params = self.reducer.params
+        held = [(p, p.grad) for p in params if p.grad is not None]
+        for p, _ in held:
+            p.grad = None
+        with deferred.scope():
+            fn()
+        twice = [(p, g) for p, g in held if p.grad is not None]
+        if twice:
+            torch._foreach_add_([p.grad for p, _ in twice], [g for _, g in twice])
+        for p, g in held:
+            if p.grad is None:
+                p.grad = g
 
     def _replay_teacher(self, img):
         """side stream: copy the image into the teacher graph's input and replay it; returns the completion event."""
@@ -261,9 +304,8 @@ class KDTrainer:
         main = torch.cuda.current_stream()
         if getattr(self, '_t_graph', None) is not None:
             img = batch['img']
-            key = (img.data_ptr(), img._version)
-            if self._primed is not None and self._primed[0] == key:
-                ev = self._primed[1]                                   # replayed during the previous iteration
+            if self._primed is not None and self._primed[0] is img and self._primed[1] == img._version:
+                ev = self._primed[2]                                   # replayed during the previous iteration (same tensor object, unmodified)
             else:
                 m._side_stream.wait_stream(main)
                 ev = self._replay_teacher(img)
@@ -276,7 +318,7 @@ class KDTrainer:
                 copied.record(main)
                 m._side_stream.wait_event(copied)
                 nimg = next_batch['img']
-                self._primed = ((nimg.data_ptr(), nimg._version), self._replay_teacher(nimg))   # overlaps everything below
+                self._primed = (nimg, nimg._version, self._replay_teacher(nimg))   # overlaps everything below
         for k, v in batch.items():
             if isinstance(v, torch.Tensor):
                 self._static[k].copy_(v, non_blocking=True)
@@ -313,28 +355,32 @@ class KDTrainer:
     # ---- checkpoint / resume -----------------------------------------------------------------------------------------
     # The reference checkpoints the whole SDModule including the frozen teacher (mmcv CheckpointHook) and loses the
     # distillation step counter on resume (warm-up / early-decay / shuffle schedules restart).  Here the
-    # checkpoint holds the STUDENT (plus trainable align projections), the optimizer state, the iteration and `cnt`.
+    # file keeps mmcv's layout -- {'meta', 'state_dict', 'optimizer'} -- with 'state_dict' = the STUDENT segmentor's own keys
+    # (backbone.*, decode_head.*: what the reference's test / inference tooling and this repo's load_checkpoint / `s_pretrain`
+    # load straight into an EncoderDecoder), meta = {'iter', 'cnt'}, plus the trainable align projections.
     def state_dict(self):
         m = self.model
-        sd = {'iter': self.iter, 'cnt': getattr(m, 'cnt', self.iter), 'optimizer': self.optimizer.state_dict()}
+        sd = {'meta': {'iter': self.iter, 'cnt': getattr(m, 'cnt', self.iter)}, 'optimizer': self.optimizer.state_dict()}
         if hasattr(m, 'student'):
-            sd['student'] = m.student.state_dict()
+            sd['state_dict'] = m.student.state_dict()
             sd['distillation_loss'] = m.distillation_loss.state_dict()
         else:
-            sd['model'] = m.state_dict()
+            sd['state_dict'] = m.state_dict()
         return sd
 
     def load_state_dict(self, sd):
         m = self.model
-        if 'student' in sd:
-            m.student.load_state_dict(sd['student'])
+        weights = sd['state_dict'] if 'state_dict' in sd else sd.get('student', sd.get('model'))   # 'student' / 'model': round-1 files
+        if hasattr(m, 'student'):
+            m.student.load_state_dict(weights)
             m.distillation_loss.load_state_dict(sd.get('distillation_loss', {}), strict=False)
         else:
-            m.load_state_dict(sd['model'])
+            m.load_state_dict(weights)
         self.optimizer.load_state_dict(sd['optimizer'])
-        self.iter = int(sd['iter'])
+        meta = sd.get('meta', sd)
+        self.iter = int(meta['iter'])
         if hasattr(m, 'cnt'):
-            m.cnt = int(sd['cnt'])
+            m.cnt = int(meta['cnt'])
 
     def save(self, path):
         import os

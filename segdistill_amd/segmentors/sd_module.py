@@ -146,7 +146,9 @@ class SDModule(BaseSegmentor):
         if not (self.distillation and img.is_cuda) or self._taps_override is not None or not self.prefetch_ok:
             return
         taps, ev = self._launch_teacher(img)
-        self._prefetched = (img.data_ptr(), img._version, tuple(img.shape), taps, ev)
+        # the image tensor itself is kept and matched BY IDENTITY (+ its in-place version): an address / shape key could match a different
+        # batch that the allocator placed at the freed address, and the student would be distilled against another image's features
+        self._prefetched = (img, img._version, taps, ev)
 
     def forward_train(self, img, img_metas=None, gt_semantic_seg=None):
         if not self.external_step:
@@ -155,8 +157,8 @@ class SDModule(BaseSegmentor):
         if self.distillation and self._taps_override is None:
             pre = self._prefetched
             self._prefetched = None
-            if pre is not None and pre[:3] == (img.data_ptr(), img._version, tuple(img.shape)):
-                pending = (pre[3], pre[4])                                  # launched during the previous iteration
+            if pre is not None and pre[0] is img and pre[1] == img._version:
+                pending = (pre[2], pre[3])                                  # launched during the previous iteration
             elif img.is_cuda and self.teacher_on_side_stream:
                 pending = self._launch_teacher(img, img_metas, gt_semantic_seg)   # overlaps with the student forward below
         loss_dict = self.student(img, img_metas, return_loss=True, gt_semantic_seg=gt_semantic_seg)

@@ -67,7 +67,7 @@ def pspnet_main():
     torch.distributed.destroy_process_group()
 
 
-def main():
+def main(upstream_tap=False):
     import segdistill_amd
     from segdistill_amd.builder import build_segmentor
     from segdistill_amd.engine import KDTrainer, SyntheticADE, init_distributed
@@ -84,17 +84,26 @@ def main():
                                      dropout_ratio=1e-12, num_classes=150, norm_cfg=norm, align_corners=False, decoder_params=dict(embed_dim=e),
                                      loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)))
     bil = dict(mode='bilinear', align_corners=False)
+    distillation = [dict(student_layer='decode_head.linear_pred', teacher_layer='decode_head.linear_pred', loss_name='KLDLoss',
+                         loss_config=dict(alpha=3, tau=4, resize_config=bil, shuffle_config={'interval': 3},
+                                          transform_config={'loss_type': 'channel', 'group_size': 8}))]
+    if upstream_tap:
+        # a KD tap IN FRONT of the chained norm (config 5 taps decode_head.linear_c1..4): backbone and linear_c1 parameters get a KD
+        # gradient in the walk from the loss and a CE gradient in the walk that continues behind the norm's backward
+        distillation.append(dict(student_layer='decode_head.linear_c1', teacher_layer='decode_head.linear_c1', loss_name='KLDLoss',
+                                 loss_config=dict(alpha=30, tau=1, transform_config={'loss_type': 'channel', 'group_size': 8})))
     cfg = dict(type='SDModule', cfg_s=seg('b0', [32, 64, 160, 256], 256), cfg_t=seg('b0', [32, 64, 160, 256], 256),
-               distillation=[dict(student_layer='decode_head.linear_pred', teacher_layer='decode_head.linear_pred', loss_name='KLDLoss',
-                                  loss_config=dict(alpha=3, tau=4, resize_config=bil, shuffle_config={'interval': 3},
-                                                   transform_config={'loss_type': 'channel', 'group_size': 8}))],
-               t_pretrain=None, train_cfg=dict(), test_cfg=dict(mode='whole'))
+               distillation=distillation, t_pretrain=None, train_cfg=dict(), test_cfg=dict(mode='whole'))
     sd_module.SYNTHETIC_WEIGHTS_OK = True
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         torch.manual_seed(0)
         ref = build_segmentor(cfg)
     ref.student.backbone.reset_drop_path(0.)
+    if upstream_tap:
+        with torch.no_grad():   # identical student / teacher initialisation would make the feature-level KD term (and its gradient) vanish
+            for p in ref.teacher.parameters():
+                p.mul_(1.25)
     ref = ref.cuda()
     gra = copy.deepcopy(ref)
     bn_e, bn_g = ref.student.decode_head.linear_fuse.norm, gra.student.decode_head.linear_fuse.norm
@@ -115,9 +124,7 @@ def main():
         out['cuts'] = t_g._seg.cuts
     out['cnt_after_capture'] = gra.cnt
     out['tracked_after_capture'] = int(bn_g.num_batches_tracked) - int(bn_e.num_batches_tracked)
-    bn_g.num_batches_tracked.copy_(bn_e.num_batches_tracked)   # the capture's warm-up passes advanced the running statistics
-    bn_g.running_mean.copy_(bn_e.running_mean)
-    bn_g.running_var.copy_(bn_e.running_var)
+    out['running_stats_moved_by_capture'] = float((bn_g.running_mean - bn_e.running_mean).abs().max() + (bn_g.running_var - bn_e.running_var).abs().max())
     steps = []
     cur = data_g.next()
     for it in range(5):
@@ -144,4 +151,5 @@ def main():
 
 
 if __name__ == '__main__':
-    pspnet_main() if (len(sys.argv) > 1 and sys.argv[1] == 'pspnet') else main()
+    mode = sys.argv[1] if len(sys.argv) > 1 else ''
+    pspnet_main() if mode == 'pspnet' else main(upstream_tap=(mode == 'upstream'))

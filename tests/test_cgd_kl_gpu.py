@@ -246,6 +246,26 @@ def test_r2_golden_reference_outputs(golden):
         assert np.sqrt((grad.astype(np.float64) ** 2).sum()) == pytest.approx(float(golden[key + '/grad_l2']), rel=1e-4), key
 
 
+def test_module_golden_non_integer_and_anisotropic_resize(golden):
+    """Reference outputs G2/resize_* (losses.py:25-33 with label sizes 40x56, 16x16 = no resize, 24x100 from 16x16 taps: non-integer and
+    anisotropic factors, which the fused kernels do not cover) THROUGH THE PRODUCT MODULE, called as the reference's plug-in is called:
+    ``criterion(x_student, x_teacher, gt_semantic_seg, n_iter)``.  Falls to ATen resize + the R1 kernels; also the plain KLDLoss spelling."""
+    from segdistill_amd.distillation.losses import CGDLoss, KLDLoss
+    dev = _dev()
+    s0, t0 = golden['G2/inputs/s'], golden['G2/inputs/t']
+    for hw in [(40, 56), (16, 16), (24, 100)]:
+        key = f'G2/resize_{hw[0]}x{hw[1]}'
+        gt = torch.zeros(2, 1, *hw, dtype=torch.int64, device=dev)
+        for crit in (CGDLoss(8, 3, 4),
+                     KLDLoss(alpha=3, tau=4, resize_config={'mode': 'bilinear', 'align_corners': False}, shuffle_config={'interval': 1000},
+                             transform_config={'loss_type': 'channel', 'group_size': 8})):
+            s = torch.tensor(s0, device=dev, requires_grad=True)
+            loss = crit(s, torch.tensor(t0, device=dev), gt, 1)
+            loss.backward()
+            assert float(loss) == pytest.approx(float(golden[key + '/loss']), rel=LOSS_RTOL), key
+            assert _rel_l2(s.grad.cpu().numpy(), golden[key + '/grad']) < GRAD_RL2, key
+
+
 # ------------------------------------------------------------------ pixel-wise criterion
 PIX_CASES = [(2, 6, 8, 8, 1.0, 1.0), (2, 150, 16, 16, 1.0, 1.0), (1, 19, 13, 7, 2.0, 3.0), (1, 150, 64, 64, 4.0, 2.0), (3, 5, 32, 20, 0.5, 1.0)]
 

@@ -6,6 +6,8 @@ import sys
 import textwrap
 
 import numpy as np
+import copy
+
 import pytest
 import torch
 import torch.distributed as dist
@@ -328,8 +330,18 @@ def test_checkpoint_resume_restores_iteration_and_distillation_step(tmp_path):
     path = str(tmp_path / 'latest.pth')
     t1.save(path)
     ck = torch.load(path, weights_only=False)
-    assert set(ck) == {'iter', 'cnt', 'optimizer', 'student', 'distillation_loss'} and ck['iter'] == 2 and ck['cnt'] == 2
-    assert not any(k.startswith('teacher') for k in ck['student'])
+    # mmcv's checkpoint layout (what the reference's tooling reads): 'meta' / 'state_dict' / 'optimizer'; state_dict = the student's own keys
+    assert set(ck) == {'meta', 'state_dict', 'optimizer', 'distillation_loss'} and ck['meta'] == {'iter': 2, 'cnt': 2}
+    assert not any(k.startswith(('teacher', 'student')) for k in ck['state_dict']) and 'backbone.patch_embed1.proj.weight' in ck['state_dict']
+    # ... so the trained student loads into a bare segmentor through this repo's own loader (round 1: zero keys matched, silently)
+    from segdistill_amd.checkpoint import load_checkpoint
+    bare = build_segmentor(copy.deepcopy(_tiny_sd_cfg()['cfg_s']))
+    res = load_checkpoint(bare, path, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for a, b in zip(m1.student.parameters(), bare.parameters()):
+        assert torch.equal(a, b)
+    with pytest.raises(KeyError, match='none of its'):
+        load_checkpoint(torch.nn.Linear(3, 3), path)              # a checkpoint that matches nothing is an error, not a silent no-op
     m2, t2 = make(1)                      # different init: everything must come from the checkpoint
     t2.resume(path)
     assert t2.iter == 2 and m2.cnt == 2
@@ -465,3 +477,24 @@ def test_chained_sync_batchnorm_is_a_plain_syncbn_outside_a_recording():
     net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 1), bn, ChainedSyncBatchNorm(8))
     assert segments.attach(net, rec) == 2 and bn._segments is rec
     assert segments.attach(net, None) == 2 and bn._segments is None
+
+
+def test_bench_launcher_builds_one_rank_per_gpu(monkeypatch):
+    """bench.py --gpus N outside torchrun: the parent only builds and runs the launcher command (it must not initialise the GPU)."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, cwd=None, **kw):
+        seen['cmd'], seen['env'] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(subprocess, 'run', fake_run)
+    rc = bench.spawn_ranks(4, ['--gpus', '4', '--steps', '3'])
+    assert rc == 7                                             # the children's status is the parent's status
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-4:] == ['--gpus', '4', '--steps', '3']
+    assert cmd[-5].endswith('bench.py') and seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    import torch
+    assert not torch.cuda.is_initialized()

@@ -40,7 +40,8 @@ def _results(res):
 def _check(r):
     assert r['chained'] and r['graph'], r.get('warnings')
     assert r['graphs'] == 3 and r['cuts'] == 2          # forward | statistics | rest of forward + backward | dy sums | backward
-    assert r['cnt_after_capture'] == 0
+    assert r['cnt_after_capture'] == 0 and r['tracked_after_capture'] == 0     # neither the step counter nor the BN buffers moved
+    assert r['running_stats_moved_by_capture'] == 0.0
     for it, (ve, vg) in enumerate(r['steps']):
         assert list(ve) == list(vg)
         for k in ve:
@@ -62,6 +63,22 @@ def test_segmented_graph_two_ranks_gloo():
         _check(r)
     assert out[0]['digest'] == out[1]['digest']          # replicas stay identical
     assert out[0]['steps'] == out[1]['steps']            # log values are rank means
+
+
+def test_segmented_graph_with_kd_tap_upstream_of_the_norm():
+    """Config 5's situation: a KD tap on decode_head.linear_c1 puts backbone / linear_c1 parameters into BOTH autograd walks of the
+    segmented backward.  Round 1 ran both walks inside one deferred scope and silently dropped the second walk's contribution for
+    every deferred parameter gradient (LayerNorm / Linear / depth-wise weights); the segmented step must match the eager step."""
+    env = dict(os.environ, SEGDISTILL_DIST_BACKEND='gloo', SEGDISTILL_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), WORKER, 'upstream']
+    out = _results(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
+    assert sorted(r['rank'] for r in out) == [0, 1]
+    for r in out:
+        assert len([k for k in r['steps'][0][0] if k.startswith('loss_')]) == 2
+        assert any(k.startswith('loss_decode_head.linear_c1') and v[0][k] > 1e-3 for v in r['steps'] for k in v[0])   # a live KD term
+        _check(r)
+    assert out[0]['digest'] == out[1]['digest']
 
 
 def test_segmented_graph_one_rank_rccl():

@@ -30,3 +30,19 @@ def test_bench_two_ranks_on_one_gpu(config, batch, mode, segments):
     assert d['config']['hip_graph'] == mode and d['config']['graph_segments'] == segments and d['scaling'] == 'weak' and d['value'] > 0
     assert all(v == v and abs(v) < 1e6 for v in d['final_log_vars'].values())
     assert 'cpu_baseline' not in d                       # N=1 only
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment (how the driver may invoke it): the process must launch the two ranks
+    itself -- before touching the GPU -- and relay rank 0's line; reporting n_gpus = 1 here was round 1's defect."""
+    env = dict(os.environ, SEGDISTILL_DIST_BACKEND='gloo', SEGDISTILL_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '2', '--batch', '1', '--no-roofline',
+           '--graph', 'off']
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['rccl_ranks'] == 2 and d['config']['parallelism'] == 'dp2' and d['config']['dist_backend'] == 'gloo'

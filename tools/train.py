@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py CONFIG --launcher pytorch
 
 CONFIG is a reference-dialect config file (the reference's local_configs/** KD configs load unchanged, or configs/kd/*.py).
-Data: synthetic ADE20K-shaped batches (the dataset pipeline is outside the scope of this repository).
+Data: the config's data.train (the reference's ADE20K dataset + pipeline dialect, segdistill_amd/data -- DESIGN.md section 6c; `--data-root`
+points it at a directory tree) or, when the config has no data.train entry, synthetic ADE20K-shaped batches.
 Per iteration, like mmcv's IterBasedRunner + OptimizerHook: lr update -> zero grad -> train_step -> backward ->
 gradient all-reduce -> optimizer step; a text log line every log_config.interval iterations; a checkpoint every
 checkpoint_config.interval iterations (student + optimizer + iteration + distillation step counter)."""
@@ -93,12 +94,17 @@ def main():
     mode = args.graph if args.graph != 'auto' else 'on'
     warm = 0
     t0 = time.perf_counter()
+    cur = data.next()
     while trainer.iter < n_iters:
-        trainer.step(data.next())
-        warm += 1
         if warm == 3 and device.type == 'cuda' and mode != 'off':
-            if not (mode == 'on' and trainer.enable_graph(data.next())):
-                trainer.enable_hybrid_graph(data.next())
+            # the batch about to be trained on serves as the capture's example (no batch is consumed by the capture; the student's
+            # BatchNorm buffers are restored after its warm-up passes -- KDTrainer.enable_graph)
+            if not (mode == 'on' and trainer.enable_graph(cur)):
+                trainer.enable_hybrid_graph(cur)
+        nxt = data.next() if trainer.iter + 1 < n_iters else None
+        trainer.step(cur, nxt)                # the frozen teacher's forward for `nxt` overlaps this iteration's backward
+        cur = nxt
+        warm += 1
         it = trainer.iter
         if it % log_every == 0 or it == n_iters:
             vals = trainer.log_values()  # the only device->host sync
