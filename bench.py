@@ -105,17 +105,22 @@ def roofline_leg(device, B, C=150, HW=512, g=8, tau=4.0, reps=20):
     tf, tb = avg_ms(fwd), avg_ms(bwd)
     N = S.numel()
     achieved = 5 * N * 4 / ((tf + tb) * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic_r01.json')
-    if os.path.isfile(tpath):
+    # HBM traffic of one fwd+bwd from the PMC counters.  NOT measured by this run (PMC collection needs rocprofv3): it is read from the
+    # newest profiles/traffic_rNN.json, which tools/refresh_profiles.sh produced from separate --pmc FETCH_SIZE / WRITE_SIZE passes over
+    # tools/kernel_rooflines.py with THESE kernels; `traffic_source` names the file (null when there is none).
+    traffic, traffic_source = None, None
+    import glob
+    for tpath in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'traffic_r*.json')), reverse=True):
         try:
             traffic = json.load(open(tpath)).get('cgd_kl_r1_fwd_bwd_bytes')
+            traffic_source = 'stored: ' + os.path.relpath(tpath, ROOT)
+            break
         except Exception:
             traffic = None
     del S, T, dS
     return {
         'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-        'traffic': traffic,
+        'traffic': traffic, 'traffic_source': traffic_source,
         'kernel': 'cgd_fwd_partials + cgd_bwd (R1, operands at softmax resolution)',
         'operand_shape': [B, C, HW, HW], 'algorithmic_bytes': 5 * N * 4,
         'fwd_ms': round(tf, 4), 'bwd_ms': round(tb, 4),
@@ -335,6 +340,10 @@ def main():
             torch.cuda.empty_cache()
             line['roofline'] = roofline_leg(device, B)
             line['roofline']['fused_r2'] = fused_leg(device, B)
+            # every other hand-written kernel of the path at its BASELINE shape against ITS bound (HBM / MFMA / VALU)
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import kernel_rooflines
+            line['roofline']['kernels'] = kernel_rooflines.run(device, only=['r2', 'align', 'pix', 'at', 'ifvd', 'ce', 'r1_bf16'], reps=10)
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_leg(cfg, max_threads=args.cpu_threads)
         print(json.dumps(line))

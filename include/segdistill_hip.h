@@ -218,6 +218,22 @@ int sd_linear_wgrad(const void *dY, const void *X, float *dW, float *dbias /* [o
                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * nn.Linear on token-major activations, forward and input gradient, as exact-f32 MFMA GEMMs (csrc/token_gemm.hip):
+ *   forward   Y [tokens][out] = act( X [tokens][in] . W[out][in]^T + bias[out] ) (+ residual [tokens][out])
+ *   bwd-data  dX [tokens][in] = dY [tokens][out] . W[out][in]
+ * Replaces the F.linear / autograd mm of every Linear of the MiT encoders (q, kv, proj, fc1, fc2: mix_transformer.py:24-27,48-55,
+ * 75-84,107-133) and of the SegFormer head (MLP.proj, the per-branch blocks of linear_fuse, linear_pred: segformer_head.py:22-33,
+ * 75-98).  dtype: SD_F32 only (bf16 activations stay on the library's bf16 GEMM).  act: 0 = none, 1 = exact (erf) GELU.
+ * bias / residual may be NULL.  X, Y, dY, dX dense row-major; W rows `w_row_stride` elements apart (0 = in_features; a column block of a wider
+ * matrix -- the per-branch blocks of linear_fuse -- is passed without a copy).  16-byte loads are used when rows are 16-byte aligned; any shape
+ * is accepted.
+ */
+int sd_linear_fwd(const void *X, const float *W, long w_row_stride, const float *bias, const void *residual, void *Y, int dtype, long tokens,
+                  int in_features, int out_features, int act, void *stream);
+int sd_linear_bwd_data(const void *dY, const float *W, long w_row_stride, void *dX, int dtype, long tokens, int in_features, int out_features,
+                       void *stream);
+
+/* ---------------------------------------------------------------------------
  * Forward of a Linear with a LONG reduction axis and a small output: Y [rows][out] (fp32) = X [rows][in] . W[out][in]^T + bias.
  * Used for the SR-attention spatial reduction (mix_transformer.py:86-88,112-116: Conv2d(dim, dim, r, stride=r) ==
  * Linear over r*r*dim patch features, in = up to 4096, out = dim, rows = B*256): the reduction axis is split over

@@ -9,7 +9,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import _lib, deferred
+from . import _lib, deferred, token_gemm
 from .ops import _DT, _stream_ptr
 
 MIN_TOKENS = 1     # every training Linear: below 8192 tokens dW is the library's GEMM, but the bias gradient still avoids ATen's
@@ -18,6 +18,27 @@ MIN_TOKENS = 1     # every training Linear: below 8192 tokens dW is the library'
 # library's un-split 64-workgroup kernel is slow in isolation (183 us) but leaves the chip to the concurrently running
 # student/teacher stream, while the split-K version occupies all CUs.  Kept as an opt-in (SEGDISTILL_LONGK=1).
 _LONGK_ENABLED = os.environ.get('SEGDISTILL_LONGK') == '1'
+
+
+# Forward and input gradient on the exact-f32 MFMA kernels of csrc/token_gemm.hip instead of the library GEMM (fp32 only; SEGDISTILL_TOKEN_GEMM=0
+# restores the library for A/B runs).  `_gemm_preferred` is the measured dispatch (tools/gemm_bench.py on MI355X): the kernels win wherever the
+# token count fills the chip with 128-row tiles; small products (stage 4: 2048 tokens) stay on the library, whose split-K / small-tile kernels
+# cover them better.
+_TOKEN_GEMM = os.environ.get('SEGDISTILL_TOKEN_GEMM', '1') == '1'
+
+
+def _gemm_preferred(tokens, k, n):
+    if not _TOKEN_GEMM:
+        return False
+    bm, bn = (256, 32) if n <= 32 else ((128, 64) if n <= 64 else (128, 128))
+    tiles = -(-tokens // bm) * -(-n // bn)
+    return tiles >= 192
+
+
+def _fwd(x, weight, bias):
+    if x.dtype == torch.float32 and token_gemm.supported(x, weight) and _gemm_preferred(x.numel() // x.shape[-1], x.shape[-1], weight.shape[0]):
+        return token_gemm.linear_fwd(x, weight, bias)
+    return F.linear(x, weight, bias)
 
 
 class _TokenLinear(torch.autograd.Function):
@@ -36,7 +57,7 @@ class _TokenLinear(torch.autograd.Function):
                 y = F.linear(xc, wc, None if bias is None else bias.to(dt))
             ctx.save_for_backward(xc, wc)
         else:
-            y = F.linear(x, weight, bias)
+            y = _fwd(x, weight, bias)
             ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.in_dtype, ctx.w_dtype = x.dtype, weight.dtype
@@ -50,7 +71,10 @@ class _TokenLinear(torch.autograd.Function):
         if dy2.dtype != x.dtype:
             dy2 = dy2.to(x.dtype)
         if ctx.needs_input_grad[0]:
-            dx = (dy2 @ weight).reshape(x.shape).to(ctx.in_dtype)
+            if dy2.dtype == torch.float32 and token_gemm.supported(dy2, weight.t()) and _gemm_preferred(dy2.shape[0], weight.shape[0], weight.shape[1]):
+                dx = token_gemm.linear_bwd_data(dy2, weight).reshape(x.shape)
+            else:
+                dx = (dy2 @ weight).reshape(x.shape).to(ctx.in_dtype)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             x2 = x.reshape(-1, x.shape[-1])
@@ -109,6 +133,8 @@ def token_linear(x, weight, bias=None, defer_ok=False, defer_bias_ok=None):
            and (amp or not torch.is_autocast_enabled()) and x.numel() // x.shape[-1] >= MIN_TOKENS)
     if use:
         return _TokenLinear.apply(x, weight, bias, defer_ok, defer_ok if defer_bias_ok is None else defer_bias_ok)
+    if x.is_cuda and not torch.is_autocast_enabled() and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)):
+        return _fwd(x, weight, bias)           # frozen network (the teacher): no graph to build
     return F.linear(x, weight, bias)
 
 

@@ -1,0 +1,86 @@
+"""csrc/token_gemm.hip: the token-major Linear forward (+ bias / exact GELU / residual) and input gradient on the f32-input MFMA, against
+fp64 torch arithmetic.  The MFMA result is bit-equal to an fp32 fmaf chain, so the error budget is that of a K-term fp32 dot product
+(~1e-7 sqrt(K) relative to |x|.|w|); shapes cover every tile configuration (N <= 32, <= 64, > 64), ragged M / N / K edges, the unaligned
+(scalar-load) path (K or N not a multiple of 4: linear_pred's 150 classes), single- and many-step K loops, and the asymmetric-identity check
+that catches a transposed accumulator layout."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [  # tokens, in_features (K), out_features (N)
+    (4096, 32, 32), (1000, 32, 128), (4099, 64, 64), (2048, 128, 32), (777, 160, 640), (512, 640, 160), (300, 256, 150), (260, 150, 256),
+    (129, 36, 40), (64, 1024, 64), (2048, 512, 2048), (31, 7, 5), (16384, 64, 256),
+]
+
+
+def _rel(a, b):
+    return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize('T,K,N', SHAPES)
+def test_linear_fwd_and_bwd_data_match_fp64(T, K, N):
+    from segdistill_amd import token_gemm
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(T * 7 + K * 3 + N)
+    x = torch.randn(T, K, device=dev, generator=g)
+    w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    b = torch.randn(N, device=dev, generator=g)
+    r = torch.randn(T, N, device=dev, generator=g)
+    dy = torch.randn(T, N, device=dev, generator=g)
+    x64, w64, b64 = x.double(), w.double(), b.double()
+    ref = x64 @ w64.t() + b64
+    tol = 3e-7 * max(8.0, K ** 0.5)
+    assert _rel(token_gemm.linear_fwd(x, w, b), ref) < tol
+    assert _rel(token_gemm.linear_fwd(x, w), x64 @ w64.t()) < tol
+    assert _rel(token_gemm.linear_fwd(x, w, b, act='gelu'), torch.nn.functional.gelu(ref)) < tol + 2e-7
+    assert _rel(token_gemm.linear_fwd(x, w, b, residual=r), ref + r.double()) < tol
+    assert _rel(token_gemm.linear_bwd_data(dy, w), dy.double() @ w64) < 3e-7 * max(8.0, N ** 0.5)
+
+
+def test_asymmetric_identity_and_3d_input():
+    """W = [I | 0] with an asymmetric X: a swapped row/column map in the accumulator write or the operand fragments cannot pass."""
+    from segdistill_amd import token_gemm
+    dev = torch.device('cuda:0')
+    T, K, N = 192, 96, 80
+    x = (torch.arange(T * K, device=dev, dtype=torch.float32).reshape(2, T // 2, K) % 251) - 100.0     # exact small integers
+    w = torch.zeros(N, K, device=dev)
+    w[torch.arange(N), torch.arange(N)] = 1.0
+    y = token_gemm.linear_fwd(x, w)
+    assert y.shape == (2, T // 2, N) and torch.equal(y, x[..., :N])
+    dy = (torch.arange(T * N, device=dev, dtype=torch.float32).reshape(2, T // 2, N) % 127) - 60.0
+    dx = token_gemm.linear_bwd_data(dy, w)
+    assert torch.equal(dx[..., :N], dy) and float(dx[..., N:].abs().max()) == 0.0
+
+
+def test_row_strided_weight_view_is_taken_without_a_copy():
+    """The per-branch [E, E] blocks of the SegFormer head's linear_fuse weight [E, 4E]: unit column stride, rows 4E apart."""
+    from segdistill_amd import token_gemm
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(3)
+    big = torch.randn(96, 4 * 96, device=dev, generator=g) / 10
+    blk = big[:, 96:192]
+    x = torch.randn(3000, 96, device=dev, generator=g)
+    dy = torch.randn(3000, 96, device=dev, generator=g)
+    assert _rel(token_gemm.linear_fwd(x, blk), x.double() @ blk.double().t()) < 3e-6
+    assert _rel(token_gemm.linear_bwd_data(dy, blk), dy.double() @ blk.double()) < 3e-6
+
+
+def test_token_linear_autograd_uses_the_kernels_and_matches_torch():
+    """The autograd op every MiT / head Linear goes through (segdistill_amd/linear.py) against torch's own Linear in fp64."""
+    from segdistill_amd.linear import token_linear
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(2, 8192, 64, device=dev, generator=g, requires_grad=True)
+    w = (torch.randn(256, 64, device=dev, generator=g) / 8).requires_grad_(True)
+    b = torch.randn(256, device=dev, generator=g).requires_grad_(True)
+    up = torch.randn(2, 8192, 256, device=dev, generator=g)
+    y = token_linear(x, w, b)
+    y.backward(up)
+    x64, w64, b64 = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    y64 = torch.nn.functional.linear(x64, w64, b64)
+    y64.backward(up.double())
+    assert _rel(y, y64.detach()) < 3e-6
+    assert _rel(x.grad, x64.grad) < 3e-6 and _rel(w.grad, w64.grad) < 3e-5 and _rel(b.grad, b64.grad) < 3e-5
+    with torch.no_grad():     # the frozen teacher's path
+        assert _rel(token_linear(x, w.detach(), b.detach()), y64.detach()) < 3e-6

@@ -1,0 +1,264 @@
+"""Every hand-written kernel of the KD step at its BASELINE shape, through the C ABI, timed with HIP events on the stream the
+kernels are launched on, against the roofline that bounds it.
+
+    python tools/kernel_rooflines.py [--only align,r2,...] [--reps 20] [--json out.json]
+
+Standalone it is also the program the rocprofv3 passes of tools/refresh_profiles.sh run (kernel trace; FETCH_SIZE / WRITE_SIZE /
+SQ_* counters in separate --pmc passes).  bench.py imports `run()` for the `roofline.kernels` list of its JSON line.
+
+Peaks (MI355X_MICROARCH.md): HBM 8.0 TB/s; f32-input MFMA 157.3 TF (dense, = the vector rate); bf16 MFMA 2500 TF dense;
+VALU 256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 78.6 T lane-instructions/s (a transcendental counts 4: quarter rate).
+Algorithmic work per launch is stated per entry (`work`), so achieved = work / time is checkable."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM = 8000.0          # GB/s
+MFMA_F32 = 157.3      # TFLOP/s, v_mfma_f32_32x32x2_f32
+MFMA_BF16 = 2500.0    # TFLOP/s dense
+VALU = 78.6           # T lane-instructions / s
+
+
+def _time(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
+    return ts[len(ts) // 2]
+
+
+def _entry(name, kernels, shape, dtype, ms, bound, work, unit_peak, note=None):
+    """work: algorithmic bytes (hbm) / flops (mfma) / lane-instructions (valu) of ONE launch."""
+    if bound == 'hbm':
+        ach, unit = work / (ms * 1e-3) / 1e9, 'GB/s'
+    elif bound == 'mfma':
+        ach, unit = work / (ms * 1e-3) / 1e12, 'TFLOP/s'
+    else:
+        ach, unit = work / (ms * 1e-3) / 1e12, 'T lane-inst/s'
+    e = {'name': name, 'kernels': kernels, 'shape': shape, 'dtype': dtype, 'ms': round(ms, 4), 'bound': bound, 'work': int(work),
+         'achieved': round(ach, 2), 'peak': unit_peak, 'unit': unit, 'frac': round(ach / unit_peak, 4)}
+    if note:
+        e['note'] = note
+    return e
+
+
+def _ok(rc, what):
+    from segdistill_amd import _lib
+    _lib.check(rc, what)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def bench_r1(dev, reps, B=8, C=150, HW=512, g=8, tau=4.0, dtype=torch.float32):
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    DT = 0 if dtype == torch.float32 else 1
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    S = (2 * torch.randn(B, C, HW, HW, device=dev, generator=gen)).to(dtype)
+    T = (2 * torch.randn(B, C, HW, HW, device=dev, generator=gen)).to(dtype)
+    rows = B * (-(-C // g))
+    lse, kl, loss, dS = torch.empty(rows, 2, device=dev), torch.empty(rows, device=dev), torch.empty((), device=dev), torch.empty_like(S)
+    wsb = L.sd_cgd_kl_workspace_bytes(B, C, HW, HW, g)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    tf = _time(lambda: _ok(L.sd_cgd_kl_fwd(S.data_ptr(), T.data_ptr(), DT, B, C, HW, HW, g, 1 / tau, 3.0 / rows, None, lse.data_ptr(), kl.data_ptr(),
+                                            loss.data_ptr(), ws.data_ptr(), wsb, st), 'fwd'), reps)
+    tb = _time(lambda: _ok(L.sd_cgd_kl_bwd(S.data_ptr(), T.data_ptr(), DT, B, C, HW, HW, g, 1 / tau, 3.0 / (rows * tau), None, lse.data_ptr(), None,
+                                            dS.data_ptr(), st), 'bwd'), reps)
+    N, e = S.numel(), S.element_size()
+    tag = 'f32' if dtype == torch.float32 else 'bf16'
+    return [_entry(f'cgd_kl R1 fwd ({tag})', 'cgd_fwd_partials + cgd_fwd_rows + cgd_fwd_loss', [B, C, HW, HW], tag, tf, 'hbm', 2 * N * e, HBM),
+            _entry(f'cgd_kl R1 bwd ({tag})', 'cgd_bwd', [B, C, HW, HW], tag, tb, 'hbm', 3 * N * e, HBM)]
+
+
+def bench_r2(dev, reps, B=8, C=150, hw=128, F=4, g=8, tau=4.0):
+    """VALU-bound: per OUTPUT element and tensor ~ (1 + 3/F) interpolation FMAs + the online-softmax fold (~5 VALU + 1.06 exp for the pair)."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    s = 2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)
+    t = 2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)
+    H = hw * F
+    rows = B * (-(-C // g))
+    lse, kl, loss, ds = torch.empty(rows, 2, device=dev), torch.empty(rows, device=dev), torch.empty((), device=dev), torch.empty_like(s)
+    wsb = L.sd_cgd_kl_up_workspace_bytes(B, C, hw, hw, H, H, g)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    tf = _time(lambda: _ok(L.sd_cgd_kl_up_fwd(s.data_ptr(), t.data_ptr(), 0, B, C, hw, hw, H, H, g, 1 / tau, 3.0 / rows, None, lse.data_ptr(),
+                                               kl.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, st), 'fwd'), reps)
+    tb = _time(lambda: _ok(L.sd_cgd_kl_up_bwd(s.data_ptr(), t.data_ptr(), 0, B, C, hw, hw, H, H, g, 1 / tau, 3.0 / (rows * tau), None,
+                                               lse.data_ptr(), None, ds.data_ptr(), st), 'bwd'), reps)
+    N = B * C * H * H
+    # lane-instruction model per output element (both tensors), see DESIGN.md section 3.2: forward 2*(1.75 lerp FMA) + fold 9 + 2.125 exp*4
+    fwd_ops = N * (2 * 1.75 + 9 + 2.125 * 4)
+    bwd_ops = N * (2 * 1.75 + 6 + 2 * 4 + 2.0)      # recompute lerps, two exponentials, dS, transposed-interpolation FMAs
+    note = 'exp/VALU-bound by design (reads only the taps: 5*B*C*h*w*e bytes); lane-instruction count is a MODEL, the measured SQ_INSTS_VALU is in profiles/'
+    return [_entry('cgd_kl R2 fwd (fused x4 upsample)', 'cgd_up_fwd_partials (+ rows, loss)', [B, C, hw, hw, '->', H, H], 'f32', tf, 'valu', fwd_ops, VALU, note),
+            _entry('cgd_kl R2 bwd (fused x4 upsample)', 'cgd_up_bwd', [B, C, hw, hw, '->', H, H], 'f32', tb, 'valu', bwd_ops, VALU, note)]
+
+
+def bench_align(dev, reps, B, Cs, Ct, h, dtype, tag):
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    DT = 0 if dtype == torch.float32 else 1
+    gen = torch.Generator(device=dev).manual_seed(7)
+    x = torch.randn(B, Cs, h, h, device=dev, generator=gen).to(dtype)
+    w = torch.randn(Ct, Cs, device=dev, generator=gen) * 0.05
+    b = torch.randn(Ct, device=dev, generator=gen) * 0.05
+    y = torch.empty(B, Ct, h, h, device=dev, dtype=dtype)
+    dy = torch.randn(B, Ct, h, h, device=dev, generator=gen).to(dtype)
+    dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(b)
+    wsb = L.sd_align1x1_workspace_bytes(B, Cs, Ct, h, h)
+    ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    tf = _time(lambda: _ok(L.sd_align1x1_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), DT, B, Cs, Ct, h, h, st), 'fwd'), reps)
+    td = _time(lambda: _ok(L.sd_align1x1_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), DT, B, Cs, Ct, h, h, st), 'bwd_data'), reps)
+    tw = _time(lambda: _ok(L.sd_align1x1_bwd_weight(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), DT, B, Cs, Ct, h, h, ws.data_ptr(), wsb, st),
+                           'bwd_weight'), reps)
+    flops = 2.0 * Ct * Cs * B * h * h
+    e = x.element_size()
+    peak = MFMA_F32 if dtype == torch.float32 else MFMA_BF16
+    shape = {'B': B, 'Cs': Cs, 'Ct': Ct, 'h': h, 'w': h, 'gemm': f'M={Ct} K={Cs} N={B * h * h}'}
+    out = []
+    for nm, ms, byt in (('fwd', tf, (x.numel() + y.numel()) * e), ('bwd_data', td, (dy.numel() + dx.numel()) * e), ('bwd_weight', tw, (dy.numel() + x.numel()) * e)):
+        ent = _entry(f'align1x1 {nm} {tag}', f'sd_align1x1_{nm}', shape, 'f32' if dtype == torch.float32 else 'bf16', ms, 'mfma', flops, peak)
+        ent['hbm_GBps'] = round(byt / (ms * 1e-3) / 1e9, 1)
+        ent['hbm_frac'] = round(ent['hbm_GBps'] / HBM, 4)
+        ent['algorithmic_bytes'] = int(byt)
+        out.append(ent)
+    return out
+
+
+def bench_pix(dev, reps, B=8, C=150, HW=512):
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    S = 2 * torch.randn(B, C, HW, HW, device=dev, generator=gen)
+    T = 2 * torch.randn(B, C, HW, HW, device=dev, generator=gen)
+    rows = B * HW * HW
+    lse, loss, dS = torch.empty(2, rows, device=dev), torch.empty((), device=dev), torch.empty_like(S)
+    wsb = L.sd_pix_kl_workspace_bytes(B, C, HW, HW)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    up = torch.ones((), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    tf = _time(lambda: _ok(L.sd_pix_kl_fwd(S.data_ptr(), T.data_ptr(), 0, B, C, HW, HW, 1.0, 1.0 / rows, lse.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, st),
+                           'pix fwd'), reps)
+    tb = _time(lambda: _ok(L.sd_pix_kl_bwd(S.data_ptr(), T.data_ptr(), 0, B, C, HW, HW, 1.0, 1.0 / rows, lse.data_ptr(), up.data_ptr(), dS.data_ptr(), st),
+                           'pix bwd'), reps)
+    N = S.numel()
+    return [_entry('pix_kl fwd (PDLoss at label resolution)', 'pix_fwd (+ loss)', [B, C, HW, HW], 'f32', tf, 'hbm', 2 * N * 4, HBM),
+            _entry('pix_kl bwd', 'pix_bwd', [B, C, HW, HW], 'f32', tb, 'hbm', 3 * N * 4, HBM)]
+
+
+def bench_at(dev, reps, B=8, C=150, hw=128):
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    S = 2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)
+    T = 2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)
+    planes, loss, dS = torch.empty(3, B * hw * hw, device=dev), torch.empty((), device=dev), torch.empty_like(S)
+    wsb = L.sd_pix_kl_workspace_bytes(B, C, hw, hw)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    up = torch.ones((), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    tf = _time(lambda: _ok(L.sd_at_kl_fwd(S.data_ptr(), T.data_ptr(), 0, B, C, hw, hw, planes.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, st), 'at fwd'), reps)
+    tb = _time(lambda: _ok(L.sd_at_kl_bwd(S.data_ptr(), T.data_ptr(), 0, B, C, hw, hw, planes.data_ptr(), up.data_ptr(), dS.data_ptr(), st), 'at bwd'), reps)
+    N = S.numel()
+    note = '78.6 MB operands: they fit the 256 MiB Infinity Cache when launched back to back, so the rate may exceed the HBM peak'
+    return [_entry('at_kl fwd (ATLoss, logits at tap resolution)', 'at_fwd', [B, C, hw, hw], 'f32', tf, 'hbm', 2 * N * 4, HBM, note),
+            _entry('at_kl bwd', 'at_bwd', [B, C, hw, hw], 'f32', tb, 'hbm', 3 * N * 4, HBM, note)]
+
+
+def bench_ifvd(dev, reps, B=8, C=150, hw=128):
+    from segdistill_amd import ops
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    S = (2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)).requires_grad_(True)
+    T = 2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)
+    cls = torch.randint(0, C, (B, hw, hw), device=dev, generator=gen, dtype=torch.int32)
+    tf = _time(lambda: ops.ifvd_term(S.detach(), T, cls, C), reps)
+    loss = ops.ifvd_term(S, T, cls, C)
+    tb = _time(lambda: torch.autograd.grad(loss, S, retain_graph=True), reps)
+    N = S.numel()
+    note = 'through the autograd binding (includes the per-image class sort and small allocations); L2/Infinity-Cache resident at this size'
+    return [_entry('ifvd fwd (class means + cosine pass, both networks)', 'ifvd_seg_sum x2 + ifvd_cos x2', [B, C, hw, hw], 'f32', tf, 'hbm', 4 * N * 4, HBM, note),
+            _entry('ifvd bwd', 'ifvd_seg_sum x2 + ifvd_bwd', [B, C, hw, hw], 'f32', tb, 'hbm', 3 * N * 4, HBM, note)]
+
+
+def bench_ce(dev, reps, B=8, C=150, hw=128, F=4):
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    x = 2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)
+    H = hw * F
+    lab = torch.randint(0, C, (B, H, H), device=dev, generator=gen, dtype=torch.int32)
+    lab[torch.rand(B, H, H, device=dev, generator=gen) < 0.05] = 255
+    loss_pix, lse2 = torch.empty(B, H, H, device=dev), torch.empty(B, H, H, device=dev)
+    correct = torch.empty(1, dtype=torch.int32, device=dev)
+    dx = torch.empty_like(x)
+    up = torch.full((1,), 1.0 / (B * H * H), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    tf = _time(lambda: _ok(L.sd_ce_up_fwd(x.data_ptr(), lab.data_ptr(), loss_pix.data_ptr(), lse2.data_ptr(), correct.data_ptr(), 0, B, C, hw, hw, H, H, 255, st),
+                           'ce fwd'), reps)
+    tb = _time(lambda: _ok(L.sd_ce_up_bwd(x.data_ptr(), lab.data_ptr(), lse2.data_ptr(), up.data_ptr(), 0, 1.0, dx.data_ptr(), 0, B, C, hw, hw, H, H, 255, st),
+                           'ce bwd'), reps)
+    N = B * C * H * H
+    note = 'exp/VALU-bound (reads only the taps + the label map); lane-instruction MODEL: ~9 VALU + 1 exp (x4) per output pixel and class'
+    return [_entry('ce_up fwd (fused x4 upsample + log-softmax + NLL + top-1)', 'ce_up_fwd_col', [B, C, hw, hw, '->', H, H], 'f32', tf, 'valu', N * (9 + 4), VALU, note),
+            _entry('ce_up bwd', 'ce_up_bwd', [B, C, hw, hw, '->', H, H], 'f32', tb, 'valu', N * (8 + 4), VALU, note)]
+
+
+GROUPS = {
+    'r1': lambda dev, reps: bench_r1(dev, reps),
+    'r1_bf16': lambda dev, reps: bench_r1(dev, reps, C=768, HW=128, dtype=torch.bfloat16),      # config 5 stage 1
+    'r2': lambda dev, reps: bench_r2(dev, reps),
+    'align': lambda dev, reps: (bench_align(dev, reps, 8, 128, 512, 64, torch.float32, 'cfg4 f32')
+                                + sum((bench_align(dev, reps, 8, 256, 768, h, torch.bfloat16, f'cfg5 stage{i + 1} bf16') for i, h in enumerate((128, 64, 32, 16))), [])
+                                + bench_align(dev, reps, 8, 256, 768, 128, torch.float32, 'cfg5-shape f32')),
+    'pix': lambda dev, reps: bench_pix(dev, reps),
+    'at': lambda dev, reps: bench_at(dev, reps),
+    'ifvd': lambda dev, reps: bench_ifvd(dev, reps),
+    'ce': lambda dev, reps: bench_ce(dev, reps),
+}
+
+
+def run(device, only=None, reps=20):
+    out = []
+    for name, fn in GROUPS.items():
+        if only and name not in only:
+            continue
+        out += fn(device, reps)
+        torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default=None)
+    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--json', default=None)
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    res = run(dev, a.only.split(',') if a.only else None, a.reps)
+    for e in res:
+        extra = f"  [{e['hbm_GBps']} GB/s = {e['hbm_frac']:.2%} of HBM]" if 'hbm_GBps' in e else ''
+        print(f"{e['name']:<58} {e['ms']:8.4f} ms  {e['achieved']:10.2f} {e['unit']:<14} {e['frac']:7.2%} of {e['bound']} peak{extra}")
+    if a.json:
+        json.dump(res, open(a.json, 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
