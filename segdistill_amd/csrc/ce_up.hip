@@ -28,17 +28,24 @@ namespace {
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
 
-// Forward: a thread owns ONE output column (its two horizontal taps and weight are fixed) and the F output rows of a gap; the
-// class loop is innermost with an online softmax, the label pick and the running arg-max per pixel.  Coalesced label reads and
-// per-pixel stores.  VALU-bound (~12 vector ops + one exponential per pixel and class; 310 us at config-2 size -- an earlier
-// form with one thread per tap column and F x F pixels per thread ran at the same speed with a quarter of the waves).
+// Forward: a thread owns ONE output column (its two horizontal taps and weight are fixed) and the F output rows of G consecutive gaps
+// (G+1 tap rows: the shared row is loaded once).  The class loop is innermost, in CHUNKS of 8 classes: the chunk's values are formed in
+// registers, ONE max and ONE rescale exponential are spent per chunk and pixel (as cgd_device.h::fold does per 16 elements), then one
+// fma + exponential + add per class -- 7 vector issues + 1 transcendental per pixel and class instead of the 13 + 1 of a per-class
+// online update with the label pick and the arg-max compare inside the loop.  Those two leave the loop altogether:
+//   * the label's logit is ONE interpolation per pixel of the label's own class plane (4 gathered taps), formed by the very same
+//     fmaf sequence as in the loop, hence bit-equal to the value the loop saw;
+//   * top-1: the loop only remembers in which chunk the running maximum last rose (strictly); a pixel whose label logit EQUALS the
+//     maximum (the only candidates for a hit) re-forms that one chunk and takes the first class that attains the maximum -- exactly
+//     the first-index rule of an arg-max, ties included.
 // Arithmetic as up_device.h::hrow, operation for operation: fmaf(lambda, right - left, left).
-// grid: (ceil(W / blockDim), nband, B)
-template <typename T, int F>
-__global__ __launch_bounds__(512) void ce_up_fwd_col(const T *__restrict__ s, const int32_t *__restrict__ label, float *__restrict__ loss_pix,
-                                                      float *__restrict__ lse2_out, int *__restrict__ correct, int C, int h, int w, int nband,
+// grid: (ceil(W / blockDim), ceil((h + 1) / G), B)
+template <typename T, int F, int G>
+__global__ __launch_bounds__(256) void ce_up_fwd_col(const T *__restrict__ s, const int32_t *__restrict__ label, float *__restrict__ loss_pix,
+                                                      float *__restrict__ lse2_out, int *__restrict__ correct, int C, int h, int w,
                                                       int ignore_index) {
-    const int b = blockIdx.z, k = blockIdx.y;
+    constexpr int CH = 8, P = F * G;
+    const int b = blockIdx.z;
     const int H = F * h, W = F * w;
     const int X = blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = X < W;
@@ -48,52 +55,100 @@ __global__ __launch_bounds__(512) void ce_up_fwd_col(const T *__restrict__ s, co
     const int xa = left ? max(kx - 1, 0) : kx;
     const int xb = left ? kx : min(kx + 1, w - 1);
     const float lx = (left ? rx + F / 2 + 0.5f : rx - F / 2 + 0.5f) / F;
-    const int j0 = k, j1 = (k == nband - 1) ? h + 1 : min(h, j0 + 1);
+    const int j0 = blockIdx.y * G;                    // gaps j0 .. j0+G-1 (gap j lies between tap rows j-1 and j; gaps beyond h do not exist)
     const size_t plane = (size_t)h * w;
     const T *sb = s + (size_t)b * C * plane;
     const int32_t *lb = label + (size_t)b * H * W;
-    int hits = 0;
-    for (int j = j0; j < j1; ++j) {
-        const int rp = max(j - 1, 0), rc = min(j, h - 1);
-        const int Y0 = F * j - F / 2;
-        int lab[F], bi[F];
-        float m[F], z[F], xl[F], best[F];
+    // tap rows j0-1 .. j0+G-1, clamped into the map (the half gaps at the borders repeat the edge row)
+    size_t roff[G + 1];
 #pragma unroll
-        for (int q = 0; q < F; ++q) {
-            const int Y = Y0 + q;
-            lab[q] = (active && Y >= 0 && Y < H) ? lb[(size_t)Y * W + X] : ignore_index;
-            m[q] = kNegBig; z[q] = 0.f; xl[q] = 0.f; best[q] = kNegBig; bi[q] = -1;
-        }
-        const T *pa = sb + (size_t)rp * w, *pb = sb + (size_t)rc * w;
-        for (int c = 0; c < C; ++c) {
-            const float a0 = VecIO<T>::load1(pa + xa), b0 = VecIO<T>::load1(pa + xb);
-            const float a1 = VecIO<T>::load1(pb + xa), b1 = VecIO<T>::load1(pb + xb);
-            pa += plane;
-            pb += plane;
-            const float sp = fmaf(lx, b0 - a0, a0), sc = fmaf(lx, b1 - a1, a1);
+    for (int g = 0; g <= G; ++g) roff[g] = (size_t)min(max(j0 - 1 + g, 0), h - 1) * w;
+    float m[P], z[P];
+    int mc[P];
 #pragma unroll
-            for (int q = 0; q < F; ++q) {
-                const float lam = (q + 0.5f) / F;
-                const float v = fmaf(lam, sc - sp, sp);
-                const float d = v - m[q];
-                const float e = ex2(-fabsf(d) * kLog2e);
-                z[q] = d > 0.f ? fmaf(z[q], e, 1.f) : z[q] + e;
-                m[q] = fmaxf(m[q], v);
-                if (c == lab[q]) xl[q] = v;
-                if (v > best[q]) { best[q] = v; bi[q] = c; }
+    for (int p = 0; p < P; ++p) { m[p] = kNegBig; z[p] = 0.f; mc[p] = 0; }
+
+    // values of `n` classes starting at c0 for the P pixels of this thread (classes beyond C: -big)
+    auto chunk = [&](int c0, int n, float (&v)[P][CH]) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = min(c0 + i, C - 1);
+            const T *pc = sb + (size_t)c * plane;
+            float t[G + 1];
+#pragma unroll
+            for (int g = 0; g <= G; ++g) {
+                const float a0 = VecIO<T>::load1(pc + roff[g] + xa), b0 = VecIO<T>::load1(pc + roff[g] + xb);
+                t[g] = fmaf(lx, b0 - a0, a0);
+            }
+            const bool in = i < n;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float d = t[g + 1] - t[g];
+#pragma unroll
+                for (int q = 0; q < F; ++q) v[g * F + q][i] = in ? fmaf((q + 0.5f) / F, d, t[g]) : kNegBig;
             }
         }
-        if (active) {
+    };
+
+    for (int c0 = 0, ci = 0; c0 < C; c0 += CH, ++ci) {
+        float v[P][CH];
+        chunk(c0, min(CH, C - c0), v);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float cm = v[p][0];
+#pragma unroll
+            for (int i = 1; i < CH; ++i) cm = fmaxf(cm, v[p][i]);
+            mc[p] = cm > m[p] ? ci : mc[p];
+            const float nm = fmaxf(m[p], cm);
+            float zz = z[p] * ex2((m[p] - nm) * kLog2e);
+            const float off = -nm * kLog2e;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) zz += ex2(fmaf(v[p][i], kLog2e, off));
+            z[p] = zz;
+            m[p] = nm;
+        }
+    }
+
+    int hits = 0;
+    if (active) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int j = j0 + g;
+            if (j > h) continue;
 #pragma unroll
             for (int q = 0; q < F; ++q) {
-                const int Y = Y0 + q;
+                const int Y = F * j - F / 2 + q, p = g * F + q;
                 if (Y < 0 || Y >= H) continue;
-                const float l2 = __builtin_amdgcn_logf(z[q]);  // v_log_f32 = log2
                 const size_t o = (size_t)b * H * W + (size_t)Y * W + X;
-                const bool valid = lab[q] != ignore_index;
-                loss_pix[o] = valid ? (m[q] + l2 * kLn2 - xl[q]) : 0.f;
-                lse2_out[o] = fmaf(m[q], kLog2e, l2);
-                hits += (bi[q] == lab[q]) ? 1 : 0;
+                const int lab = lb[(size_t)Y * W + X];
+                const bool valid = lab != ignore_index && lab >= 0 && lab < C;
+                float xl = 0.f;
+                if (valid) {
+                    const T *pc = sb + (size_t)lab * plane;
+                    const float a0 = VecIO<T>::load1(pc + roff[g] + xa), b0 = VecIO<T>::load1(pc + roff[g] + xb);
+                    const float a1 = VecIO<T>::load1(pc + roff[g + 1] + xa), b1 = VecIO<T>::load1(pc + roff[g + 1] + xb);
+                    const float t0 = fmaf(lx, b0 - a0, a0), t1 = fmaf(lx, b1 - a1, a1);
+                    xl = fmaf((q + 0.5f) / F, t1 - t0, t0);
+                }
+                const float l2 = __builtin_amdgcn_logf(z[p]);  // v_log_f32 = log2
+                loss_pix[o] = valid ? (m[p] + l2 * kLn2 - xl) : 0.f;
+                lse2_out[o] = fmaf(m[p], kLog2e, l2);
+                if (valid && xl == m[p]) {
+                    // the label attains the maximum: it is the arg-max unless an earlier class attains it too -- look at the chunk where
+                    // the maximum first appeared
+                    const int c0 = mc[p] * CH;
+                    int first = -1;
+                    for (int i = CH - 1; i >= 0; --i) {
+                        const int c = c0 + i;
+                        if (c >= C) continue;
+                        const T *pc = sb + (size_t)c * plane;
+                        const float a0 = VecIO<T>::load1(pc + roff[g] + xa), b0 = VecIO<T>::load1(pc + roff[g] + xb);
+                        const float a1 = VecIO<T>::load1(pc + roff[g + 1] + xa), b1 = VecIO<T>::load1(pc + roff[g + 1] + xb);
+                        const float t0 = fmaf(lx, b0 - a0, a0), t1 = fmaf(lx, b1 - a1, a1);
+                        if (fmaf((q + 0.5f) / F, t1 - t0, t0) == m[p]) first = c;
+                    }
+                    hits += (first == lab) ? 1 : 0;
+                }
             }
         }
     }
@@ -206,21 +261,21 @@ int sd_ce_up_fwd(const void *logits, const int32_t *label, float *loss_pix, floa
     const int F = sd::ce_factor(h, w, H, W);
     if (!F) return SD_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // the forward keeps no state across gaps (the channel loop is innermost): one gap per workgroup row, one output column per thread
-    const int nband = h, threads = W >= 512 ? 512 : (W + 63) / 64 * 64;
+    // the forward keeps no state across gaps (the class loop is innermost): G gaps (h + 1 of them: the two border gaps are half gaps) per
+    // workgroup row, one output column per thread
+    const int threads = W >= 256 ? 256 : (W + 63) / 64 * 64;
     hipLaunchKernelGGL(sd::zero_counter, dim3(1), dim3(1), 0, st, correct);
-    dim3 grid((W + threads - 1) / threads, nband, B);
-#define SD_CE_FWD(TT, FF)                                                                                                            \
-    hipLaunchKernelGGL((sd::ce_up_fwd_col<TT, FF>), grid, dim3(threads), 0, st, (const TT *)logits, label, loss_pix, pix_lse2, correct, C, h, \
-                       w, nband, ignore_index)
+#define SD_CE_FWD(TT, FF, GG)                                                                                                        \
+    hipLaunchKernelGGL((sd::ce_up_fwd_col<TT, FF, GG>), dim3((W + threads - 1) / threads, (h + 1 + GG - 1) / GG, B), dim3(threads), 0, st, \
+                       (const TT *)logits, label, loss_pix, pix_lse2, correct, C, h, w, ignore_index)
     if (dtype == SD_F32) {
-        if (F == 2) SD_CE_FWD(float, 2);
-        else if (F == 4) SD_CE_FWD(float, 4);
-        else SD_CE_FWD(float, 8);
+        if (F == 2) SD_CE_FWD(float, 2, 4);
+        else if (F == 4) SD_CE_FWD(float, 4, 2);
+        else SD_CE_FWD(float, 8, 1);
     } else {
-        if (F == 2) SD_CE_FWD(sd::bf16_t, 2);
-        else if (F == 4) SD_CE_FWD(sd::bf16_t, 4);
-        else SD_CE_FWD(sd::bf16_t, 8);
+        if (F == 2) SD_CE_FWD(sd::bf16_t, 2, 4);
+        else if (F == 4) SD_CE_FWD(sd::bf16_t, 4, 2);
+        else SD_CE_FWD(sd::bf16_t, 8, 1);
     }
 #undef SD_CE_FWD
     return (int)hipGetLastError();

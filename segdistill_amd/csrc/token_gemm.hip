@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "sd_common.h"
 
 namespace sd {
@@ -35,21 +37,36 @@ __device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.f + 
 // clamped (their products are never stored), k beyond `K` is zero.  VEC: rows are 16-byte aligned and K % 4 == 0 (block-uniform).
 template <int ROWS> struct KTile { float4 v[ROWS / 32]; };
 
-template <int ROWS, bool VEC>
+// A 16-byte global load the compiler can neither sink nor reorder (asm volatile): hipcc's scheduler / sinking moves ordinary loads down to
+// their first use -- here the LDS stores half a k-step later -- which exposes the whole memory latency in every step.  The price: the
+// compiler does not count these loads in vmcnt, so the consumer must be preceded by an explicit wait (wait_loads() below).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 pinned_load16(const float *p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int ROWS, bool VEC, bool FULLK>
 __device__ __forceinline__ void load_ktile(KTile<ROWS> &f, const float *__restrict__ src, long ld, long r0, long rmax, int k0, int K) {
     const int t = threadIdx.x, c = (t & 7) * 4;
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
         long row = r0 + (t >> 3) + 32 * i;
         row = row < rmax ? row : rmax - 1;
-        const float *p = src + row * ld + k0 + c;
-        if (VEC) {
-            f.v[i] = (k0 + c < K) ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // branch-free: the address is clamped into the row, the value of an out-of-range k is zeroed by a select afterwards
+        if (VEC && FULLK) {
+            f.v[i] = pinned_load16(src + row * ld + k0 + c);                          // K % 32 == 0: every chunk of every k-step exists
+        } else if (VEC) {
+            const bool in = k0 + c < K;                                   // K % 4 == 0: a chunk is entirely in or out
+            const float4 v = *reinterpret_cast<const float4 *>(src + row * ld + (in ? k0 + c : 0));
+            f.v[i] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-            f.v[i].x = (k0 + c + 0 < K) ? p[0] : 0.f;
-            f.v[i].y = (k0 + c + 1 < K) ? p[1] : 0.f;
-            f.v[i].z = (k0 + c + 2 < K) ? p[2] : 0.f;
-            f.v[i].w = (k0 + c + 3 < K) ? p[3] : 0.f;
+            const float *p = src + row * ld;
+            const int k = k0 + c;
+            const float x = p[min(k, K - 1)], y = p[min(k + 1, K - 1)], z = p[min(k + 2, K - 1)], w = p[min(k + 3, K - 1)];
+            f.v[i] = make_float4(k < K ? x : 0.f, k + 1 < K ? y : 0.f, k + 2 < K ? z : 0.f, k + 3 < K ? w : 0.f);
         }
     }
 }
@@ -64,23 +81,27 @@ __device__ __forceinline__ void store_ktile(const KTile<ROWS> &f, float *dst /* 
 // n-contiguous source tile (bwd-data B operand): BK k-rows x COLS n.  thread -> (k = t / (COLS/4) + (1024/COLS) i, chunk = t % (COLS/4)).
 template <int COLS> struct NTile { float4 v[BK * COLS / 1024]; };
 
-template <int COLS, bool VEC>
+template <int COLS, bool VEC, bool FULLK>
 __device__ __forceinline__ void load_ntile(NTile<COLS> &f, const float *__restrict__ src, long ld, int n0, int N, int k0, int K) {
     constexpr int CH = COLS / 4, KSTEP = 256 / CH;
     const int t = threadIdx.x, c = (t % CH) * 4, kk = t / CH;
 #pragma unroll
     for (int i = 0; i < BK / KSTEP; ++i) {
         int k = k0 + kk + KSTEP * i;
-        const bool kin = k < K;
+        const bool kin = FULLK || k < K;
         k = kin ? k : K - 1;
-        const float *p = src + (long)k * ld + n0 + c;
-        if (VEC) {
-            f.v[i] = (kin && n0 + c < N) ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float *p = src + (long)k * ld;
+        const int n = n0 + c;
+        if (VEC && FULLK) {
+            // columns beyond N are clamped, not zeroed: they only feed output columns that are never stored
+            f.v[i] = pinned_load16(p + (n < N ? n : N - 4));
+        } else if (VEC) {
+            const bool in = kin && n < N;                                 // N % 4 == 0: a chunk is entirely in or out
+            const float4 v = *reinterpret_cast<const float4 *>(p + (n < N ? n : 0));
+            f.v[i] = in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-            f.v[i].x = (kin && n0 + c + 0 < N) ? p[0] : 0.f;
-            f.v[i].y = (kin && n0 + c + 1 < N) ? p[1] : 0.f;
-            f.v[i].z = (kin && n0 + c + 2 < N) ? p[2] : 0.f;
-            f.v[i].w = (kin && n0 + c + 3 < N) ? p[3] : 0.f;
+            const float x = p[min(n, N - 1)], y = p[min(n + 1, N - 1)], z = p[min(n + 2, N - 1)], w = p[min(n + 3, N - 1)];
+            f.v[i] = make_float4(kin && n < N ? x : 0.f, kin && n + 1 < N ? y : 0.f, kin && n + 2 < N ? z : 0.f, kin && n + 3 < N ? w : 0.f);
         }
     }
 }
@@ -96,10 +117,10 @@ __device__ __forceinline__ void store_ntile(const NTile<COLS> &f, float *dst /* 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------------------
 // C[M x N] = epilogue( A[M x K] . B ),  B(k, n) = BT ? Bm[n * ldb + k] : Bm[k * ldb + n].
 // ACT: 0 none, 1 exact GELU.  bias (per n) and residual (C-shaped) optional.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, bool VEC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, bool VEC, bool FULLK, int EPI>
 __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ A, const float *__restrict__ Bm, float *__restrict__ C,
                                                        const float *__restrict__ bias, const float *__restrict__ residual, long M, int N, int K,
-                                                       long lda, long ldb, long ldc, int act, int tiles_n) {
+                                                       long lda, long ldb, long ldc, int tiles_n, int vec_out) {
     static_assert(WAVES_M * WAVES_N == 4, "four waves");
     constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
     constexpr int A_ELEMS = BM * KP;
@@ -116,7 +137,7 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
     const long m0 = tm_idx * BM;
     const int n0 = tn_idx * BN;
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform values stay scalar
     const int wm = (wave / WAVES_N) * (TM * 32), wn = (wave % WAVES_N) * (TN * 32);
     const int r = lane & 31, kh = lane >> 5;
 
@@ -127,92 +148,165 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    // n-tiles of this wave that hold at least one real column (N = 150, 160 ...: do not multiply padding)
-    bool live[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) live[j] = n0 + wn + 32 * j < N;
+    // NB no "skip the MFMAs of padding columns" test anywhere: each wave has its own SIMD, so a wave multiplying padding (N = 150, 160 in the
+    // last tile column) delays nobody, whereas ANY branch inside the k-step splits it into basic blocks and the compiler then sinks the global
+    // loads down to their use (measured: loads issued right in front of the LDS stores, full latency exposed every step)
 
     KTile<BM> fa;
     KTile<BN> fbt;
     NTile<BN> fbn;
     const int nk = (K + BK - 1) / BK;
-    load_ktile<BM, VEC>(fa, A, lda, m0, M, 0, K);
-    if (BT) load_ktile<BN, VEC>(fbt, Bm, ldb, n0, N, 0, K);
-    else load_ntile<BN, VEC>(fbn, Bm, ldb, n0, N, 0, K);
+    load_ktile<BM, VEC, FULLK>(fa, A, lda, m0, M, 0, K);
+    if (BT) load_ktile<BN, VEC, FULLK>(fbt, Bm, ldb, n0, N, 0, K);
+    else load_ntile<BN, VEC, FULLK>(fbn, Bm, ldb, n0, N, 0, K);
+    if (FULLK) wait_loads();
     store_ktile<BM>(fa, lds);
     if (BT) store_ktile<BN>(fbt, lds + A_ELEMS);
     else store_ntile<BN>(fbn, lds + A_ELEMS);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const float *As = lds + (kt & 1) * (A_ELEMS + B_ELEMS);
-        const float *Bs = As + A_ELEMS;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            load_ktile<BM, VEC>(fa, A, lda, m0, M, (kt + 1) * BK, K);
-            if (BT) load_ktile<BN, VEC>(fbt, Bm, ldb, n0, N, (kt + 1) * BK, K);
-            else load_ntile<BN, VEC>(fbn, Bm, ldb, n0, N, (kt + 1) * BK, K);
+    // Fragments of one quad (8 consecutive k): per lane 4 k-values of TM A rows and TN B columns.
+    struct Frag { float a[TM][4], b[TN][4]; };
+    auto read_frag = [&](Frag &f, const float *As, const float *Bs, int q4) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float4 v = *reinterpret_cast<const float4 *>(As + (wm + 32 * i + r) * KP + 8 * q4 + 4 * kh);
+            f.a[i][0] = v.x, f.a[i][1] = v.y, f.a[i][2] = v.z, f.a[i][3] = v.w;
         }
 #pragma unroll
-        for (int q4 = 0; q4 < BK / 8; ++q4) {
-            float4 a[TM];
-            float b[TN][4];
+        for (int j = 0; j < TN; ++j) {
+            if (BT) {
+                const float4 v = *reinterpret_cast<const float4 *>(Bs + (wn + 32 * j + r) * KP + 8 * q4 + 4 * kh);
+                f.b[j][0] = v.x, f.b[j][1] = v.y, f.b[j][2] = v.z, f.b[j][3] = v.w;
+            } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4 *>(As + (wm + 32 * i + r) * KP + 8 * q4 + 4 * kh);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (BT) {
-                    const float4 v = *reinterpret_cast<const float4 *>(Bs + (wn + 32 * j + r) * KP + 8 * q4 + 4 * kh);
-                    b[j][0] = v.x, b[j][1] = v.y, b[j][2] = v.z, b[j][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) b[j][e] = Bs[(8 * q4 + 4 * kh + e) * (BN + 4) + wn + 32 * j + r];
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float av = e == 0 ? a[i].x : (e == 1 ? a[i].y : (e == 2 ? a[i].z : a[i].w));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        if (live[j]) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[j][e], acc[i][j], 0, 0, 0);
-                }
+                for (int e = 0; e < 4; ++e) f.b[j][e] = Bs[(8 * q4 + 4 * kh + e) * (BN + 4) + wn + 32 * j + r];
             }
         }
-        if (more) {
-            float *An = lds + ((kt + 1) & 1) * (A_ELEMS + B_ELEMS);
-            store_ktile<BM>(fa, An);
-            if (BT) store_ktile<BN>(fbt, An + A_ELEMS);
-            else store_ntile<BN>(fbn, An + A_ELEMS);
-        }
+    };
+    auto mma = [&](const Frag &f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
+    };
+    // Software pipeline of one k-step (4 quads of 16 ... 4 MFMAs per wave):
+    //   quad 0   | issue the global loads of tile kt+1, MFMAs
+    //   quad 1-2 | the loads have landed behind ~2 quads of MFMAs: write them to the OTHER LDS buffer (free since the barrier of step kt-1);
+    //            | ds_write issue slots between MFMAs are free -- the matrix pipe is busy 64 cycles per instruction
+    //   quad 3   | its fragments are already in registers: BARRIER first (tile kt+1 visible, tile kt no longer read by anyone), read the
+    //            | first fragments of tile kt+1, THEN the MFMAs of quad 3 -- the barrier wait and the LDS latency of the next step's first
+    //            | read sit behind 16 MFMAs (1024 cycles) instead of in front of them.  One barrier per k-step.
+    // Two co-resident workgroups run this same program nearly in lockstep, so a bubble in one is not filled by the other (measured: 68 % MFMA
+    // utilisation with the plain load / multiply / store / barrier order).
+    Frag f0, f1;
+    read_frag(f0, lds, lds + A_ELEMS, 0);
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const float *cur = lds + (kt & 1) * (A_ELEMS + B_ELEMS);
+        float *nxt = lds + ((kt + 1) & 1) * (A_ELEMS + B_ELEMS);
+        load_ktile<BM, VEC, FULLK>(fa, A, lda, m0, M, (kt + 1) * BK, K);
+        if (BT) load_ktile<BN, VEC, FULLK>(fbt, Bm, ldb, n0, N, (kt + 1) * BK, K);
+        else load_ntile<BN, VEC, FULLK>(fbn, Bm, ldb, n0, N, (kt + 1) * BK, K);
+        __builtin_amdgcn_sched_barrier(0);      // keep the loads HERE: the scheduler otherwise sinks them to just above the LDS stores
+        read_frag(f1, cur, cur + A_ELEMS, 1);
+        mma(f0);
+        read_frag(f0, cur, cur + A_ELEMS, 2);
+        mma(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FULLK) wait_loads();
+        store_ktile<BM>(fa, nxt);
+        if (BT) store_ktile<BN>(fbt, nxt + A_ELEMS);
+        else store_ntile<BN>(fbn, nxt + A_ELEMS);
+        read_frag(f1, cur, cur + A_ELEMS, 3);
+        mma(f0);
+        __syncthreads();
+        read_frag(f0, nxt, nxt + A_ELEMS, 0);
+        mma(f1);
+    }
+    {
+        const float *cur = lds + ((nk - 1) & 1) * (A_ELEMS + B_ELEMS);
+        read_frag(f1, cur, cur + A_ELEMS, 1);
+        mma(f0);
+        read_frag(f0, cur, cur + A_ELEMS, 2);
+        mma(f1);
+        read_frag(f1, cur, cur + A_ELEMS, 3);
+        mma(f0);
+        mma(f1);
         __syncthreads();
     }
-    // epilogue; C/D layout of the 32x32 accumulator: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    // ---- epilogue (EPI: bit 0 = + residual, bit 1 = exact GELU; compile-time, so the plain Linear carries none of their registers) ----
+    constexpr bool RES = (EPI & 1) != 0, ACT = (EPI & 2) != 0;
+    if (vec_out) {
+        // Row-major through LDS (the staging buffers are free after the loop's last barrier): a wave parks 32 rows of its tile in a
+        // private [32][TN*32 + 4] image (ds_write_b32 straight from the accumulator layout, conflict-free), reads whole rows back and
+        // stores 16 bytes per lane -- full 128/256-byte row segments, a quarter of the store instructions; bias / residual are applied
+        // row-wise with 16-byte loads.  Needs 16-byte aligned rows of C, of the residual and of the bias (checked by the launcher).
+        constexpr int WCOLS = TN * 32, WP = WCOLS + 4, LPR = WCOLS / 4, RPI = 64 / LPR;   // lanes per row, rows per store instruction
+        float *img = lds + wave * (32 * WP);
+        const int lr = lane / LPR, lc = (lane % LPR) * 4;
+        const int ncol = n0 + wn + lc;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && ncol < N) bv = *reinterpret_cast<const float4 *>(bias + ncol);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) img[((e & 3) + 8 * (e >> 2) + 4 * kh) * WP + 32 * j + r] = acc[i][j][e];
+            __syncthreads();
+            auto rows_out = [&](auto inner) {
+                constexpr bool IN = decltype(inner)::value;          // interior tile: no per-row / per-column predicate at all
+#pragma unroll
+                for (int rr = 0; rr < 32; rr += RPI) {
+                    const long m = m0 + wm + 32 * i + rr + lr;
+                    float4 v = *reinterpret_cast<const float4 *>(img + (rr + lr) * WP + lc);
+                    v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                    if (ACT) v.x = gelu_exact(v.x), v.y = gelu_exact(v.y), v.z = gelu_exact(v.z), v.w = gelu_exact(v.w);
+                    if (IN || (m < M && ncol < N)) {
+                        if (RES) {
+                            const float4 rv = *reinterpret_cast<const float4 *>(residual + m * ldc + ncol);
+                            v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
+                        }
+                        *reinterpret_cast<float4 *>(C + m * ldc + ncol) = v;
+                    }
+                }
+            };
+            if (m0 + BM <= M && n0 + BN <= N) rows_out(std::true_type{});
+            else rows_out(std::false_type{});
+            __syncthreads();
+        }
+        return;
+    }
+    // unaligned output (N % 4 != 0: the 150 classes of linear_pred): element stores in the accumulator layout -- col = lane & 31,
+    // row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn + 32 * j + r;
-        if (n >= N) continue;
-        const float bv = bias ? bias[n] : 0.f;
+        const bool nin = n < N;
+        const int nc = nin ? n : N - 1;
+        const float bv = bias ? bias[nc] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const long m = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                if (m < M) {
-                    float v = acc[i][j][e] + bv;
-                    if (act == 1) v = gelu_exact(v);
-                    if (residual) v += residual[m * ldc + n];
-                    C[m * ldc + n] = v;
-                }
+                const long mc = m < M ? m : M - 1;
+                float v = acc[i][j][e] + bv;
+                if (ACT) v = gelu_exact(v);
+                if (RES) v += residual[mc * ldc + nc];
+                if (nin && m < M) C[m * ldc + nc] = v;
             }
         }
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT>
-int launch(const float *A, const float *Bm, float *C, const float *bias, const float *residual, long M, int N, int K, long lda, long ldb, long ldc,
-           int act, hipStream_t st) {
-    constexpr size_t lds_bytes = 2 * (size_t)(BM * KP + (BT ? BN * KP : BK * (BN + 4))) * sizeof(float);
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, int EPI>
+int launch_epi(const float *A, const float *Bm, float *C, const float *bias, const float *residual, long M, int N, int K, long lda, long ldb,
+               long ldc, hipStream_t st) {
+    // two staging buffers, or ONE when the whole reduction is a single k-step (K <= 32: the stage-1 products -- HBM-bound, so what matters
+    // there is how many workgroups, i.e. bytes in flight, a CU holds)
+    const size_t lds_bytes = (K > BK ? 2 : 1) * (size_t)(BM * KP + (BT ? BN * KP : BK * (BN + 4))) * sizeof(float);
     const long tiles_m = (M + BM - 1) / BM;
     const int tiles_n = (N + BN - 1) / BN;
     const long nblk = tiles_m * tiles_n;
@@ -220,25 +314,50 @@ int launch(const float *A, const float *Bm, float *C, const float *bias, const f
     // 16-byte loads need aligned rows: base pointers, leading dimensions, and (k-contiguous tiles) K % 4, (n-contiguous) N % 4
     const bool vec = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bm) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
                      K % 4 == 0 && (BT || N % 4 == 0);
-    auto kern = vec ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true> : token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, false>;
+    const bool fullk = vec && K % BK == 0;
+    auto kern = fullk ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, true, EPI>
+                      : (vec ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, false, EPI>
+                             : token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, false, false, EPI>);
     if (lds_bytes > 64 * 1024) {
-        static bool raised[2] = {false, false};      // per instantiation (this function template) and load flavour; idempotent, so a race is harmless
-        if (!raised[vec]) {
+        static bool raised[3] = {false, false, false};   // per instantiation (this function template) and load flavour; idempotent, so a race is harmless
+        const int flavour = fullk ? 2 : (vec ? 1 : 0);
+        if (!raised[flavour]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) return (int)e;
-            raised[vec] = true;
+            raised[flavour] = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, act, tiles_n);
+    // row-major 16-byte epilogue: rows of C (and of the residual, the bias vector) 16-byte aligned and N % 4 == 0
+    const int vec_out = ((reinterpret_cast<uintptr_t>(C) & 15) == 0 && ldc % 4 == 0 && N % 4 == 0 && (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0) &&
+                         (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0)) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, tiles_n, vec_out);
     return (int)hipGetLastError();
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT>
+int launch(const float *A, const float *Bm, float *C, const float *bias, const float *residual, long M, int N, int K, long lda, long ldb, long ldc,
+           int act, hipStream_t st) {
+    if constexpr (!BT) {    // bwd-data: never an epilogue
+        return launch_epi<BM, BN, WAVES_M, WAVES_N, BT, 0>(A, Bm, C, bias, nullptr, M, N, K, lda, ldb, ldc, st);
+    } else {
+        const int epi = (residual ? 1 : 0) | (act == 1 ? 2 : 0);
+        switch (epi) {
+            case 0: return launch_epi<BM, BN, WAVES_M, WAVES_N, BT, 0>(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, st);
+            case 1: return launch_epi<BM, BN, WAVES_M, WAVES_N, BT, 1>(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, st);
+            case 2: return launch_epi<BM, BN, WAVES_M, WAVES_N, BT, 2>(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, st);
+            default: return launch_epi<BM, BN, WAVES_M, WAVES_N, BT, 3>(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, st);
+        }
+    }
 }
 
 template <bool BT>
 int dispatch(const float *A, const float *Bm, float *C, const float *bias, const float *residual, long M, int N, int K, long lda, long ldb, long ldc,
              int act, hipStream_t st) {
-    if (N <= 32) return launch<256, 32, 4, 1, BT>(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, act, st);
-    if (N <= 64) return launch<128, 64, 2, 2, BT>(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, act, st);
-    return launch<128, 128, 2, 2, BT>(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, act, st);
+    // widest column tile whose padding wastes at most a quarter of the MFMAs (N = 150 / 160: 3 x 64 instead of 2 x 128)
+    auto waste_ok = [&](int bn) { return (long)((N + bn - 1) / bn) * bn * 4 <= (long)N * 5; };
+    if (N > 64 && waste_ok(128)) return launch<128, 128, 2, 2, BT>(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, act, st);
+    if (N > 32) return launch<128, 64, 2, 2, BT>(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, act, st);
+    return launch<256, 32, 4, 1, BT>(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, act, st);
 }
 
 }  // namespace

@@ -21,18 +21,16 @@ _LONGK_ENABLED = os.environ.get('SEGDISTILL_LONGK') == '1'
 
 
 # Forward and input gradient on the exact-f32 MFMA kernels of csrc/token_gemm.hip instead of the library GEMM (fp32 only; SEGDISTILL_TOKEN_GEMM=0
-# restores the library for A/B runs).  `_gemm_preferred` is the measured dispatch (tools/gemm_bench.py on MI355X): the kernels win wherever the
-# token count fills the chip with 128-row tiles; small products (stage 4: 2048 tokens) stay on the library, whose split-K / small-tile kernels
-# cover them better.
+# restores the library for A/B runs).  `_gemm_preferred` is the MEASURED dispatch (tools/gemm_bench.py on MI355X, device time inside a replayed
+# graph, profiles/r02_gemm_bench.txt): hipBLASLt's fp32 kernels already run these shapes at 1.4-2x their roofline and the software-pipelined
+# kernel here only matches that (MFMA-bound shapes: 76 % vs 79 % of the f32-input MFMA peak), so it is used where it is measurably ahead --
+# the short-reduction products of stages 1-2 (K <= 64 over >= 32768 tokens: 9.7 vs 12.8 us for 32 -> 32, 38.8 vs 42.6 us for 32 -> 256) --
+# and the library everywhere else.
 _TOKEN_GEMM = os.environ.get('SEGDISTILL_TOKEN_GEMM', '1') == '1'
 
 
 def _gemm_preferred(tokens, k, n):
-    if not _TOKEN_GEMM:
-        return False
-    bm, bn = (256, 32) if n <= 32 else ((128, 64) if n <= 64 else (128, 128))
-    tiles = -(-tokens // bm) * -(-n // bn)
-    return tiles >= 192
+    return _TOKEN_GEMM and tokens >= 32768 and k <= 64
 
 
 def _fwd(x, weight, bias):

@@ -14,18 +14,32 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def timeit(fn, reps=20, warm=3):
+def timeit(fn, reps=20, warm=3, per_graph=10):
+    """DEVICE time per call in us: `per_graph` calls are captured into a hipGraph and the graph is replayed -- an eager loop measures the host
+    (hipBLASLt's dispatch alone costs ~23 us per call, more than most of these kernels run)."""
     for _ in range(warm):
         fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        fn()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(per_graph):
+                fn()
+    torch.cuda.synchronize()
+    g.replay()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
     ev[0].record()
     for i in range(reps):
-        fn()
+        g.replay()
         ev[i + 1].record()
     torch.cuda.synchronize()
     ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
-    return ts[len(ts) // 2] * 1e3   # us
+    return ts[len(ts) // 2] * 1e3 / per_graph   # us
 
 
 def mit_shapes(dims, depths, B=8, side=512):

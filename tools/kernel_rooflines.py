@@ -28,18 +28,45 @@ MFMA_BF16 = 2500.0    # TFLOP/s dense
 VALU = 78.6           # T lane-instructions / s
 
 
-def _time(fn, reps):
-    for _ in range(3):
+def _time(fn, reps, per_graph=5):
+    """DEVICE ms per call: `per_graph` calls captured into a hipGraph, the graph replayed `reps` times, HIP events around each replay on the
+    stream the kernels run on (median).  An eager loop would measure the host for the kernels that run under ~20 us."""
+    fn0 = fn
+
+    def fn():
+        return fn0(torch.cuda.current_stream().cuda_stream)      # the stream current at CALL time: the capture below runs on a side stream
+
+    for _ in range(2):
         fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.stream(side):
+            fn()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(per_graph):
+                    fn()
+        run = g.replay
+    except Exception:  # noqa: BLE001 -- an op that cannot be captured: time the eager loop instead
+        torch.cuda.synchronize()
+
+        def run():
+            for _ in range(per_graph):
+                fn()
+    torch.cuda.synchronize()
+    run()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
     ev[0].record()
     for i in range(reps):
-        fn()
+        run()
         ev[i + 1].record()
     torch.cuda.synchronize()
     ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
-    return ts[len(ts) // 2]
+    return ts[len(ts) // 2] / per_graph
 
 
 def _entry(name, kernels, shape, dtype, ms, bound, work, unit_peak, note=None):
@@ -74,10 +101,9 @@ def bench_r1(dev, reps, B=8, C=150, HW=512, g=8, tau=4.0, dtype=torch.float32):
     lse, kl, loss, dS = torch.empty(rows, 2, device=dev), torch.empty(rows, device=dev), torch.empty((), device=dev), torch.empty_like(S)
     wsb = L.sd_cgd_kl_workspace_bytes(B, C, HW, HW, g)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    st = torch.cuda.current_stream().cuda_stream
-    tf = _time(lambda: _ok(L.sd_cgd_kl_fwd(S.data_ptr(), T.data_ptr(), DT, B, C, HW, HW, g, 1 / tau, 3.0 / rows, None, lse.data_ptr(), kl.data_ptr(),
+    tf = _time(lambda st: _ok(L.sd_cgd_kl_fwd(S.data_ptr(), T.data_ptr(), DT, B, C, HW, HW, g, 1 / tau, 3.0 / rows, None, lse.data_ptr(), kl.data_ptr(),
                                             loss.data_ptr(), ws.data_ptr(), wsb, st), 'fwd'), reps)
-    tb = _time(lambda: _ok(L.sd_cgd_kl_bwd(S.data_ptr(), T.data_ptr(), DT, B, C, HW, HW, g, 1 / tau, 3.0 / (rows * tau), None, lse.data_ptr(), None,
+    tb = _time(lambda st: _ok(L.sd_cgd_kl_bwd(S.data_ptr(), T.data_ptr(), DT, B, C, HW, HW, g, 1 / tau, 3.0 / (rows * tau), None, lse.data_ptr(), None,
                                             dS.data_ptr(), st), 'bwd'), reps)
     N, e = S.numel(), S.element_size()
     tag = 'f32' if dtype == torch.float32 else 'bf16'
@@ -97,10 +123,9 @@ def bench_r2(dev, reps, B=8, C=150, hw=128, F=4, g=8, tau=4.0):
     lse, kl, loss, ds = torch.empty(rows, 2, device=dev), torch.empty(rows, device=dev), torch.empty((), device=dev), torch.empty_like(s)
     wsb = L.sd_cgd_kl_up_workspace_bytes(B, C, hw, hw, H, H, g)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    st = torch.cuda.current_stream().cuda_stream
-    tf = _time(lambda: _ok(L.sd_cgd_kl_up_fwd(s.data_ptr(), t.data_ptr(), 0, B, C, hw, hw, H, H, g, 1 / tau, 3.0 / rows, None, lse.data_ptr(),
+    tf = _time(lambda st: _ok(L.sd_cgd_kl_up_fwd(s.data_ptr(), t.data_ptr(), 0, B, C, hw, hw, H, H, g, 1 / tau, 3.0 / rows, None, lse.data_ptr(),
                                                kl.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, st), 'fwd'), reps)
-    tb = _time(lambda: _ok(L.sd_cgd_kl_up_bwd(s.data_ptr(), t.data_ptr(), 0, B, C, hw, hw, H, H, g, 1 / tau, 3.0 / (rows * tau), None,
+    tb = _time(lambda st: _ok(L.sd_cgd_kl_up_bwd(s.data_ptr(), t.data_ptr(), 0, B, C, hw, hw, H, H, g, 1 / tau, 3.0 / (rows * tau), None,
                                                lse.data_ptr(), None, ds.data_ptr(), st), 'bwd'), reps)
     N = B * C * H * H
     # lane-instruction model per output element (both tensors), see DESIGN.md section 3.2: forward 2*(1.75 lerp FMA) + fold 9 + 2.125 exp*4
@@ -124,10 +149,9 @@ def bench_align(dev, reps, B, Cs, Ct, h, dtype, tag):
     dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(b)
     wsb = L.sd_align1x1_workspace_bytes(B, Cs, Ct, h, h)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
-    st = torch.cuda.current_stream().cuda_stream
-    tf = _time(lambda: _ok(L.sd_align1x1_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), DT, B, Cs, Ct, h, h, st), 'fwd'), reps)
-    td = _time(lambda: _ok(L.sd_align1x1_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), DT, B, Cs, Ct, h, h, st), 'bwd_data'), reps)
-    tw = _time(lambda: _ok(L.sd_align1x1_bwd_weight(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), DT, B, Cs, Ct, h, h, ws.data_ptr(), wsb, st),
+    tf = _time(lambda st: _ok(L.sd_align1x1_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), DT, B, Cs, Ct, h, h, st), 'fwd'), reps)
+    td = _time(lambda st: _ok(L.sd_align1x1_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), DT, B, Cs, Ct, h, h, st), 'bwd_data'), reps)
+    tw = _time(lambda st: _ok(L.sd_align1x1_bwd_weight(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), DT, B, Cs, Ct, h, h, ws.data_ptr(), wsb, st),
                            'bwd_weight'), reps)
     flops = 2.0 * Ct * Cs * B * h * h
     e = x.element_size()
@@ -154,10 +178,9 @@ def bench_pix(dev, reps, B=8, C=150, HW=512):
     wsb = L.sd_pix_kl_workspace_bytes(B, C, HW, HW)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     up = torch.ones((), device=dev)
-    st = torch.cuda.current_stream().cuda_stream
-    tf = _time(lambda: _ok(L.sd_pix_kl_fwd(S.data_ptr(), T.data_ptr(), 0, B, C, HW, HW, 1.0, 1.0 / rows, lse.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, st),
+    tf = _time(lambda st: _ok(L.sd_pix_kl_fwd(S.data_ptr(), T.data_ptr(), 0, B, C, HW, HW, 1.0, 1.0 / rows, lse.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, st),
                            'pix fwd'), reps)
-    tb = _time(lambda: _ok(L.sd_pix_kl_bwd(S.data_ptr(), T.data_ptr(), 0, B, C, HW, HW, 1.0, 1.0 / rows, lse.data_ptr(), up.data_ptr(), dS.data_ptr(), st),
+    tb = _time(lambda st: _ok(L.sd_pix_kl_bwd(S.data_ptr(), T.data_ptr(), 0, B, C, HW, HW, 1.0, 1.0 / rows, lse.data_ptr(), up.data_ptr(), dS.data_ptr(), st),
                            'pix bwd'), reps)
     N = S.numel()
     return [_entry('pix_kl fwd (PDLoss at label resolution)', 'pix_fwd (+ loss)', [B, C, HW, HW], 'f32', tf, 'hbm', 2 * N * 4, HBM),
@@ -174,9 +197,8 @@ def bench_at(dev, reps, B=8, C=150, hw=128):
     wsb = L.sd_pix_kl_workspace_bytes(B, C, hw, hw)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     up = torch.ones((), device=dev)
-    st = torch.cuda.current_stream().cuda_stream
-    tf = _time(lambda: _ok(L.sd_at_kl_fwd(S.data_ptr(), T.data_ptr(), 0, B, C, hw, hw, planes.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, st), 'at fwd'), reps)
-    tb = _time(lambda: _ok(L.sd_at_kl_bwd(S.data_ptr(), T.data_ptr(), 0, B, C, hw, hw, planes.data_ptr(), up.data_ptr(), dS.data_ptr(), st), 'at bwd'), reps)
+    tf = _time(lambda st: _ok(L.sd_at_kl_fwd(S.data_ptr(), T.data_ptr(), 0, B, C, hw, hw, planes.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, st), 'at fwd'), reps)
+    tb = _time(lambda st: _ok(L.sd_at_kl_bwd(S.data_ptr(), T.data_ptr(), 0, B, C, hw, hw, planes.data_ptr(), up.data_ptr(), dS.data_ptr(), st), 'at bwd'), reps)
     N = S.numel()
     note = '78.6 MB operands: they fit the 256 MiB Infinity Cache when launched back to back, so the rate may exceed the HBM peak'
     return [_entry('at_kl fwd (ATLoss, logits at tap resolution)', 'at_fwd', [B, C, hw, hw], 'f32', tf, 'hbm', 2 * N * 4, HBM, note),
@@ -189,9 +211,9 @@ def bench_ifvd(dev, reps, B=8, C=150, hw=128):
     S = (2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)).requires_grad_(True)
     T = 2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)
     cls = torch.randint(0, C, (B, hw, hw), device=dev, generator=gen, dtype=torch.int32)
-    tf = _time(lambda: ops.ifvd_term(S.detach(), T, cls, C), reps)
+    tf = _time(lambda st: ops.ifvd_term(S.detach(), T, cls, C), reps)
     loss = ops.ifvd_term(S, T, cls, C)
-    tb = _time(lambda: torch.autograd.grad(loss, S, retain_graph=True), reps)
+    tb = _time(lambda st: torch.autograd.grad(loss, S, retain_graph=True), reps)
     N = S.numel()
     note = 'through the autograd binding (includes the per-image class sort and small allocations); L2/Infinity-Cache resident at this size'
     return [_entry('ifvd fwd (class means + cosine pass, both networks)', 'ifvd_seg_sum x2 + ifvd_cos x2', [B, C, hw, hw], 'f32', tf, 'hbm', 4 * N * 4, HBM, note),
@@ -210,10 +232,9 @@ def bench_ce(dev, reps, B=8, C=150, hw=128, F=4):
     correct = torch.empty(1, dtype=torch.int32, device=dev)
     dx = torch.empty_like(x)
     up = torch.full((1,), 1.0 / (B * H * H), device=dev)
-    st = torch.cuda.current_stream().cuda_stream
-    tf = _time(lambda: _ok(L.sd_ce_up_fwd(x.data_ptr(), lab.data_ptr(), loss_pix.data_ptr(), lse2.data_ptr(), correct.data_ptr(), 0, B, C, hw, hw, H, H, 255, st),
+    tf = _time(lambda st: _ok(L.sd_ce_up_fwd(x.data_ptr(), lab.data_ptr(), loss_pix.data_ptr(), lse2.data_ptr(), correct.data_ptr(), 0, B, C, hw, hw, H, H, 255, st),
                            'ce fwd'), reps)
-    tb = _time(lambda: _ok(L.sd_ce_up_bwd(x.data_ptr(), lab.data_ptr(), lse2.data_ptr(), up.data_ptr(), 0, 1.0, dx.data_ptr(), 0, B, C, hw, hw, H, H, 255, st),
+    tb = _time(lambda st: _ok(L.sd_ce_up_bwd(x.data_ptr(), lab.data_ptr(), lse2.data_ptr(), up.data_ptr(), 0, 1.0, dx.data_ptr(), 0, B, C, hw, hw, H, H, 255, st),
                            'ce bwd'), reps)
     N = B * C * H * H
     note = 'exp/VALU-bound (reads only the taps + the label map); lane-instruction MODEL: ~9 VALU + 1 exp (x4) per output pixel and class'
