@@ -218,6 +218,20 @@ int sd_linear_wgrad(const void *dY, const void *X, float *dW, float *dbias /* [o
                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * CGD / CD criterion on TOKEN-MAJOR operands S, T [B][P][C] (C contiguous; P = h*w pixels): the decoder features of a SegFormer head
+ * (decode_head.linear_c1..4 emit [B, h*w, E]; SURVEY a-16, reference opts.py:25-27 / the reshape helper commented out at
+ * losses.py:300-318).  Same rows, closed form, row_lse2 / row_kl / loss outputs and `perm` semantics as sd_cgd_kl_fwd / _bwd
+ * (losses.py:105-112, gather :39-41, pad :55-58) -- only the memory layout differs, so no transpose copy of either tap or of the
+ * gradient is needed.  Requires C % 4 == 0 (fp32) / C % 8 == 0 (bf16) and 16-byte aligned bases (else SD_E_UNSUPPORTED / SD_E_ALIGN:
+ * view as NCHW and use the R1 entry points); with `perm`, C <= 2048.
+ */
+size_t sd_cgd_kl_tok_workspace_bytes(int B, int C, long P);
+int sd_cgd_kl_tok_fwd(const void *S, const void *T, int dtype, int B, int C, long P, int g, float inv_tau, float loss_scale,
+                      const int32_t *perm, float *row_lse2, float *row_kl, float *loss, void *workspace, size_t workspace_bytes, void *stream);
+int sd_cgd_kl_tok_bwd(const void *S, const void *T, int dtype, int B, int C, long P, int g, float inv_tau, float coef, const int32_t *perm,
+                      const float *row_lse2, const float *upstream, void *dS, void *stream);
+
+/* ---------------------------------------------------------------------------
  * nn.Linear on token-major activations, forward and input gradient, as exact-f32 MFMA GEMMs (csrc/token_gemm.hip):
  *   forward   Y [tokens][out] = act( X [tokens][in] . W[out][in]^T + bias[out] ) (+ residual [tokens][out])
  *   bwd-data  dX [tokens][in] = dY [tokens][out] . W[out][in]

@@ -23,6 +23,13 @@
 
 namespace sd {
 
+// fp32 operands go through the software-pipelined kernel of token_gemm.hip (one barrier per k-step, loads in flight behind the MFMAs,
+// 16-byte row-major epilogue); the single-buffered gemm_mfma_* kernels below remain for bf16 STORAGE in NCHW layout (direct callers only:
+// config 5's token-major taps take the token Linear + csrc/cgd_tok.hip route) and for the generic split-K Linear weight gradient.
+int align_f32_fwd(const float *X, const float *W, const float *bias, float *Y, int B, int Cs, int Ct, long P, hipStream_t st);
+int align_f32_bwd_data(const float *dY, const float *W, float *dX, int B, int Cs, int Ct, long P, hipStream_t st);
+int align_f32_bwd_weight_slabs(const float *dY, const float *X, float *slabs, int B, int Cs, int Ct, long P, int nsplit, int klen, hipStream_t st);
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16, PITCH = BM + 4;
@@ -344,16 +351,22 @@ int align_bwd_data(const void *dY, const void *W, void *dX, int B, int Cs, int C
 template <typename T>
 int align_bwd_weight(const void *dY, const void *X, float *dW, float *db, void *ws, size_t ws_bytes, int B, int Cs, int Ct, long P,
                      hipStream_t st) {
-    const int nsplit = wgrad_splits(B, P);
-    const int klen = (int)(((P + nsplit - 1) / nsplit + BK - 1) / BK * BK);
+    int nsplit = wgrad_splits(B, P);
+    const int klen = (int)(((P + nsplit - 1) / nsplit + 31) / 32 * 32);    // multiple of the k-step of either kernel
+    nsplit = (int)((P + klen - 1) / klen);                                  // after rounding: every split owns at least one pixel
     const int nz = B * nsplit;
     const long slab = (long)Ct * Cs;
     if (ws_bytes < (size_t)nz * slab * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
     float *slabs = static_cast<float *>(ws);
-    // A = dY_b [M=Ct][K=P] (X-major), B = X_b^T given as X_b [N=Cs][K=P] (X-major); C = slab z
-    dim3 grid((Cs + BN - 1) / BN, (Ct + BM - 1) / BM, nz);
-    launch_gemm<T, T, float, false, false>(grid, st, (const T *)dY, (const T *)X, slabs, nullptr, Ct,
-                       Cs, (int)P, P, P, (long)Cs, (long)Ct * P, (long)Cs * P, slab, nsplit, klen);
+    if constexpr (sizeof(T) == 4) {
+        const int rc = align_f32_bwd_weight_slabs((const float *)dY, (const float *)X, slabs, B, Cs, Ct, P, nsplit, klen, st);
+        if (rc) return rc;
+    } else {
+        // A = dY_b [M=Ct][K=P] (X-major), B = X_b^T given as X_b [N=Cs][K=P] (X-major); C = slab z
+        dim3 grid((Cs + BN - 1) / BN, (Ct + BM - 1) / BM, nz);
+        launch_gemm<T, T, float, false, false>(grid, st, (const T *)dY, (const T *)X, slabs, nullptr, Ct,
+                           Cs, (int)P, P, P, (long)Cs, (long)Ct * P, (long)Cs * P, slab, nsplit, klen);
+    }
     hipLaunchKernelGGL((slab_reduce<float>), dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, slabs, dW, slab, nz);
     if (db) hipLaunchKernelGGL((bias_grad<T>), dim3(Ct), dim3(256), 0, st, (const T *)dY, db, B, Ct, P);
     return (int)hipGetLastError();
@@ -702,7 +715,7 @@ int sd_align1x1_fwd(const void *X, const float *W, const float *bias, void *Y, i
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long P = (long)h * w;
-    if (dtype == SD_F32) return sd::align_fwd<float>(X, W, bias, Y, B, Cs, Ct, P, st);
+    if (dtype == SD_F32) return sd::align_f32_fwd((const float *)X, W, bias, (float *)Y, B, Cs, Ct, P, st);
     return sd::align_fwd<sd::bf16_t>(X, W, bias, Y, B, Cs, Ct, P, st);
 }
 
@@ -711,7 +724,7 @@ int sd_align1x1_bwd_data(const void *dY, const float *W, void *dX, int dtype, in
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long P = (long)h * w;
-    if (dtype == SD_F32) return sd::align_bwd_data<float>(dY, W, dX, B, Cs, Ct, P, st);
+    if (dtype == SD_F32) return sd::align_f32_bwd_data((const float *)dY, W, (float *)dX, B, Cs, Ct, P, st);
     return sd::align_bwd_data<sd::bf16_t>(dY, W, dX, B, Cs, Ct, P, st);
 }
 

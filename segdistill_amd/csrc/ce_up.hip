@@ -28,6 +28,28 @@ namespace {
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
 
+// One element load the compiler can neither sink nor reorder (asm volatile), returned as raw bits; wait_pinned_loads() before the first use.
+template <typename T> __device__ __forceinline__ unsigned pinned_load1(const T *p);
+template <> __device__ __forceinline__ unsigned pinned_load1<float>(const float *p) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <> __device__ __forceinline__ unsigned pinned_load1<bf16_t>(const bf16_t *p) {
+    unsigned v;
+    asm volatile("global_load_ushort %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+// "memory" orders memory operations only: the register copies / arithmetic that consume the loaded registers could still be scheduled above
+// the wait, so a scheduling barrier follows it (cdna_hip_programming.md section 5.4 rule 18).
+__device__ __forceinline__ void wait_pinned_loads() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <typename T> __device__ __forceinline__ float raw_to_float(unsigned v);
+template <> __device__ __forceinline__ float raw_to_float<float>(unsigned v) { return __uint_as_float(v); }
+template <> __device__ __forceinline__ float raw_to_float<bf16_t>(unsigned v) { return __uint_as_float(v << 16); }
+
 // Forward: a thread owns ONE output column (its two horizontal taps and weight are fixed) and the F output rows of G consecutive gaps
 // (G+1 tap rows: the shared row is loaded once).  The class loop is innermost, in CHUNKS of 8 classes: the chunk's values are formed in
 // registers, ONE max and ONE rescale exponential are spent per chunk and pixel (as cgd_device.h::fold does per 16 elements), then one
@@ -68,16 +90,30 @@ __global__ __launch_bounds__(256) void ce_up_fwd_col(const T *__restrict__ s, co
 #pragma unroll
     for (int p = 0; p < P; ++p) { m[p] = kNegBig; z[p] = 0.f; mc[p] = 0; }
 
-    // values of `n` classes starting at c0 for the P pixels of this thread (classes beyond C: -big)
-    auto chunk = [&](int c0, int n, float (&v)[P][CH]) {
+    // Raw taps of a chunk of CH classes: (G+1) tap rows x 2 tap columns per class, 48 registers at F = 4.  The taps of chunk i+1 are
+    // requested BEFORE chunk i is folded and waited for after it: the kernel is otherwise bound by the latency of these (L1/L2-resident)
+    // loads, not by its arithmetic -- measured 239 us against ~50 us of vector issue.  The loads are asm volatile (the compiler would sink
+    // ordinary loads down to the register copy at the end of the iteration, i.e. behind the fold) and therefore waited for explicitly.
+    struct Taps { unsigned a[CH][G + 1], b[CH][G + 1]; };
+    auto request = [&](Taps &tp, int c0) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const int c = min(c0 + i, C - 1);
-            const T *pc = sb + (size_t)c * plane;
+            const T *pc = sb + (size_t)min(c0 + i, C - 1) * plane;       // classes beyond C are clamped here and masked in fold_chunk
+#pragma unroll
+            for (int g = 0; g <= G; ++g) {
+                tp.a[i][g] = pinned_load1<T>(pc + roff[g] + xa);
+                tp.b[i][g] = pinned_load1<T>(pc + roff[g] + xb);
+            }
+        }
+    };
+    auto fold_chunk = [&](const Taps &tp, int n, int ci) {
+        float v[P][CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
             float t[G + 1];
 #pragma unroll
             for (int g = 0; g <= G; ++g) {
-                const float a0 = VecIO<T>::load1(pc + roff[g] + xa), b0 = VecIO<T>::load1(pc + roff[g] + xb);
+                const float a0 = raw_to_float<T>(tp.a[i][g]), b0 = raw_to_float<T>(tp.b[i][g]);
                 t[g] = fmaf(lx, b0 - a0, a0);
             }
             const bool in = i < n;
@@ -88,11 +124,6 @@ __global__ __launch_bounds__(256) void ce_up_fwd_col(const T *__restrict__ s, co
                 for (int q = 0; q < F; ++q) v[g * F + q][i] = in ? fmaf((q + 0.5f) / F, d, t[g]) : kNegBig;
             }
         }
-    };
-
-    for (int c0 = 0, ci = 0; c0 < C; c0 += CH, ++ci) {
-        float v[P][CH];
-        chunk(c0, min(CH, C - c0), v);
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             float cm = v[p][0];
@@ -107,6 +138,15 @@ __global__ __launch_bounds__(256) void ce_up_fwd_col(const T *__restrict__ s, co
             z[p] = zz;
             m[p] = nm;
         }
+    };
+    Taps cur, nxt;
+    request(cur, 0);
+    wait_pinned_loads();
+    for (int c0 = 0, ci = 0; c0 < C; c0 += CH, ++ci) {
+        request(nxt, c0 + CH);                     // (the request past the last chunk re-reads class C-1: harmless, never folded)
+        fold_chunk(cur, min(CH, C - c0), ci);
+        wait_pinned_loads();
+        cur = nxt;
     }
 
     int hits = 0;

@@ -46,7 +46,10 @@ __device__ __forceinline__ float4 pinned_load16(const float *p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
     return make_float4(v.x, v.y, v.z, v.w);
 }
-__device__ __forceinline__ void wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_loads() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);      // "memory" orders memory operations only; nothing that reads the loaded registers may move above the wait
+}
 
 template <int ROWS, bool VEC, bool FULLK>
 __device__ __forceinline__ void load_ktile(KTile<ROWS> &f, const float *__restrict__ src, long ld, long r0, long rmax, int k0, int K) {
@@ -115,17 +118,29 @@ __device__ __forceinline__ void store_ntile(const NTile<COLS> &f, float *dst /* 
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------------------
-// C[M x N] = epilogue( A[M x K] . B ),  B(k, n) = BT ? Bm[n * ldb + k] : Bm[k * ldb + n].
-// ACT: 0 none, 1 exact GELU.  bias (per n) and residual (C-shaped) optional.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, bool VEC, bool FULLK, int EPI>
+// C_z[M x N] = epilogue( A_z[M x K] . B_z ),  z = blockIdx.y (operand strides sA / sB / sC elements, 0 = shared),
+//   A(m, k) = AKC ? A[m * lda + k] : A[k * lda + m],   B(k, n) = BT ? Bm[n * ldb + k] : Bm[k * ldb + n].
+// EPI: bit 0 = + residual (C-shaped), bit 1 = exact GELU.  bias optional: per column n, or per row m when BIAS_ROW (the NCHW 1x1 projection).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, bool VEC, bool FULLK, int EPI, bool AKC = true, bool BIAS_ROW = false>
 __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ A, const float *__restrict__ Bm, float *__restrict__ C,
                                                        const float *__restrict__ bias, const float *__restrict__ residual, long M, int N, int K,
-                                                       long lda, long ldb, long ldc, int tiles_n, int vec_out) {
+                                                       long lda, long ldb, long ldc, int tiles_n, int vec_out, long sA, long sB, long sC,
+                                                       int nsplit, int klen) {
     static_assert(WAVES_M * WAVES_N == 4, "four waves");
     constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
-    constexpr int A_ELEMS = BM * KP;
+    constexpr int A_ELEMS = AKC ? BM * KP : BK * (BM + 4);
     constexpr int B_ELEMS = BT ? BN * KP : BK * (BN + 4);
     extern __shared__ __attribute__((aligned(16))) float lds[];        // [2][A_ELEMS + B_ELEMS]
+    // z = batch * nsplit + split: a split covers k in [split * klen, min(K, (split + 1) * klen)) and writes its own C slab (split-K)
+    {
+        const int zb = blockIdx.y / nsplit, sp = blockIdx.y - zb * nsplit;
+        const long k0 = (long)sp * klen;
+        A += (long)zb * sA + (AKC ? k0 : k0 * lda);
+        Bm += (long)zb * sB + (BT ? k0 : k0 * ldb);
+        C += (long)blockIdx.y * sC;
+        if (residual) residual += (long)blockIdx.y * sC;
+        K = (int)min((long)klen, (long)K - k0);
+    }
     // XCD-aware order: consecutive workgroup ids land on different XCDs; give each XCD a contiguous band of M-tiles (they share the B
     // operand through that XCD's L2 and, for one M-tile, the A rows across the N-tiles)
     const long nblk = gridDim.x;
@@ -153,24 +168,38 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
     // loads down to their use (measured: loads issued right in front of the LDS stores, full latency exposed every step)
 
     KTile<BM> fa;
+    NTile<BM> fan;
     KTile<BN> fbt;
     NTile<BN> fbn;
     const int nk = (K + BK - 1) / BK;
-    load_ktile<BM, VEC, FULLK>(fa, A, lda, m0, M, 0, K);
-    if (BT) load_ktile<BN, VEC, FULLK>(fbt, Bm, ldb, n0, N, 0, K);
-    else load_ntile<BN, VEC, FULLK>(fbn, Bm, ldb, n0, N, 0, K);
+    auto load_tiles = [&](int k0) {
+        if (AKC) load_ktile<BM, VEC, FULLK>(fa, A, lda, m0, M, k0, K);
+        else load_ntile<BM, VEC, FULLK>(fan, A, lda, (int)m0, (int)M, k0, K);
+        if (BT) load_ktile<BN, VEC, FULLK>(fbt, Bm, ldb, n0, N, k0, K);
+        else load_ntile<BN, VEC, FULLK>(fbn, Bm, ldb, n0, N, k0, K);
+    };
+    auto store_tiles = [&](float *buf) {
+        if (AKC) store_ktile<BM>(fa, buf);
+        else store_ntile<BM>(fan, buf);
+        if (BT) store_ktile<BN>(fbt, buf + A_ELEMS);
+        else store_ntile<BN>(fbn, buf + A_ELEMS);
+    };
+    load_tiles(0);
     if (FULLK) wait_loads();
-    store_ktile<BM>(fa, lds);
-    if (BT) store_ktile<BN>(fbt, lds + A_ELEMS);
-    else store_ntile<BN>(fbn, lds + A_ELEMS);
+    store_tiles(lds);
     __syncthreads();
     // Fragments of one quad (8 consecutive k): per lane 4 k-values of TM A rows and TN B columns.
     struct Frag { float a[TM][4], b[TN][4]; };
     auto read_frag = [&](Frag &f, const float *As, const float *Bs, int q4) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const float4 v = *reinterpret_cast<const float4 *>(As + (wm + 32 * i + r) * KP + 8 * q4 + 4 * kh);
-            f.a[i][0] = v.x, f.a[i][1] = v.y, f.a[i][2] = v.z, f.a[i][3] = v.w;
+            if (AKC) {
+                const float4 v = *reinterpret_cast<const float4 *>(As + (wm + 32 * i + r) * KP + 8 * q4 + 4 * kh);
+                f.a[i][0] = v.x, f.a[i][1] = v.y, f.a[i][2] = v.z, f.a[i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f.a[i][e] = As[(8 * q4 + 4 * kh + e) * (BM + 4) + wm + 32 * i + r];
+            }
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -205,9 +234,7 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
     for (int kt = 0; kt + 1 < nk; ++kt) {
         const float *cur = lds + (kt & 1) * (A_ELEMS + B_ELEMS);
         float *nxt = lds + ((kt + 1) & 1) * (A_ELEMS + B_ELEMS);
-        load_ktile<BM, VEC, FULLK>(fa, A, lda, m0, M, (kt + 1) * BK, K);
-        if (BT) load_ktile<BN, VEC, FULLK>(fbt, Bm, ldb, n0, N, (kt + 1) * BK, K);
-        else load_ntile<BN, VEC, FULLK>(fbn, Bm, ldb, n0, N, (kt + 1) * BK, K);
+        load_tiles((kt + 1) * BK);
         __builtin_amdgcn_sched_barrier(0);      // keep the loads HERE: the scheduler otherwise sinks them to just above the LDS stores
         read_frag(f1, cur, cur + A_ELEMS, 1);
         mma(f0);
@@ -215,9 +242,7 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
         mma(f1);
         __builtin_amdgcn_sched_barrier(0);
         if (FULLK) wait_loads();
-        store_ktile<BM>(fa, nxt);
-        if (BT) store_ktile<BN>(fbt, nxt + A_ELEMS);
-        else store_ntile<BN>(fbn, nxt + A_ELEMS);
+        store_tiles(nxt);
         read_frag(f1, cur, cur + A_ELEMS, 3);
         mma(f0);
         __syncthreads();
@@ -247,7 +272,7 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
         const int lr = lane / LPR, lc = (lane % LPR) * 4;
         const int ncol = n0 + wn + lc;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias && ncol < N) bv = *reinterpret_cast<const float4 *>(bias + ncol);
+        if (!BIAS_ROW && bias && ncol < N) bv = *reinterpret_cast<const float4 *>(bias + ncol);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -261,7 +286,12 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
                 for (int rr = 0; rr < 32; rr += RPI) {
                     const long m = m0 + wm + 32 * i + rr + lr;
                     float4 v = *reinterpret_cast<const float4 *>(img + (rr + lr) * WP + lc);
-                    v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                    if (BIAS_ROW) {
+                        const float br = bias ? bias[m < M ? m : M - 1] : 0.f;
+                        v.x += br, v.y += br, v.z += br, v.w += br;
+                    } else {
+                        v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
+                    }
                     if (ACT) v.x = gelu_exact(v.x), v.y = gelu_exact(v.y), v.z = gelu_exact(v.z), v.w = gelu_exact(v.w);
                     if (IN || (m < M && ncol < N)) {
                         if (RES) {
@@ -285,14 +315,14 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
         const int n = n0 + wn + 32 * j + r;
         const bool nin = n < N;
         const int nc = nin ? n : N - 1;
-        const float bv = bias ? bias[nc] : 0.f;
+        const float bv = (bias && !BIAS_ROW) ? bias[nc] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const long m = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * kh;
                 const long mc = m < M ? m : M - 1;
-                float v = acc[i][j][e] + bv;
+                float v = acc[i][j][e] + (BIAS_ROW ? (bias ? bias[mc] : 0.f) : bv);
                 if (ACT) v = gelu_exact(v);
                 if (RES) v += residual[mc * ldc + nc];
                 if (nin && m < M) C[m * ldc + nc] = v;
@@ -301,23 +331,24 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, int EPI>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, int EPI, bool AKC = true, bool BIAS_ROW = false>
 int launch_epi(const float *A, const float *Bm, float *C, const float *bias, const float *residual, long M, int N, int K, long lda, long ldb,
-               long ldc, hipStream_t st) {
+               long ldc, hipStream_t st, int batch = 1, long sA = 0, long sB = 0, long sC = 0, int nsplit = 1, int klen = 0) {
+    if (klen <= 0 || nsplit <= 1) { nsplit = 1; klen = K; }
     // two staging buffers, or ONE when the whole reduction is a single k-step (K <= 32: the stage-1 products -- HBM-bound, so what matters
     // there is how many workgroups, i.e. bytes in flight, a CU holds)
-    const size_t lds_bytes = (K > BK ? 2 : 1) * (size_t)(BM * KP + (BT ? BN * KP : BK * (BN + 4))) * sizeof(float);
+    const size_t lds_bytes = (klen > BK ? 2 : 1) * (size_t)((AKC ? BM * KP : BK * (BM + 4)) + (BT ? BN * KP : BK * (BN + 4))) * sizeof(float);
     const long tiles_m = (M + BM - 1) / BM;
     const int tiles_n = (N + BN - 1) / BN;
     const long nblk = tiles_m * tiles_n;
-    if (nblk > 0x7fffffffL) return SD_E_SHAPE;
-    // 16-byte loads need aligned rows: base pointers, leading dimensions, and (k-contiguous tiles) K % 4, (n-contiguous) N % 4
+    if (nblk > 0x7fffffffL || batch < 1 || (long)batch * nsplit > 65535) return SD_E_SHAPE;
+    // 16-byte loads need aligned rows: base pointers, leading dimensions, batch strides, and the contiguous axis of each operand a multiple of 4
     const bool vec = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bm) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
-                     K % 4 == 0 && (BT || N % 4 == 0);
-    const bool fullk = vec && K % BK == 0;
-    auto kern = fullk ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, true, EPI>
-                      : (vec ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, false, EPI>
-                             : token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, false, false, EPI>);
+                     sA % 4 == 0 && sB % 4 == 0 && klen % 4 == 0 && (AKC ? K % 4 == 0 : M % 4 == 0) && (BT ? K % 4 == 0 : N % 4 == 0);
+    const bool fullk = vec && K % BK == 0 && klen % BK == 0 && (AKC || M >= 4) && (BT || N >= 4);
+    auto kern = fullk ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, true, EPI, AKC, BIAS_ROW>
+                      : (vec ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, false, EPI, AKC, BIAS_ROW>
+                             : token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, false, false, EPI, AKC, BIAS_ROW>);
     if (lds_bytes > 64 * 1024) {
         static bool raised[3] = {false, false, false};   // per instantiation (this function template) and load flavour; idempotent, so a race is harmless
         const int flavour = fullk ? 2 : (vec ? 1 : 0);
@@ -327,10 +358,12 @@ int launch_epi(const float *A, const float *Bm, float *C, const float *bias, con
             raised[flavour] = true;
         }
     }
-    // row-major 16-byte epilogue: rows of C (and of the residual, the bias vector) 16-byte aligned and N % 4 == 0
-    const int vec_out = ((reinterpret_cast<uintptr_t>(C) & 15) == 0 && ldc % 4 == 0 && N % 4 == 0 && (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0) &&
-                         (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0)) ? 1 : 0;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds_bytes, st, A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, tiles_n, vec_out);
+    // row-major 16-byte epilogue: rows of C (and of the residual, a per-column bias vector) 16-byte aligned and N % 4 == 0
+    const int vec_out = ((reinterpret_cast<uintptr_t>(C) & 15) == 0 && ldc % 4 == 0 && sC % 4 == 0 && N % 4 == 0 &&
+                         (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0) &&
+                         (BIAS_ROW || !bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0)) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)(batch * nsplit)), dim3(256), lds_bytes, st, A, Bm, C, bias, residual, M, N, K, lda, ldb,
+                       ldc, tiles_n, vec_out, sA, sB, sC, nsplit, klen);
     return (int)hipGetLastError();
 }
 
@@ -361,6 +394,27 @@ int dispatch(const float *A, const float *Bm, float *C, const float *bias, const
 }
 
 }  // namespace
+
+// ---- the NCHW 1x1 feature-align projection in fp32 on the same kernel (entry points in align1x1.hip; SURVEY a-15) --------------------------
+//   forward   Y_b [Ct x P] = W [Ct x Cs] . X_b [Cs x P] + bias[Ct]      A = W (k-contiguous, shared by the batch), B = X_b ([k][n]), row bias
+//   bwd-data  dX_b [Cs x P] = W^T . dY_b [Ct x P]                        A = W read as [k][m] (m-contiguous), B = dY_b ([k][n])
+//   bwd-wgt   slab_z [Ct x Cs] = dY_b[:, chunk] . X_b[:, chunk]^T        A = dY_b ([m][k]), B = X_b ([n][k]); z = (image, pixel chunk), combined
+//                                                                         by the caller's deterministic slab reduction
+int align_f32_fwd(const float *X, const float *W, const float *bias, float *Y, int B, int Cs, int Ct, long P, hipStream_t st) {
+    return launch_epi<128, 128, 2, 2, false, 0, true, true>(W, X, Y, bias, nullptr, Ct, (int)P, Cs, Cs, P, P, st, B, 0L, (long)Cs * P, (long)Ct * P);
+}
+
+int align_f32_bwd_data(const float *dY, const float *W, float *dX, int B, int Cs, int Ct, long P, hipStream_t st) {
+    return launch_epi<128, 128, 2, 2, false, 0, false, false>(W, dY, dX, nullptr, nullptr, Cs, (int)P, Ct, Cs, P, P, st, B, 0L, (long)Ct * P,
+                                                              (long)Cs * P);
+}
+
+int align_f32_bwd_weight_slabs(const float *dY, const float *X, float *slabs, int B, int Cs, int Ct, long P, int nsplit, int klen, hipStream_t st) {
+    // z = image * nsplit + pixel chunk; slab z = dY_b[:, chunk] . X_b[:, chunk]^T  (both operands k-contiguous along the pixels)
+    return launch_epi<128, 128, 2, 2, true, 0, true, false>(dY, X, slabs, nullptr, nullptr, Ct, Cs, (int)P, P, P, Cs, st, B, (long)Ct * P, (long)Cs * P,
+                                                            (long)Ct * Cs, nsplit, klen);
+}
+
 }  // namespace sd
 
 extern "C" {

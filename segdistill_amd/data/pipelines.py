@@ -87,6 +87,7 @@ class Resize:
             self.img_scale = None
         else:
             self.img_scale = img_scale if isinstance(img_scale, list) else [img_scale]
+            assert all(isinstance(s, tuple) for s in self.img_scale)      # mmcv.is_list_of(img_scale, tuple), transforms.py:264
         if ratio_range is not None:
             assert self.img_scale is None or len(self.img_scale) == 1
         else:
@@ -268,6 +269,22 @@ class Pad:
         results.update(img=img, pad_shape=img.shape, pad_fixed_size=self.size, pad_size_divisor=self.size_divisor)
         for key in results.get('seg_fields', []):
             results[key] = imops.impad(results[key], img.shape[:2], self.seg_pad_val)
+        return results
+
+
+@PIPELINES.register_module()
+class SegRescale:
+    """transforms.py:1070-1096: rescale the label maps only (nearest), e.g. to the stride of an auxiliary output."""
+
+    def __init__(self, scale_factor=1):
+        self.scale_factor = scale_factor
+
+    def __call__(self, results):
+        for key in results.get('seg_fields', []):
+            if self.scale_factor != 1:
+                seg = results[key]
+                h, w = seg.shape[:2]
+                results[key] = imops.imresize(seg, (int(w * float(self.scale_factor) + 0.5), int(h * float(self.scale_factor) + 0.5)), 'nearest')
         return results
 
 

@@ -138,8 +138,22 @@ class KLDLoss(nn.Module):
         self.host_prepare(n_iter, channels)
         self.sync_device_state(channels, device)
 
-    def forward(self, x_student, x_teacher, gt, n_iter):
-        channels = x_student.shape[1]
+    # ---- token-major taps [B, N, C] (SegFormer decoder features; SURVEY a-16) ----------------------------------------------------
+    def tokens_ok(self, x_teacher):
+        """This criterion can run on token-major operands as they are: 'channel' rows, no resize (a token sequence has no (h, w) to resize
+        to the label size; config 5 uses resize_config=None), whole 16-byte channel vectors."""
+        if self.resize_config or not self.transform_config or self.transform_config.get('loss_type') != 'channel':
+            return False
+        n = 4 if x_teacher.dtype == torch.float32 else 8
+        return x_teacher.is_cuda and x_teacher.dtype in (torch.float32, torch.bfloat16) and x_teacher.shape[2] % n == 0 and \
+            (not self.shuffle_config or x_teacher.shape[2] <= 2048)
+
+    def forward_tokens(self, x_student, x_teacher, gt, n_iter):
+        """forward() for token-major operands [B, N, C] (same schedule / shuffle state machine, csrc/cgd_tok.hip kernels)."""
+        return self.forward(x_student, x_teacher, gt, n_iter, _tokens=True)
+
+    def forward(self, x_student, x_teacher, gt, n_iter, _tokens=False):
+        channels = x_student.shape[2] if _tokens else x_student.shape[1]
         self._seen = (channels, x_student.device)
         capturing = x_student.is_cuda and torch.cuda.is_current_stream_capturing()
         if not capturing:
@@ -152,7 +166,10 @@ class KLDLoss(nn.Module):
         else:
             alpha, alpha_t = self.alpha, None
             perm = None if self._perm_host is None else self._perm_host.to(device=x_student.device, dtype=torch.int32)
-        loss = self._device_part(x_student, x_teacher, gt, alpha, perm)
+        if _tokens:
+            loss = ops.cgd_kl_tokens(x_student, x_teacher, group_size=self.transform_config['group_size'], tau=self.tau, alpha=alpha, perm=perm)
+        else:
+            loss = self._device_part(x_student, x_teacher, gt, alpha, perm)
         return loss if alpha_t is None else loss * alpha_t
 
     def _device_part(self, x_student, x_teacher, gt, alpha, perm):

@@ -72,6 +72,16 @@ class FeatureAlign(nn.Module):
     def forward(self, x):
         return ops.align1x1(x, self.weight, self.bias)
 
+    def forward_tokens(self, x):
+        """The same projection on a token-major tap [B, N, Cs] -> [B, N, Ct]: in this layout a 1x1 conv IS a Linear over the tokens, so it
+        runs through the token Linear machinery (library / MFMA GEMM forward, split-K MFMA weight gradient, deferred bias column sums) and
+        nothing is transposed.  bf16 taps: bf16 products with fp32 accumulation, fp32 master weight (as under autocast)."""
+        from ..linear import token_linear
+        if x.dtype == torch.bfloat16 and not torch.is_autocast_enabled():
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                return token_linear(x, self.weight, self.bias, defer_ok=True)
+        return token_linear(x, self.weight, self.bias, defer_ok=True)
+
     def extra_repr(self):
         return f'{self.weight.shape[1]} -> {self.weight.shape[0]}'
 
@@ -120,16 +130,31 @@ class DistillationLoss(nn.Module):
             if hasattr(c, 'prepare_replay'):
                 c.prepare_replay(step)
 
+    def entry_loss(self, i, x_student, x_teacher, gt_semantic_seg, step):
+        """Entry i of the config on RAW taps ([B,C,h,w], or token-major [B,N,C] as decode_head.linear_c1..4 emit them): align projection of
+        the student feature (when the entry has channel_nums) + criterion.  Token-major taps stay token-major when the criterion has a
+        token form for them (KLDLoss 'channel' rows without a resize: csrc/cgd_tok.hip) -- no [B,C,h,w] view, hence no transpose copy of
+        either tap or of the gradient; otherwise they are viewed as [B,C,h,w] (reference opts.py:25-27)."""
+        crit = self.criteria[i]
+        align = self.aligns[str(i)] if str(i) in self.aligns else None
+        if x_student.dim() == 3 and x_teacher.dim() == 3 and hasattr(crit, 'tokens_ok'):
+            ct = x_teacher.shape[2]
+            cs_out = align.weight.shape[0] if align is not None else x_student.shape[2]
+            if cs_out == ct and x_student.shape[:2] == x_teacher.shape[:2] and crit.tokens_ok(x_teacher):
+                y = align.forward_tokens(x_student) if align is not None else x_student
+                return crit.forward_tokens(y, x_teacher, gt_semantic_seg, step)
+        x_s, x_t = _to_nchw(x_student), _to_nchw(x_teacher)
+        if align is not None:
+            x_s = align(x_s)
+        return crit(x_s, x_t, gt_semantic_seg, step)
+
     def forward(self, student_features, teacher_features, gt_semantic_seg, step, student=None, teacher=None):
         out = {}
         for i, entry in enumerate(self.distillation):
             s_name, t_name = entry['student_layer'], entry['teacher_layer']
             if isinstance(s_name, list):
                 raise NotImplementedError('list-typed layers (attention-pair criteria) are not used by any shipped config')
-            x_s, x_t = _to_nchw(student_features[s_name]), _to_nchw(teacher_features[t_name])
-            if str(i) in self.aligns:
-                x_s = self.aligns[str(i)](x_s)
-            loss = self.criteria[i](x_s, x_t, gt_semantic_seg, step)
+            loss = self.entry_loss(i, student_features[s_name], teacher_features[t_name], gt_semantic_seg, step)
             try:
                 info = entry['loss_config']['transform_config']
             except (KeyError, TypeError):

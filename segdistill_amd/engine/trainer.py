@@ -269,9 +269,12 @@ class KDTrainer:
         into two walks.  Every walk therefore gets its own scope and starts from `.grad = None`; gradients of earlier walks are set
         aside and added back (one multi-tensor add, and only for parameters that really were reached twice)."""
         cuda = loss.is_cuda
-        with (deferred.scope() if cuda else contextlib.nullcontext()):
-            loss.backward()
         seg = getattr(self, '_seg', None)
+        # later walks may pass through nodes this one has already visited (a KD tap upstream of a chained norm shares the backbone with the
+        # path through the norm): keep the graph until the last walk (finish_backward frees it there)
+        keep = seg is not None and bool(seg.records)
+        with (deferred.scope() if cuda else contextlib.nullcontext()):
+            loss.backward(retain_graph=keep)
         if seg is not None and seg.records:
             seg.finish_backward(walk=self._isolated_walk if cuda else None)
 

@@ -77,6 +77,65 @@ def cgd_kl(S, T, *, group_size, tau, alpha, perm=None, return_rows=False):
     return (loss, rows) if return_rows else loss
 
 
+class _CGDKLTokFunction(torch.autograd.Function):
+    """The same criterion on token-major operands [B, P, C] (csrc/cgd_tok.hip): no NCHW view / transpose copy of the taps."""
+
+    @staticmethod
+    def forward(ctx, S, T, group_size, tau, alpha, perm):
+        _require_gpu(S, T)
+        if S.shape != T.shape or S.dim() != 3:
+            raise ValueError(f'expected equal token-major [B, P, C] shapes, got {tuple(S.shape)} and {tuple(T.shape)}')
+        if S.dtype != T.dtype or S.dtype not in _DT:
+            raise TypeError(f'unsupported dtypes {S.dtype}/{T.dtype}')
+        S, T = S.contiguous(), T.contiguous()
+        B, P, Cc = S.shape
+        g = int(group_size)
+        rows = B * (-(-Cc // g))
+        L = _lib.lib()
+        if perm is not None:
+            perm = perm.to(device=S.device, dtype=torch.int32).contiguous()
+            if perm.numel() != Cc:
+                raise ValueError('perm must have C entries')
+        ws_bytes = L.sd_cgd_kl_tok_workspace_bytes(B, Cc, P)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=S.device)
+        row_lse2 = torch.empty(rows, 2, dtype=torch.float32, device=S.device)
+        row_kl = torch.empty(rows, dtype=torch.float32, device=S.device)
+        loss = torch.empty((), dtype=torch.float32, device=S.device)
+        rc = L.sd_cgd_kl_tok_fwd(S.data_ptr(), T.data_ptr(), _DT[S.dtype], B, Cc, P, g, 1.0 / float(tau), float(alpha) / rows, _ptr(perm),
+                                 row_lse2.data_ptr(), row_kl.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr())
+        _lib.check(rc, 'sd_cgd_kl_tok_fwd')
+        ctx.save_for_backward(S, T, row_lse2, perm if perm is not None else torch.empty(0, device=S.device))
+        ctx.meta = (g, float(tau), float(alpha), rows, perm is not None)
+        ctx.mark_non_differentiable(row_kl)
+        return loss, row_kl
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_rows):
+        S, T, row_lse2, perm = ctx.saved_tensors
+        g, tau, alpha, rows, has_perm = ctx.meta
+        B, P, Cc = S.shape
+        dS = torch.empty_like(S)
+        up = grad_loss.to(torch.float32).contiguous()
+        rc = _lib.lib().sd_cgd_kl_tok_bwd(S.data_ptr(), T.data_ptr(), _DT[S.dtype], B, Cc, P, g, 1.0 / tau, alpha / (rows * tau),
+                                          perm.data_ptr() if has_perm else None, row_lse2.data_ptr(), up.data_ptr(), dS.data_ptr(), _stream_ptr())
+        _lib.check(rc, 'sd_cgd_kl_tok_bwd')
+        return dS, None, None, None, None, None
+
+
+def cgd_kl_tokens_supported(S, T, perm_len=None):
+    """Token-major [B, P, C] operands the kernels of csrc/cgd_tok.hip take: whole 16-byte channel vectors per pixel."""
+    if S.dim() != 3 or S.shape != T.shape or S.dtype != T.dtype or S.dtype not in _DT or not S.is_cuda:
+        return False
+    n = 4 if S.dtype == torch.float32 else 8
+    return S.shape[2] % n == 0 and (perm_len is None or S.shape[2] <= 2048)
+
+
+def cgd_kl_tokens(S, T, *, group_size, tau, alpha, perm=None, return_rows=False):
+    """Channel-group KL on token-major operands [B, P, C] at equal resolution.  HIP only."""
+    loss, rows = _CGDKLTokFunction.apply(S, T, group_size, tau, alpha, perm)
+    return (loss, rows) if return_rows else loss
+
+
 # ------------------------------------------------------------------------------------------------
 def can_fuse_resize(x_student, x_teacher, out_size, transform_config=None) -> bool:
     """True when the fused-upsample CGD kernels cover this case (same tap shapes, integer factor

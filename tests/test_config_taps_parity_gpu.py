@@ -3,7 +3,9 @@ path, with the CPU oracle evaluated ON THE VERY TAPS THE GPU PRODUCED.  Configs 
 (the 1x1 align projection and token-major taps: SURVEY a-15 / a-16), so they cannot be pinned by a reference-generated train-step
 fixture; what pins them is the composed flow
 
-    raw tap ([B,C,h,w] or token-major [B,N,C]) -> NCHW view -> align W.x + b -> (resize) -> grouped softmax KL
+    raw tap ([B,C,h,w] or token-major [B,N,C]) -> align W.x + b -> (resize) -> grouped softmax KL
+    (token-major taps are kept token-major by the product: align as a token Linear, criterion by csrc/cgd_tok.hip; the ORACLE views them
+    as [B,C,h,w] the way the reference's docstring / commented helper describe, so both the layout-free kernels and the view are checked)
 
 restated in fp64 by oracle/kd_ref.py (itself pinned to the reference's losses.py outputs, tests/test_oracle_golden.py).
 
@@ -87,7 +89,6 @@ CFGS = {'cfg1': ('cfg1_pspnet_r101_r18_cd.py', 2), 'cfg3': ('cfg3_segformer_b2_b
 def test_kd_entries_match_oracle_on_gpu_taps(tag):
     import bench
     from segdistill_amd.config import Config
-    from segdistill_amd.distillation.opts import _to_nchw
     from segdistill_amd.engine import KDTrainer, SyntheticADE
     fname, B = CFGS[tag]
     path = os.path.join(ROOT, 'configs', 'kd', fname)
@@ -139,10 +140,8 @@ def test_kd_entries_match_oracle_on_gpu_taps(tag):
             xs_b = xs[b:b + 1].clone().requires_grad_(True)
             if align is not None:
                 align.weight.grad = align.bias.grad = None
-            y = _to_nchw(xs_b)
-            if align is not None:
-                y = align(y)
-            val = crit(y, _to_nchw(xt[b:b + 1]), gt_dummy, seen['step'])
+            # the product's own per-entry flow on the RAW taps (token-major taps stay token-major: csrc/cgd_tok.hip + the token Linear)
+            val = dl.entry_loss(i, xs_b, xt[b:b + 1], gt_dummy, seen['step'])
             slice_vals.append(float(val))
             if b in (0, B - 1):
                 val.backward()

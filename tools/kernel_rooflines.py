@@ -28,7 +28,7 @@ MFMA_BF16 = 2500.0    # TFLOP/s dense
 VALU = 78.6           # T lane-instructions / s
 
 
-def _time(fn, reps, per_graph=5):
+def _time(fn, reps, per_graph=5, graph=True):
     """DEVICE ms per call: `per_graph` calls captured into a hipGraph, the graph replayed `reps` times, HIP events around each replay on the
     stream the kernels run on (median).  An eager loop would measure the host for the kernels that run under ~20 us."""
     fn0 = fn
@@ -43,6 +43,8 @@ def _time(fn, reps, per_graph=5):
     side.wait_stream(torch.cuda.current_stream())
     g = torch.cuda.CUDAGraph()
     try:
+        if not graph:
+            raise RuntimeError('eager timing requested')
         with torch.cuda.stream(side):
             fn()
             torch.cuda.synchronize()
@@ -211,9 +213,10 @@ def bench_ifvd(dev, reps, B=8, C=150, hw=128):
     S = (2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)).requires_grad_(True)
     T = 2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)
     cls = torch.randint(0, C, (B, hw, hw), device=dev, generator=gen, dtype=torch.int32)
-    tf = _time(lambda st: ops.ifvd_term(S.detach(), T, cls, C), reps)
+    # through the autograd binding (host-side sort / allocations inside): timed eagerly, not captured
+    tf = _time(lambda st: ops.ifvd_term(S.detach(), T, cls, C), reps, graph=False)
     loss = ops.ifvd_term(S, T, cls, C)
-    tb = _time(lambda st: torch.autograd.grad(loss, S, retain_graph=True), reps)
+    tb = _time(lambda st: torch.autograd.grad(loss, S, retain_graph=True), reps, graph=False)
     N = S.numel()
     note = 'through the autograd binding (includes the per-image class sort and small allocations); L2/Infinity-Cache resident at this size'
     return [_entry('ifvd fwd (class means + cosine pass, both networks)', 'ifvd_seg_sum x2 + ifvd_cos x2', [B, C, hw, hw], 'f32', tf, 'hbm', 4 * N * 4, HBM, note),
@@ -261,7 +264,9 @@ def run(device, only=None, reps=20):
     for name, fn in GROUPS.items():
         if only and name not in only:
             continue
+        print(f'[kernel_rooflines] {name} ...', file=sys.stderr, flush=True)
         out += fn(device, reps)
+        torch.cuda.synchronize()
         torch.cuda.empty_cache()
     return out
 
