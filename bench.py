@@ -173,6 +173,21 @@ def fused_leg(device, B, C=150, hw=128, F=4, g=8, tau=4.0, reps=20):
     return out
 
 
+def kernel_roofline_entries(groups=('r2', 'r1_bf16', 'tok', 'align', 'ce', 'pix', 'at', 'ifvd'), reps=10):
+    import subprocess
+    import tempfile
+    out = []
+    for g in groups:
+        with tempfile.NamedTemporaryFile(suffix='.json') as f:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'kernel_rooflines.py'), '--only', g, '--reps', str(reps), '--json', f.name],
+                               cwd=ROOT, capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                out.append({'name': g, 'error': f'kernel_rooflines.py --only {g} exited with {r.returncode}'})
+                continue
+            out += json.load(open(f.name))
+    return out
+
+
 def _usable_cores():
     """Host cores this process may really use: min(affinity mask, cgroup cpu quota)."""
     n = os.cpu_count() or 1
@@ -340,10 +355,10 @@ def main():
             torch.cuda.empty_cache()
             line['roofline'] = roofline_leg(device, B)
             line['roofline']['fused_r2'] = fused_leg(device, B)
-            # every other hand-written kernel of the path at its BASELINE shape against ITS bound (HBM / MFMA / VALU)
-            sys.path.insert(0, os.path.join(ROOT, 'tools'))
-            import kernel_rooflines
-            line['roofline']['kernels'] = kernel_rooflines.run(device, only=['r2', 'align', 'pix', 'at', 'ifvd', 'ce', 'r1_bf16'], reps=10)
+            # every other hand-written kernel of the path at its BASELINE shape against ITS bound (HBM / MFMA / VALU): tools/kernel_rooflines.py,
+            # one child process per kernel family (each captures and replays its own hipGraphs; isolation keeps a fault in one family from
+            # taking the bench line down with it)
+            line['roofline']['kernels'] = kernel_roofline_entries()
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_leg(cfg, max_threads=args.cpu_threads)
         print(json.dumps(line))

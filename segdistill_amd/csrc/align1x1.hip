@@ -324,10 +324,11 @@ __global__ __launch_bounds__(256) void bias_grad(const T *__restrict__ dY, float
 }
 
 int wgrad_splits(int B, long P) {
-    // aim for >= 512 workgroups in flight: tiles(M,N) are few (e.g. 4), so split the pixel axis
+    // tiles(M,N) are few (e.g. 4), so the pixel axis is split -- but every split writes (and the combine re-reads) a Ct x Cs slab, so no
+    // further than ~64 slabs in all: 4 tiles x 64 = one workgroup per CU, 16 k-steps each at config 4
     int per_img = (int)((P + 2047) / 2048);
     if (per_img < 1) per_img = 1;
-    while ((long)B * per_img < 128 && P / per_img > 256) per_img *= 2;
+    while ((long)B * per_img < 64 && P / per_img > 512) per_img *= 2;
     return per_img;
 }
 

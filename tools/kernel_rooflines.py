@@ -113,6 +113,34 @@ def bench_r1(dev, reps, B=8, C=150, HW=512, g=8, tau=4.0, dtype=torch.float32):
             _entry(f'cgd_kl R1 bwd ({tag})', 'cgd_bwd', [B, C, HW, HW], tag, tb, 'hbm', 3 * N * e, HBM)]
 
 
+def bench_tok(dev, reps, B=8, C=768, g=8, tau=4.0, dtype=torch.bfloat16):
+    """Token-major criterion at the four config-5 stage shapes [8, h*h, 768] (bf16 taps), h = 128, 64, 32, 16."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    DT = 0 if dtype == torch.float32 else 1
+    out = []
+    for h in (128, 64, 32, 16):
+        P = h * h
+        gen = torch.Generator(device=dev).manual_seed(1234)
+        S = (2 * torch.randn(B, P, C, device=dev, generator=gen)).to(dtype)
+        T = (2 * torch.randn(B, P, C, device=dev, generator=gen)).to(dtype)
+        rows = B * (-(-C // g))
+        lse, kl, loss, dS = torch.empty(rows, 2, device=dev), torch.empty(rows, device=dev), torch.empty((), device=dev), torch.empty_like(S)
+        wsb = L.sd_cgd_kl_tok_workspace_bytes(B, C, P)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        tf = _time(lambda st: _ok(L.sd_cgd_kl_tok_fwd(S.data_ptr(), T.data_ptr(), DT, B, C, P, g, 1 / tau, 3.0 / rows, None, lse.data_ptr(), kl.data_ptr(),
+                                                      loss.data_ptr(), ws.data_ptr(), wsb, st), 'tok fwd'), reps)
+        tb = _time(lambda st: _ok(L.sd_cgd_kl_tok_bwd(S.data_ptr(), T.data_ptr(), DT, B, C, P, g, 1 / tau, 3.0 / (rows * tau), None, lse.data_ptr(), None,
+                                                      dS.data_ptr(), st), 'tok bwd'), reps)
+        N, e = S.numel(), S.element_size()
+        tag = 'bf16' if dtype == torch.bfloat16 else 'f32'
+        note = None if h >= 64 else 'operands fit the 256 MiB Infinity Cache / launch-bound at this size'
+        out += [_entry(f'cgd_kl token-major fwd, cfg5 stage {(128, 64, 32, 16).index(h) + 1} ({tag})', 'cgd_tok_fwd_partials + cgd_fwd_rows + cgd_fwd_loss',
+                       [B, P, C], tag, tf, 'hbm', 2 * N * e, HBM, note),
+                _entry(f'cgd_kl token-major bwd, cfg5 stage {(128, 64, 32, 16).index(h) + 1} ({tag})', 'cgd_tok_bwd', [B, P, C], tag, tb, 'hbm', 3 * N * e, HBM, note)]
+    return out
+
+
 def bench_r2(dev, reps, B=8, C=150, hw=128, F=4, g=8, tau=4.0):
     """VALU-bound: per OUTPUT element and tensor ~ (1 + 3/F) interpolation FMAs + the online-softmax fold (~5 VALU + 1.06 exp for the pair)."""
     from segdistill_amd import _lib
@@ -249,9 +277,12 @@ GROUPS = {
     'r1': lambda dev, reps: bench_r1(dev, reps),
     'r1_bf16': lambda dev, reps: bench_r1(dev, reps, C=768, HW=128, dtype=torch.bfloat16),      # config 5 stage 1
     'r2': lambda dev, reps: bench_r2(dev, reps),
+    'tok': lambda dev, reps: bench_tok(dev, reps),
+    # config 4 (fp32, NCHW taps) is THE user of the NCHW align kernels; config 5's token-major taps take the token Linear (library bf16 GEMM +
+    # sd_linear_wgrad) -- the bf16 NCHW entry is kept as the direct-caller reference of the C ABI
     'align': lambda dev, reps: (bench_align(dev, reps, 8, 128, 512, 64, torch.float32, 'cfg4 f32')
-                                + sum((bench_align(dev, reps, 8, 256, 768, h, torch.bfloat16, f'cfg5 stage{i + 1} bf16') for i, h in enumerate((128, 64, 32, 16))), [])
-                                + bench_align(dev, reps, 8, 256, 768, 128, torch.float32, 'cfg5-shape f32')),
+                                + bench_align(dev, reps, 8, 256, 768, 128, torch.float32, 'C 256->768 at 128x128 f32')
+                                + bench_align(dev, reps, 8, 256, 768, 128, torch.bfloat16, 'C 256->768 at 128x128 bf16 (NCHW, direct callers)')),
     'pix': lambda dev, reps: bench_pix(dev, reps),
     'at': lambda dev, reps: bench_at(dev, reps),
     'ifvd': lambda dev, reps: bench_ifvd(dev, reps),

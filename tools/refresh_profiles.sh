@@ -1,31 +1,54 @@
 #!/bin/bash
 # Regenerate the round's measurement artifacts on an MI355X box (run from the repo root; writes under gpurun_out/refresh/).
-#   1 bench.json              the default `python bench.py` line (roofline + cpu_baseline)
+#   1 bench.json              the default `python bench.py` line (roofline + roofline.kernels + cpu_baseline)
 #   2 bench_kernel_stats.csv  rocprofv3 --kernel-trace --stats of the same command (+ the line it printed under the profiler)
 #   3 train_step_kernels.txt  per-step kernel table of the steady-state steps (tools/prof_summary.py)
 #   4 other_configs.txt       the other BASELINE configs, graph and hybrid mode
-#   5 microbench.txt          per-kernel micro-benchmarks (tools/kbench_step_kernels.py, tools/sra_bench.py)
+#   5 kernels_*.csv / pmc_*.json   rocprofv3 of tools/kernel_rooflines.py: kernel trace, then FETCH_SIZE / WRITE_SIZE / SQ_* in SEPARATE --pmc passes
+#   6 gemm_bench.txt          token-major Linear products: library vs csrc/token_gemm.hip, device time
+# rocprofv3 is always given the python program directly after `--`.
 set -u
 R=$(pwd)
 OUT=$R/gpurun_out/refresh
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py 2>/dev/null | tail -1 > $OUT/bench.json
+export PYTHONUNBUFFERED=1
+echo "[1] bench" | tee $OUT/progress.txt
+python bench.py 2>$OUT/bench.err | tail -1 > $OUT/bench.json
+echo "[2] bench under rocprof" | tee -a $OUT/progress.txt
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python3 $R/bench.py --no-cpu-baseline > /tmp/bench_prof.out 2>/dev/null )
 tail -1 /tmp/bench_prof.out > $OUT/bench_under_rocprof.json
 cp $(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1) $OUT/bench_kernel_stats.csv 2>/dev/null
-# per-step table: the same steps without the roofline legs (they launch the marker kernel too)
+echo "[3] per-step table" | tee -a $OUT/progress.txt
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_step -o step -- python3 $R/bench.py --no-cpu-baseline --no-roofline > /dev/null 2>&1 )
 python tools/prof_summary.py /tmp/prof_step --skip 8 --top 70 --out $OUT/train_step_kernels.txt > /dev/null
+echo "[4] other configs" | tee -a $OUT/progress.txt
 : > $OUT/other_configs.txt
 CONFIGS=${CONFIGS:-"cfg3_segformer_b2_b0_cgd_cd cfg5_segformer_b4_b1_multistage_bf16 cfg1_pspnet_r101_r18_cd cfg4_pspnet_r18_swin_b_cgd_align"}
 for c in $CONFIGS; do
   for g in on hybrid; do
     timeout 900 python bench.py --config configs/kd/$c.py --steps 10 --warmup 4 --graph $g --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | \
       python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$c', 'graph=$g', d['config']['hip_graph'], d['value'], 'imgs/s', d['ms_per_step'], 'ms/step', d['dtype'], 'B=%d' % d['config']['per_gpu_batch'])" >> $OUT/other_configs.txt 2>&1
+    echo "   $c $g done" | tee -a $OUT/progress.txt
   done
 done
-( python tools/kbench_step_kernels.py; python tools/sra_bench.py; python tools/sra_bench.py bf16 ) 2>/dev/null | grep -v amdgpu.ids > $OUT/microbench.txt
-ls -la $OUT
-cat $OUT/bench.json | cut -c1-1500
+echo "[5] kernel rooflines: trace + PMC passes" | tee -a $OUT/progress.txt
+for g in r1 tok r2 ce align; do
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kr_$g -o k -- python3 $R/tools/kernel_rooflines.py --only $g > $OUT/kernels_$g.txt 2>/dev/null )
+  cp $(find /tmp/kr_$g -name '*kernel_stats.csv' | head -1) $OUT/kernels_${g}_stats.csv 2>/dev/null
+done
+for g in r1 tok; do
+  ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$g -o p -- python3 $R/tools/kernel_rooflines.py --only $g > /dev/null 2>&1 )
+  ( cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$g -o p -- python3 $R/tools/kernel_rooflines.py --only $g > /dev/null 2>&1 )
+  python tools/pmc_summary.py /tmp/pf_$g /tmp/pw_$g --out $OUT/pmc_traffic_$g.json > /dev/null
+done
+for g in r2 ce; do
+  ( cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pv_$g -o p -- python3 $R/tools/kernel_rooflines.py --only $g > /dev/null 2>&1 )
+  ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pvf_$g -o p -- python3 $R/tools/kernel_rooflines.py --only $g > /dev/null 2>&1 )
+  python tools/pmc_summary.py /tmp/pv_$g /tmp/pvf_$g --out $OUT/pmc_valu_$g.json > /dev/null
+done
+echo "[6] gemm bench" | tee -a $OUT/progress.txt
+python tools/gemm_bench.py 2>/dev/null | grep -v amdgpu.ids > $OUT/gemm_bench.txt
+ls -la $OUT | tee -a $OUT/progress.txt
+cut -c1-600 $OUT/bench.json
 cat $OUT/other_configs.txt
