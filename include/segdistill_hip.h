@@ -241,11 +241,15 @@ int sd_cgd_kl_tok_bwd(const void *S, const void *T, int dtype, int B, int C, lon
  * bias / residual may be NULL.  X, Y, dY, dX dense row-major; W rows `w_row_stride` elements apart (0 = in_features; a column block of a wider
  * matrix -- the per-branch blocks of linear_fuse -- is passed without a copy).  16-byte loads are used when rows are 16-byte aligned; any shape
  * is accepted.
+ * mode: 0 = v_mfma_f32_32x32x2_f32 (bit-equal to an fp32 fmaf chain); 1 = split-bf16 ("bf16x3"): every fp32 operand is split exactly into
+ * three bf16 terms and a product is the sum of the six bf16 products of weight >= 2^-16 on v_mfma_f32_32x32x16_bf16 (fp32 accumulation) --
+ * the same error level as mode 0 (dropped terms <= 2^-24 relative; tests/test_token_gemm_gpu.py holds both modes to one bound) at 12
+ * instead of 32 matrix-pipe cycles per k.  mode 1: act == 0 only.
  */
 int sd_linear_fwd(const void *X, const float *W, long w_row_stride, const float *bias, const void *residual, void *Y, int dtype, long tokens,
-                  int in_features, int out_features, int act, void *stream);
+                  int in_features, int out_features, int act, int mode, void *stream);
 int sd_linear_bwd_data(const void *dY, const float *W, long w_row_stride, void *dX, int dtype, long tokens, int in_features, int out_features,
-                       void *stream);
+                       int mode, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Forward of a Linear with a LONG reduction axis and a small output: Y [rows][out] (fp32) = X [rows][in] . W[out][in]^T + bias.

@@ -52,8 +52,8 @@ SIGNATURES = {
     'sd_align1x1_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'sd_align1x1_bwd_data': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'sd_align1x1_bwd_weight': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
-    'sd_linear_fwd': (_i, [_vp, _vp, C.c_long, _vp, _vp, _vp, _i, C.c_long, _i, _i, _i, _vp]),
-    'sd_linear_bwd_data': (_i, [_vp, _vp, C.c_long, _vp, _i, C.c_long, _i, _i, _vp]),
+    'sd_linear_fwd': (_i, [_vp, _vp, C.c_long, _vp, _vp, _vp, _i, C.c_long, _i, _i, _i, _i, _vp]),
+    'sd_linear_bwd_data': (_i, [_vp, _vp, C.c_long, _vp, _i, C.c_long, _i, _i, _i, _vp]),
     'sd_linear_wgrad_workspace_bytes': (_sz, [C.c_long, _i, _i]),
     'sd_linear_longk_workspace_bytes': (_sz, [_i, _i, _i]),
     'sd_linear_longk_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -19,7 +19,9 @@
 namespace sd {
 namespace {
 
-constexpr int kTokU = 4;          // pixels per lane and step (independent 16-byte loads per operand in flight)
+constexpr int kTokU = 4;          // pixels per lane and step, fp32 (independent 16-byte loads per operand in flight); bf16: 2 -- 8 channel states per
+                                  // lane leave no room for more without dropping below 4 waves per SIMD
+template <typename T> constexpr int tok_u() { return VecIO<T>::N == 8 ? 2 : kTokU; }
 constexpr int kMaxPermC = 2048;   // inverse-permutation table in LDS
 
 struct TokGeo {
@@ -36,12 +38,29 @@ TokGeo tok_geometry(int C, long P) {
     q.r = 256 / q.VS < 1 ? 1 : 256 / q.VS;             // pixel lanes per vector position
     q.threads = (q.VS * q.r + 63) / 64 * 64;
     // ~64 pixels per lane and chunk, at least 4 chunks per image when the image is large enough: >= 1024 waves at the config-5 shapes
-    long chunk = (long)q.r * kTokU * 16;
-    while (chunk > (long)q.r * kTokU && (P + chunk - 1) / chunk < 4) chunk /= 2;
+    const int U = tok_u<T>();
+    long chunk = (long)q.r * U * (64 / U);
+    while (chunk > (long)q.r * U && (P + chunk - 1) / chunk < 4) chunk /= 2;
     q.pix_chunk = (int)chunk;
     q.nchunk = (int)((P + chunk - 1) / chunk);
     return q;
 }
+
+// 16-byte vector kept RAW in registers (4 VGPRs whatever the storage type); elements are widened on use.  The forward holds 2*U of
+// these per lane next to N online-softmax states: widening at load time (8 floats per bf16 vector) cost 136 VGPRs = 3 waves per SIMD.
+template <typename T> struct RawIO;
+template <> struct RawIO<float> {
+    typedef float raw_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ raw_t load(const float *p) { return __builtin_nontemporal_load(reinterpret_cast<const raw_t *>(p)); }
+    static __device__ __forceinline__ float elem(const raw_t &v, int i) { return v[i]; }
+};
+template <> struct RawIO<bf16_t> {
+    typedef unsigned int raw_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ raw_t load(const bf16_t *p) { return __builtin_nontemporal_load(reinterpret_cast<const raw_t *>(p)); }
+    static __device__ __forceinline__ float elem(const raw_t &v, int i) {
+        return (i & 1) ? __uint_as_float(v[i >> 1] & 0xffff0000u) : __uint_as_float(v[i >> 1] << 16);
+    }
+};
 
 // per-channel fold of U elements (cgd_device.h::fold with the element axis across pixels)
 template <int U>
@@ -54,9 +73,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void cgd_tok_fwd_partials(const T *__restrict__ S, const T *__restrict__ Tt, const int32_t *__restrict__ perm,
                                                              RowPart *__restrict__ part, int C, long P, int VS, int r, int nvb, int pix_chunk,
                                                              int nchunk, float c2) {
-    constexpr int N = VecIO<T>::N, U = kTokU;
-    __shared__ RowPart red[256 * N];
-    __shared__ int inv[kMaxPermC];
+    constexpr int N = VecIO<T>::N, U = tok_u<T>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char tok_smem[];   // RowPart red[(r-1) * VS * N], then int inv[C] when perm
+    RowPart *red = reinterpret_cast<RowPart *>(tok_smem);
+    int *inv = reinterpret_cast<int *>(tok_smem + (size_t)(r - 1) * VS * N * sizeof(RowPart));
     const int b = blockIdx.y;
     const int k = blockIdx.x / nvb, vb = blockIdx.x - k * nvb;
     const int t = threadIdx.x;
@@ -73,26 +93,36 @@ __global__ __launch_bounds__(256) void cgd_tok_fwd_partials(const T *__restrict_
 #pragma unroll
     for (int i = 0; i < N; ++i) st[i] = {kNegBig, 0.f, kNegBig, 0.f, 0.f};
     if (lane_ok) {
-        for (long p0 = p_lo + pr; p0 < p_hi; p0 += (long)r * U) {
-            float s[U][N], tt[U][N];
+        // software-pipelined: the vectors of step i+1 are requested before step i is folded (addresses clamped into the chunk, values masked)
+        typedef typename RawIO<T>::raw_t raw_t;
+        raw_t s[U], tt[U], sn[U], tn[U];
+        auto request = [&](long p0, raw_t (&a)[U], raw_t (&bq)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const long p = p0 + (long)u * r;
-                const long pc = p < p_hi ? p : p_hi - 1;          // clamped address, masked value
-                VecIO<T>::load(ps + (size_t)pc * C, s[u]);
-                VecIO<T>::load(pt + (size_t)pc * C, tt[u]);
-                if (p >= p_hi) {
-#pragma unroll
-                    for (int i = 0; i < N; ++i) s[u][i] = tt[u][i] = kNegBig;   // contributes exp(-big) = 0 and (t - s) = 0
-                }
+                const long pc = p < p_hi ? p : p_hi - 1;
+                a[u] = RawIO<T>::load(ps + (size_t)pc * C);
+                bq[u] = RawIO<T>::load(pt + (size_t)pc * C);
             }
+        };
+        request(p_lo + pr, s, tt);
+        for (long p0 = p_lo + pr; p0 < p_hi; p0 += (long)r * U) {
+            request(p0 + (long)r * U, sn, tn);
+            bool in[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) in[u] = p0 + (long)u * r < p_hi;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 float sv[U], tv[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) { sv[u] = s[u][i]; tv[u] = tt[u][i]; }
+                for (int u = 0; u < U; ++u) {                    // a masked element contributes exp(-big) = 0 and (t - s) = 0
+                    sv[u] = in[u] ? RawIO<T>::elem(s[u], i) : kNegBig;
+                    tv[u] = in[u] ? RawIO<T>::elem(tt[u], i) : kNegBig;
+                }
                 fold_channel<U>(st[i], sv, tv, c2);
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { s[u] = sn[u]; tt[u] = tn[u]; }
         }
     }
     // combine the r pixel lanes of a vector position (deterministic order), lane pr == 0 writes the N channel partials
@@ -122,8 +152,9 @@ template <typename T, bool NT>
 __global__ __launch_bounds__(256) void cgd_tok_bwd(const T *__restrict__ S, const T *__restrict__ Tt, const int32_t *__restrict__ perm,
                                                     const float *__restrict__ row_lse2, const float *__restrict__ upstream, T *__restrict__ dS,
                                                     int C, long P, int g, int G, int VS, int r, int nvb, int pix_chunk, float c2, float coef) {
-    constexpr int N = VecIO<T>::N, U = kTokU;
-    __shared__ int inv[kMaxPermC];
+    constexpr int N = VecIO<T>::N, U = tok_u<T>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char tok_smem[];   // int inv[C] when perm
+    int *inv = reinterpret_cast<int *>(tok_smem);
     const int b = blockIdx.y;
     const int k = blockIdx.x / nvb, vb = blockIdx.x - k * nvb;
     const int t = threadIdx.x;
@@ -186,7 +217,8 @@ int tok_fwd(const void *S, const void *Tt, int B, int C, long P, int g, float in
     if (ws_bytes < (size_t)B * C * q.nchunk * sizeof(RowPart) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
     const float c2 = inv_tau * 1.44269504088896340736f;
     RowPart *part = static_cast<RowPart *>(ws);
-    hipLaunchKernelGGL((cgd_tok_fwd_partials<T>), dim3((unsigned)(q.nchunk * q.nvb), B), dim3(q.threads), 0, st, (const T *)S, (const T *)Tt, perm,
+    const size_t lds = (size_t)(q.r - 1) * q.VS * q.N * sizeof(RowPart) + (perm ? (size_t)C * sizeof(int) : 0);
+    hipLaunchKernelGGL((cgd_tok_fwd_partials<T>), dim3((unsigned)(q.nchunk * q.nvb), B), dim3(q.threads), lds, st, (const T *)S, (const T *)Tt, perm,
                        part, C, P, q.VS, q.r, q.nvb, q.pix_chunk, q.nchunk, c2);
     launch_row_finalize(part, row_lse2, row_kl, loss, B, C, g, q.nchunk, c2, inv_tau, loss_scale, st);
     return (int)hipGetLastError();
@@ -198,7 +230,7 @@ int tok_bwd(const void *S, const void *Tt, int B, int C, long P, int g, float in
     const TokGeo q = tok_geometry<T>(C, P);
     const float c2 = inv_tau * 1.44269504088896340736f;
     const int G = (C + g - 1) / g;
-    hipLaunchKernelGGL((cgd_tok_bwd<T, true>), dim3((unsigned)(q.nchunk * q.nvb), B), dim3(q.threads), 0, st, (const T *)S, (const T *)Tt, perm,
+    hipLaunchKernelGGL((cgd_tok_bwd<T, true>), dim3((unsigned)(q.nchunk * q.nvb), B), dim3(q.threads), perm ? (size_t)C * sizeof(int) : 0, st, (const T *)S, (const T *)Tt, perm,
                        row_lse2, upstream, (T *)dS, C, P, g, G, q.VS, q.r, q.nvb, q.pix_chunk, c2, coef);
     return (int)hipGetLastError();
 }

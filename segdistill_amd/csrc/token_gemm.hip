@@ -28,6 +28,7 @@ namespace sd {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int BK = 32, KP = BK + 4;   // k-contiguous LDS rows: 36 floats = 144 B (16-byte aligned, conflict-free ds_read_b128 / ds_write_b128)
 
 __device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
@@ -121,7 +122,7 @@ __device__ __forceinline__ void store_ntile(const NTile<COLS> &f, float *dst /* 
 // C_z[M x N] = epilogue( A_z[M x K] . B_z ),  z = blockIdx.y (operand strides sA / sB / sC elements, 0 = shared),
 //   A(m, k) = AKC ? A[m * lda + k] : A[k * lda + m],   B(k, n) = BT ? Bm[n * ldb + k] : Bm[k * ldb + n].
 // EPI: bit 0 = + residual (C-shaped), bit 1 = exact GELU.  bias optional: per column n, or per row m when BIAS_ROW (the NCHW 1x1 projection).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, bool VEC, bool FULLK, int EPI, bool AKC = true, bool BIAS_ROW = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, bool VEC, bool FULLK, int EPI, bool AKC = true, bool BIAS_ROW = false, bool X3 = false>
 __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ A, const float *__restrict__ Bm, float *__restrict__ C,
                                                        const float *__restrict__ bias, const float *__restrict__ residual, long M, int N, int K,
                                                        long lda, long ldb, long ldc, int tiles_n, int vec_out, long sA, long sB, long sC,
@@ -229,6 +230,81 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
     //            | read sit behind 16 MFMAs (1024 cycles) instead of in front of them.  One barrier per k-step.
     // Two co-resident workgroups run this same program nearly in lockstep, so a bubble in one is not filled by the other (measured: 68 % MFMA
     // utilisation with the plain load / multiply / store / barrier order).
+    if constexpr (X3) {
+        // ---- split-bf16 products ("bf16x3"): every fp32 operand value is split EXACTLY into three bf16 terms x = hi + mid + lo (8 + 8 + 8
+        // significand bits; each residual of a round-to-nearest is exactly representable), and a product a.b is formed from the six
+        // bf16 x bf16 products whose weight is >= 2^-16 of the leading one -- hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid -- on
+        // v_mfma_f32_32x32x16_bf16 (products exact, fp32 accumulation).  The dropped terms (mid.lo, lo.mid, lo.lo) are <= 2^-24 relative:
+        // the rounding level of an fp32 fma chain itself (tests hold this path to the SAME error bound as the f32-input MFMA path).
+        // 16 k per instruction at 32 cycles, six instructions: 12 cycles per k against 32 for v_mfma_f32_32x32x2_f32.
+        // The split happens on the fragments (registers), so LDS holds plain fp32 tiles exactly as in the f32 path.
+        struct Frag2 { float a[TM][8], b[TN][8]; };
+        auto read_frag2 = [&](Frag2 &f, const float *As, const float *Bs, int s2) {
+            Frag lo4, hi4;
+            read_frag(lo4, As, Bs, 2 * s2);
+            read_frag(hi4, As, Bs, 2 * s2 + 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) { f.a[i][e] = lo4.a[i][e]; f.a[i][4 + e] = hi4.a[i][e]; }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) { f.b[j][e] = lo4.b[j][e]; f.b[j][4 + e] = hi4.b[j][e]; }
+            }
+        };
+        auto split8 = [&](const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const __bf16 hh = static_cast<__bf16>(x[e]);
+                const float r1 = x[e] - static_cast<float>(hh);
+                const __bf16 mm = static_cast<__bf16>(r1);
+                const float r2 = r1 - static_cast<float>(mm);
+                h[e] = hh, m[e] = mm, l[e] = static_cast<__bf16>(r2);
+            }
+        };
+        auto mma16 = [&](const Frag2 &f) {
+            bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) split8(f.a[i], ah[i], am[i], al[i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) split8(f.b[j], bh[j], bm[j], bl[j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], c, 0, 0, 0);      // small terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        };
+        Frag2 g0, g1;
+        read_frag2(g0, lds, lds + A_ELEMS, 0);
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const float *cur = lds + (kt & 1) * (A_ELEMS + B_ELEMS);
+            float *nxt = lds + ((kt + 1) & 1) * (A_ELEMS + B_ELEMS);
+            load_tiles((kt + 1) * BK);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frag2(g1, cur, cur + A_ELEMS, 1);
+            mma16(g0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (FULLK) wait_loads();
+            store_tiles(nxt);
+            __syncthreads();
+            read_frag2(g0, nxt, nxt + A_ELEMS, 0);
+            mma16(g1);
+        }
+        {
+            const float *cur = lds + ((nk - 1) & 1) * (A_ELEMS + B_ELEMS);
+            read_frag2(g1, cur, cur + A_ELEMS, 1);
+            mma16(g0);
+            mma16(g1);
+            __syncthreads();
+        }
+    } else {
     Frag f0, f1;
     read_frag(f0, lds, lds + A_ELEMS, 0);
     for (int kt = 0; kt + 1 < nk; ++kt) {
@@ -260,6 +336,7 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
         mma(f1);
         __syncthreads();
     }
+    }   // !X3
     // ---- epilogue (EPI: bit 0 = + residual, bit 1 = exact GELU; compile-time, so the plain Linear carries none of their registers) ----
     constexpr bool RES = (EPI & 1) != 0, ACT = (EPI & 2) != 0;
     if (vec_out) {
@@ -331,7 +408,7 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, int EPI, bool AKC = true, bool BIAS_ROW = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, int EPI, bool AKC = true, bool BIAS_ROW = false, bool X3 = false>
 int launch_epi(const float *A, const float *Bm, float *C, const float *bias, const float *residual, long M, int N, int K, long lda, long ldb,
                long ldc, hipStream_t st, int batch = 1, long sA = 0, long sB = 0, long sC = 0, int nsplit = 1, int klen = 0) {
     if (klen <= 0 || nsplit <= 1) { nsplit = 1; klen = K; }
@@ -346,9 +423,9 @@ int launch_epi(const float *A, const float *Bm, float *C, const float *bias, con
     const bool vec = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bm) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
                      sA % 4 == 0 && sB % 4 == 0 && klen % 4 == 0 && (AKC ? K % 4 == 0 : M % 4 == 0) && (BT ? K % 4 == 0 : N % 4 == 0);
     const bool fullk = vec && K % BK == 0 && klen % BK == 0 && (AKC || M >= 4) && (BT || N >= 4);
-    auto kern = fullk ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, true, EPI, AKC, BIAS_ROW>
-                      : (vec ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, false, EPI, AKC, BIAS_ROW>
-                             : token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, false, false, EPI, AKC, BIAS_ROW>);
+    auto kern = fullk ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, true, EPI, AKC, BIAS_ROW, X3>
+                      : (vec ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, false, EPI, AKC, BIAS_ROW, X3>
+                             : token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, false, false, EPI, AKC, BIAS_ROW, X3>);
     if (lds_bytes > 64 * 1024) {
         static bool raised[3] = {false, false, false};   // per instantiation (this function template) and load flavour; idempotent, so a race is harmless
         const int flavour = fullk ? 2 : (vec ? 1 : 0);
@@ -381,6 +458,14 @@ int launch(const float *A, const float *Bm, float *C, const float *bias, const f
             default: return launch_epi<BM, BN, WAVES_M, WAVES_N, BT, 3>(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, st);
         }
     }
+}
+
+// split-bf16 arithmetic (mode 1): only the 128x128 tile (these are the MFMA-bound, wide products) and the plain / + residual epilogues
+template <bool BT>
+int dispatch_x3(const float *A, const float *Bm, float *C, const float *bias, const float *residual, long M, int N, int K, long lda, long ldb,
+                long ldc, hipStream_t st) {
+    if (residual) return launch_epi<128, 128, 2, 2, BT, 1, true, false, true>(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, st);
+    return launch_epi<128, 128, 2, 2, BT, 0, true, false, true>(A, Bm, C, bias, nullptr, M, N, K, lda, ldb, ldc, st);
 }
 
 template <bool BT>
@@ -420,25 +505,35 @@ int align_f32_bwd_weight_slabs(const float *dY, const float *X, float *slabs, in
 extern "C" {
 
 int sd_linear_fwd(const void *X, const float *W, long w_row_stride, const float *bias, const void *residual, void *Y, int dtype, long tokens,
-                  int in_features, int out_features, int act, void *stream) {
+                  int in_features, int out_features, int act, int mode, void *stream) {
     if (!X || !W || !Y) return SD_E_NULL;
     if (dtype != SD_F32) return SD_E_DTYPE;
     if (tokens <= 0 || in_features <= 0 || out_features <= 0) return SD_E_SHAPE;
     if (w_row_stride == 0) w_row_stride = in_features;
     if (w_row_stride < in_features) return SD_E_SHAPE;
     if (act != 0 && act != 1) return SD_E_UNSUPPORTED;
+    if (mode != 0 && mode != 1) return SD_E_UNSUPPORTED;
+    if (mode == 1) {
+        if (act != 0) return SD_E_UNSUPPORTED;
+        return sd::dispatch_x3<true>((const float *)X, W, (float *)Y, bias, (const float *)residual, tokens, out_features, in_features, in_features,
+                                     w_row_stride, out_features, static_cast<hipStream_t>(stream));
+    }
     return sd::dispatch<true>((const float *)X, W, (float *)Y, bias, (const float *)residual, tokens, out_features, in_features, in_features,
                               w_row_stride, out_features, act, static_cast<hipStream_t>(stream));
 }
 
 int sd_linear_bwd_data(const void *dY, const float *W, long w_row_stride, void *dX, int dtype, long tokens, int in_features, int out_features,
-                       void *stream) {
+                       int mode, void *stream) {
     if (!dY || !W || !dX) return SD_E_NULL;
     if (dtype != SD_F32) return SD_E_DTYPE;
     if (tokens <= 0 || in_features <= 0 || out_features <= 0) return SD_E_SHAPE;
     if (w_row_stride == 0) w_row_stride = in_features;
     if (w_row_stride < in_features) return SD_E_SHAPE;
     // C[T x in] = dY[T x out] . W[out x in]: K = out_features, B(k, n) = W[k * ldw + n]
+    if (mode != 0 && mode != 1) return SD_E_UNSUPPORTED;
+    if (mode == 1)
+        return sd::dispatch_x3<false>((const float *)dY, W, (float *)dX, nullptr, nullptr, tokens, in_features, out_features, out_features, w_row_stride,
+                                      in_features, static_cast<hipStream_t>(stream));
     return sd::dispatch<false>((const float *)dY, W, (float *)dX, nullptr, nullptr, tokens, in_features, out_features, out_features, w_row_stride,
                                in_features, 0, static_cast<hipStream_t>(stream));
 }

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from ..builder import HEADS, build_loss
 from ..layers import ConvModule, frozen_derived, resize, tokens_of
-from ..linear import call_linear, token_linear
+from ..linear import call_linear, linear_forward, token_linear
 from .decode_head import BaseDecodeHead
 
 
@@ -77,9 +77,9 @@ class SegFormerHead(BaseDecodeHead):
             if fold:
                 # W_i P_i and W_i b_i: four small products per call -- cached while both parameters are frozen (the teacher)
                 wp, bp = mlp.proj.weight, mlp.proj.bias
-                w_fold = frozen_derived(w, ('fold_w', i), lambda: (wi @ wp).t().contiguous(), wp)
+                w_fold = frozen_derived(w, ('fold_w', i), lambda: (wi @ wp).contiguous(), wp)          # [E, Cin]: the layout of a Linear weight
                 b_fold = frozen_derived(w, ('fold_b', i), lambda: wi @ bp, bp)
-                z = torch.addmm(b_fold, tokens.reshape(-1, tokens.shape[-1]), w_fold)
+                z = linear_forward(tokens.reshape(-1, tokens.shape[-1]), w_fold, b_fold)              # measured dispatch: library / MFMA kernels
             else:
                 z = token_linear(mlp(feat).reshape(-1, e), wi)        # module call keeps forward hooks (taps) alive
             zs.append(z.reshape(n, -1, e))                            # token-major [B, h_i*w_i, E]

@@ -25,6 +25,7 @@ torch.batch_norm_gather_stats_with_counts, so a chained step and a plain torch S
 from __future__ import annotations
 
 import gc
+import os
 import time
 
 import torch
@@ -42,7 +43,11 @@ def quiesce_collectives():
 
 
 CAPTURE_MODE = 'thread_local'
-MAX_CHAINED_NORMS = 8   # more cuts than this (ResNet students: 28 SyncBN layers) and the hybrid mode is the better trade
+# Every chained norm costs two cuts = two more graph launches and two eager collectives per replayed step (~50 us in all).  Up to 8 that is
+# always a win over the hybrid mode; a ResNet-18 student has 28 + 5 of them (~70 segments): still a whole-step replay, but the networks that
+# have that many norms are bound by their 3x3 convolutions, not by launches, so the default stays conservative.  SEGDISTILL_MAX_CHAINED_NORMS
+# lifts it (tests/test_segmented_graph_gpu.py runs the ResNet-18 student with 64).
+MAX_CHAINED_NORMS = int(os.environ.get('SEGDISTILL_MAX_CHAINED_NORMS', '8'))
 
 
 class _Record:

@@ -20,23 +20,47 @@ MIN_TOKENS = 1     # every training Linear: below 8192 tokens dW is the library'
 _LONGK_ENABLED = os.environ.get('SEGDISTILL_LONGK') == '1'
 
 
-# Forward and input gradient on the exact-f32 MFMA kernels of csrc/token_gemm.hip instead of the library GEMM (fp32 only; SEGDISTILL_TOKEN_GEMM=0
-# restores the library for A/B runs).  `_gemm_preferred` is the MEASURED dispatch (tools/gemm_bench.py on MI355X, device time inside a replayed
-# graph, profiles/r02_gemm_bench.txt): hipBLASLt's fp32 kernels already run these shapes at 1.4-2x their roofline and the software-pipelined
-# kernel here only matches that (MFMA-bound shapes: 76 % vs 79 % of the f32-input MFMA peak), so it is used where it is measurably ahead --
-# the short-reduction products of stages 1-2 (K <= 64 over >= 32768 tokens: 9.7 vs 12.8 us for 32 -> 32, 38.8 vs 42.6 us for 32 -> 256) --
-# and the library everywhere else.
+# Forward and input gradient of fp32 Linears: the library GEMM, or the kernels of csrc/token_gemm.hip in one of two arithmetic modes.
+# `_gemm_mode` is the MEASURED dispatch (tools/gemm_bench.py on MI355X, device time inside a replayed graph; profiles/r02_gemm_bench.txt):
+#   'x3'   split-bf16 products on the bf16 matrix pipe (fp32-level accuracy: every fp32 operand is split exactly into three bf16 terms, six
+#          products kept; tests/test_token_gemm_gpu.py holds it to the f32 path's error bound).  12 matrix-pipe cycles per k instead of 32:
+#          ahead of the library by 14-26 % on the wide products that fill the chip with 128 x 128 tiles (head fuse 256 -> 256: 119 vs 139 us,
+#          teacher fc1 320 -> 1280: 52 vs 61 us, 32 -> 256: 31.6 vs 42.8 us);
+#   'f32'  v_mfma_f32_32x32x2_f32, bit-equal to an fmaf chain: matches the library on the MFMA-bound shapes (76 % vs 79 % of the f32-input peak)
+#          and is ahead only on the short-reduction products of stages 1-2 (K <= 64 over >= 32768 tokens: 9.7 vs 12.8 us for 32 -> 32);
+#   'lib'  everything else (few tokens, long reductions: the library's split-K / small-tile kernels).
+# SEGDISTILL_TOKEN_GEMM=0 forces the library everywhere, SEGDISTILL_SPLIT_BF16=0 keeps the kernels on exact-f32 arithmetic only (A/B runs).
 _TOKEN_GEMM = os.environ.get('SEGDISTILL_TOKEN_GEMM', '1') == '1'
+_SPLIT_BF16 = os.environ.get('SEGDISTILL_SPLIT_BF16', '1') == '1'
 
 
-def _gemm_preferred(tokens, k, n):
-    return _TOKEN_GEMM and tokens >= 32768 and k <= 64
+def _gemm_mode(tokens, k, n):
+    if not _TOKEN_GEMM:
+        return 'lib'
+    if _SPLIT_BF16 and n >= 128 and k % 32 == 0 and n % 4 == 0 and -(-tokens // 128) * -(-n // 128) >= 192 and \
+            (-(-n // 128) * 128) * 4 <= n * 5:
+        return 'x3'
+    if tokens >= 32768 and k <= 64:
+        return 'f32'
+    return 'lib'
 
 
-def _fwd(x, weight, bias):
-    if x.dtype == torch.float32 and token_gemm.supported(x, weight) and _gemm_preferred(x.numel() // x.shape[-1], x.shape[-1], weight.shape[0]):
-        return token_gemm.linear_fwd(x, weight, bias)
+def linear_forward(x, weight, bias):
+    """x . W^T + bias without autograd bookkeeping (frozen networks, and the forward of _TokenLinear): the measured three-way dispatch."""
+    if x.dtype == torch.float32 and token_gemm.supported(x, weight):
+        mode = _gemm_mode(x.numel() // x.shape[-1], x.shape[-1], weight.shape[0])
+        if mode != 'lib':
+            return token_gemm.linear_fwd(x, weight, bias, split_bf16=(mode == 'x3'))
     return F.linear(x, weight, bias)
+
+
+def _bwd_data(dy2, weight):
+    """dy2 [T, N] . W [N, K] -> [T, K] (None: not ours, use the library)."""
+    if dy2.dtype == torch.float32 and weight.dtype == torch.float32 and dy2.is_cuda and weight.dim() == 2:
+        mode = _gemm_mode(dy2.shape[0], weight.shape[0], weight.shape[1])
+        if mode != 'lib':
+            return token_gemm.linear_bwd_data(dy2, weight, split_bf16=(mode == 'x3'))
+    return None
 
 
 class _TokenLinear(torch.autograd.Function):
@@ -55,7 +79,7 @@ class _TokenLinear(torch.autograd.Function):
                 y = F.linear(xc, wc, None if bias is None else bias.to(dt))
             ctx.save_for_backward(xc, wc)
         else:
-            y = _fwd(x, weight, bias)
+            y = linear_forward(x, weight, bias)
             ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.in_dtype, ctx.w_dtype = x.dtype, weight.dtype
@@ -69,10 +93,8 @@ class _TokenLinear(torch.autograd.Function):
         if dy2.dtype != x.dtype:
             dy2 = dy2.to(x.dtype)
         if ctx.needs_input_grad[0]:
-            if dy2.dtype == torch.float32 and token_gemm.supported(dy2, weight.t()) and _gemm_preferred(dy2.shape[0], weight.shape[0], weight.shape[1]):
-                dx = token_gemm.linear_bwd_data(dy2, weight).reshape(x.shape)
-            else:
-                dx = (dy2 @ weight).reshape(x.shape).to(ctx.in_dtype)
+            dx = _bwd_data(dy2, weight)
+            dx = dx.reshape(x.shape) if dx is not None else (dy2 @ weight).reshape(x.shape).to(ctx.in_dtype)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             x2 = x.reshape(-1, x.shape[-1])
@@ -132,7 +154,7 @@ def token_linear(x, weight, bias=None, defer_ok=False, defer_bias_ok=None):
     if use:
         return _TokenLinear.apply(x, weight, bias, defer_ok, defer_ok if defer_bias_ok is None else defer_bias_ok)
     if x.is_cuda and not torch.is_autocast_enabled() and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)):
-        return _fwd(x, weight, bias)           # frozen network (the teacher): no graph to build
+        return linear_forward(x, weight, bias)           # frozen network (the teacher): no graph to build
     return F.linear(x, weight, bias)
 
 

@@ -26,8 +26,9 @@ def _rows(x):
     return x2 if x2.is_contiguous() else x2.contiguous()
 
 
-def linear_fwd(x, weight, bias=None, residual=None, act=None):
-    """act(x . W^T + bias) (+ residual); x [..., K] fp32, W [N, K] fp32 -> [..., N] fp32."""
+def linear_fwd(x, weight, bias=None, residual=None, act=None, split_bf16=False):
+    """act(x . W^T + bias) (+ residual); x [..., K] fp32, W [N, K] fp32 -> [..., N] fp32.  split_bf16: the bf16x3 arithmetic of
+    csrc/token_gemm.hip (fp32-level accuracy on the bf16 matrix pipe)."""
     x2 = _rows(x)
     w, ldw = _weight(weight)
     T, K = x2.shape
@@ -40,18 +41,18 @@ def linear_fwd(x, weight, bias=None, residual=None, act=None):
             raise ValueError('residual must be fp32 of the output shape')
     b = None if bias is None else (bias if bias.dtype == torch.float32 and bias.is_contiguous() else bias.float().contiguous())
     rc = _lib.lib().sd_linear_fwd(x2.data_ptr(), w.data_ptr(), ldw, None if b is None else b.data_ptr(), None if r2 is None else r2.data_ptr(),
-                                  y.data_ptr(), _lib.SD_F32, T, K, N, 1 if act == 'gelu' else 0, _stream_ptr())
+                                  y.data_ptr(), _lib.SD_F32, T, K, N, 1 if act == 'gelu' else 0, 1 if split_bf16 else 0, _stream_ptr())
     _lib.check(rc, 'sd_linear_fwd')
     return y.reshape(*x.shape[:-1], N)
 
 
-def linear_bwd_data(dy, weight):
+def linear_bwd_data(dy, weight, split_bf16=False):
     """dy . W; dy [..., N] fp32, W [N, K] fp32 -> [..., K] fp32."""
     d2 = _rows(dy)
     w, ldw = _weight(weight)
     T, N = d2.shape
     K = w.shape[1]
     dx = torch.empty(T, K, dtype=torch.float32, device=dy.device)
-    rc = _lib.lib().sd_linear_bwd_data(d2.data_ptr(), w.data_ptr(), ldw, dx.data_ptr(), _lib.SD_F32, T, K, N, _stream_ptr())
+    rc = _lib.lib().sd_linear_bwd_data(d2.data_ptr(), w.data_ptr(), ldw, dx.data_ptr(), _lib.SD_F32, T, K, N, 1 if split_bf16 else 0, _stream_ptr())
     _lib.check(rc, 'sd_linear_bwd_data')
     return dx.reshape(*dy.shape[:-1], K)

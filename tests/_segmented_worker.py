@@ -48,7 +48,8 @@ def pspnet_main():
     with warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter('always')
         out['full'] = bool(tr.enable_graph(data.next()))
-        out['hybrid'] = bool(tr.enable_hybrid_graph(data.next()))
+        out['segments'] = len(tr._seg.items) if out['full'] else 0
+        out['hybrid'] = False if out['full'] else bool(tr.enable_hybrid_graph(data.next()))
     out['warnings'] = [str(w.message)[:200] for w in caught if 'capture failed' in str(w.message)]
     out['backbone_graphed'] = getattr(model.student, '_graphed_backbone', None) is not None
     out['teacher_graphed'] = model._graphed_teacher is not None

@@ -104,3 +104,19 @@ def test_resnet_student_two_ranks_falls_back_cleanly():
         assert r['hybrid'] is True and r['teacher_graphed'] and not r['backbone_graphed']
         assert all(math.isfinite(v) for step in r['steps'] for v in step.values())
     assert out[0]['digest'] == out[1]['digest'] and out[0]['steps'] == out[1]['steps']
+
+
+def test_resnet_student_two_ranks_whole_step_replay_when_the_limit_is_lifted():
+    """SEGDISTILL_MAX_CHAINED_NORMS=64: the same PSPNet-R18 student (28 + 5 synchronised norms) is captured WHOLE -- ~70 graph segments with
+    the SyncBN collectives between them -- and both ranks keep training in step with finite losses."""
+    import math
+    env = dict(os.environ, SEGDISTILL_DIST_BACKEND='gloo', SEGDISTILL_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0', SEGDISTILL_MAX_CHAINED_NORMS='64')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), WORKER, 'pspnet']
+    out = _results(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900))
+    assert sorted(r['rank'] for r in out) == [0, 1]
+    for r in out:
+        assert r['full'] is True, r['warnings']
+        assert r['segments'] >= 2 * 28 + 1
+        assert all(math.isfinite(v) for step in r['steps'] for v in step.values())
+    assert out[0]['digest'] == out[1]['digest'] and out[0]['steps'] == out[1]['steps']

@@ -36,6 +36,13 @@ def test_linear_fwd_and_bwd_data_match_fp64(T, K, N):
     assert _rel(token_gemm.linear_fwd(x, w, b, act='gelu'), torch.nn.functional.gelu(ref)) < tol + 2e-7
     assert _rel(token_gemm.linear_fwd(x, w, b, residual=r), ref + r.double()) < tol
     assert _rel(token_gemm.linear_bwd_data(dy, w), dy.double() @ w64) < 3e-7 * max(8.0, N ** 0.5)
+    # split-bf16 arithmetic: the SAME bound as the f32-input MFMA path, and its error measured next to that path's
+    y3, y1 = token_gemm.linear_fwd(x, w, b, split_bf16=True), token_gemm.linear_fwd(x, w, b)
+    assert _rel(y3, ref) < tol
+    assert _rel(token_gemm.linear_fwd(x, w, b, residual=r, split_bf16=True), ref + r.double()) < tol
+    assert _rel(token_gemm.linear_bwd_data(dy, w, split_bf16=True), dy.double() @ w64) < 3e-7 * max(8.0, N ** 0.5)
+    e3, e1 = float((y3.double() - ref).norm() / ref.norm()), float((y1.double() - ref).norm() / ref.norm())
+    assert e3 < 2.0 * e1 + 1e-8, (e3, e1)          # rel-L2 error of the split path within 2x of the exact-f32 path
 
 
 def test_asymmetric_identity_and_3d_input():

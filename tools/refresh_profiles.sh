@@ -13,6 +13,10 @@ OUT=$R/gpurun_out/refresh
 mkdir -p $OUT
 export TMPDIR=/tmp
 export PYTHONUNBUFFERED=1
+# heartbeat: a quiet step (MIOpen find for the ResNet / Swin configs takes minutes) must not look like a hang to the GPU-box watchdog
+( while true; do sleep 45; echo "[heartbeat] $(date +%T)" >> $OUT/progress.txt; done ) &
+HB=$!
+trap "kill $HB 2>/dev/null" EXIT
 echo "[1] bench" | tee $OUT/progress.txt
 python bench.py 2>$OUT/bench.err | tail -1 > $OUT/bench.json
 echo "[2] bench under rocprof" | tee -a $OUT/progress.txt
