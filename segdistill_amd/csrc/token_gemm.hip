@@ -237,7 +237,11 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
         // v_mfma_f32_32x32x16_bf16 (products exact, fp32 accumulation).  The dropped terms (mid.lo, lo.mid, lo.lo) are <= 2^-24 relative:
         // the rounding level of an fp32 fma chain itself (tests hold this path to the SAME error bound as the f32-input MFMA path).
         // 16 k per instruction at 32 cycles, six instructions: 12 cycles per k against 32 for v_mfma_f32_32x32x2_f32.
-        // The split happens on the fragments (registers), so LDS holds plain fp32 tiles exactly as in the f32 path.
+        // The split happens on the fragments (registers), so LDS holds plain fp32 tiles exactly as in the f32 path.  (A variant that
+        // splits ONCE at staging into three bf16 LDS planes per operand -- no redundant splits, the multiply phase nothing but fragment
+        // reads and MFMAs -- measured the same: 121.9 vs 119.1 us at 256 -> 256 over 131072 tokens.  With a third of the matrix-pipe
+        // time this mode is bound by the operand stream (268 MB of HBM traffic = 43 us at that shape, one tile of loads in flight per
+        // workgroup), not by the split arithmetic; it was removed again.)
         struct Frag2 { float a[TM][8], b[TN][8]; };
         auto read_frag2 = [&](Frag2 &f, const float *As, const float *Bs, int s2) {
             Frag lo4, hi4;
@@ -283,6 +287,10 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
         };
         Frag2 g0, g1;
         read_frag2(g0, lds, lds + A_ELEMS, 0);
+        // (Tried and dropped, both for registers: two tiles of loads in flight in two register sets -- the step body then exists in several
+        // inlined copies and hipcc doubles the accumulators, 254 VGPR + 128 AGPR = one wave per SIMD; and parking the next tile at the END of
+        // the step -- both fragment sets plus their bf16 planes live at once: 213 + 128.  The form below fits 136 + 64.)
+        {
         for (int kt = 0; kt + 1 < nk; ++kt) {
             const float *cur = lds + (kt & 1) * (A_ELEMS + B_ELEMS);
             float *nxt = lds + ((kt + 1) & 1) * (A_ELEMS + B_ELEMS);
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
             read_frag2(g1, cur, cur + A_ELEMS, 1);
             mma16(g0);
             __builtin_amdgcn_sched_barrier(0);
-            if (FULLK) wait_loads();
+            if (FULLK) wait_loads();                      // the pinned (asm) loads are not counted by the compiler
             store_tiles(nxt);
             __syncthreads();
             read_frag2(g0, nxt, nxt + A_ELEMS, 0);
@@ -303,6 +311,7 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
             mma16(g0);
             mma16(g1);
             __syncthreads();
+        }
         }
     } else {
     Frag f0, f1;
@@ -460,175 +469,10 @@ int launch(const float *A, const float *Bm, float *C, const float *bias, const f
     }
 }
 
-// ---- split-bf16 forward with the split done ONCE, at staging ("planes") -------------------------------------------------------------------
-// The X3 variant above splits fragments in registers: every value is split by each of the two waves that use it and the ~450 vector
-// instructions per k-step sit in front of that wave's 48 MFMAs (measured: 34 % matrix-pipe utilisation).  Here, for two k-contiguous operands
-// (the forward Linear: activations [T][K], weight [N][K]), the staging pass splits each value once and LDS holds three bf16 planes per
-// operand ([plane][row][32 + 8] bf16, 80-byte rows: conflict-free ds_read_b128 of a ready 8-element MFMA fragment).  The multiply phase is
-// then nothing but fragment reads and MFMAs; the staging phase (wait for the prefetched fp32 registers, split, 24 ds_write_b64) is covered
-// by the co-resident workgroup's multiply phase (61 KB of LDS: two workgroups per CU).  Two barriers per k-step (one LDS stage).
-constexpr int PK = BK + 8;                                   // bf16 elements per plane row
-__device__ __forceinline__ void split4(const float4 v, uint2 &h, uint2 &m, uint2 &l) {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    unsigned short hb[4], mb[4], lb[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const __bf16 hh = static_cast<__bf16>(x[e]);
-        const float r1 = x[e] - static_cast<float>(hh);
-        const __bf16 mm = static_cast<__bf16>(r1);
-        const float r2 = r1 - static_cast<float>(mm);
-        const __bf16 ll = static_cast<__bf16>(r2);
-        hb[e] = __builtin_bit_cast(unsigned short, hh), mb[e] = __builtin_bit_cast(unsigned short, mm), lb[e] = __builtin_bit_cast(unsigned short, ll);
-    }
-    h = make_uint2((unsigned)hb[0] | ((unsigned)hb[1] << 16), (unsigned)hb[2] | ((unsigned)hb[3] << 16));
-    m = make_uint2((unsigned)mb[0] | ((unsigned)mb[1] << 16), (unsigned)mb[2] | ((unsigned)mb[3] << 16));
-    l = make_uint2((unsigned)lb[0] | ((unsigned)lb[1] << 16), (unsigned)lb[2] | ((unsigned)lb[3] << 16));
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256) void token_gemm_x3p(const float *__restrict__ A, const float *__restrict__ Bm, float *__restrict__ C,
-                                                       const float *__restrict__ bias, const float *__restrict__ residual, long M, int N, int K,
-                                                       long lda, long ldb, long ldc, int tiles_n) {
-    constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
-    constexpr int PLANE = 128 * PK;                           // bf16 elements of one plane of one operand
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    unsigned short *pl = reinterpret_cast<unsigned short *>(lds);   // [A: h, m, l][B: h, m, l], each [128][PK]
-    const long nblk = gridDim.x, id = blockIdx.x;
-    const long qq = nblk / 8, rem = nblk % 8, xcd = id % 8;
-    const long tile = (xcd < rem ? xcd * (qq + 1) : rem * (qq + 1) + (xcd - rem) * qq) + id / 8;
-    const long tm_idx = tile / tiles_n;
-    const int tn_idx = (int)(tile - tm_idx * tiles_n);
-    const long m0 = tm_idx * BM;
-    const int n0 = tn_idx * BN;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int r = lane & 31, kh = lane >> 5;
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    KTile<BM> fa;
-    KTile<BN> fb;
-    const int nk = K / BK;                                    // the launcher guarantees K % 32 == 0 and aligned rows (FULLK)
-    auto stage = [&]() {                                      // split the prefetched fp32 registers into the six planes
-        const int t = threadIdx.x, c = (t & 7) * 4;
-#pragma unroll
-        for (int i = 0; i < BM / 32; ++i) {
-            const int row = (t >> 3) + 32 * i;
-            uint2 h, m, l;
-            split4(fa.v[i], h, m, l);
-            *reinterpret_cast<uint2 *>(pl + 0 * PLANE + row * PK + c) = h;
-            *reinterpret_cast<uint2 *>(pl + 1 * PLANE + row * PK + c) = m;
-            *reinterpret_cast<uint2 *>(pl + 2 * PLANE + row * PK + c) = l;
-            split4(fb.v[i], h, m, l);
-            *reinterpret_cast<uint2 *>(pl + 3 * PLANE + row * PK + c) = h;
-            *reinterpret_cast<uint2 *>(pl + 4 * PLANE + row * PK + c) = m;
-            *reinterpret_cast<uint2 *>(pl + 5 * PLANE + row * PK + c) = l;
-        }
-    };
-    auto multiply = [&]() {
-#pragma unroll
-        for (int s2 = 0; s2 < BK / 16; ++s2) {
-            bf16x8 a[3][TM], b[3][TN];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[p][i] = *reinterpret_cast<const bf16x8 *>(pl + p * PLANE + (wm + 32 * i + r) * PK + 16 * s2 + 8 * kh);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[p][j] = *reinterpret_cast<const bf16x8 *>(pl + (3 + p) * PLANE + (wn + 32 * j + r) * PK + 16 * s2 + 8 * kh);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);      // small terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
-        }
-    };
-    load_ktile<BM, true, true>(fa, A, lda, m0, M, 0, K);
-    load_ktile<BN, true, true>(fb, Bm, ldb, n0, N, 0, K);
-    wait_loads();
-    stage();
-    __syncthreads();
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-        load_ktile<BM, true, true>(fa, A, lda, m0, M, (kt + 1) * BK, K);
-        load_ktile<BN, true, true>(fb, Bm, ldb, n0, N, (kt + 1) * BK, K);
-        __builtin_amdgcn_sched_barrier(0);
-        multiply();
-        __syncthreads();                                      // everybody has read the planes of tile kt
-        wait_loads();
-        stage();
-        __syncthreads();
-    }
-    multiply();
-    __syncthreads();
-    // ---- epilogue: row-major through LDS, as token_gemm_f32 (the launcher guarantees aligned C / bias / residual and N % 4 == 0) ----
-    constexpr bool RES = (EPI & 1) != 0;
-    constexpr int WCOLS = TN * 32, WP = WCOLS + 4, LPR = WCOLS / 4, RPI = 64 / LPR;
-    float *img = lds + wave * (32 * WP);
-    const int lr = lane / LPR, lc = (lane % LPR) * 4;
-    const int ncol = n0 + wn + lc;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias && ncol < N) bv = *reinterpret_cast<const float4 *>(bias + ncol);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) img[((e & 3) + 8 * (e >> 2) + 4 * kh) * WP + 32 * j + r] = acc[i][j][e];
-        __syncthreads();
-#pragma unroll
-        for (int rr = 0; rr < 32; rr += RPI) {
-            const long m = m0 + wm + 32 * i + rr + lr;
-            float4 v = *reinterpret_cast<const float4 *>(img + (rr + lr) * WP + lc);
-            v.x += bv.x, v.y += bv.y, v.z += bv.z, v.w += bv.w;
-            if (m < M && ncol < N) {
-                if (RES) {
-                    const float4 rv = *reinterpret_cast<const float4 *>(residual + m * ldc + ncol);
-                    v.x += rv.x, v.y += rv.y, v.z += rv.z, v.w += rv.w;
-                }
-                *reinterpret_cast<float4 *>(C + m * ldc + ncol) = v;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// can the planes kernel take this forward product?  (16-byte aligned k-contiguous rows, K a multiple of the k-step, aligned 16-byte epilogue)
-inline bool x3p_ok(const float *A, const float *Bm, const float *C, const float *bias, const float *residual, int N, int K, long lda, long ldb, long ldc) {
-    auto al = [](const void *p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    return al(A) && al(Bm) && al(C) && al(bias) && al(residual) && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && K % BK == 0 && N % 4 == 0;
-}
-
-int launch_x3p(const float *A, const float *Bm, float *C, const float *bias, const float *residual, long M, int N, int K, long lda, long ldb,
-               long ldc, hipStream_t st) {
-    const size_t lds_bytes = 6 * (size_t)128 * PK * sizeof(unsigned short);      // 61440 B; the epilogue image (34816 B) reuses it
-    const long tiles_m = (M + 127) / 128;
-    const int tiles_n = (N + 127) / 128;
-    const long nblk = tiles_m * tiles_n;
-    if (nblk > 0x7fffffffL) return SD_E_SHAPE;
-    if (residual) hipLaunchKernelGGL(token_gemm_x3p<1>, dim3((unsigned)nblk), dim3(256), lds_bytes, st, A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, tiles_n);
-    else hipLaunchKernelGGL(token_gemm_x3p<0>, dim3((unsigned)nblk), dim3(256), lds_bytes, st, A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, tiles_n);
-    return (int)hipGetLastError();
-}
-
 // split-bf16 arithmetic (mode 1): only the 128x128 tile (these are the MFMA-bound, wide products) and the plain / + residual epilogues
 template <bool BT>
 int dispatch_x3(const float *A, const float *Bm, float *C, const float *bias, const float *residual, long M, int N, int K, long lda, long ldb,
                 long ldc, hipStream_t st) {
-    if constexpr (BT) {
-        if (x3p_ok(A, Bm, C, bias, residual, N, K, lda, ldb, ldc)) return launch_x3p(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, st);
-    }
     if (residual) return launch_epi<128, 128, 2, 2, BT, 1, true, false, true>(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, st);
     return launch_epi<128, 128, 2, 2, BT, 0, true, false, true>(A, Bm, C, bias, nullptr, M, N, K, lda, ldb, ldc, st);
 }

@@ -58,10 +58,6 @@ def _bwd_data(dy2, weight):
     """dy2 [T, N] . W [N, K] -> [T, K] (None: not ours, use the library)."""
     if dy2.dtype == torch.float32 and weight.dtype == torch.float32 and dy2.is_cuda and weight.dim() == 2:
         mode = _gemm_mode(dy2.shape[0], weight.shape[0], weight.shape[1])
-        if mode == 'x3' and dy2.shape[0] * weight.shape[0] * weight.shape[1] >= (1 << 31):
-            # big enough to pay for one transposed copy of the (small) weight: dy . W = linear_forward(dy, W^T), and two k-contiguous
-            # operands take the planes kernel (token_gemm_x3p), ~2x the rate of the fragment-split form the [k][n] weight layout needs
-            return token_gemm.linear_fwd(dy2, weight.t().contiguous(), None, split_bf16=True)
         if mode != 'lib':
             return token_gemm.linear_bwd_data(dy2, weight, split_bf16=(mode == 'x3'))
     return None
