@@ -268,7 +268,10 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
         // The split of the NEXT fragments is independent of the MFMAs on the CURRENT planes: both are issued in one scheduling region so
         // that the ~230 vector instructions of a split run in the shadow of the 24 MFMAs (an MFMA holds the SIMD's vector issue for 8 of
         // its 32 cycles only).  Before this the two phases alternated: PMC showed matrix pipe 39 % + vector ALU 48 % busy, never together.
-        // (De-phasing the co-resident workgroups with an initial s_sleep on every other one changed nothing: 117.8 vs 113.5 us.)
+        // (De-phasing the co-resident workgroups with an initial s_sleep on every other one changed nothing: 117.8 vs 113.5 us.  A form with
+        // the WEIGHT split beforehand -- its fragments loaded as 16-byte rows of bf16 planes straight from global memory, the activations
+        // split once at staging into LDS planes, no vector arithmetic left in the multiply loop -- was SLOWER: 142 vs 119 us at 256 -> 256
+        // over 131072 tokens, 72 vs 54 us at 320 -> 1280 over 8192: fragment-shaped global loads touch 32 cache lines per wave instruction.)
         struct Planes { bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN]; };
         auto split_frag = [&](const Frag2 &f, Planes &P) {
 #pragma unroll
