@@ -126,5 +126,10 @@ __device__ __forceinline__ RowPart block_combine(RowPart st, float c2) {
 // part: [B*C*nchunk] partials laid out [(b*C + slot)*nchunk + k].
 void launch_row_finalize(const RowPart *part, float *row_lse2, float *row_kl, float *loss, int B, int C, int g, int nchunk,
                          float c2, float inv_tau, float loss_scale, hipStream_t st);
+// general layout: partial (image b, slot s, chunk k) at b*batch_stride + chan(s)*slot_stride + k*chunk_stride,
+// chan(s) = chan_of_slot ? chan_of_slot[s] : s
+void launch_row_finalize_strided(const RowPart *part, float *row_lse2, float *row_kl, float *loss, int B, int C, int g, int nchunk,
+                                 long batch_stride, long slot_stride, long chunk_stride, const int32_t *chan_of_slot, float c2, float inv_tau,
+                                 float loss_scale, hipStream_t st);
 
 }  // namespace sd

@@ -86,20 +86,29 @@ __global__ __launch_bounds__(kThreads) void cgd_fwd_partials(const T *__restrict
 // One wave per row; row (b,j) owns partials [(b*C + j*g)*nchunk, (b*C + min(C,(j+1)*g))*nchunk).
 __global__ __launch_bounds__(kThreads) void cgd_fwd_rows(const RowPart *__restrict__ part, float *__restrict__ row_lse2,
                                                           float *__restrict__ row_kl, int rows, int C, int g, int G,
-                                                          int nchunk, float c2, float inv_tau) {
+                                                          int nchunk, float c2, float inv_tau, long batch_stride, long slot_stride,
+                                                          long chunk_stride, const int32_t *__restrict__ chan_of_slot) {
     const int row = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     if (row >= rows) return;  // whole wave exits together
     const int lane = threadIdx.x & 63;
     const int b = row / G, j = row - b * G;
     const int c_lo = j * g, c_hi = min(C, c_lo + g);
-    const RowPart *p = part + ((size_t)b * C + c_lo) * nchunk;
+    // partial (slot s, chunk k) sits at b*batch_stride + chan(s)*slot_stride + k*chunk_stride; the slot-major layout of the NCHW kernels
+    // makes that p[i]
+    const RowPart *pb = part + (size_t)b * batch_stride;
+    const bool dense = chan_of_slot == nullptr && slot_stride == nchunk && chunk_stride == 1;
+    auto at = [&](int i) -> const RowPart & {
+        if (dense) return pb[(size_t)c_lo * nchunk + i];
+        const int s = c_lo + i / nchunk, k = i - (i / nchunk) * nchunk;
+        return pb[(size_t)(chan_of_slot ? chan_of_slot[s] : s) * slot_stride + (size_t)k * chunk_stride];
+    };
     const int n = (c_hi - c_lo) * nchunk;
     float ms = kNegBig, mt = kNegBig;
-    for (int i = lane; i < n; i += 64) { ms = fmaxf(ms, p[i].ms); mt = fmaxf(mt, p[i].mt); }
+    for (int i = lane; i < n; i += 64) { const RowPart &q = at(i); ms = fmaxf(ms, q.ms); mt = fmaxf(mt, q.mt); }
     ms = wave_max(ms); mt = wave_max(mt);
     double zs = 0, zt = 0, a = 0;
     for (int i = lane; i < n; i += 64) {
-        const RowPart q = p[i];
+        const RowPart q = at(i);
         const double fs = exp2((double)(q.ms - ms) * (double)c2), ft = exp2((double)(q.mt - mt) * (double)c2);
         zs += (double)q.zs * fs;
         zt += (double)q.zt * ft;
@@ -280,13 +289,19 @@ int bwd_impl(const void *S, const void *Tt, int B, int C, int H, int W, int g, f
 
 }  // namespace
 
-void launch_row_finalize(const RowPart *part, float *row_lse2, float *row_kl, float *loss, int B, int C, int g, int nchunk,
-                         float c2, float inv_tau, float loss_scale, hipStream_t st) {
+void launch_row_finalize_strided(const RowPart *part, float *row_lse2, float *row_kl, float *loss, int B, int C, int g, int nchunk,
+                                 long batch_stride, long slot_stride, long chunk_stride, const int32_t *chan_of_slot, float c2, float inv_tau,
+                                 float loss_scale, hipStream_t st) {
     const int G = (C + g - 1) / g, rows = B * G;
     const int rows_per_wg = kThreads / 64;
     hipLaunchKernelGGL(cgd_fwd_rows, dim3((rows + rows_per_wg - 1) / rows_per_wg), dim3(kThreads), 0, st, part, row_lse2, row_kl, rows,
-                       C, g, G, nchunk, c2, inv_tau);
+                       C, g, G, nchunk, c2, inv_tau, batch_stride, slot_stride, chunk_stride, chan_of_slot);
     hipLaunchKernelGGL(cgd_fwd_loss, dim3(1), dim3(kThreads), 0, st, row_kl, loss, rows, loss_scale);
+}
+
+void launch_row_finalize(const RowPart *part, float *row_lse2, float *row_kl, float *loss, int B, int C, int g, int nchunk,
+                         float c2, float inv_tau, float loss_scale, hipStream_t st) {
+    launch_row_finalize_strided(part, row_lse2, row_kl, loss, B, C, g, nchunk, (long)C * nchunk, nchunk, 1, nullptr, c2, inv_tau, loss_scale, st);
 }
 
 int cgd_tunable(const char *key, int set, int v) {
