@@ -126,6 +126,8 @@ def lib():
     if v != ABI_VERSION:
         raise SegDistillLibError(f'ABI version mismatch: library {v}, binding {ABI_VERSION}')
     _lib = h
+    if os.environ.get('SEGDISTILL_SPLIT_BF16', '1') == '0':   # A/B switch shared with linear.py: exact-f32 MFMA everywhere
+        h.sd_set_tunable(b'sra_split_bf16', 0)
     return h
 
 

@@ -27,6 +27,7 @@ int sd_set_tunable(const char *key, int value) {
     if (!key) return SD_E_NULL;
     int rc = sd::cgd_tunable(key, 1, value);
     if (rc == SD_E_UNSUPPORTED) rc = sd::cgd_up_tunable(key, 1, value);
+    if (rc == SD_E_UNSUPPORTED) rc = sd::sra_tunable(key, 1, value);
     return rc;
 }
 
@@ -34,6 +35,7 @@ int sd_get_tunable(const char *key) {
     if (!key) return SD_E_NULL;
     int rc = sd::cgd_tunable(key, 0, 0);
     if (rc == SD_E_UNSUPPORTED) rc = sd::cgd_up_tunable(key, 0, 0);
+    if (rc == SD_E_UNSUPPORTED) rc = sd::sra_tunable(key, 0, 0);
     return rc;
 }
 

@@ -21,5 +21,6 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
 // returns the value (set == 0) or SD_OK / an SD_E_* code (set != 0); SD_E_UNSUPPORTED if the key is not ours
 int cgd_tunable(const char *key, int set, int v);
 int cgd_up_tunable(const char *key, int set, int v);
+int sra_tunable(const char *key, int set, int v);
 
 }  // namespace sd

@@ -19,6 +19,7 @@
 // was limited by scalar-load latency x the ~100 SGPRs of a wave: 110-130 us per stage-1 layer, slower than the library.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "cgd_device.h"
 
@@ -187,6 +188,295 @@ __global__ __launch_bounds__(NW * 64) void sra_fwd(const T *__restrict__ q, cons
                                  make_float4(O[db][4 * g] * inv, O[db][4 * g + 1] * inv, O[db][4 * g + 2] * inv, O[db][4 * g + 3] * inv));
             if (half == 0) lse[((size_t)b * heads + h) * N + n] = m + __builtin_amdgcn_logf(lsum);   // base-2 lse of the scaled scores
         }
+    }
+}
+
+// ---- forward on the bf16 matrix pipe with fp32-grade arithmetic ("split-bf16") ------------------------------------------------
+// Every fp32 operand x is split exactly into three bf16 planes x = hi + mid + lo (round-to-nearest residual splits) and a product is
+// the six cross terms >= 2^-16 relative (mid.mid, lo.hi, hi.lo, mid.hi, hi.mid, hi.hi) on v_mfma_f32_32x32x16_bf16, accumulated in
+// fp32, small terms first -- the dropped terms are <= 2^-24 relative, the rounding level of an fp32 fma chain itself (same scheme and
+// same error bound as token_gemm.hip).  16 k per 32-cycle instruction x 6 = 12 cycles per k against 32 for v_mfma_f32_32x32x2_f32.
+// Same ownership as sra_fwd (a wave owns 32 queries, S^T = K Q^T, P stays in registers between the two products), what changes:
+//   * K is staged ONCE per workgroup as three bf16 planes [key][d] (row pitch 2 D + 16 bytes: conflict-free ds_read_b128), V as three
+//     TRANSPOSED planes [d][key slot] whose key order inside a block of 32 is the order in which a lane of the 32x32 C layout holds the
+//     rows of S^T (slot 16 s + 8 half + i <-> key (i & 3) + 8 (2 s + (i >> 2)) + 4 half): the 8 probabilities a lane owns for k-step s
+//     ARE its B fragment, and the matching A fragment of V^T is one 16-byte LDS read;
+//   * q is split once per tile in registers, P per k-step (8 values -> 3 x 4 VGPRs);
+//   * head_dim 64: the six planes of 256 keys are 207 KB, more than the CU's 160 KB of LDS -- PHASED: the K planes are staged, S^T and
+//     the softmax run, then the V planes replace them for the second product (two more barriers per tile, K / V re-read from L2).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hh = static_cast<__bf16>(x[e]);
+        const float r1 = x[e] - static_cast<float>(hh);
+        const __bf16 mm = static_cast<__bf16>(r1);
+        const float r2 = r1 - static_cast<float>(mm);
+        h[e] = hh, m[e] = mm, l[e] = static_cast<__bf16>(r2);
+    }
+}
+// acc += A . B over 16 k with A = ah + am + al, B = bh + bm + bl
+__device__ __forceinline__ f32x16 mfma_x3(bf16x8 ah, bf16x8 am, bf16x8 al, bf16x8 bh, bf16x8 bm, bf16x8 bl, f32x16 c) {
+    c = mfma16(am, bm, c);
+    c = mfma16(al, bh, c);
+    c = mfma16(ah, bl, c);
+    c = mfma16(am, bh, c);
+    c = mfma16(ah, bm, c);
+    return mfma16(ah, bh, c);
+}
+template <int D> struct X3Geo {
+    static constexpr int KP = 2 * D + 16;                                   // bytes per K-plane row
+    static __host__ __device__ constexpr int vp(int rows) { return 2 * rows + 16; }   // bytes per V^T-plane row
+    static __host__ __device__ constexpr size_t k_bytes(int rows) { return (size_t)3 * rows * KP; }
+    static __host__ __device__ constexpr size_t v_bytes(int rows) { return (size_t)3 * D * vp(rows); }
+};
+// K of head h of image b -> three bf16 planes [rows][KP] (rows >= KV zero).  NG = groups of 8 values per thread at the full 256 keys:
+// all their loads are issued before the first conversion (one memory latency per staging, not one per group).
+template <typename T, int D, int NT>
+__device__ __forceinline__ void stage_k_planes(const T *__restrict__ kv, unsigned char *Kimg, int b, int h, int KV, int heads, int rows) {
+    constexpr int KP = X3Geo<D>::KP, G = D / 8, NG = (kSraKeys * G + NT - 1) / NT;
+    const int C = heads * D;
+    float x[NG][8];
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+        const int idx = threadIdx.x + u * NT;
+        const int j = idx / G, d0 = (idx % G) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[u][e] = 0.f;
+        if (idx < rows * G && j < KV) load_span<T, 8>(kv + ((size_t)b * KV + j) * 2 * C + h * D + d0, x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+        const int idx = threadIdx.x + u * NT;
+        if (idx < rows * G) {
+            const int j = idx / G, d0 = (idx % G) * 8;
+            bf16x8 ph, pm, pl;
+            split8(x[u], ph, pm, pl);
+            unsigned char *dst = Kimg + (size_t)j * KP + d0 * 2;
+            *reinterpret_cast<bf16x8 *>(dst) = ph;
+            *reinterpret_cast<bf16x8 *>(dst + (size_t)rows * KP) = pm;
+            *reinterpret_cast<bf16x8 *>(dst + (size_t)2 * rows * KP) = pl;
+        }
+    }
+}
+// V of head h of image b -> three transposed bf16 planes [D][vp(rows)], keys of a 32-block in C-layout order (see above)
+template <typename T, int D, int NT, int UG>
+__device__ __forceinline__ void stage_v_planes(const T *__restrict__ kv, unsigned char *Vimg, int b, int h, int KV, int heads, int rows) {
+    constexpr int NG = (D * (kSraKeys / 8) + NT - 1) / NT;                   // groups of 8 key slots per thread, UG of them in flight
+    const int VP = X3Geo<D>::vp(rows);
+    const int C = heads * D;
+#pragma unroll
+    for (int u0 = 0; u0 < NG; u0 += UG) {
+        float x[UG][8];
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int idx = threadIdx.x + (u0 + u) * NT;
+            const int d = idx % D, pg = idx / D;                             // pg: group of 8 key slots
+            const int blk = pg >> 2, s = (pg >> 1) & 1, half = pg & 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int key = blk * 32 + (i & 3) + 8 * (2 * s + (i >> 2)) + 4 * half;
+                x[u][i] = (u0 + u < NG && idx < D * (rows / 8) && key < KV) ? VecIO<T>::load1(kv + ((size_t)b * KV + key) * 2 * C + C + h * D + d) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            const int idx = threadIdx.x + (u0 + u) * NT;
+            if (u0 + u < NG && idx < D * (rows / 8)) {
+                const int d = idx % D, pg = idx / D;
+                bf16x8 ph, pm, pl;
+                split8(x[u], ph, pm, pl);
+                unsigned char *dst = Vimg + (size_t)d * VP + pg * 16;
+                *reinterpret_cast<bf16x8 *>(dst) = ph;
+                *reinterpret_cast<bf16x8 *>(dst + (size_t)D * VP) = pm;
+                *reinterpret_cast<bf16x8 *>(dst + (size_t)2 * D * VP) = pl;
+            }
+        }
+    }
+}
+
+// FULL: KV == 256 (every MiT stage at 512 x 512) -- eight whole key blocks, no masks, no branches: one basic block per phase, so the
+// compiler can run the split of the next fragments under the MFMAs of the current ones.
+template <typename T, int D, int NW, int QT, bool PHASED, bool FULL>
+__global__ __launch_bounds__(NW * 64) void sra_fwd_x3(const T *__restrict__ q, const T *__restrict__ kv, T *__restrict__ out,
+                                                       float *__restrict__ lse, int N, int KV, int heads, float cs /* scale*log2e */,
+                                                       unsigned long long *__restrict__ stamps /* diagnostics, normally null */) {
+    constexpr int KP = X3Geo<D>::KP, DB = D / 32, KS = D / 16;
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0)
+            stamps[(threadIdx.x >> 6) * 32 + stamp_i] = __builtin_amdgcn_s_memtime();
+        ++stamp_i;
+    };
+    stamp();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
+    const int nblk = FULL ? 8 : (KV + 31) / 32, rows = nblk * 32;
+    const int VP = X3Geo<D>::vp(rows);
+    unsigned char *Kimg = smem_x3, *Vimg = PHASED ? smem_x3 : smem_x3 + X3Geo<D>::k_bytes(rows);
+    const size_t kplane = (size_t)rows * KP, vplane = (size_t)D * VP;
+    const int h = blockIdx.y, b = blockIdx.z, C = heads * D;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, half = l >> 5;
+    if (!PHASED) {
+        stage_k_planes<T, D, NW * 64>(kv, Kimg, b, h, KV, heads, rows);
+        stage_v_planes<T, D, NW * 64, (PHASED ? 2 : 4)>(kv, Vimg, b, h, KV, heads, rows);
+        __syncthreads();
+    }
+    stamp();                                                                 // 1: staged
+    for (int qt = 0; qt < QT; ++qt) {
+        const int n = (blockIdx.x * QT + qt) * (NW * 32) + w * 32 + c;
+        const bool live = n < N;
+        // q row of this lane's query, k-steps of 16: elements ks*16 + 8*half .. +8 (B fragment: B[k = 8 half + i][j = c])
+        float qx[KS][8];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qx[ks][e] = 0.f;
+            if (live) load_span<T, 8>(q + ((size_t)b * N + n) * C + h * D + ks * 16 + 8 * half, qx[ks]);
+        }
+        if (PHASED) {
+            if (qt) __syncthreads();                                         // the V planes of the previous tile have been consumed
+            stage_k_planes<T, D, NW * 64>(kv, Kimg, b, h, KV, heads, rows);
+            __syncthreads();
+        }
+        bf16x8 qh[KS], qm[KS], ql[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qx[ks][e] *= cs;
+            split8(qx[ks], qh[ks], qm[ks], ql[ks]);
+        }
+        stamp();                                                             // q planes ready
+        f32x16 S[8];
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[blk][e] = 0.f;
+        // two key blocks at a time: their accumulation chains are independent, the MFMAs alternate between them
+#pragma unroll
+        for (int bp = 0; bp < 8; bp += 2) {
+            if (FULL || bp < nblk) {
+                const unsigned char *k0 = Kimg + (size_t)(bp * 32 + c) * KP + half * 16;
+                const unsigned char *k1 = k0 + (size_t)32 * KP;
+                const bool two = FULL || bp + 1 < nblk;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(k0 + ks * 32);
+                    const bf16x8 am = *reinterpret_cast<const bf16x8 *>(k0 + ks * 32 + kplane);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8 *>(k0 + ks * 32 + 2 * kplane);
+                    if (two) {
+                        const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(k1 + ks * 32);
+                        const bf16x8 bm = *reinterpret_cast<const bf16x8 *>(k1 + ks * 32 + kplane);
+                        const bf16x8 bl = *reinterpret_cast<const bf16x8 *>(k1 + ks * 32 + 2 * kplane);
+                        f32x16 x = S[bp], y = S[bp + 1];
+                        x = mfma16(am, qm[ks], x); y = mfma16(bm, qm[ks], y);
+                        x = mfma16(al, qh[ks], x); y = mfma16(bl, qh[ks], y);
+                        x = mfma16(ah, ql[ks], x); y = mfma16(bh, ql[ks], y);
+                        x = mfma16(am, qh[ks], x); y = mfma16(bm, qh[ks], y);
+                        x = mfma16(ah, qm[ks], x); y = mfma16(bh, qm[ks], y);
+                        x = mfma16(ah, qh[ks], x); y = mfma16(bh, qh[ks], y);
+                        S[bp] = x; S[bp + 1] = y;
+                    } else {
+                        S[bp] = mfma_x3(ah, am, al, qh[ks], qm[ks], ql[ks], S[bp]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                               // keep the fragment reads of later blocks from piling up in registers
+        }
+        stamp();                                                             // S^T issued
+        if (!FULL) {
+#pragma unroll
+            for (int blk = 0; blk < 8; ++blk) {
+                if (blk * 32 + 32 > KV) {                                    // wave-uniform: only the ragged / absent blocks pay for the mask
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (blk * 32 + crow(e, half) >= KV) S[blk][e] = kNegBig;
+                }
+            }
+        }
+        float m = kNegBig;
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) m = fmaxf(m, S[blk][e]);
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float lsum = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                S[blk][e] = ex2(S[blk][e] - m);                              // masked / absent keys: exp2(-1e30 - m) = 0
+                lsum += S[blk][e];
+            }
+        }
+        lsum += __shfl_xor(lsum, 32, 64);
+        stamp();                                                             // softmax done
+        if (PHASED) {
+            __syncthreads();                                                 // every wave is done with the K planes
+            stage_v_planes<T, D, NW * 64, (PHASED ? 2 : 4)>(kv, Vimg, b, h, KV, heads, rows);
+            __syncthreads();
+        }
+        f32x16 O[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) O[db][e] = 0.f;
+        // 16 k-steps (key block, s).  Software pipeline, one scheduling region per step: the V^T fragments of step i + 1 are read and the
+        // probabilities of step i + 1 split while the MFMAs of step i run -- spelled out with sched_group_barrier (1 MFMA, then a share of
+        // the ~44 vector instructions of a split) because left alone the scheduler issues the split first and the six MFMAs after it.
+        bf16x8 ph[2], pm[2], pl[2], vh[2][DB], vm[2][DB], vl[2][DB];
+        auto read_v = [&](int st, int buf) {
+            const int blk = st >> 1, s = st & 1;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const unsigned char *vrow = Vimg + (size_t)(db * 32 + c) * VP + (blk * 32 + s * 16 + half * 8) * 2;
+                vh[buf][db] = *reinterpret_cast<const bf16x8 *>(vrow);
+                vm[buf][db] = *reinterpret_cast<const bf16x8 *>(vrow + vplane);
+                vl[buf][db] = *reinterpret_cast<const bf16x8 *>(vrow + 2 * vplane);
+            }
+        };
+        // (taking the exponentials here too, step by step under the MFMAs, was slower: 35.8 vs 32.5 us at stage 1 -- the step becomes
+        // issue-bound at ~76 vector instructions per 6 MFMAs)
+        auto split_p = [&](int st, int buf) {
+            float pv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pv[i] = S[st >> 1][8 * (st & 1) + i];
+            split8(pv, ph[buf], pm[buf], pl[buf]);
+        };
+        read_v(0, 0);
+        split_p(0, 0);
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int blk = st >> 1, cur = st & 1;
+            if (FULL || blk < nblk) {
+                if (st + 1 < 16) {
+                    read_v(st + 1, cur ^ 1);
+                    split_p(st + 1, cur ^ 1);
+                }
+#pragma unroll
+                for (int db = 0; db < DB; ++db) O[db] = mfma_x3(vh[cur][db], vm[cur][db], vl[cur][db], ph[cur], pm[cur], pl[cur], O[db]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3 * DB, 0);      // the LDS reads of the next step first
+#pragma unroll
+                for (int i = 0; i < 6 * DB; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, (48 + 6 * DB - 1) / (6 * DB), 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp();                                                             // PV issued
+        if (live) {
+            const float inv = 1.f / lsum;
+            T *orow = out + ((size_t)b * N + n) * C + h * D;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    Q4<T>::store(orow + db * 32 + 8 * g + 4 * half,
+                                 make_float4(O[db][4 * g] * inv, O[db][4 * g + 1] * inv, O[db][4 * g + 2] * inv, O[db][4 * g + 3] * inv));
+            if (half == 0) lse[((size_t)b * heads + h) * N + n] = m + __builtin_amdgcn_logf(lsum);   // base-2 lse of the scaled scores
+        }
+        stamp();                                                             // stored
     }
 }
 
@@ -427,8 +717,36 @@ int sra_fwd_launch_nw(const void *q, const void *kv, void *out, float *lse, int 
                        scale * kLog2e);
     return (int)hipGetLastError();
 }
+unsigned long long *g_sra_stamps = nullptr;   // diagnostics (sd_debug_sra_stamps): [8 waves][32] s_memtime values of workgroup 0
+int g_sra_split_bf16 = 1;   // tunable "sra_split_bf16": fp32 storage runs the products on the bf16 matrix pipe, operands split in three
+
+template <typename T, int D, int NW, int QT, bool FULL>
+int sra_fwd_x3_launch_full(const void *q, const void *kv, void *out, float *lse, int B, int N, int KV, int heads, float scale, hipStream_t st) {
+    constexpr bool PHASED = D == 64;
+    const dim3 grid((N + NW * 32 * QT - 1) / (NW * 32 * QT), heads, B);
+    const int rows = (KV + 31) / 32 * 32;
+    const size_t kb = X3Geo<D>::k_bytes(rows), vb = X3Geo<D>::v_bytes(rows);
+    const size_t lds = PHASED ? (kb > vb ? kb : vb) : kb + vb;
+    static bool raised = false;
+    int rc = sra_raise_lds(sra_fwd_x3<T, D, NW, QT, PHASED, FULL>, raised);
+    if (rc) return rc;
+    hipLaunchKernelGGL((sra_fwd_x3<T, D, NW, QT, PHASED, FULL>), grid, dim3(NW * 64), lds, st, (const T *)q, (const T *)kv, (T *)out, lse, N,
+                       KV, heads, scale * kLog2e, g_sra_stamps);
+    return (int)hipGetLastError();
+}
+template <typename T, int D, int NW, int QT>
+int sra_fwd_x3_launch_nw(const void *q, const void *kv, void *out, float *lse, int B, int N, int KV, int heads, float scale, hipStream_t st) {
+    return KV == kSraKeys ? sra_fwd_x3_launch_full<T, D, NW, QT, true>(q, kv, out, lse, B, N, KV, heads, scale, st)
+                          : sra_fwd_x3_launch_full<T, D, NW, QT, false>(q, kv, out, lse, B, N, KV, heads, scale, st);
+}
+
 template <typename T, int D>
 int sra_fwd_launch(const void *q, const void *kv, void *out, float *lse, int B, int N, int KV, int heads, float scale, hipStream_t st) {
+    if constexpr (sizeof(T) == 4) if (g_sra_split_bf16) {
+        if (N >= 8192 && D == 32) return sra_fwd_x3_launch_nw<T, D, 8, 2>(q, kv, out, lse, B, N, KV, heads, scale, st);   // (PHASED restages per tile)
+        return sra_wide(N) ? sra_fwd_x3_launch_nw<T, D, 8, 1>(q, kv, out, lse, B, N, KV, heads, scale, st)
+                           : sra_fwd_x3_launch_nw<T, D, 4, 1>(q, kv, out, lse, B, N, KV, heads, scale, st);
+    }
     if (N >= 8192) return sra_fwd_launch_nw<T, D, 8, 2>(q, kv, out, lse, B, N, KV, heads, scale, st);   // 512 queries per K/V copy
     return sra_wide(N) ? sra_fwd_launch_nw<T, D, 8, 1>(q, kv, out, lse, B, N, KV, heads, scale, st)
                        : sra_fwd_launch_nw<T, D, 4, 1>(q, kv, out, lse, B, N, KV, heads, scale, st);
@@ -460,9 +778,21 @@ int sra_bwd_launch(const void *q, const void *kv, const void *out, const void *d
 }
 
 }  // namespace
+
+int sra_tunable(const char *key, int set, int v) {
+    if (strcmp(key, "sra_split_bf16")) return SD_E_UNSUPPORTED;
+    if (set) {
+        if (v != 0 && v != 1) return SD_E_SHAPE;
+        g_sra_split_bf16 = v;
+        return SD_OK;
+    }
+    return g_sra_split_bf16;
+}
 }  // namespace sd
 
 extern "C" {
+
+void sd_debug_sra_stamps(void *buf) { sd::g_sra_stamps = static_cast<unsigned long long *>(buf); }
 
 int sd_sra_supported(int head_dim) { return (head_dim == 32 || head_dim == 64) ? 1 : 0; }
 

@@ -197,6 +197,38 @@ def bench_align(dev, reps, B, Cs, Ct, h, dtype, tag):
     return out
 
 
+def bench_sra(dev, reps, B=8):
+    """MiT spatial-reduction attention at the config-2 shapes: student B0 (head_dim 32) forward + backward, teacher B2 (head_dim 64) forward.
+    Both arithmetic modes: exact f32-input MFMA and split-bf16 (tunable sra_split_bf16)."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    out = []
+    for D, tag, with_bwd in ((32, 'student B0', True), (64, 'teacher B2', False)):
+        for N, heads in ((16384, 1), (4096, 2), (1024, 5), (256, 8)):
+            KV, C = 256, heads * D
+            q = torch.randn(B, N, C, device=dev, generator=gen)
+            kv = torch.randn(B, KV, 2 * C, device=dev, generator=gen)
+            do = torch.randn(B, N, C, device=dev, generator=gen)
+            o, dq, dkv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(kv)
+            lse = torch.empty(B, heads, N, device=dev)
+            wsb = L.sd_sra_workspace_bytes(B, N, KV, heads, D)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            flops = 4.0 * B * heads * N * KV * D
+            for mode, mtag, peak in ((1, 'split-bf16', MFMA_BF16 / 6), (0, 'f32 MFMA', MFMA_F32)):
+                _lib.set_tunable('sra_split_bf16', mode)
+                tf = _time(lambda st: _ok(L.sd_sra_fwd(q.data_ptr(), kv.data_ptr(), o.data_ptr(), lse.data_ptr(), 0, B, N, KV, heads, D, D ** -0.5, st), 'sra fwd'), reps)
+                note = 'peak = dense bf16 MFMA / 6 cross products' if mode else None
+                out.append(_entry(f'sra fwd {tag} N={N} heads={heads} ({mtag})', 'sra_fwd_x3' if mode else 'sra_fwd', [B, N, KV, heads, D], 'f32', tf, 'mfma', flops, round(peak, 1), note))
+                if with_bwd:
+                    tb = _time(lambda st: _ok(L.sd_sra_bwd(q.data_ptr(), kv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), dq.data_ptr(), dkv.data_ptr(), 0, B, N, KV,
+                                                           heads, D, D ** -0.5, ws.data_ptr(), wsb, st), 'sra bwd'), reps)
+                    out.append(_entry(f'sra bwd {tag} N={N} heads={heads} ({mtag})', 'sra_bwd_dq + sra_bwd_dkv + sra_dkv_reduce', [B, N, KV, heads, D], 'f32', tb, 'mfma',
+                                      2.5 * flops, round(peak, 1), note))
+            _lib.set_tunable('sra_split_bf16', 1)
+    return out
+
+
 def bench_pix(dev, reps, B=8, C=150, HW=512):
     from segdistill_amd import _lib
     L = _lib.lib()
@@ -285,6 +317,7 @@ GROUPS = {
                                 + bench_align(dev, reps, 8, 256, 768, 128, torch.bfloat16, 'C 256->768 at 128x128 bf16 (NCHW, direct callers)')),
     'pix': lambda dev, reps: bench_pix(dev, reps),
     'at': lambda dev, reps: bench_at(dev, reps),
+    'sra': lambda dev, reps: bench_sra(dev, reps),
     'ifvd': lambda dev, reps: bench_ifvd(dev, reps),
     'ce': lambda dev, reps: bench_ce(dev, reps),
 }
