@@ -234,7 +234,8 @@ template <int D> struct X3Geo {
 // K of head h of image b -> three bf16 planes [rows][KP] (rows >= KV zero).  NG = groups of 8 values per thread at the full 256 keys:
 // all their loads are issued before the first conversion (one memory latency per staging, not one per group).
 template <typename T, int D, int NT>
-__device__ __forceinline__ void stage_k_planes(const T *__restrict__ kv, unsigned char *Kimg, int b, int h, int KV, int heads, int rows) {
+__device__ __forceinline__ void stage_k_planes(const T *__restrict__ kv, unsigned char *Kimg, int b, int h, int KV, int heads, int rows,
+                                               int col0 = 0 /* 0: K, heads*D: V */, float *f32_copy = nullptr /* [rows][D + 4] */) {
     constexpr int KP = X3Geo<D>::KP, G = D / 8, NG = (kSraKeys * G + NT - 1) / NT;
     const int C = heads * D;
     float x[NG][8];
@@ -244,7 +245,7 @@ __device__ __forceinline__ void stage_k_planes(const T *__restrict__ kv, unsigne
         const int j = idx / G, d0 = (idx % G) * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[u][e] = 0.f;
-        if (idx < rows * G && j < KV) load_span<T, 8>(kv + ((size_t)b * KV + j) * 2 * C + h * D + d0, x[u]);
+        if (idx < rows * G && j < KV) load_span<T, 8>(kv + ((size_t)b * KV + j) * 2 * C + col0 + h * D + d0, x[u]);
     }
 #pragma unroll
     for (int u = 0; u < NG; ++u) {
@@ -257,6 +258,11 @@ __device__ __forceinline__ void stage_k_planes(const T *__restrict__ kv, unsigne
             *reinterpret_cast<bf16x8 *>(dst) = ph;
             *reinterpret_cast<bf16x8 *>(dst + (size_t)rows * KP) = pm;
             *reinterpret_cast<bf16x8 *>(dst + (size_t)2 * rows * KP) = pl;
+            if (f32_copy) {
+                float *fr = f32_copy + (size_t)j * (D + 4) + d0;
+                *reinterpret_cast<float4 *>(fr) = make_float4(x[u][0], x[u][1], x[u][2], x[u][3]);
+                *reinterpret_cast<float4 *>(fr + 4) = make_float4(x[u][4], x[u][5], x[u][6], x[u][7]);
+            }
         }
     }
 }
@@ -543,6 +549,92 @@ __global__ __launch_bounds__(NW * 64) void sra_bwd_dq(const T *__restrict__ q, c
     if (half == 0) delta[((size_t)b * heads + h) * N + n] = dl;
 }
 
+// ---- backward, queries, split-bf16 for the two recomputed products (head_dim 32): S^T = K Q^T and dP^T = V dO^T run on bf16 planes of K and
+// V ([key][d], staged once per workgroup) against planes of q and dO split once per tile; dQ^T += K^T dS^T stays on the exact f32 MFMA with
+// an fp32 copy of K beside the planes (planes of K^T as well would need 173 KB of LDS; these three are 156 KB).  Per 32-key block:
+// 24 x 32 + 16 x 64 cycles of matrix pipe against 48 x 64.
+template <typename T, int NW, int QT>
+__global__ __launch_bounds__(NW * 64) void sra_bwd_dq_x3(const T *__restrict__ q, const T *__restrict__ kv, const T *__restrict__ out,
+                                                          const T *__restrict__ dout, const float *__restrict__ lse, T *__restrict__ dq,
+                                                          float *__restrict__ delta, int N, int KV, int heads, float cs, float scale) {
+    constexpr int D = 32, KP = X3Geo<D>::KP, PD = D + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dq[];
+    const int nblk = (KV + 31) / 32, rows = nblk * 32;
+    const size_t plane = (size_t)rows * KP;
+    unsigned char *Kp = smem_dq, *Vp = smem_dq + 3 * plane;
+    float *Kf = reinterpret_cast<float *>(smem_dq + 6 * plane);
+    const int h = blockIdx.y, b = blockIdx.z, C = heads * D;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, half = l >> 5;
+    stage_k_planes<T, D, NW * 64>(kv, Kp, b, h, KV, heads, rows, 0, Kf);
+    stage_k_planes<T, D, NW * 64>(kv, Vp, b, h, KV, heads, rows, C, nullptr);
+    __syncthreads();
+    for (int qt = 0; qt < QT; ++qt) {
+        const int n = (blockIdx.x * QT + qt) * (NW * 32) + w * 32 + c;
+        const bool live = n < N;
+        float qx[2][8], gx[2][8];
+        float dl = 0.f, L = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float ox[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { qx[ks][e] = 0.f; gx[ks][e] = 0.f; ox[e] = 0.f; }
+            if (live) {
+                const size_t row = ((size_t)b * N + n) * C + h * D + ks * 16 + 8 * half;
+                load_span<T, 8>(q + row, qx[ks]);
+                load_span<T, 8>(dout + row, gx[ks]);
+                load_span<T, 8>(out + row, ox);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl = fmaf(gx[ks][e], ox[e], dl);
+        }
+        if (live) L = lse[((size_t)b * heads + h) * N + n];
+        dl += __shfl_xor(dl, 32, 64);
+        bf16x8 qh[2], qm[2], ql[2], gh[2], gm[2], gl[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qx[ks][e] *= cs;
+            split8(qx[ks], qh[ks], qm[ks], ql[ks]);
+            split8(gx[ks], gh[ks], gm[ks], gl[ks]);
+        }
+        f32x16 G;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) G[e] = 0.f;
+        for (int blk = 0; blk < nblk; ++blk) {
+            f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dp = s;
+            const unsigned char *kr = Kp + (size_t)(blk * 32 + c) * KP + half * 16, *vr = Vp + (size_t)(blk * 32 + c) * KP + half * 16;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kh = *reinterpret_cast<const bf16x8 *>(kr + ks * 32), km = *reinterpret_cast<const bf16x8 *>(kr + ks * 32 + plane),
+                             kl = *reinterpret_cast<const bf16x8 *>(kr + ks * 32 + 2 * plane);
+                const bf16x8 vh = *reinterpret_cast<const bf16x8 *>(vr + ks * 32), vm = *reinterpret_cast<const bf16x8 *>(vr + ks * 32 + plane),
+                             vl = *reinterpret_cast<const bf16x8 *>(vr + ks * 32 + 2 * plane);
+                s = mfma_x3(kh, km, kl, qh[ks], qm[ks], ql[ks], s);
+                dp = mfma_x3(vh, vm, vl, gh[ks], gm[ks], gl[ks], dp);
+            }
+            if (blk * 32 + 32 <= KV) {                        // wave-uniform: whole blocks carry no mask
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[e] = ex2(s[e] - L) * (dp[e] - dl);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p = (blk * 32 + crow(e, half) < KV) ? ex2(s[e] - L) : 0.f;
+                    s[e] = p * (dp[e] - dl);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) G = mfma(Kf[(blk * 32 + crow(e, half)) * PD + c], s[e], G);
+        }
+        if (live) {
+            T *grow = dq + ((size_t)b * N + n) * C + h * D;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                Q4<T>::store(grow + 8 * g + 4 * half, make_float4(G[4 * g] * scale, G[4 * g + 1] * scale, G[4 * g + 2] * scale, G[4 * g + 3] * scale));
+            if (half == 0) delta[((size_t)b * heads + h) * N + n] = dl;
+        }
+    }
+}
+
 // ---- backward, keys.  grid (nchunk, heads, B): a workgroup walks `qchunk` queries (32 at a time through LDS); wave w keeps the
 // key columns 64w .. 64w+63 (two 32-column blocks) of K and V in registers and accumulates their dK^T / dV^T tiles.
 // part: [b][h][chunk][2 (k,v)][KV][D] fp32
@@ -647,6 +739,143 @@ __global__ __launch_bounds__(kSraThreads) void sra_bwd_dkv(const T *__restrict__
     }
 }
 
+// ---- backward, keys, split-bf16 (head_dim 32).  Same ownership and partial layout as sra_bwd_dkv: wave w keeps key columns
+// 64w .. 64w+63 -- here as bf16 planes of K (pre-scaled) and V in registers -- and 32-query tiles stream through LDS, split ONCE at
+// staging into planes in two layouts: [q][d] (A operand of S = Q K^T and dP = dO V^T) and transposed [d][q slot] (A operand of
+// dV^T += dO^T P and dK^T += Q^T dS; q slots in the order a lane of the S tile holds its rows, so the 8 values a lane owns per k-step are
+// its B fragment).  All four products run as six bf16 MFMAs per 16 k: 48 x 32 cycles per (tile, key block) against 64 x 64.
+template <typename T>
+__global__ __launch_bounds__(kSraThreads) void sra_bwd_dkv_x3(const T *__restrict__ q, const T *__restrict__ kv, const T *__restrict__ dout,
+                                                               const float *__restrict__ lse, const float *__restrict__ delta,
+                                                               float *__restrict__ part, int N, int KV, int heads, int nchunk, int qchunk,
+                                                               float cs, float scale) {
+    constexpr int D = 32, RP = 80, PL = 32 * RP;              // plane row pitch (64 B of bf16 + 16), bytes per plane
+    __shared__ __attribute__((aligned(16))) unsigned char Qp[3 * PL], Gp[3 * PL], QTp[3 * PL], GTp[3 * PL];
+    __shared__ float Ls[32], Ds[32];
+    const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z, C = heads * D;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, half = l >> 5;
+    bf16x8 kh[2][2], km[2][2], kl[2][2], vh[2][2], vm[2][2], vl[2][2];    // [key block][k-step of 16 over d]
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int j = 64 * w + 32 * cb + c;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float kx[8], vx[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kx[e] = 0.f; vx[e] = 0.f; }
+            if (j < KV) {
+                const T *row = kv + ((size_t)b * KV + j) * 2 * C + h * D + ks * 16 + 8 * half;
+                load_span<T, 8>(row, kx);
+                load_span<T, 8>(row + C, vx);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kx[e] *= cs;
+            split8(kx, kh[cb][ks], km[cb][ks], kl[cb][ks]);
+            split8(vx, vh[cb][ks], vm[cb][ks], vl[cb][ks]);
+        }
+    }
+    f32x16 aK[2], aV[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { aK[cb][e] = 0.f; aV[cb][e] = 0.f; }
+    const bool wave_live = 64 * w < KV;                       // waves whose key columns are all padding only help with the staging
+    const int i0 = chunk * qchunk, i1 = min(N, i0 + qchunk);
+    const T *qb = q + (size_t)b * N * C + h * D;
+    const T *gb = dout + (size_t)b * N * C + h * D;
+    const float *lb = lse + ((size_t)b * heads + h) * N;
+    const float *db_ = delta + ((size_t)b * heads + h) * N;
+    // staging role of this thread: threads 0..127 split the Q tile, 128..255 the dO tile; query row sr, 8 consecutive d from sd0, and the
+    // row's slot in the transposed planes
+    const bool stage_q = threadIdx.x < 128;
+    const int sr = (threadIdx.x & 127) >> 2, sd0 = (threadIdx.x & 3) * 8;
+    const int sslot = 16 * (sr >> 4) + 8 * ((sr >> 2) & 1) + (sr & 3) + 4 * ((sr >> 3) & 1);   // r = (i&3) + 8(2s + (i>>2)) + 4 half -> 16 s + 8 half + i
+    const T *sb = stage_q ? qb : gb;
+    unsigned char *const P_ = stage_q ? Qp : Gp, *const PT_ = stage_q ? QTp : GTp;
+    // the rows of tile i + 1 (and its lse / delta) are requested before tile i is computed: one exposed memory latency per workgroup
+    float x[8], ld = 0.f;
+    auto request = [&](int t0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = 0.f;
+        if (t0 + sr < i1) load_span<T, 8>(sb + (size_t)(t0 + sr) * C + sd0, x);
+        ld = 0.f;
+        if (threadIdx.x < 32) { if (t0 + threadIdx.x < i1) ld = lb[t0 + threadIdx.x]; }
+        else if (threadIdx.x < 64) { if (t0 + threadIdx.x - 32 < i1) ld = db_[t0 + threadIdx.x - 32]; }
+    };
+    request(i0);
+    for (int t0 = i0; t0 < i1; t0 += 32) {
+        bf16x8 p0, p1, p2;
+        split8(x, p0, p1, p2);
+        const float ld_now = ld;
+        __syncthreads();                                      // the previous tile has been consumed
+        {
+            unsigned char *d_ = P_ + sr * RP + sd0 * 2;
+            *reinterpret_cast<bf16x8 *>(d_) = p0; *reinterpret_cast<bf16x8 *>(d_ + PL) = p1; *reinterpret_cast<bf16x8 *>(d_ + 2 * PL) = p2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                unsigned char *t_ = PT_ + (sd0 + e) * RP + sslot * 2;
+                *reinterpret_cast<__bf16 *>(t_) = p0[e]; *reinterpret_cast<__bf16 *>(t_ + PL) = p1[e]; *reinterpret_cast<__bf16 *>(t_ + 2 * PL) = p2[e];
+            }
+        }
+        if (threadIdx.x < 32) Ls[threadIdx.x] = ld_now;
+        else if (threadIdx.x < 64) Ds[threadIdx.x - 32] = ld_now;
+        if (t0 + 32 < i1) request(t0 + 32);
+        __syncthreads();
+        if (!wave_live) continue;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            // S tile (rows = queries of the LDS tile, cols = this block's keys) and dP tile
+            f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned char *qa = Qp + c * RP + ks * 32 + half * 16, *ga = Gp + c * RP + ks * 32 + half * 16;
+                const bf16x8 qh_ = *reinterpret_cast<const bf16x8 *>(qa), qm_ = *reinterpret_cast<const bf16x8 *>(qa + PL),
+                             ql_ = *reinterpret_cast<const bf16x8 *>(qa + 2 * PL);
+                const bf16x8 gh_ = *reinterpret_cast<const bf16x8 *>(ga), gm_ = *reinterpret_cast<const bf16x8 *>(ga + PL),
+                             gl_ = *reinterpret_cast<const bf16x8 *>(ga + 2 * PL);
+                s = mfma_x3(qh_, qm_, ql_, kh[cb][ks], km[cb][ks], kl[cb][ks], s);
+                dp = mfma_x3(gh_, gm_, gl_, vh[cb][ks], vm[cb][ks], vl[cb][ks], dp);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = crow(e, half);
+                const float p = ex2(s[e] - Ls[r]);            // padded query rows: q = dO = 0, lse = delta = 0 -> contribute exactly 0
+                dp[e] = p * (dp[e] - Ds[r]);
+                s[e] = p;
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                float pv[8], dv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { pv[i] = s[8 * st + i]; dv[i] = dp[8 * st + i]; }
+                bf16x8 ph, pm, pl, dh, dm, dl;
+                split8(pv, ph, pm, pl);
+                split8(dv, dh, dm, dl);
+                const unsigned char *ga = GTp + c * RP + (16 * st + 8 * half) * 2, *qa = QTp + c * RP + (16 * st + 8 * half) * 2;
+                const bf16x8 gh_ = *reinterpret_cast<const bf16x8 *>(ga), gm_ = *reinterpret_cast<const bf16x8 *>(ga + PL),
+                             gl_ = *reinterpret_cast<const bf16x8 *>(ga + 2 * PL);
+                const bf16x8 qh_ = *reinterpret_cast<const bf16x8 *>(qa), qm_ = *reinterpret_cast<const bf16x8 *>(qa + PL),
+                             ql_ = *reinterpret_cast<const bf16x8 *>(qa + 2 * PL);
+                aV[cb] = mfma_x3(gh_, gm_, gl_, ph, pm, pl, aV[cb]);    // dV^T += dO^T P
+                aK[cb] = mfma_x3(qh_, qm_, ql_, dh, dm, dl, aK[cb]);    // dK^T += Q^T dS
+            }
+        }
+    }
+    float *pk = part + (((size_t)b * heads + h) * nchunk + chunk) * 2 * KV * D;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int j = 64 * w + 32 * cb + c;
+        if (j >= KV) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float *dst = pk + (size_t)j * D + 8 * g + 4 * half;
+            *reinterpret_cast<float4 *>(dst) = make_float4(aK[cb][4 * g] * scale, aK[cb][4 * g + 1] * scale, aK[cb][4 * g + 2] * scale,
+                                                           aK[cb][4 * g + 3] * scale);
+            *reinterpret_cast<float4 *>(dst + (size_t)KV * D) = make_float4(aV[cb][4 * g], aV[cb][4 * g + 1], aV[cb][4 * g + 2], aV[cb][4 * g + 3]);
+        }
+    }
+}
+
 // dkv[b][j][which][h][d] = sum_chunk part[b][h][chunk][which][j][d].  one thread per 4 output elements
 template <typename T>
 __global__ __launch_bounds__(256) void sra_dkv_reduce(const float *__restrict__ part, T *__restrict__ dkv, int B, int KV, int heads, int D,
@@ -663,7 +892,15 @@ __global__ __launch_bounds__(256) void sra_dkv_reduce(const float *__restrict__ 
     const int b = (int)(r / KV);
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     const float *p = part + ((((size_t)b * heads + h) * nchunk) * 2 + which) * KV * D + (size_t)j * D + d;
-    for (int ch = 0; ch < nchunk; ++ch) {
+    int ch = 0;
+    for (; ch + 8 <= nchunk; ch += 8) {                       // 8 independent loads in flight, summed in chunk order
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(p + (size_t)(ch + u) * 2 * KV * D);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+    }
+    for (; ch < nchunk; ++ch) {
         const float4 v = *reinterpret_cast<const float4 *>(p + (size_t)ch * 2 * KV * D);
         a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
@@ -759,18 +996,46 @@ int sra_bwd_launch(const void *q, const void *kv, const void *out, const void *d
     float *delta = static_cast<float *>(ws);
     float *part = delta + (((size_t)B * heads * N + 3) & ~(size_t)3);
     const size_t lds = sra_lds_bytes<D>(KV);
-    static bool raised4 = false, raised8 = false;
-    int rc = sra_wide(N) ? sra_raise_lds(sra_bwd_dq<T, D, 8>, raised8) : sra_raise_lds(sra_bwd_dq<T, D, 4>, raised4);
-    if (rc) return rc;
-    if (sra_wide(N))
-        hipLaunchKernelGGL((sra_bwd_dq<T, D, 8>), dim3((N + 255) / 256, heads, B), dim3(512), lds, st, (const T *)q, (const T *)kv,
-                           (const T *)out, (const T *)dout, lse, (T *)dq, delta, N, KV, heads, scale * kLog2e, scale);
-    else
-        hipLaunchKernelGGL((sra_bwd_dq<T, D, 4>), dim3((N + 127) / 128, heads, B), dim3(256), lds, st, (const T *)q, (const T *)kv,
-                           (const T *)out, (const T *)dout, lse, (T *)dq, delta, N, KV, heads, scale * kLog2e, scale);
+    bool split = false;
+    if constexpr (sizeof(T) == 4 && D == 32) split = g_sra_split_bf16 != 0;
+    if (split) {
+        if constexpr (D == 32) {
+            const int rows = (KV + 31) / 32 * 32;
+            const size_t lds3 = (size_t)6 * rows * X3Geo<32>::KP + (size_t)rows * 36 * sizeof(float);
+            static bool r82 = false, r81 = false, r41 = false;
+            int rc;
+            if (N >= 8192) {
+                if ((rc = sra_raise_lds(sra_bwd_dq_x3<T, 8, 2>, r82))) return rc;
+                hipLaunchKernelGGL((sra_bwd_dq_x3<T, 8, 2>), dim3((N + 511) / 512, heads, B), dim3(512), lds3, st, (const T *)q, (const T *)kv,
+                                   (const T *)out, (const T *)dout, lse, (T *)dq, delta, N, KV, heads, scale * kLog2e, scale);
+            } else if (sra_wide(N)) {
+                if ((rc = sra_raise_lds(sra_bwd_dq_x3<T, 8, 1>, r81))) return rc;
+                hipLaunchKernelGGL((sra_bwd_dq_x3<T, 8, 1>), dim3((N + 255) / 256, heads, B), dim3(512), lds3, st, (const T *)q, (const T *)kv,
+                                   (const T *)out, (const T *)dout, lse, (T *)dq, delta, N, KV, heads, scale * kLog2e, scale);
+            } else {
+                if ((rc = sra_raise_lds(sra_bwd_dq_x3<T, 4, 1>, r41))) return rc;
+                hipLaunchKernelGGL((sra_bwd_dq_x3<T, 4, 1>), dim3((N + 127) / 128, heads, B), dim3(256), lds3, st, (const T *)q, (const T *)kv,
+                                   (const T *)out, (const T *)dout, lse, (T *)dq, delta, N, KV, heads, scale * kLog2e, scale);
+            }
+        }
+    } else {
+        static bool raised4 = false, raised8 = false;
+        int rc = sra_wide(N) ? sra_raise_lds(sra_bwd_dq<T, D, 8>, raised8) : sra_raise_lds(sra_bwd_dq<T, D, 4>, raised4);
+        if (rc) return rc;
+        if (sra_wide(N))
+            hipLaunchKernelGGL((sra_bwd_dq<T, D, 8>), dim3((N + 255) / 256, heads, B), dim3(512), lds, st, (const T *)q, (const T *)kv,
+                               (const T *)out, (const T *)dout, lse, (T *)dq, delta, N, KV, heads, scale * kLog2e, scale);
+        else
+            hipLaunchKernelGGL((sra_bwd_dq<T, D, 4>), dim3((N + 127) / 128, heads, B), dim3(256), lds, st, (const T *)q, (const T *)kv,
+                               (const T *)out, (const T *)dout, lse, (T *)dq, delta, N, KV, heads, scale * kLog2e, scale);
+    }
     const dim3 gk(p.nchunk, heads, B);
-    hipLaunchKernelGGL((sra_bwd_dkv<T, D>), gk, dim3(kSraThreads), 0, st, (const T *)q, (const T *)kv, (const T *)dout, lse, delta, part, N, KV,
-                       heads, p.nchunk, p.qchunk, scale * kLog2e, scale);
+    if (split)
+        hipLaunchKernelGGL((sra_bwd_dkv_x3<T>), gk, dim3(kSraThreads), 0, st, (const T *)q, (const T *)kv, (const T *)dout, lse, delta, part, N, KV,
+                           heads, p.nchunk, p.qchunk, scale * kLog2e, scale);
+    else
+        hipLaunchKernelGGL((sra_bwd_dkv<T, D>), gk, dim3(kSraThreads), 0, st, (const T *)q, (const T *)kv, (const T *)dout, lse, delta, part, N,
+                           KV, heads, p.nchunk, p.qchunk, scale * kLog2e, scale);
     const size_t total = (size_t)B * KV * 2 * heads * (D / 4);
     hipLaunchKernelGGL((sra_dkv_reduce<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, (T *)dkv, B, KV, heads, D,
                        p.nchunk);
