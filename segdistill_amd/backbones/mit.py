@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from ..builder import BACKBONES
 from ..layers import DropPath, frozen_derived, nchw_view_of_tokens, tokens_of, trunc_normal_
 from ..layernorm import HipLayerNorm, add_layernorm, add_layernorm_supported
-from ..linear import call_linear, longk_linear
+from ..linear import call_linear, longk_linear, patch_linear_forward, patch_linear_supported
 
 
 def _mit_init(m):
@@ -122,9 +122,13 @@ class SRAttention(nn.Module):
         H, W = hw
         if conv._forward_hooks or H % r or W % r:
             return conv(x.transpose(1, 2).reshape(b, c, H, W)).flatten(2).transpose(1, 2)
+        cl = conv.weight.is_contiguous(memory_format=torch.channels_last)
+        if cl and patch_linear_supported(x, hw, r, conv.weight):
+            # frozen network: the gather happens inside the GEMM's operand staging (csrc/align1x1.hip: gemm_nt_patch), no patch copy
+            return patch_linear_forward(x, hw, r, conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c), conv.bias)
         patches = x.reshape(b, H // r, r, W // r, r, c).permute(0, 1, 3, 2, 4, 5).reshape(b, (H // r) * (W // r), r * r * c)
         # (ky, kx, cin) order to match the patches; the re-layout is cached for a frozen network
-        if conv.weight.is_contiguous(memory_format=torch.channels_last):
+        if cl:
             w2 = conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c)     # a view: the storage already has this order
             return longk_linear(patches, w2, conv.bias, weight_is_view=True)
         w2 = frozen_derived(conv.weight, 'sr_patch', lambda: conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c).contiguous())

@@ -18,6 +18,10 @@ MIN_TOKENS = 1     # every training Linear: below 8192 tokens dW is the library'
 # library's un-split 64-workgroup kernel is slow in isolation (183 us) but leaves the chip to the concurrently running
 # student/teacher stream, while the split-K version occupies all CUs.  Kept as an opt-in (SEGDISTILL_LONGK=1).
 _LONGK_ENABLED = os.environ.get('SEGDISTILL_LONGK') == '1'
+# The frozen network's SR conv with the patch gather inside the GEMM (patch_linear_forward) removes the [rows, r*r*C] copy, but as a split-K
+# kernel it hits the same wall: A/B on MI355X (config 2, same box, 30 steps, twice): 659.5 / 662.8 imgs/s with it, 670.8 / 671.3 without.
+# Opt-in (SEGDISTILL_PATCH_GEMM=1).
+_PATCH_GEMM = os.environ.get('SEGDISTILL_PATCH_GEMM') == '1'
 
 
 # Forward and input gradient of fp32 Linears: the library GEMM, or the kernels of csrc/token_gemm.hip in one of two arithmetic modes.
@@ -195,6 +199,30 @@ class _LongKLinear(torch.autograd.Function):
         dw = (dy2.t() @ x2) if ctx.needs_input_grad[1] else None
         db = deferred.column_sum(dy2.contiguous(), False).to(dy2.dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
+
+
+def patch_linear_supported(x, hw, r, weight, enabled=None):
+    """The SR patch projection straight from the tokens (sd_linear_patch_fwd): fp32, no graph to build (the frozen teacher), whole patches."""
+    return ((_PATCH_GEMM if enabled is None else enabled) and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous()
+            and not torch.is_autocast_enabled() and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad))
+            and hw[0] % r == 0 and hw[1] % r == 0 and (r * x.shape[-1]) % 16 == 0 and weight.shape[0] <= 512
+            and x.shape[0] * (hw[0] // r) * (hw[1] // r) <= 16384)
+
+
+def patch_linear_forward(x, hw, r, weight, bias=None):
+    """y[b, (py, px), :] = W . patch(x, py, px) + bias for the r x r patches of tokens x [B, H*W, C]; W [out, r*r*C] in (ky, kx, c) order."""
+    B, _, c = x.shape
+    H, W = hw
+    L = _lib.lib()
+    rows, N, K = B * (H // r) * (W // r), weight.shape[0], r * r * c
+    w = weight if weight.is_contiguous() else weight.contiguous()
+    y = torch.empty(B, rows // B, N, dtype=torch.float32, device=x.device)
+    wsb = L.sd_linear_longk_workspace_bytes(rows, N, K)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    b = None if bias is None else bias.detach().float().contiguous()
+    _lib.check(L.sd_linear_patch_fwd(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), B, H, W, c, r, N, ws.data_ptr(), wsb,
+                                     _stream_ptr()), 'sd_linear_patch_fwd')
+    return y
 
 
 def longk_linear(x, weight, bias=None, weight_is_view=False):
