@@ -17,15 +17,25 @@ export PYTHONUNBUFFERED=1
 ( while true; do sleep 45; echo "[heartbeat] $(date +%T)" >> $OUT/progress.txt; done ) &
 HB=$!
 trap "kill $HB 2>/dev/null" EXIT
-echo "[1] bench" | tee $OUT/progress.txt
+STEPS=${STEPS:-"1 2 3 4 5 6"}     # a full pass is ~17 GPU-minutes: STEPS="1 2 3 4" and STEPS="5 6" fit two calls
+want() { [[ " $STEPS " == *" $1 "* ]]; }
+echo "start $(date +%T) steps: $STEPS" | tee $OUT/progress.txt
+if want 1; then
+echo "[1] bench" | tee -a $OUT/progress.txt
 python bench.py 2>$OUT/bench.err | tail -1 > $OUT/bench.json
+fi
+if want 2; then
 echo "[2] bench under rocprof" | tee -a $OUT/progress.txt
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python3 $R/bench.py --no-cpu-baseline > /tmp/bench_prof.out 2>/dev/null )
 tail -1 /tmp/bench_prof.out > $OUT/bench_under_rocprof.json
 cp $(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1) $OUT/bench_kernel_stats.csv 2>/dev/null
+fi
+if want 3; then
 echo "[3] per-step table" | tee -a $OUT/progress.txt
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_step -o step -- python3 $R/bench.py --no-cpu-baseline --no-roofline > /dev/null 2>&1 )
 python tools/prof_summary.py /tmp/prof_step --skip 8 --top 70 --out $OUT/train_step_kernels.txt > /dev/null
+fi
+if want 4; then
 echo "[4] other configs" | tee -a $OUT/progress.txt
 : > $OUT/other_configs.txt
 CONFIGS=${CONFIGS:-"cfg3_segformer_b2_b0_cgd_cd cfg5_segformer_b4_b1_multistage_bf16 cfg1_pspnet_r101_r18_cd cfg4_pspnet_r18_swin_b_cgd_align"}
@@ -36,8 +46,10 @@ for c in $CONFIGS; do
     echo "   $c $g done" | tee -a $OUT/progress.txt
   done
 done
+fi
+if want 5; then
 echo "[5] kernel rooflines: trace + PMC passes" | tee -a $OUT/progress.txt
-for g in r1 tok r2 ce align; do
+for g in r1 tok r2 ce align sra; do
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kr_$g -o k -- python3 $R/tools/kernel_rooflines.py --only $g > $OUT/kernels_$g.txt 2>/dev/null )
   cp $(find /tmp/kr_$g -name '*kernel_stats.csv' | head -1) $OUT/kernels_${g}_stats.csv 2>/dev/null
 done
@@ -51,8 +63,12 @@ for g in r2 ce; do
   ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pvf_$g -o p -- python3 $R/tools/kernel_rooflines.py --only $g > /dev/null 2>&1 )
   python tools/pmc_summary.py /tmp/pv_$g /tmp/pvf_$g --out $OUT/pmc_valu_$g.json > /dev/null
 done
+fi
+if want 6; then
 echo "[6] gemm bench" | tee -a $OUT/progress.txt
 python tools/gemm_bench.py 2>/dev/null | grep -v amdgpu.ids > $OUT/gemm_bench.txt
+fi
 ls -la $OUT | tee -a $OUT/progress.txt
-cut -c1-600 $OUT/bench.json
-cat $OUT/other_configs.txt
+[ -f $OUT/bench.json ] && cut -c1-600 $OUT/bench.json
+[ -f $OUT/other_configs.txt ] && cat $OUT/other_configs.txt
+exit 0
