@@ -63,7 +63,11 @@ const char *sd_error_string(int code);
  * set them before sizing workspaces, never between a *_workspace_bytes() call and its launch).
  * keys: "cgd_fwd_chunk_iters" / "cgd_bwd_chunk_iters" (rounds of 4 x 16-byte loads per
  *       operand per lane per workgroup), "cgd_bwd_nt_store" (0|1), "cgd_bwd_unroll" (2|4|8),
- *       "cgd_up_band_rows" (tap rows per workgroup of the fused-upsample kernels). */
+ *       "cgd_up_band_rows" (tap rows per workgroup of the fused-upsample kernels),
+ *       "sra_split_bf16" (0|1, default 1: fp32-storage attention products on the bf16 matrix pipe with every operand split exactly
+ *       into three bf16 terms -- fp32-grade results; 0 = v_mfma_f32_32x32x2_f32), "sra_bf16_mfma" (0|1, default 1: bf16-storage
+ *       attention forward on the bf16 matrix pipe with P rounded to bf16; 0 = the exact f32-input MFMA kernel).  The two sra_* keys
+ *       select arithmetic, not geometry: no workspace size depends on them. */
 int sd_set_tunable(const char *key, int value);
 int sd_get_tunable(const char *key);
 
@@ -361,8 +365,11 @@ int sd_add_layernorm_bwd(const void *xsum, const void *dy, const float *gamma, c
  *   kv   [B, KV, 2*heads*D]   the kv Linear output as it is (inner order: k|v, head, D -- the reference's reshape :116)
  *   out  [B, N, heads*D]      what the proj Linear consumes (the reference's transpose(1,2).reshape :123)
  *   lse  [B, heads, N] fp32   base-2 log-sum-exp of the scaled scores (saved for the backward)
- * head_dim D in {32, 64}; any N; KV <= 256 (K and V of a head are staged in LDS; KV = 256 at 512x512).  fp32-exact MFMA
- * (v_mfma_f32_32x32x2_f32), bf16 storage optional.  dkv has kv's layout.
+ * head_dim D in {32, 64}; any N; KV <= 256 (K and V of a head are staged in LDS; KV = 256 at 512x512).  Arithmetic: fp32 storage --
+ * split-bf16 products on the bf16 matrix pipe (three exact bf16 terms per operand, six cross products, fp32 accumulation: the error
+ * bound of the exact v_mfma_f32_32x32x2_f32 kernels, which remain behind tunable sra_split_bf16 = 0 and serve the head_dim-64
+ * backward); bf16 storage -- forward on the bf16 matrix pipe with P rounded to bf16 (tunable sra_bf16_mfma), backward on the
+ * f32-input MFMA.  dkv has kv's layout.
  */
 int sd_sra_supported(int head_dim);
 size_t sd_sra_workspace_bytes(int B, int N, int KV, int heads, int D);   /* backward only */

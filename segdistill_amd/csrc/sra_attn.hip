@@ -486,6 +486,117 @@ __global__ __launch_bounds__(NW * 64) void sra_fwd_x3(const T *__restrict__ q, c
     }
 }
 
+// ---- forward for bf16 STORAGE on the bf16 matrix pipe (config 5) -------------------------------------------------------------------
+// q, K and V are bf16 in memory, so each is ONE exact plane: K rows are copied as they are into LDS ([key][d], pitch 2D + 16 bytes), V goes
+// in transposed with the key-slot order of sra_fwd_x3 ([d][key slot]), a lane's q fragment is a 16-byte global load.  S^T = K Q^T is exact
+// products with fp32 accumulation; the scale is applied with the subtraction of the maximum (one fma); P is rounded to bf16 for the second
+// product (as every bf16 attention does; row sums are taken before the rounding), accumulation fp32.  2 + 2 D/32 MFMAs per 32-key block
+// against 16 + 16 D/32 f32-input ones at twice the cycles each; 71 KB of LDS at head_dim 64.
+template <int D, int NW, int QT>
+__global__ __launch_bounds__(NW * 64) void sra_fwd_b16(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kv, bf16_t *__restrict__ out,
+                                                        float *__restrict__ lse, int N, int KV, int heads, float cs /* scale*log2e */) {
+    constexpr int KP = 2 * D + 16, DB = D / 32, KS = D / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b16[];
+    const int nblk = (KV + 31) / 32, rows = nblk * 32;
+    const int VP = 2 * rows + 16;
+    unsigned char *Kimg = smem_b16, *Vimg = smem_b16 + (size_t)rows * KP;
+    const int h = blockIdx.y, b = blockIdx.z, C = heads * D;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, half = l >> 5;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    for (int idx = threadIdx.x; idx < rows * (D / 8); idx += NW * 64) {          // K: 16-byte pieces, rows >= KV zero
+        const int j = idx / (D / 8), d0 = (idx % (D / 8)) * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (j < KV) v = *reinterpret_cast<const u32x4 *>(kv + ((size_t)b * KV + j) * 2 * C + h * D + d0);
+        *reinterpret_cast<u32x4 *>(Kimg + (size_t)j * KP + d0 * 2) = v;
+    }
+    for (int idx = threadIdx.x; idx < rows * (D / 8); idx += NW * 64) {          // V: 16-byte loads along d, 2-byte transposed stores
+        const int j = idx / (D / 8), d0 = (idx % (D / 8)) * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (j < KV) v = *reinterpret_cast<const u32x4 *>(kv + ((size_t)b * KV + j) * 2 * C + C + h * D + d0);
+        const int r = j & 31, slot = (j & ~31) + 16 * (r >> 4) + 8 * ((r >> 2) & 1) + (r & 3) + 4 * ((r >> 3) & 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            *reinterpret_cast<unsigned short *>(Vimg + (size_t)(d0 + e) * VP + slot * 2) = (unsigned short)((e & 1) ? (v[e >> 1] >> 16) : (v[e >> 1] & 0xffffu));
+    }
+    __syncthreads();
+    for (int qt = 0; qt < QT; ++qt) {
+        const int n = (blockIdx.x * QT + qt) * (NW * 32) + w * 32 + c;
+        const bool live = n < N;
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (live) v = *reinterpret_cast<const u32x4 *>(q + ((size_t)b * N + n) * C + h * D + ks * 16 + 8 * half);
+            qf[ks] = __builtin_bit_cast(bf16x8, v);
+        }
+        f32x16 S[8];
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[blk][e] = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk) {
+            if (blk < nblk) {
+                const unsigned char *krow = Kimg + (size_t)(blk * 32 + c) * KP + half * 16;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) S[blk] = mfma16(*reinterpret_cast<const bf16x8 *>(krow + ks * 32), qf[ks], S[blk]);
+            }
+        }
+        float m = kNegBig;
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk) {
+            if (blk * 32 + 32 > KV) {                             // wave-uniform: only ragged / absent blocks are masked
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (blk * 32 + crow(e, half) >= KV) S[blk][e] = kNegBig;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) m = fmaxf(m, S[blk][e]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        const float mc = -m * cs;
+        float lsum = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 8; ++blk)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                S[blk][e] = ex2(fmaf(S[blk][e], cs, mc));         // masked / absent keys: exp2(-1e30 cs + ...) = 0
+                lsum += S[blk][e];
+            }
+        lsum += __shfl_xor(lsum, 32, 64);
+        f32x16 O[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) O[db][e] = 0.f;
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int blk = st >> 1, s2 = st & 1;
+            if (blk < nblk) {
+                bf16x8 pf;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pf[i] = static_cast<__bf16>(S[blk][8 * s2 + i]);
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const unsigned char *vrow = Vimg + (size_t)(db * 32 + c) * VP + (blk * 32 + s2 * 16 + half * 8) * 2;
+                    O[db] = mfma16(*reinterpret_cast<const bf16x8 *>(vrow), pf, O[db]);
+                }
+            }
+        }
+        if (live) {
+            const float inv = 1.f / lsum;
+            bf16_t *orow = out + ((size_t)b * N + n) * C + h * D;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    Q4<bf16_t>::store(orow + db * 32 + 8 * g + 4 * half,
+                                      make_float4(O[db][4 * g] * inv, O[db][4 * g + 1] * inv, O[db][4 * g + 2] * inv, O[db][4 * g + 3] * inv));
+            if (half == 0) lse[((size_t)b * heads + h) * N + n] = m * cs + __builtin_amdgcn_logf(lsum);   // base-2 lse of the scaled scores
+        }
+    }
+}
+
 // ---- backward, queries: dq and delta = sum_d dO*O.  Same grid / ownership as the forward ------------------------------------
 template <typename T, int D, int NW>
 __global__ __launch_bounds__(NW * 64) void sra_bwd_dq(const T *__restrict__ q, const T *__restrict__ kv, const T *__restrict__ out,
@@ -977,8 +1088,28 @@ int sra_fwd_x3_launch_nw(const void *q, const void *kv, void *out, float *lse, i
                           : sra_fwd_x3_launch_full<T, D, NW, QT, false>(q, kv, out, lse, B, N, KV, heads, scale, st);
 }
 
+template <int D, int NW, int QT>
+int sra_fwd_b16_launch(const void *q, const void *kv, void *out, float *lse, int B, int N, int KV, int heads, float scale, hipStream_t st) {
+    const dim3 grid((N + NW * 32 * QT - 1) / (NW * 32 * QT), heads, B);
+    const int rows = (KV + 31) / 32 * 32;
+    const size_t lds = (size_t)rows * (2 * D + 16) + (size_t)D * (2 * rows + 16);
+    static bool raised = false;
+    int rc = sra_raise_lds(sra_fwd_b16<D, NW, QT>, raised);
+    if (rc) return rc;
+    hipLaunchKernelGGL((sra_fwd_b16<D, NW, QT>), grid, dim3(NW * 64), lds, st, (const bf16_t *)q, (const bf16_t *)kv, (bf16_t *)out, lse, N, KV,
+                       heads, scale * kLog2e);
+    return (int)hipGetLastError();
+}
+
+int g_sra_bf16_mfma = 1;   // tunable "sra_bf16_mfma": bf16 storage runs the forward on the bf16 matrix pipe (P rounded to bf16)
+
 template <typename T, int D>
 int sra_fwd_launch(const void *q, const void *kv, void *out, float *lse, int B, int N, int KV, int heads, float scale, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) if (g_sra_bf16_mfma) {
+        if (N >= 8192) return sra_fwd_b16_launch<D, 8, 2>(q, kv, out, lse, B, N, KV, heads, scale, st);
+        return sra_wide(N) ? sra_fwd_b16_launch<D, 8, 1>(q, kv, out, lse, B, N, KV, heads, scale, st)
+                           : sra_fwd_b16_launch<D, 4, 1>(q, kv, out, lse, B, N, KV, heads, scale, st);
+    }
     if constexpr (sizeof(T) == 4) if (g_sra_split_bf16) {
         if (N >= 8192 && D == 32) return sra_fwd_x3_launch_nw<T, D, 8, 2>(q, kv, out, lse, B, N, KV, heads, scale, st);   // (PHASED restages per tile)
         return sra_wide(N) ? sra_fwd_x3_launch_nw<T, D, 8, 1>(q, kv, out, lse, B, N, KV, heads, scale, st)
@@ -1045,13 +1176,16 @@ int sra_bwd_launch(const void *q, const void *kv, const void *out, const void *d
 }  // namespace
 
 int sra_tunable(const char *key, int set, int v) {
-    if (strcmp(key, "sra_split_bf16")) return SD_E_UNSUPPORTED;
+    int *p = nullptr;
+    if (!strcmp(key, "sra_split_bf16")) p = &g_sra_split_bf16;
+    else if (!strcmp(key, "sra_bf16_mfma")) p = &g_sra_bf16_mfma;
+    if (!p) return SD_E_UNSUPPORTED;
     if (set) {
         if (v != 0 && v != 1) return SD_E_SHAPE;
-        g_sra_split_bf16 = v;
+        *p = v;
         return SD_OK;
     }
-    return g_sra_split_bf16;
+    return *p;
 }
 }  // namespace sd
 

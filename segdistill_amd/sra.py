@@ -19,9 +19,10 @@ def supported(q, kv, heads):
 
 def preferred(n_queries, n_keys, head_dim, q):
     """Policy, from tools/sra_bench.py on MI355X (profiles/r01_step_kernels_microbench.txt).  fp32: the kernels beat both library
-    forms (fused SDPA, bmm+softmax) at every MiT stage shape, forward and forward+backward.  bf16 storage: the kernels still
-    compute on the fp32 MFMA path while the library's fused kernel uses bf16 MFMA, so they only win where the library's
-    backward collapses -- training with >= 8192 queries (1.3-1.5x); elsewhere the library is used.
+    forms (fused SDPA, bmm+softmax) at every MiT stage shape, forward and forward+backward.  bf16 storage: the FORWARD has a bf16-MFMA
+    kernel (sra_fwd_b16), used whenever no graph is built (the frozen teacher: 41 layers of B4 in config 5); the backward kernels still
+    compute on the fp32 MFMA path while the library's fused kernel uses bf16 MFMA, so for training they only win where the library's
+    backward collapses -- >= 8192 queries (1.3-1.5x); elsewhere the library is used.
     SEGDISTILL_SRA=off|train|all overrides (benchmarking / bisecting)."""
     import os
     mode = os.environ.get('SEGDISTILL_SRA', 'auto')
@@ -34,7 +35,7 @@ def preferred(n_queries, n_keys, head_dim, q):
         return training
     if q.dtype == torch.float32:
         return True
-    return training and n_queries >= 8192
+    return (not training) or n_queries >= 8192
 
 
 class _SRAttention(torch.autograd.Function):
