@@ -66,7 +66,8 @@ const char *sd_error_string(int code);
  *       "cgd_up_band_rows" (tap rows per workgroup of the fused-upsample kernels),
  *       "sra_split_bf16" (0|1, default 1: fp32-storage attention products on the bf16 matrix pipe with every operand split exactly
  *       into three bf16 terms -- fp32-grade results; 0 = v_mfma_f32_32x32x2_f32), "sra_bf16_mfma" (0|1, default 1: bf16-storage
- *       attention forward on the bf16 matrix pipe with P rounded to bf16; 0 = the exact f32-input MFMA kernel).  The two sra_* keys
+ *       attention forward on the bf16 matrix pipe with P rounded to bf16; 0 = the exact f32-input MFMA kernel), "align_split_bf16"
+ *       (0|1, default 1: the three fp32 products of the 1x1 align projection in split-bf16 arithmetic).  The sra_* and align_* keys
  *       select arithmetic, not geometry: no workspace size depends on them. */
 int sd_set_tunable(const char *key, int value);
 int sd_get_tunable(const char *key);

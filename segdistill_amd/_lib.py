@@ -129,6 +129,7 @@ def lib():
     _lib = h
     if os.environ.get('SEGDISTILL_SPLIT_BF16', '1') == '0':   # A/B switch shared with linear.py: exact-f32 MFMA everywhere
         h.sd_set_tunable(b'sra_split_bf16', 0)
+        h.sd_set_tunable(b'align_split_bf16', 0)
     return h
 
 

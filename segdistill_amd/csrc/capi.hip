@@ -28,6 +28,7 @@ int sd_set_tunable(const char *key, int value) {
     int rc = sd::cgd_tunable(key, 1, value);
     if (rc == SD_E_UNSUPPORTED) rc = sd::cgd_up_tunable(key, 1, value);
     if (rc == SD_E_UNSUPPORTED) rc = sd::sra_tunable(key, 1, value);
+    if (rc == SD_E_UNSUPPORTED) rc = sd::token_gemm_tunable(key, 1, value);
     return rc;
 }
 
@@ -36,6 +37,7 @@ int sd_get_tunable(const char *key) {
     int rc = sd::cgd_tunable(key, 0, 0);
     if (rc == SD_E_UNSUPPORTED) rc = sd::cgd_up_tunable(key, 0, 0);
     if (rc == SD_E_UNSUPPORTED) rc = sd::sra_tunable(key, 0, 0);
+    if (rc == SD_E_UNSUPPORTED) rc = sd::token_gemm_tunable(key, 0, 0);
     return rc;
 }
 

@@ -22,5 +22,6 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
 int cgd_tunable(const char *key, int set, int v);
 int cgd_up_tunable(const char *key, int set, int v);
 int sra_tunable(const char *key, int set, int v);
+int token_gemm_tunable(const char *key, int set, int v);
 
 }  // namespace sd

@@ -19,6 +19,7 @@
 // 256 threads = 4 waves; tiles 128x128 (waves 2x2, 2x2 MFMA tiles each), 128x64 (2x2, 2x1), 256x32 (4x1, 2x1) chosen by N.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -503,19 +504,40 @@ int dispatch(const float *A, const float *Bm, float *C, const float *bias, const
 //   bwd-data  dX_b [Cs x P] = W^T . dY_b [Ct x P]                        A = W read as [k][m] (m-contiguous), B = dY_b ([k][n])
 //   bwd-wgt   slab_z [Ct x Cs] = dY_b[:, chunk] . X_b[:, chunk]^T        A = dY_b ([m][k]), B = X_b ([n][k]); z = (image, pixel chunk), combined
 //                                                                         by the caller's deterministic slab reduction
+int g_align_split_bf16 = 1;   // tunable "align_split_bf16": the three align products in split-bf16 arithmetic (same error bound as f32 MFMA)
+
 int align_f32_fwd(const float *X, const float *W, const float *bias, float *Y, int B, int Cs, int Ct, long P, hipStream_t st) {
+    if (g_align_split_bf16 && Cs % 32 == 0)
+        return launch_epi<128, 128, 2, 2, false, 0, true, true, true>(W, X, Y, bias, nullptr, Ct, (int)P, Cs, Cs, P, P, st, B, 0L, (long)Cs * P,
+                                                                      (long)Ct * P);
     return launch_epi<128, 128, 2, 2, false, 0, true, true>(W, X, Y, bias, nullptr, Ct, (int)P, Cs, Cs, P, P, st, B, 0L, (long)Cs * P, (long)Ct * P);
 }
 
 int align_f32_bwd_data(const float *dY, const float *W, float *dX, int B, int Cs, int Ct, long P, hipStream_t st) {
+    if (g_align_split_bf16 && Ct % 32 == 0)
+        return launch_epi<128, 128, 2, 2, false, 0, false, false, true>(W, dY, dX, nullptr, nullptr, Cs, (int)P, Ct, Cs, P, P, st, B, 0L, (long)Ct * P,
+                                                                        (long)Cs * P);
     return launch_epi<128, 128, 2, 2, false, 0, false, false>(W, dY, dX, nullptr, nullptr, Cs, (int)P, Ct, Cs, P, P, st, B, 0L, (long)Ct * P,
                                                               (long)Cs * P);
 }
 
 int align_f32_bwd_weight_slabs(const float *dY, const float *X, float *slabs, int B, int Cs, int Ct, long P, int nsplit, int klen, hipStream_t st) {
     // z = image * nsplit + pixel chunk; slab z = dY_b[:, chunk] . X_b[:, chunk]^T  (both operands k-contiguous along the pixels)
+    if (g_align_split_bf16 && klen % 32 == 0 && P % 32 == 0)
+        return launch_epi<128, 128, 2, 2, true, 0, true, false, true>(dY, X, slabs, nullptr, nullptr, Ct, Cs, (int)P, P, P, Cs, st, B, (long)Ct * P,
+                                                                      (long)Cs * P, (long)Ct * Cs, nsplit, klen);
     return launch_epi<128, 128, 2, 2, true, 0, true, false>(dY, X, slabs, nullptr, nullptr, Ct, Cs, (int)P, P, P, Cs, st, B, (long)Ct * P, (long)Cs * P,
                                                             (long)Ct * Cs, nsplit, klen);
+}
+
+int token_gemm_tunable(const char *key, int set, int v) {
+    if (strcmp(key, "align_split_bf16")) return SD_E_UNSUPPORTED;
+    if (set) {
+        if (v != 0 && v != 1) return SD_E_SHAPE;
+        g_align_split_bf16 = v;
+        return SD_OK;
+    }
+    return g_align_split_bf16;
 }
 
 }  // namespace sd

@@ -179,21 +179,29 @@ def bench_align(dev, reps, B, Cs, Ct, h, dtype, tag):
     dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(b)
     wsb = L.sd_align1x1_workspace_bytes(B, Cs, Ct, h, h)
     ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
-    tf = _time(lambda st: _ok(L.sd_align1x1_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), DT, B, Cs, Ct, h, h, st), 'fwd'), reps)
-    td = _time(lambda st: _ok(L.sd_align1x1_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), DT, B, Cs, Ct, h, h, st), 'bwd_data'), reps)
-    tw = _time(lambda st: _ok(L.sd_align1x1_bwd_weight(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), DT, B, Cs, Ct, h, h, ws.data_ptr(), wsb, st),
-                           'bwd_weight'), reps)
     flops = 2.0 * Ct * Cs * B * h * h
     e = x.element_size()
-    peak = MFMA_F32 if dtype == torch.float32 else MFMA_BF16
     shape = {'B': B, 'Cs': Cs, 'Ct': Ct, 'h': h, 'w': h, 'gemm': f'M={Ct} K={Cs} N={B * h * h}'}
     out = []
-    for nm, ms, byt in (('fwd', tf, (x.numel() + y.numel()) * e), ('bwd_data', td, (dy.numel() + dx.numel()) * e), ('bwd_weight', tw, (dy.numel() + x.numel()) * e)):
-        ent = _entry(f'align1x1 {nm} {tag}', f'sd_align1x1_{nm}', shape, 'f32' if dtype == torch.float32 else 'bf16', ms, 'mfma', flops, peak)
-        ent['hbm_GBps'] = round(byt / (ms * 1e-3) / 1e9, 1)
-        ent['hbm_frac'] = round(ent['hbm_GBps'] / HBM, 4)
-        ent['algorithmic_bytes'] = int(byt)
-        out.append(ent)
+    # fp32 storage has two arithmetic modes (tunable align_split_bf16): split-bf16 on the bf16 matrix pipe (shipped) and exact f32 MFMA
+    modes = ((1, 'split-bf16', MFMA_BF16 / 6), (0, 'f32 MFMA', MFMA_F32)) if dtype == torch.float32 else ((None, 'bf16', MFMA_BF16),)
+    for mode, mtag, peak in modes:
+        if mode is not None:
+            _lib.set_tunable('align_split_bf16', mode)
+        tf = _time(lambda st: _ok(L.sd_align1x1_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), DT, B, Cs, Ct, h, h, st), 'fwd'), reps)
+        td = _time(lambda st: _ok(L.sd_align1x1_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), DT, B, Cs, Ct, h, h, st), 'bwd_data'), reps)
+        tw = _time(lambda st: _ok(L.sd_align1x1_bwd_weight(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), DT, B, Cs, Ct, h, h, ws.data_ptr(), wsb, st),
+                               'bwd_weight'), reps)
+        for nm, ms, byt in (('fwd', tf, (x.numel() + y.numel()) * e), ('bwd_data', td, (dy.numel() + dx.numel()) * e), ('bwd_weight', tw, (dy.numel() + x.numel()) * e)):
+            ent = _entry(f'align1x1 {nm} {tag} ({mtag})' if mode is not None else f'align1x1 {nm} {tag}', f'sd_align1x1_{nm}', shape,
+                         'f32' if dtype == torch.float32 else 'bf16', ms, 'mfma', flops, round(peak, 1),
+                         'peak = dense bf16 MFMA / 6 cross products; %.0f %% of the f32-input MFMA peak' % (100 * flops / (ms * 1e-3) / 1e12 / MFMA_F32) if mode == 1 else None)
+            ent['hbm_GBps'] = round(byt / (ms * 1e-3) / 1e9, 1)
+            ent['hbm_frac'] = round(ent['hbm_GBps'] / HBM, 4)
+            ent['algorithmic_bytes'] = int(byt)
+            out.append(ent)
+    if dtype == torch.float32:
+        _lib.set_tunable('align_split_bf16', 1)
     return out
 
 
