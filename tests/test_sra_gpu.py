@@ -95,3 +95,34 @@ def test_mit_attention_module_uses_the_kernel_and_matches_the_explicit_form():
     assert _err(y, y2) < 1e-5 and _err(gx, x.grad) < 1e-4
     for n, p in m.named_parameters():
         assert _err(gp[n], p.grad) < 1e-4, n
+
+
+@pytest.mark.parametrize('case', [(2, 4096, 256, 2, 32), (1, 1000, 77, 2, 32), (2, 2048, 256, 1, 64), (8, 16384, 256, 1, 32)])
+def test_split_bf16_error_bound(case):
+    """The split-bf16 kernels (fp32 storage; three exact bf16 terms per operand, six cross products on the bf16 matrix pipe) against fp64:
+    <= 2e-6 max-norm relative on out / dq / dkv, and no worse than 3x the exact f32-MFMA kernels on the same inputs (tunable sra_split_bf16
+    selects the arithmetic; head_dim 64 has a split forward only, its backward runs the exact kernels in both modes)."""
+    from segdistill_amd import _lib, sra
+    B, N, KV, heads, D = case
+    C = heads * D
+    g = torch.Generator().manual_seed(7 * N + KV)
+    q, kv, do = torch.randn(B, N, C, generator=g), torch.randn(B, KV, 2 * C, generator=g), torch.randn(B, N, C, generator=g)
+    scale = D ** -0.5
+    q64, kv64 = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    ref = _reference(q64, kv64, heads, scale)
+    ref.backward(do.double())
+    dev = torch.device('cuda:0')
+    errs = {}
+    try:
+        for mode in (1, 0):
+            _lib.set_tunable('sra_split_bf16', mode)
+            qg, kvg = q.to(dev).requires_grad_(True), kv.to(dev).requires_grad_(True)
+            out = sra.sr_attention(qg, kvg, heads, scale)
+            out.backward(do.to(dev))
+            errs[mode] = (_err(out, ref), _err(qg.grad, q64.grad), _err(kvg.grad, kv64.grad))
+    finally:
+        _lib.set_tunable('sra_split_bf16', 1)
+    print(case, 'split-bf16 out/dq/dkv %.2e %.2e %.2e | f32 MFMA %.2e %.2e %.2e' % (errs[1] + errs[0]))
+    for e_split, e_exact in zip(errs[1], errs[0]):
+        assert e_split < 2e-6
+        assert e_split < 3 * e_exact + 1e-7
