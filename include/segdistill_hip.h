@@ -66,7 +66,7 @@ const char *sd_error_string(int code);
  *       "cgd_up_band_rows" (tap rows per workgroup of the fused-upsample kernels),
  *       "sra_split_bf16" (0|1, default 1: fp32-storage attention products on the bf16 matrix pipe with every operand split exactly
  *       into three bf16 terms -- fp32-grade results; 0 = v_mfma_f32_32x32x2_f32), "sra_bf16_mfma" (0|1, default 1: bf16-storage
- *       attention forward on the bf16 matrix pipe with P rounded to bf16; 0 = the exact f32-input MFMA kernel), "align_split_bf16"
+ *       attention forward and backward on the bf16 matrix pipe with P / dS rounded to bf16; 0 = the f32-input MFMA kernels), "align_split_bf16"
  *       (0|1, default 1: the three fp32 products of the 1x1 align projection in split-bf16 arithmetic).  The sra_* and align_* keys
  *       select arithmetic, not geometry: no workspace size depends on them. */
 int sd_set_tunable(const char *key, int value);
@@ -369,8 +369,8 @@ int sd_add_layernorm_bwd(const void *xsum, const void *dy, const float *gamma, c
  * head_dim D in {32, 64}; any N; KV <= 256 (K and V of a head are staged in LDS; KV = 256 at 512x512).  Arithmetic: fp32 storage --
  * split-bf16 products on the bf16 matrix pipe (three exact bf16 terms per operand, six cross products, fp32 accumulation: the error
  * bound of the exact v_mfma_f32_32x32x2_f32 kernels, which remain behind tunable sra_split_bf16 = 0 and serve the head_dim-64
- * backward); bf16 storage -- forward on the bf16 matrix pipe with P rounded to bf16 (tunable sra_bf16_mfma), backward on the
- * f32-input MFMA.  dkv has kv's layout.
+ * backward); bf16 storage -- forward and backward on the bf16 matrix pipe with P / dS rounded to bf16 for the second-stage products
+ * (tunable sra_bf16_mfma; 0 = the f32-input MFMA kernels on the widened values).  dkv has kv's layout.
  */
 int sd_sra_supported(int head_dim);
 size_t sd_sra_workspace_bytes(int B, int N, int KV, int heads, int D);   /* backward only */

@@ -205,6 +205,9 @@ __global__ __launch_bounds__(NW * 64) void sra_fwd(const T *__restrict__ q, cons
 //   * head_dim 64: the six planes of 256 keys are 207 KB, more than the CU's 160 KB of LDS -- PHASED: the K planes are staged, S^T and
 //     the softmax run, then the V planes replace them for the second product (two more barriers per tile, K / V re-read from L2).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int sra_slot(int r) { return 16 * (r >> 4) + 8 * ((r >> 2) & 1) + (r & 3) + 4 * ((r >> 3) & 1); }   // row of a 32-block -> k slot
+__device__ __forceinline__ float bf16_lane(const u32x4 &v, int e) { return (e & 1) ? __uint_as_float(v[e >> 1] & 0xffff0000u) : __uint_as_float(v[e >> 1] << 16); }
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
 #pragma unroll
@@ -502,7 +505,6 @@ __global__ __launch_bounds__(NW * 64) void sra_fwd_b16(const bf16_t *__restrict_
     unsigned char *Kimg = smem_b16, *Vimg = smem_b16 + (size_t)rows * KP;
     const int h = blockIdx.y, b = blockIdx.z, C = heads * D;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, half = l >> 5;
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     for (int idx = threadIdx.x; idx < rows * (D / 8); idx += NW * 64) {          // K: 16-byte pieces, rows >= KV zero
         const int j = idx / (D / 8), d0 = (idx % (D / 8)) * 8;
         u32x4 v = {0u, 0u, 0u, 0u};
@@ -987,6 +989,220 @@ __global__ __launch_bounds__(kSraThreads) void sra_bwd_dkv_x3(const T *__restric
     }
 }
 
+// ---- backward for bf16 STORAGE on the bf16 matrix pipe (config 5).  Same ownership, partial layout and saved statistics as the kernels
+// above; every operand is one exact bf16 plane (copies, no splits), P and dS are rounded to bf16 for the three gradient products (as every
+// bf16 attention backward does), accumulation fp32, the scale enters through the exponent's fma.
+
+template <int D, int NW, int QT>
+__global__ __launch_bounds__(NW * 64) void sra_bwd_dq_b16(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kv, const bf16_t *__restrict__ out,
+                                                           const bf16_t *__restrict__ dout, const float *__restrict__ lse, bf16_t *__restrict__ dq,
+                                                           float *__restrict__ delta, int N, int KV, int heads, float cs, float scale) {
+    constexpr int KP = 2 * D + 16, DB = D / 32, KS = D / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dqb[];
+    const int nblk = (KV + 31) / 32, rows = nblk * 32;
+    const int TP = 2 * rows + 16;
+    unsigned char *Kp = smem_dqb, *Vp = Kp + (size_t)rows * KP, *KTp = Vp + (size_t)rows * KP;
+    const int h = blockIdx.y, b = blockIdx.z, C = heads * D;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, half = l >> 5;
+    for (int idx = threadIdx.x; idx < rows * (D / 8); idx += NW * 64) {
+        const int j = idx / (D / 8), d0 = (idx % (D / 8)) * 8;
+        u32x4 kx = {0u, 0u, 0u, 0u}, vx = kx;
+        if (j < KV) {
+            const bf16_t *row = kv + ((size_t)b * KV + j) * 2 * C + h * D + d0;
+            kx = *reinterpret_cast<const u32x4 *>(row);
+            vx = *reinterpret_cast<const u32x4 *>(row + C);
+        }
+        *reinterpret_cast<u32x4 *>(Kp + (size_t)j * KP + d0 * 2) = kx;
+        *reinterpret_cast<u32x4 *>(Vp + (size_t)j * KP + d0 * 2) = vx;
+        const int slot = (j & ~31) + sra_slot(j & 31);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            *reinterpret_cast<unsigned short *>(KTp + (size_t)(d0 + e) * TP + slot * 2) = (unsigned short)((e & 1) ? (kx[e >> 1] >> 16) : (kx[e >> 1] & 0xffffu));
+    }
+    __syncthreads();
+    for (int qt = 0; qt < QT; ++qt) {
+        const int n = (blockIdx.x * QT + qt) * (NW * 32) + w * 32 + c;
+        const bool live = n < N;
+        bf16x8 qf[KS], gf[KS];
+        float dl = 0.f, L = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 qx = {0u, 0u, 0u, 0u}, gx = qx, ox = qx;
+            if (live) {
+                const size_t row = ((size_t)b * N + n) * C + h * D + ks * 16 + 8 * half;
+                qx = *reinterpret_cast<const u32x4 *>(q + row);
+                gx = *reinterpret_cast<const u32x4 *>(dout + row);
+                ox = *reinterpret_cast<const u32x4 *>(out + row);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl = fmaf(bf16_lane(gx, e), bf16_lane(ox, e), dl);
+            qf[ks] = __builtin_bit_cast(bf16x8, qx);
+            gf[ks] = __builtin_bit_cast(bf16x8, gx);
+        }
+        if (live) L = lse[((size_t)b * heads + h) * N + n];
+        dl += __shfl_xor(dl, 32, 64);
+        f32x16 G[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) G[db][e] = 0.f;
+        for (int blk = 0; blk < nblk; ++blk) {
+            f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dp = s;
+            const unsigned char *kr = Kp + (size_t)(blk * 32 + c) * KP + half * 16, *vr = Vp + (size_t)(blk * 32 + c) * KP + half * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s = mfma16(*reinterpret_cast<const bf16x8 *>(kr + ks * 32), qf[ks], s);
+                dp = mfma16(*reinterpret_cast<const bf16x8 *>(vr + ks * 32), gf[ks], dp);
+            }
+            const bool whole = blk * 32 + 32 <= KV;            // wave-uniform
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float p = ex2(fmaf(s[e], cs, -L));
+                if (!whole && blk * 32 + crow(e, half) >= KV) p = 0.f;
+                s[e] = p * (dp[e] - dl);
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 df;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) df[i] = static_cast<__bf16>(s[8 * st + i]);
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+                    G[db] = mfma16(*reinterpret_cast<const bf16x8 *>(KTp + (size_t)(db * 32 + c) * TP + (blk * 32 + 16 * st + 8 * half) * 2), df, G[db]);
+            }
+        }
+        if (live) {
+            bf16_t *grow = dq + ((size_t)b * N + n) * C + h * D;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    Q4<bf16_t>::store(grow + db * 32 + 8 * g + 4 * half, make_float4(G[db][4 * g] * scale, G[db][4 * g + 1] * scale,
+                                                                                      G[db][4 * g + 2] * scale, G[db][4 * g + 3] * scale));
+            if (half == 0) delta[((size_t)b * heads + h) * N + n] = dl;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kSraThreads) void sra_bwd_dkv_b16(const bf16_t *__restrict__ q, const bf16_t *__restrict__ kv,
+                                                                const bf16_t *__restrict__ dout, const float *__restrict__ lse,
+                                                                const float *__restrict__ delta, float *__restrict__ part, int N, int KV, int heads,
+                                                                int nchunk, int qchunk, float cs, float scale) {
+    constexpr int KP = 2 * D + 16, TP = 80, DB = D / 32, KS = D / 16, PIECES = 32 * (D / 8), NIT = 2 * PIECES / kSraThreads;
+    __shared__ __attribute__((aligned(16))) unsigned char Qp[32 * KP], Gp[32 * KP], QTp[D * TP], GTp[D * TP];
+    __shared__ float Ls[32], Ds[32];
+    const int chunk = blockIdx.x, h = blockIdx.y, b = blockIdx.z, C = heads * D;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, half = l >> 5;
+    bf16x8 kf[2][KS], vf[2][KS];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int j = 64 * w + 32 * cb + c;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x4 kx = {0u, 0u, 0u, 0u}, vx = kx;
+            if (j < KV) {
+                const bf16_t *row = kv + ((size_t)b * KV + j) * 2 * C + h * D + ks * 16 + 8 * half;
+                kx = *reinterpret_cast<const u32x4 *>(row);
+                vx = *reinterpret_cast<const u32x4 *>(row + C);
+            }
+            kf[cb][ks] = __builtin_bit_cast(bf16x8, kx);
+            vf[cb][ks] = __builtin_bit_cast(bf16x8, vx);
+        }
+    }
+    f32x16 aK[2][DB], aV[2][DB];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { aK[cb][db][e] = 0.f; aV[cb][db][e] = 0.f; }
+    const bool wave_live = 64 * w < KV;
+    const int i0 = chunk * qchunk, i1 = min(N, i0 + qchunk);
+    const bf16_t *qb = q + (size_t)b * N * C + h * D;
+    const bf16_t *gb = dout + (size_t)b * N * C + h * D;
+    const float *lb = lse + ((size_t)b * heads + h) * N;
+    const float *db_ = delta + ((size_t)b * heads + h) * N;
+    // staging pieces of this thread: piece id = threadIdx.x + it * 256 over [Q pieces | dO pieces]; a piece = 8 consecutive d of one row
+    u32x4 x[NIT];
+    float ld = 0.f;
+    auto request = [&](int t0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = threadIdx.x + it * kSraThreads, which = id / PIECES, pc = id - which * PIECES;
+            const int r = pc / (D / 8), d0 = (pc % (D / 8)) * 8;
+            x[it] = u32x4{0u, 0u, 0u, 0u};
+            if (t0 + r < i1) x[it] = *reinterpret_cast<const u32x4 *>((which ? gb : qb) + (size_t)(t0 + r) * C + d0);
+        }
+        ld = 0.f;
+        if (threadIdx.x < 32) { if (t0 + threadIdx.x < i1) ld = lb[t0 + threadIdx.x]; }
+        else if (threadIdx.x < 64) { if (t0 + threadIdx.x - 32 < i1) ld = db_[t0 + threadIdx.x - 32]; }
+    };
+    request(i0);
+    for (int t0 = i0; t0 < i1; t0 += 32) {
+        __syncthreads();                                      // the previous tile has been consumed
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = threadIdx.x + it * kSraThreads, which = id / PIECES, pc = id - which * PIECES;
+            const int r = pc / (D / 8), d0 = (pc % (D / 8)) * 8;
+            *reinterpret_cast<u32x4 *>((which ? Gp : Qp) + r * KP + d0 * 2) = x[it];
+            unsigned char *tb = (which ? GTp : QTp) + sra_slot(r) * 2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                *reinterpret_cast<unsigned short *>(tb + (d0 + e) * TP) = (unsigned short)((e & 1) ? (x[it][e >> 1] >> 16) : (x[it][e >> 1] & 0xffffu));
+        }
+        if (threadIdx.x < 32) Ls[threadIdx.x] = ld;
+        else if (threadIdx.x < 64) Ds[threadIdx.x - 32] = ld;
+        if (t0 + 32 < i1) request(t0 + 32);
+        __syncthreads();
+        if (!wave_live) continue;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            f32x16 s = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                s = mfma16(*reinterpret_cast<const bf16x8 *>(Qp + c * KP + ks * 32 + half * 16), kf[cb][ks], s);
+                dp = mfma16(*reinterpret_cast<const bf16x8 *>(Gp + c * KP + ks * 32 + half * 16), vf[cb][ks], dp);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = crow(e, half);
+                const float p = ex2(fmaf(s[e], cs, -Ls[r]));  // padded query rows: q = dO = 0, lse = delta = 0 -> contribute exactly 0
+                dp[e] = p * (dp[e] - Ds[r]);
+                s[e] = p;
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 pf, df;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { pf[i] = static_cast<__bf16>(s[8 * st + i]); df[i] = static_cast<__bf16>(dp[8 * st + i]); }
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const int off = (db * 32 + c) * TP + (16 * st + 8 * half) * 2;
+                    aV[cb][db] = mfma16(*reinterpret_cast<const bf16x8 *>(GTp + off), pf, aV[cb][db]);    // dV^T += dO^T P
+                    aK[cb][db] = mfma16(*reinterpret_cast<const bf16x8 *>(QTp + off), df, aK[cb][db]);    // dK^T += Q^T dS
+                }
+            }
+        }
+    }
+    float *pk = part + (((size_t)b * heads + h) * nchunk + chunk) * 2 * KV * D;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int j = 64 * w + 32 * cb + c;
+        if (j >= KV) continue;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float *dst = pk + (size_t)j * D + db * 32 + 8 * g + 4 * half;
+                *reinterpret_cast<float4 *>(dst) = make_float4(aK[cb][db][4 * g] * scale, aK[cb][db][4 * g + 1] * scale, aK[cb][db][4 * g + 2] * scale,
+                                                               aK[cb][db][4 * g + 3] * scale);
+                *reinterpret_cast<float4 *>(dst + (size_t)KV * D) =
+                    make_float4(aV[cb][db][4 * g], aV[cb][db][4 * g + 1], aV[cb][db][4 * g + 2], aV[cb][db][4 * g + 3]);
+            }
+    }
+}
+
 // dkv[b][j][which][h][d] = sum_chunk part[b][h][chunk][which][j][d].  one thread per 4 output elements
 template <typename T>
 __global__ __launch_bounds__(256) void sra_dkv_reduce(const float *__restrict__ part, T *__restrict__ dkv, int B, int KV, int heads, int D,
@@ -1127,6 +1343,30 @@ int sra_bwd_launch(const void *q, const void *kv, const void *out, const void *d
     float *delta = static_cast<float *>(ws);
     float *part = delta + (((size_t)B * heads * N + 3) & ~(size_t)3);
     const size_t lds = sra_lds_bytes<D>(KV);
+    if constexpr (sizeof(T) == 2) if (g_sra_bf16_mfma) {
+        const int rows = (KV + 31) / 32 * 32;
+        const size_t ldsb = (size_t)2 * rows * (2 * D + 16) + (size_t)D * (2 * rows + 16);
+        static bool r82 = false, r81 = false, r41 = false;
+        int rc;
+        if (N >= 8192) {
+            if ((rc = sra_raise_lds(sra_bwd_dq_b16<D, 8, 2>, r82))) return rc;
+            hipLaunchKernelGGL((sra_bwd_dq_b16<D, 8, 2>), dim3((N + 511) / 512, heads, B), dim3(512), ldsb, st, (const bf16_t *)q, (const bf16_t *)kv,
+                               (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dq, delta, N, KV, heads, scale * kLog2e, scale);
+        } else if (sra_wide(N)) {
+            if ((rc = sra_raise_lds(sra_bwd_dq_b16<D, 8, 1>, r81))) return rc;
+            hipLaunchKernelGGL((sra_bwd_dq_b16<D, 8, 1>), dim3((N + 255) / 256, heads, B), dim3(512), ldsb, st, (const bf16_t *)q, (const bf16_t *)kv,
+                               (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dq, delta, N, KV, heads, scale * kLog2e, scale);
+        } else {
+            if ((rc = sra_raise_lds(sra_bwd_dq_b16<D, 4, 1>, r41))) return rc;
+            hipLaunchKernelGGL((sra_bwd_dq_b16<D, 4, 1>), dim3((N + 127) / 128, heads, B), dim3(256), ldsb, st, (const bf16_t *)q, (const bf16_t *)kv,
+                               (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dq, delta, N, KV, heads, scale * kLog2e, scale);
+        }
+        hipLaunchKernelGGL((sra_bwd_dkv_b16<D>), dim3(p.nchunk, heads, B), dim3(kSraThreads), 0, st, (const bf16_t *)q, (const bf16_t *)kv,
+                           (const bf16_t *)dout, lse, delta, part, N, KV, heads, p.nchunk, p.qchunk, scale * kLog2e, scale);
+        const size_t total_b = (size_t)B * KV * 2 * heads * (D / 4);
+        hipLaunchKernelGGL((sra_dkv_reduce<T>), dim3((unsigned)((total_b + 255) / 256)), dim3(256), 0, st, part, (T *)dkv, B, KV, heads, D, p.nchunk);
+        return (int)hipGetLastError();
+    }
     bool split = false;
     if constexpr (sizeof(T) == 4 && D == 32) split = g_sra_split_bf16 != 0;
     if (split) {

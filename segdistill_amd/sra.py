@@ -18,11 +18,10 @@ def supported(q, kv, heads):
 
 
 def preferred(n_queries, n_keys, head_dim, q):
-    """Policy, from tools/sra_bench.py on MI355X (profiles/r01_step_kernels_microbench.txt).  fp32: the kernels beat both library
-    forms (fused SDPA, bmm+softmax) at every MiT stage shape, forward and forward+backward.  bf16 storage: the FORWARD has a bf16-MFMA
-    kernel (sra_fwd_b16), used whenever no graph is built (the frozen teacher: 41 layers of B4 in config 5); the backward kernels still
-    compute on the fp32 MFMA path while the library's fused kernel uses bf16 MFMA, so for training they only win where the library's
-    backward collapses -- >= 8192 queries (1.3-1.5x); elsewhere the library is used.
+    """Policy, from tools/sra_bench.py on MI355X (profiles/r01_step_kernels_microbench.txt, profiles/r02_sra_bench_bf16.txt): the kernels
+    beat both library forms (fused SDPA, bmm+softmax) at every MiT stage shape, forward and forward+backward -- fp32 storage since round 1
+    (exact f32 MFMA, now split-bf16), bf16 storage since the bf16-MFMA kernels of round 2 (sra_fwd_b16 / sra_bwd_dq_b16 / sra_bwd_dkv_b16:
+    e.g. 8 x 16384 queries, head_dim 64: forward 33 vs 39 us, forward + backward 176 vs 628 us, eager).
     SEGDISTILL_SRA=off|train|all overrides (benchmarking / bisecting)."""
     import os
     mode = os.environ.get('SEGDISTILL_SRA', 'auto')
@@ -33,9 +32,7 @@ def preferred(n_queries, n_keys, head_dim, q):
         return True
     if mode == 'train':
         return training
-    if q.dtype == torch.float32:
-        return True
-    return (not training) or n_queries >= 8192
+    return True
 
 
 class _SRAttention(torch.autograd.Function):
