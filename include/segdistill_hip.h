@@ -479,6 +479,25 @@ int sd_linear_wgrad_slabs(int dtype, long tokens, int out_features, int in_featu
 int sd_linear_wgrad_partials(const void *dY, const void *X, int dtype, long tokens, int out_features, int in_features,
                              int with_bias, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------
+ * Optimizer step: AdamW over every trainable tensor in ONE launch.
+ * Replaces torch.optim.AdamW.step() as the reference runs it through mmcv's OptimizerHook (mmseg/apis/train.py:89 builds the
+ * optimizer; the KD configs use AdamW lr 6e-5, betas (0.9, 0.999), weight_decay 0.01 with paramwise_cfg lr / decay multipliers,
+ * e.g. local_configs/exp_tab5/segformer_CGD+WS.py:60-64, psp_CD.py:70-74): fp32 parameters,
+ * gradients and moments, arithmetic order of torch/optim/adamw.py::_single_tensor_adamw (decoupled decay first, bias-corrected step).
+ *   tensors  device array of 48-byte descriptors {float *p; const float *g; float *m; float *v; float wd; int32 group_missed; int64 n}
+ *            (p, g, m, v share one dense layout, the update is elementwise over storage; group_missed = parameter-group index in bits
+ *            0-7, in bits 8-31 the number of optimizer steps the tensor took no part in: torch counts steps per tensor)
+ *   group_lr HOST array of the parameter groups' current learning rates (ngroups <= sd_adamw_max_groups(); passed by value, so the
+ *            schedule changes it every step without touching the tables)
+ *   blocks   device array of {int32 tensor; int32 first_chunk}: one workgroup per sd_adamw_chunk() consecutive elements of a tensor
+ *   step     the optimizer's step count INCLUDING this step (>= 1); bias corrections 1 - beta^(step - missed) are formed in fp64
+ */
+int sd_adamw_chunk(void);
+int sd_adamw_max_groups(void);
+int sd_adamw_multi(const void *tensors, const void *blocks, int nblocks, const float *group_lr, int ngroups, double beta1, double beta2, float eps,
+                   int step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,9 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     'sd_abi_version': (_i, []),
     'sd_error_string': (C.c_char_p, [_i]),
+    'sd_adamw_chunk': (_i, []),
+    'sd_adamw_max_groups': (_i, []),
+    'sd_adamw_multi': (_i, [_vp, _vp, _i, C.POINTER(C.c_float), _i, C.c_double, C.c_double, _f, _i, _vp]),
     'sd_set_tunable': (_i, [C.c_char_p, _i]),
     'sd_get_tunable': (_i, [C.c_char_p]),
     'sd_cgd_kl_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
