@@ -458,7 +458,7 @@ __global__ __launch_bounds__(NW * 64) void sra_fwd_x3(const T *__restrict__ q, c
         for (int st = 0; st < 16; ++st) {
             const int blk = st >> 1, cur = st & 1;
             if (FULL || blk < nblk) {
-                if (st + 1 < 16) {
+                if (st + 1 < 16 && (FULL || ((st + 1) >> 1) < nblk)) {       // never a fragment beyond the staged key blocks
                     read_v(st + 1, cur ^ 1);
                     split_p(st + 1, cur ^ 1);
                 }
