@@ -458,7 +458,7 @@ template <typename T, int TM, int TN>
 __device__ __forceinline__ void wgrad_walk(const T *__restrict__ dY, const T *__restrict__ X, long k_begin, long k_end, int kh, int M, int N,
                                            const int (&ca)[2], const int (&cb)[2], const bool (&am)[2], const bool (&bn)[2],
                                            f32x16 (&acc)[2][2], bool do_bias, float (&bs)[2]) {
-    constexpr int U = 8;   // token pairs per step: up to 32 dword loads in flight per lane and register set
+    constexpr int U = 16;   // token pairs per step: up to 64 dword loads in flight per lane and register set
     WgradFrag<TM, TN, U> fa, fb;
     const long full_end = k_begin + (k_end - k_begin) / (2 * U) * (2 * U);
     long t0 = k_begin;
