@@ -237,6 +237,34 @@ def bench_sra(dev, reps, B=8):
     return out
 
 
+def bench_optim(dev, reps):
+    """The one-launch AdamW (csrc/optim.hip) over the trainable tensors of the config-2 student (Segformer-B0 + head), next to ATen's fused path."""
+    import bench
+    from segdistill_amd.config import Config
+    from segdistill_amd.engine.optim import HipAdamW, build_optimizer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs', 'kd', 'cfg2_segformer_b2_b0_cgd.py'))
+    model = bench.build_model(cfg, dev)
+    out = []
+    for env, tag in (('1', 'adamw_multi (one launch)'), ('0', 'ATen fused AdamW (multi_tensor_apply per group)')):
+        os.environ['SEGDISTILL_HIP_ADAMW'] = env
+        opt = build_optimizer(model, dict(cfg.optimizer))
+        ps = [p for g in opt.param_groups for p in g['params']]
+        gen = torch.Generator(device=dev).manual_seed(5)
+        for p in ps:
+            p.grad = torch.randn(p.shape, device=dev, generator=gen).contiguous(memory_format=torch.channels_last) if (p.dim() == 4 and not p.is_contiguous()) \
+                else torch.randn(p.shape, device=dev, generator=gen)
+        opt.step()
+        assert isinstance(opt, HipAdamW) == (env == '1')
+        # ours is a single launch and captures; ATen's fused step is not capturable as the trainer builds it: its time includes the host side
+        t = _time(lambda st: opt.step(), reps, per_graph=4 if env == '1' else 1, graph=env == '1')
+        n = sum(p.numel() for p in ps)
+        out.append(_entry(f'AdamW step, {len(ps)} tensors / {n / 1e6:.2f} M parameters: {tag}', 'adamw_multi' if env == '1' else 'multi_tensor_apply x n', [len(ps), n],
+                          'f32', t, 'hbm', 7 * n * 4, HBM, 'device time in a replayed graph' if env == '1' else 'eager timing: includes the host side of the step'))
+    os.environ.pop('SEGDISTILL_HIP_ADAMW', None)
+    return out
+
+
 def bench_pix(dev, reps, B=8, C=150, HW=512):
     from segdistill_amd import _lib
     L = _lib.lib()
@@ -326,6 +354,7 @@ GROUPS = {
     'pix': lambda dev, reps: bench_pix(dev, reps),
     'at': lambda dev, reps: bench_at(dev, reps),
     'sra': lambda dev, reps: bench_sra(dev, reps),
+    'optim': lambda dev, reps: bench_optim(dev, reps),
     'ifvd': lambda dev, reps: bench_ifvd(dev, reps),
     'ce': lambda dev, reps: bench_ce(dev, reps),
 }
