@@ -5,7 +5,12 @@
 // LLM attention: the whole K and V of a head fit in LDS (64-128 KB of the CU's 160 KB), every query needs all of them, and
 // nothing has to be tiled or re-scaled across key blocks.  ATen runs it either as bmm -> scale -> softmax -> bmm (a
 // [B,heads,N,KV] score tensor, 134 MB per stage-1 layer, written and re-read five times fwd+bwd) or as a generic flash
-// kernel whose backward parallelises over the 256 keys only.  Here (fp32-exact v_mfma_f32_32x32x2_f32 throughout):
+// kernel whose backward parallelises over the 256 keys only.  Three kernel families share the design below:
+//   sra_fwd / sra_bwd_dq / sra_bwd_dkv           exact f32-input MFMA (v_mfma_f32_32x32x2_f32) -- round 1; behind tunable sra_split_bf16 = 0,
+//                                                 and the head_dim-64 backward of fp32 storage
+//   sra_fwd_x3 / sra_bwd_dq_x3 / sra_bwd_dkv_x3  fp32 storage, split-bf16 products on the bf16 matrix pipe (fp32-grade; the shipped path)
+//   sra_fwd_b16 / sra_bwd_dq_b16 / sra_bwd_dkv_b16  bf16 storage on the bf16 matrix pipe (config 5)
+// The exact-f32 form:
 //   * a wave owns 32 queries and computes the TRANSPOSED score tile S^T = K Q^T (keys x queries): in the MFMA C layout a
 //     lane then holds one query column, so the softmax needs no cross-lane work except one exchange with lane^32, and the
 //     probabilities are already in the B-operand layout of the second product O^T = V^T P^T -- no LDS round trip for P;
