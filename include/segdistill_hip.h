@@ -480,6 +480,20 @@ int sd_linear_wgrad_partials(const void *dY, const void *X, int dtype, long toke
                              int with_bias, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * A Linear from TOKEN-MAJOR features to contiguous class planes (fp32): the SegFormer head's `linear_pred` 1x1 conv
+ * (mmseg/models/decode_heads/segformer_head.py:73,96) on the token-major fused feature map, with the logits landing directly in the
+ * [B, out_features, P] planes the loss kernels read (sd_ce_up_*, sd_cgd_kl_up_*) and the gradient read from such planes: no
+ * [B, P, out] <-> [B, out, P] transpose copy in either direction (2 x 79 MB per step at config 2).
+ *   X  [B, P, in_features]   W [out_features, in_features]   bias [out_features] or NULL   Y / dY [B, out_features, P]
+ * Arithmetic: split-bf16 (tunable align_split_bf16) or exact f32 MFMA.  bwd_weight: deterministic slab combine; dbias may be NULL.
+ */
+size_t sd_linear_nchw_workspace_bytes(int B, long P, int in_features, int out_features);
+int sd_linear_nchw_fwd(const float *X, const float *W, const float *bias, float *Y, int B, long P, int in_features, int out_features, void *stream);
+int sd_linear_nchw_bwd_data(const float *dY, const float *W, float *dX, int B, long P, int in_features, int out_features, void *stream);
+int sd_linear_nchw_bwd_weight(const float *dY, const float *X, float *dW, float *dbias, int B, long P, int in_features, int out_features,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Optimizer step: AdamW over every trainable tensor in ONE launch.
  * Replaces torch.optim.AdamW.step() as the reference runs it through mmcv's OptimizerHook (mmseg/apis/train.py:89 builds the
  * optimizer; the KD configs use AdamW lr 6e-5, betas (0.9, 0.999), weight_decay 0.01 with paramwise_cfg lr / decay multipliers,

@@ -440,7 +440,8 @@ int launch_epi(const float *A, const float *Bm, float *C, const float *bias, con
     if (nblk > 0x7fffffffL || batch < 1 || (long)batch * nsplit > 65535) return SD_E_SHAPE;
     // 16-byte loads need aligned rows: base pointers, leading dimensions, batch strides, and the contiguous axis of each operand a multiple of 4
     const bool vec = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bm) & 15) == 0 && lda % 4 == 0 && ldb % 4 == 0 &&
-                     sA % 4 == 0 && sB % 4 == 0 && klen % 4 == 0 && (AKC ? K % 4 == 0 : M % 4 == 0) && (BT ? K % 4 == 0 : N % 4 == 0);
+                     sA % 4 == 0 && sB % 4 == 0 && ((AKC || BT) ? klen % 4 == 0 : true) && (AKC ? K % 4 == 0 : M % 4 == 0) && (BT ? K % 4 == 0 : N % 4 == 0);
+    // (a k-contiguous operand needs k origins on 16-byte boundaries; [k][m] / [k][n] operands vectorise along m / n whatever K is)
     const bool fullk = vec && K % BK == 0 && klen % BK == 0 && (AKC || M >= 4) && (BT || N >= 4);
     auto kern = fullk ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, true, EPI, AKC, BIAS_ROW, X3>
                       : (vec ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, false, EPI, AKC, BIAS_ROW, X3>
@@ -532,11 +533,67 @@ int align_f32_bwd_weight_slabs(const float *dY, const float *X, float *slabs, in
                                                             (long)Ct * Cs, nsplit, klen);
 }
 
+// ---- a Linear from TOKEN-MAJOR features to NCHW planes: the SegFormer head's `linear_pred` (1x1 conv, segformer_head.py:73,96) -------------
+// The head's fused feature map is token-major ([B, P, E], P = h*w) while everything that reads the logits (the fused up-sample + CE kernel, the
+// fused up-sample + CGD kernel) wants contiguous class planes [B, classes, P].  As a token Linear the product needs a 79 MB transpose copy of
+// its output and another of the incoming gradient (80 us each at config 2); with the operand roles swapped the same kernel writes / reads the
+// planes directly:
+//   forward   out_b [classes x P] = W [classes x E] . tokens_b^T + bias     A = W ([m][k]), B = tokens_b ([n][k]), per-row bias, batch = images
+//   bwd-data  dX_b  [P x E]       = dOut_b^T . W                            A = dOut_b read as [k][m] (m contiguous), B = W ([k][n])
+//   bwd-wgt   slab_z [classes x E] = dOut_b[:, chunk] . tokens_b[chunk, :]   A = dOut_b ([m][k]), B = tokens_b ([k][n]); z = (image, pixel chunk)
+__global__ __launch_bounds__(256) void plane_rowsum_partials(const float *__restrict__ dOut, float *__restrict__ part, int C, long P) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float *row = dOut + ((long)b * C + c) * P;
+    float acc = 0.f;
+    if ((P & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+        for (long p = 4L * threadIdx.x; p < P; p += 1024) {
+            const float4 v = *reinterpret_cast<const float4 *>(row + p);
+            acc += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (long p = threadIdx.x; p < P; p += 256) acc += row[p];
+    }
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long)b * C + c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// dW = sum of the nz slabs (fixed order); the last workgroup also folds the per-image bias partials
+__global__ __launch_bounds__(256) void pred_wgrad_reduce(const float *__restrict__ slabs, float *__restrict__ dW, long n, int nz,
+                                                          const float *__restrict__ bias_part, float *__restrict__ db, int C, int B) {
+    if ((int)blockIdx.x == (int)gridDim.x - 1) {
+        if (db)
+            for (int c = threadIdx.x; c < C; c += 256) {
+                float a = 0.f;
+                for (int b = 0; b < B; ++b) a += bias_part[(long)b * C + c];
+                db[c] = a;
+            }
+        return;
+    }
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float a = 0.f;
+    for (int z = 0; z < nz; ++z) a += slabs[(long)z * n + i];
+    dW[i] = a;
+}
+
+int g_pred_split_bf16 = 1;   // follows tunable "align_split_bf16" (set together): split-bf16 arithmetic for the three products
+
+int pred_splits(int B, long P) {
+    int per_img = (int)((P + 2047) / 2048);
+    if (per_img < 1) per_img = 1;
+    while ((long)B * per_img < 64 && P / per_img > 512) per_img *= 2;
+    return per_img;
+}
+
 int token_gemm_tunable(const char *key, int set, int v) {
     if (strcmp(key, "align_split_bf16")) return SD_E_UNSUPPORTED;
     if (set) {
         if (v != 0 && v != 1) return SD_E_SHAPE;
         g_align_split_bf16 = v;
+        g_pred_split_bf16 = v;
         return SD_OK;
     }
     return g_align_split_bf16;
@@ -562,6 +619,62 @@ int sd_linear_fwd(const void *X, const float *W, long w_row_stride, const float 
     }
     return sd::dispatch<true>((const float *)X, W, (float *)Y, bias, (const float *)residual, tokens, out_features, in_features, in_features,
                               w_row_stride, out_features, act, static_cast<hipStream_t>(stream));
+}
+
+size_t sd_linear_nchw_workspace_bytes(int B, long P, int in_features, int out_features) {
+    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0) return 0;
+    const int nsplit = sd::pred_splits(B, P);
+    return ((size_t)B * nsplit * out_features * in_features + (size_t)B * out_features) * sizeof(float) + 16;
+}
+
+int sd_linear_nchw_fwd(const float *X, const float *W, const float *bias, float *Y, int B, long P, int in_features, int out_features, void *stream) {
+    if (!X || !W || !Y) return SD_E_NULL;
+    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0 || B > 65535) return SD_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long sB = P * in_features, sC = P * out_features;
+    if (sd::g_pred_split_bf16 && in_features % 32 == 0)
+        return sd::launch_epi<128, 128, 2, 2, true, 0, true, true, true>(W, X, Y, bias, nullptr, out_features, (int)P, in_features, in_features, in_features, P,
+                                                                         st, B, 0L, sB, sC);
+    return sd::launch_epi<128, 128, 2, 2, true, 0, true, true>(W, X, Y, bias, nullptr, out_features, (int)P, in_features, in_features, in_features, P, st, B,
+                                                               0L, sB, sC);
+}
+
+int sd_linear_nchw_bwd_data(const float *dY, const float *W, float *dX, int B, long P, int in_features, int out_features, void *stream) {
+    if (!dY || !W || !dX) return SD_E_NULL;
+    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0 || B > 65535) return SD_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // C_b [P x in] = A_b . B with A_b = dY_b read as [k = class][m = pixel], B = W [k = class][n = in]
+    if (sd::g_pred_split_bf16)
+        return sd::launch_epi<128, 128, 2, 2, false, 0, false, false, true>(dY, W, dX, nullptr, nullptr, P, in_features, out_features, P, in_features,
+                                                                            in_features, st, B, P * out_features, 0L, P * in_features);
+    return sd::launch_epi<128, 128, 2, 2, false, 0, false, false>(dY, W, dX, nullptr, nullptr, P, in_features, out_features, P, in_features, in_features, st, B,
+                                                                  P * out_features, 0L, P * in_features);
+}
+
+int sd_linear_nchw_bwd_weight(const float *dY, const float *X, float *dW, float *dbias, int B, long P, int in_features, int out_features, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+    if (!dY || !X || !dW || !workspace) return SD_E_NULL;
+    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0 || B > 65535) return SD_E_SHAPE;
+    if (workspace_bytes < sd_linear_nchw_workspace_bytes(B, P, in_features, out_features) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return SD_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int nsplit = sd::pred_splits(B, P);
+    const int klen = (int)(((P + nsplit - 1) / nsplit + 31) / 32 * 32);
+    nsplit = (int)((P + klen - 1) / klen);
+    const long slab = (long)out_features * in_features;
+    float *slabs = static_cast<float *>(workspace);
+    float *bias_part = slabs + (size_t)B * sd::pred_splits(B, P) * slab;
+    int rc;
+    if (sd::g_pred_split_bf16 && klen % 32 == 0 && P % 32 == 0)
+        rc = sd::launch_epi<128, 128, 2, 2, false, 0, true, false, true>(dY, X, slabs, nullptr, nullptr, out_features, in_features, (int)P, P, in_features,
+                                                                         in_features, st, B, P * out_features, P * in_features, slab, nsplit, klen);
+    else
+        rc = sd::launch_epi<128, 128, 2, 2, false, 0, true, false>(dY, X, slabs, nullptr, nullptr, out_features, in_features, (int)P, P, in_features, in_features,
+                                                                   st, B, P * out_features, P * in_features, slab, nsplit, klen);
+    if (rc) return rc;
+    if (dbias) hipLaunchKernelGGL(sd::plane_rowsum_partials, dim3(out_features, B), dim3(256), 0, st, dY, bias_part, out_features, P);
+    hipLaunchKernelGGL(sd::pred_wgrad_reduce, dim3((unsigned)((slab + 255) / 256 + 1)), dim3(256), 0, st, slabs, dW, slab, B * nsplit, bias_part, dbias,
+                       out_features, B);
+    return (int)hipGetLastError();
 }
 
 int sd_linear_bwd_data(const void *dY, const float *W, long w_row_stride, void *dX, int dtype, long tokens, int in_features, int out_features,

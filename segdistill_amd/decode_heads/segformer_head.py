@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from ..builder import HEADS, build_loss
 from ..layers import ConvModule, frozen_derived, resize, tokens_of
-from ..linear import call_linear, linear_forward, token_linear
+from ..linear import call_linear, linear_forward, linear_to_planes, linear_to_planes_supported, token_linear
 from .decode_head import BaseDecodeHead
 
 
@@ -196,6 +196,10 @@ class SegFormerHead(BaseDecodeHead):
             # frozen network in fp32 (the teacher): W x tokens^T lands in contiguous NCHW planes directly -- no weight gradient to
             # care about, the faulty kernel is a bf16 one -- and the 79 MB transpose copy of the [8,16384,150] logits is saved
             out = torch.baddbmm(pred.bias.view(1, -1, 1), w2d.unsqueeze(0).expand(b, -1, -1), tokens.transpose(1, 2))
+        elif torch.is_grad_enabled() and linear_to_planes_supported(tokens, w2d, pred.bias):
+            # training in fp32: the swapped-role product writes the class planes directly and its backward reads the gradient planes
+            # (csrc/token_gemm.hip sd_linear_nchw_*): neither the 79 MB transpose of the logits nor that of their gradient
+            out = linear_to_planes(tokens, w2d, pred.bias)
         else:
             out = token_linear(tokens, w2d, pred.bias, defer_ok=True).transpose(1, 2).contiguous()   # w2d: a view of the leaf weight
         out = out.view(b, pred.out_channels, h, w)

@@ -201,6 +201,55 @@ class _LongKLinear(torch.autograd.Function):
         return dx, dw, db
 
 
+class _LinearToPlanes(torch.autograd.Function):
+    """y[b, :, p] = W . x[b, p, :] + bias: token-major input, contiguous class planes out (csrc/token_gemm.hip: sd_linear_nchw_*)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        w = weight.contiguous()
+        B, P, K = x.shape
+        N = w.shape[0]
+        L = _lib.lib()
+        y = torch.empty(B, N, P, dtype=torch.float32, device=x.device)
+        b = None if bias is None else bias.detach().contiguous()
+        _lib.check(L.sd_linear_nchw_fwd(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), B, P, K, N, _stream_ptr()),
+                   'sd_linear_nchw_fwd')
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        B, P, K = x.shape
+        N = w.shape[0]
+        L = _lib.lib()
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _lib.check(L.sd_linear_nchw_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, P, K, N, _stream_ptr()), 'sd_linear_nchw_bwd_data')
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            wsb = L.sd_linear_nchw_workspace_bytes(B, P, K, N)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+            _lib.check(L.sd_linear_nchw_bwd_weight(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(), B, P, K, N,
+                                                   ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_nchw_bwd_weight')
+        return dx, dw, db
+
+
+def linear_to_planes_supported(x, weight, bias):
+    return (x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and weight.dtype == torch.float32 and (bias is None or bias.dtype == torch.float32)
+            and not torch.is_autocast_enabled() and x.shape[-1] % 4 == 0 and x.shape[1] % 4 == 0 and os.environ.get('SEGDISTILL_PRED_PLANES', '1') == '1')
+
+
+def linear_to_planes(x, weight, bias=None):
+    """[B, P, in] tokens -> [B, out, P] planes (a 1x1 conv on a token-major map whose consumers want NCHW), with autograd."""
+    return _LinearToPlanes.apply(x, weight, bias)
+
+
 def patch_linear_supported(x, hw, r, weight, enabled=None):
     """The SR patch projection straight from the tokens (sd_linear_patch_fwd): fp32, no graph to build (the frozen teacher), whole patches."""
     return ((_PATCH_GEMM if enabled is None else enabled) and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous()

@@ -117,3 +117,36 @@ def test_patch_linear_gathers_inside_the_gemm(case):
     conv = torch.nn.functional.conv2d(x.double().transpose(1, 2).reshape(B, c, H, W), conv_w.double(), bias.double(), stride=r)
     assert float((conv.flatten(2).transpose(1, 2) - ref).abs().max()) < 1e-9
     assert not linear.patch_linear_supported(xd.clone().requires_grad_(True), (H, W), r, wd, enabled=True)     # a graph to build: the copy route
+
+
+@pytest.mark.parametrize('case', [(2, 1024, 256, 150), (1, 4096, 64, 19), (3, 260, 32, 150), (8, 16384, 256, 150)])
+@pytest.mark.parametrize('split', [1, 0])
+def test_linear_to_planes_matches_conv1x1(case, split):
+    """sd_linear_nchw_* (the head's linear_pred on a token-major map, logits written as class planes, gradient read from planes) against
+    the 1x1 conv it replaces in fp64: forward, input gradient, weight and bias gradients; both arithmetic modes."""
+    from segdistill_amd import _lib, linear
+    B, P, K, N = case
+    g = torch.Generator().manual_seed(P + K + N)
+    x = torch.randn(B, P, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(B, N, P, generator=g)
+    x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.einsum('bpk,nk->bnp', x64, w64) + b64[None, :, None]
+    ref.backward(dy.double())
+    dev = torch.device('cuda:0')
+    _lib.set_tunable('align_split_bf16', split)
+    try:
+        xd, wd, bd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        assert linear.linear_to_planes_supported(xd, wd, bd)
+        y = linear.linear_to_planes(xd, wd, bd)
+        y.backward(dy.to(dev))
+    finally:
+        _lib.set_tunable('align_split_bf16', 1)
+    def err(a, r):
+        return float((a.double().cpu() - r).abs().max() / r.abs().max())
+    assert y.shape == (B, N, P) and y.is_contiguous()
+    assert err(y, ref.detach()) < 2e-6
+    assert err(xd.grad, x64.grad) < 2e-6
+    assert err(wd.grad, w64.grad) < 5e-6
+    assert err(bd.grad, b64.grad) < 5e-6
