@@ -402,6 +402,13 @@ int sd_upsum_affine_fwd(const void *z1, const void *z2, const void *z3, const vo
 
 int sd_upsum_bwd(const void *dy, void *dz, int dtype, int B, int h, int w, int E, int F, void *stream);
 
+/* All three coarse branches of the SegFormer geometry (factors 2, 4, 8 of an H x W fine grid) from ONE read of dy, in two separable
+ * passes (row reduction into fp32 partials in the workspace, then column reduction): dz2 [B, (H/2)(W/2), E], dz3 [B, (H/4)(W/4), E],
+ * dz4 [B, (H/8)(W/8), E].  SD_E_UNSUPPORTED unless H % 8 == W % 8 == 0, E % 64 == 0, W <= 512. */
+size_t sd_upsum_bwd3_workspace_bytes(int B, int H, int W, int E);
+int sd_upsum_bwd3(const void *dy, void *dz2, void *dz3, void *dz4, int dtype, int B, int H, int W, int E, void *workspace, size_t workspace_bytes,
+                  void *stream);
+
 /* ---------------------------------------------------------------------------
  * Training-mode BatchNorm over token-major activations [rows][C] (C % 4 == 0, C <= 1024) with the ReLU and the channel
  * dropout that follow it fused in.  Replaces the `linear_fuse` tail of the SegFormer head -- (Sync)BatchNorm -> ReLU

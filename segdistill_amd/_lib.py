@@ -88,6 +88,8 @@ SIGNATURES = {
     'sd_upsum_fwd': (_i, [_vp] * 6 + [_i] * 8 + [_vp]),
     'sd_upsum_affine_fwd': (_i, [_vp] * 7 + [_i] + [_vp] + [_i] * 8 + [_vp]),
     'sd_upsum_bwd': (_i, [_vp, _vp] + [_i] * 6 + [_vp]),
+    'sd_upsum_bwd3_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'sd_upsum_bwd3': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'sd_multi_slab_reduce': (_i, [_vp, _i, _vp]),
     'sd_colsum_blocks': (_i, [C.c_long, _i]),
     'sd_multi_colsum_partials': (_i, [_vp, _i, _i, _vp]),

@@ -202,6 +202,88 @@ __global__ __launch_bounds__(256) void upsum_fwd_strip(const T *__restrict__ z1,
     }
 }
 
+// ---- backward of all three coarse branches in two separable passes (the SegFormer geometry F = 2, 4, 8) ----------------------------------
+// The per-branch gather below re-reads dy once per branch with a serial loop over the (2F)^2 outputs of a tap (256 iterations at F = 8 on
+// 512 workgroups: 108 + 67 + 56 us at config 2).  The interpolation weights are separable, so:
+//   rows:  r_F[b, Y, kx, :] = sum_X wx_F(X, kx) dy[b, Y, X, :]   for F = 2, 4, 8 from ONE read of the dy row (staged in LDS, 64 channels per
+//          workgroup); fp32 partials in the workspace (dy bytes x 7/8);
+//   cols:  dz_F[b, ky, kx, :] = sum_Y wy_F(Y, ky) r_F[b, Y, kx, :]  -- at most 2F coalesced vector reads per output.
+__device__ __forceinline__ float tap_weight(int o, int F, int n_in, int k) {       // weight of output index o on input tap k (0 if unused)
+    int i0, i1;
+    float lam;
+    src_of(o, F, n_in, i0, i1, lam);
+    return (i0 == k ? 1.f - lam : 0.f) + (i1 == k ? lam : 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsum_bwd_rows(const T *__restrict__ dy, float *__restrict__ r2, float *__restrict__ r4, float *__restrict__ r8,
+                                                       int H, int W, int E) {
+    constexpr int N = HV<T>::N, CP = 68;                      // 64 channels per workgroup, row pitch 68 floats
+    extern __shared__ __attribute__((aligned(16))) float row_tile[];   // [W][CP]
+    const size_t row = blockIdx.x;                            // b * H + Y
+    const int c0 = blockIdx.y * 64;
+    const T *src = dy + row * W * E + c0;
+    for (int idx = threadIdx.x; idx < W * (64 / N); idx += 256) {
+        const int X = idx / (64 / N), v = (idx % (64 / N)) * N;
+        float t[N];
+        HV<T>::load(src + (size_t)X * E + v, t);
+#pragma unroll
+        for (int i = 0; i < N; ++i) row_tile[X * CP + v + i] = t[i];
+    }
+    __syncthreads();
+    auto reduce = [&](int F, float *__restrict__ r) {
+        const int w = W / F;
+        for (int idx = threadIdx.x; idx < w * 16; idx += 256) {
+            const int kx = idx >> 4, c4 = (idx & 15) * 4;
+            const int Xa = max(0, F * kx - F / 2), Xb = min(W, F * kx + F + F / 2);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int X = Xa; X < Xb; ++X) {
+                const float wx = tap_weight(X, F, w, kx);
+                const float4 v = *reinterpret_cast<const float4 *>(row_tile + X * CP + c4);
+                a.x = fmaf(wx, v.x, a.x); a.y = fmaf(wx, v.y, a.y); a.z = fmaf(wx, v.z, a.z); a.w = fmaf(wx, v.w, a.w);
+            }
+            *reinterpret_cast<float4 *>(r + (row * w + kx) * E + c0 + c4) = a;
+        }
+    };
+    reduce(2, r2);
+    reduce(4, r4);
+    reduce(8, r8);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsum_bwd_cols(const float *__restrict__ r2, const float *__restrict__ r4, const float *__restrict__ r8,
+                                                       T *__restrict__ dz2, T *__restrict__ dz3, T *__restrict__ dz4, int B, int H, int W, int E) {
+    constexpr int N = HV<T>::N;
+    const int ev = E / N;
+    size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n2 = (size_t)B * (H / 2) * (W / 2) * ev, n4 = (size_t)B * (H / 4) * (W / 4) * ev, n8 = (size_t)B * (H / 8) * (W / 8) * ev;
+    int F;
+    const float *r;
+    T *dz;
+    if (t < n2) { F = 2; r = r2; dz = dz2; }
+    else if (t < n2 + n4) { t -= n2; F = 4; r = r4; dz = dz3; }
+    else if (t < n2 + n4 + n8) { t -= n2 + n4; F = 8; r = r8; dz = dz4; }
+    else return;
+    const int h = H / F, w = W / F;
+    const int c = (int)(t % ev) * N;
+    const size_t tap = t / ev;
+    const int kx = (int)(tap % w), ky = (int)((tap / w) % h), b = (int)(tap / ((size_t)w * h));
+    float acc[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = 0.f;
+    const int Ya = max(0, F * ky - F / 2), Yb = min(H, F * ky + F + F / 2);
+    for (int Y = Ya; Y < Yb; ++Y) {
+        const float wy = tap_weight(Y, F, h, ky);
+        const float *p = r + (((size_t)b * H + Y) * w + kx) * E + c;
+#pragma unroll
+        for (int i = 0; i < N; i += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + i);
+            acc[i] = fmaf(wy, v.x, acc[i]); acc[i + 1] = fmaf(wy, v.y, acc[i + 1]); acc[i + 2] = fmaf(wy, v.z, acc[i + 2]); acc[i + 3] = fmaf(wy, v.w, acc[i + 3]);
+        }
+    }
+    HV<T>::store(dz + tap * E + c, acc);
+}
+
 // dz[b,ky,kx,:] = sum over the outputs that use tap (ky,kx) of weight * dy.  grid: ceil(B*h*w*(E/N) / 256)
 template <typename T>
 __global__ __launch_bounds__(256) void upsum_bwd(const T *__restrict__ dy, T *__restrict__ dz, int B, int h, int w, int E, int F) {
@@ -292,6 +374,51 @@ int sd_upsum_affine_fwd(const void *z1, const void *z2, const void *z3, const vo
                         const float *shift, int relu, void *y, int dtype, int B, int H, int W, int E, int f2, int f3, int f4, void *stream) {
     if (!scale || !shift) return SD_E_NULL;
     return upsum_fwd_impl(z1, z2, z3, z4, bias, scale, shift, relu, y, dtype, B, H, W, E, f2, f3, f4, stream);
+}
+
+size_t sd_upsum_bwd3_workspace_bytes(int B, int H, int W, int E) {
+    if (B <= 0 || H <= 0 || W <= 0 || E <= 0) return 0;
+    return (size_t)B * H * (W / 2 + W / 4 + W / 8) * E * sizeof(float) + 16;
+}
+
+int sd_upsum_bwd3(const void *dy, void *dz2, void *dz3, void *dz4, int dtype, int B, int H, int W, int E, void *workspace, size_t workspace_bytes,
+                  void *stream) {
+    if (!dy || !dz2 || !dz3 || !dz4 || !workspace) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (B <= 0 || H <= 0 || W <= 0 || E <= 0) return SD_E_SHAPE;
+    if (H % 8 || W % 8 || E % 64 || W > 512) return SD_E_UNSUPPORTED;
+    if (workspace_bytes < sd_upsum_bwd3_workspace_bytes(B, H, W, E) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return SD_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *r2 = static_cast<float *>(workspace);
+    float *r4 = r2 + (size_t)B * H * (W / 2) * E;
+    float *r8 = r4 + (size_t)B * H * (W / 4) * E;
+    const size_t lds = (size_t)W * 68 * sizeof(float);
+    const size_t taps = (size_t)B * ((size_t)(H / 2) * (W / 2) + (size_t)(H / 4) * (W / 4) + (size_t)(H / 8) * (W / 8));
+    if (dtype == SD_F32) {
+        static bool raised = false;
+        if (lds > 64 * 1024 && !raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sd::upsum_bwd_rows<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            raised = true;
+        }
+        hipLaunchKernelGGL((sd::upsum_bwd_rows<float>), dim3((unsigned)(B * H), E / 64), dim3(256), lds, st, (const float *)dy, r2, r4, r8, H, W, E);
+        const size_t total = taps * (E / 4);
+        hipLaunchKernelGGL((sd::upsum_bwd_cols<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r2, r4, r8, (float *)dz2, (float *)dz3,
+                           (float *)dz4, B, H, W, E);
+    } else {
+        static bool raised = false;
+        if (lds > 64 * 1024 && !raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sd::upsum_bwd_rows<sd::bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            raised = true;
+        }
+        hipLaunchKernelGGL((sd::upsum_bwd_rows<sd::bf16_t>), dim3((unsigned)(B * H), E / 64), dim3(256), lds, st, (const sd::bf16_t *)dy, r2, r4, r8, H, W, E);
+        const size_t total = taps * (E / 8);
+        hipLaunchKernelGGL((sd::upsum_bwd_cols<sd::bf16_t>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r2, r4, r8, (sd::bf16_t *)dz2,
+                           (sd::bf16_t *)dz3, (sd::bf16_t *)dz4, B, H, W, E);
+    }
+    return (int)hipGetLastError();
 }
 
 int sd_upsum_bwd(const void *dy, void *dz, int dtype, int B, int h, int w, int E, int F, void *stream) {

@@ -1,6 +1,8 @@
 """autograd binding of the SegFormer-head up-sample-and-sum kernels (csrc/headfuse.hip)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -44,6 +46,17 @@ class _UpSum(torch.autograd.Function):
         B, _, E = dy.shape
         L = _lib.lib()
         grads = [dy if ctx.needs_input_grad[0] else None]
+        H, W = ctx.sizes[0]
+        if (tuple(ctx.fs) == (2, 4, 8) and all(ctx.needs_input_grad[1:4]) and H % 8 == 0 and W % 8 == 0 and E % 64 == 0 and W <= 512
+                and os.environ.get('SEGDISTILL_UPSUM_BWD3', '1') == '1'):
+            # all three branches from one read of dy (two separable passes, csrc/headfuse.hip: sd_upsum_bwd3)
+            dzs = [torch.empty(B, h * w, E, dtype=dy.dtype, device=dy.device) for (h, w) in ctx.sizes[1:]]
+            wsb = L.sd_upsum_bwd3_workspace_bytes(B, H, W, E)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dy.device)
+            _lib.check(L.sd_upsum_bwd3(dy.data_ptr(), dzs[0].data_ptr(), dzs[1].data_ptr(), dzs[2].data_ptr(), _DT[dy.dtype], B, H, W, E, ws.data_ptr(), wsb,
+                                       _stream_ptr()), 'sd_upsum_bwd3')
+            db = dy.sum(dim=(0, 1)).to(ctx.bias_dtype) if (ctx.has_bias and ctx.needs_input_grad[4]) else None
+            return grads[0], dzs[0], dzs[1], dzs[2], db, None
         for i, ((h, w), F) in enumerate(zip(ctx.sizes[1:], ctx.fs)):
             if not ctx.needs_input_grad[i + 1]:
                 grads.append(None)

@@ -12,7 +12,7 @@ def _err(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize('shape', [(2, 16, 16, 32), (1, 32, 24, 64), (2, 8, 8, 256)])
+@pytest.mark.parametrize('shape', [(2, 16, 16, 32), (1, 32, 24, 64), (2, 8, 8, 256), (1, 128, 128, 128)])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_upsum_fwd_bwd(shape, dtype):
     from segdistill_amd.headfuse import supported, upsum
