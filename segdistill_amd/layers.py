@@ -201,13 +201,15 @@ def frozen_derived(param, key, fn, *also):
     (requires_grad False: the teacher), keyed on the in-place version counters so a later checkpoint load invalidates it.
     A trainable parameter changes every step and is never cached.  Nothing is stored while a hipGraph is being captured
     (a tensor allocated inside a capture lives in the graph's private pool)."""
-    if param.requires_grad or any(t.requires_grad for t in also) or (param.is_cuda and torch.cuda.is_current_stream_capturing()):
+    if param.requires_grad or any(t.requires_grad for t in also):
         return fn()
     versions = (param._version, param.data_ptr()) + tuple((t._version, t.data_ptr()) for t in also)
     slot = _frozen_slot(param)
     hit = slot.get(key)
     if hit is not None and hit[0] == versions:
-        return hit[1]
+        return hit[1]                   # also while capturing: an entry made by the eager warm-up passes is an ordinary static tensor
+    if param.is_cuda and torch.cuda.is_current_stream_capturing():
+        return fn()                     # computed inside the capture (a node of the graph), never stored
     with torch.no_grad():
         value = fn()
     slot[key] = (versions, value)
