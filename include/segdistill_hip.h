@@ -506,8 +506,9 @@ int sd_linear_nchw_bwd_weight(const float *dY, const float *X, float *dW, float 
  * optimizer; the KD configs use AdamW lr 6e-5, betas (0.9, 0.999), weight_decay 0.01 with paramwise_cfg lr / decay multipliers,
  * e.g. local_configs/exp_tab5/segformer_CGD+WS.py:60-64, psp_CD.py:70-74): fp32 parameters,
  * gradients and moments, arithmetic order of torch/optim/adamw.py::_single_tensor_adamw (decoupled decay first, bias-corrected step).
- *   tensors  device array of 48-byte descriptors {float *p; const float *g; float *m; float *v; float wd; int32 group_missed; int64 n}
- *            (p, g, m, v share one dense layout, the update is elementwise over storage; group_missed = parameter-group index in bits
+ *   tensors  device array of 56-byte descriptors {float *p; const float *g; float *m; float *v; uint16 *shadow; float wd;
+ *            int32 group_missed; int64 n} (p, g, m, v -- and the optional bf16 shadow of p, NULL if none, rewritten with the new value --
+ *            share one dense layout, the update is elementwise over storage; group_missed = parameter-group index in bits
  *            0-7, in bits 8-31 the number of optimizer steps the tensor took no part in: torch counts steps per tensor)
  *   group_lr HOST array of the parameter groups' current learning rates (ngroups <= sd_adamw_max_groups(); passed by value, so the
  *            schedule changes it every step without touching the tables)

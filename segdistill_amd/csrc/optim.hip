@@ -6,6 +6,8 @@
 // walks a block table: entry = (tensor, first element); a workgroup updates up to 4096 consecutive elements of one tensor; the decay and the
 // parameter-group index come from the tensor's descriptor, the groups' current learning rates and the bias corrections from the arguments.  Elementwise over the STORAGE order:
 // parameter, gradient and both moments must share one dense layout (contiguous or channels-last alike), which the caller checks.
+// Optional per tensor: a bf16 SHADOW of the parameter, rewritten with the updated value -- under bf16 autocast the forward would cast every
+// trainable fp32 weight again each step (one tiny kernel per weight and bias); with the shadow it reads what the optimizer already wrote.
 // Arithmetic (fp32, the order of torch/optim/adamw.py::_single_tensor_adamw):
 //   p *= 1 - lr*wd;  m += (g - m)(1 - b1);  v = v*b2 + (1 - b2) g*g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps),  bc = 1 - b^k (fp64)
 #include <hip/hip_runtime.h>
@@ -16,11 +18,12 @@
 namespace sd {
 namespace {
 
-struct AdamTensor {        // 48 bytes; mirrored by segdistill_amd/engine/optim.py (struct format '<QQQQfiq')
+struct AdamTensor {        // 56 bytes; mirrored by segdistill_amd/engine/optim.py (numpy record '<u8 x5, <f4, <i4, <i8')
     float *p;
     const float *g;
     float *m;
     float *v;
+    uint16_t *shadow;      // optional bf16 copy of the parameter, rewritten with the new value (what a bf16-autocast forward would cast anyway)
     float wd;
     int group_missed;      // bits 0-7: index into the learning-rate argument (the schedule changes it every step; the table stays as it is);
                            // bits 8-31: optimizer steps this tensor took no part in (torch counts steps per tensor: its bias corrections lag)
@@ -54,6 +57,7 @@ __global__ __launch_bounds__(256) void adamw_multi(const AdamTensor *__restrict_
         v = v * beta2 + ob2 * g * g;
         p -= step_size * m / (sqrtf(v) * inv_bc2_sqrt + eps);
     };
+    uint16_t *const sh = t.shadow;
     const bool vec = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) | reinterpret_cast<uintptr_t>(t.m) |
                        reinterpret_cast<uintptr_t>(t.v)) & 15) == 0;
     if (vec) {
@@ -63,10 +67,17 @@ __global__ __launch_bounds__(256) void adamw_multi(const AdamTensor *__restrict_
             const float4 g = *reinterpret_cast<const float4 *>(t.g + i);
             update(p.x, g.x, m.x, v.x); update(p.y, g.y, m.y, v.y); update(p.z, g.z, m.z, v.z); update(p.w, g.w, m.w, v.w);
             *reinterpret_cast<float4 *>(t.p + i) = p; *reinterpret_cast<float4 *>(t.m + i) = m; *reinterpret_cast<float4 *>(t.v + i) = v;
+            if (sh) { sh[i] = f32_to_bf16(p.x); sh[i + 1] = f32_to_bf16(p.y); sh[i + 2] = f32_to_bf16(p.z); sh[i + 3] = f32_to_bf16(p.w); }
         }
-        for (long i = hi4 + threadIdx.x; i < hi; i += 256) update(t.p[i], t.g[i], t.m[i], t.v[i]);
+        for (long i = hi4 + threadIdx.x; i < hi; i += 256) {
+            update(t.p[i], t.g[i], t.m[i], t.v[i]);
+            if (sh) sh[i] = f32_to_bf16(t.p[i]);
+        }
     } else {
-        for (long i = lo + threadIdx.x; i < hi; i += 256) update(t.p[i], t.g[i], t.m[i], t.v[i]);
+        for (long i = lo + threadIdx.x; i < hi; i += 256) {
+            update(t.p[i], t.g[i], t.m[i], t.v[i]);
+            if (sh) sh[i] = f32_to_bf16(t.p[i]);
+        }
     }
 }
 

@@ -25,13 +25,13 @@ class HipAdamW(torch.optim.AdamW):
     Host side: the descriptor table lives in a numpy record array; a step whose gradient TENSORS are the ones of the previous step (graph
     replay, or gradients living in the data-parallel flat buffer) reuses the device copy after ~200 identity checks; new gradient tensors
     (eager backward) cost one column update and a 10 KB upload; only a change of the set of tensors rebuilds it."""
-    _DESC = np.dtype([('p', '<u8'), ('g', '<u8'), ('m', '<u8'), ('v', '<u8'), ('wd', '<f4'), ('gm', '<i4'), ('n', '<i8')])
+    _DESC = np.dtype([('p', '<u8'), ('g', '<u8'), ('m', '<u8'), ('v', '<u8'), ('s', '<u8'), ('wd', '<f4'), ('gm', '<i4'), ('n', '<i8')])
 
     def __init__(self, params, **kw):
         kw.pop('fused', None)
         kw.pop('foreach', None)
         super().__init__(params, foreach=False, fused=False, **kw)
-        assert self._DESC.itemsize == 48
+        assert self._DESC.itemsize == 56
         self._global = 0            # optimizer steps taken
         self._missed = None         # id(parameter) -> steps it took no part in (torch counts steps per tensor); None: derive from the state
         self._live_params = None    # parameters of the current table, in table order
@@ -40,6 +40,15 @@ class HipAdamW(torch.optim.AdamW):
         self._desc = None
         self._dev_tensors = self._dev_blocks = None
         self._nblocks = 0
+
+    @staticmethod
+    def _shadow_of(p):
+        """The bf16 shadow a low-precision forward keeps on the parameter (segdistill_amd.linear.lowp_copy): valid only for the parameter
+        version it was made from and for the parameter's own dense layout."""
+        sh = getattr(p, '_sd_shadow', None)
+        if sh is None or sh[0] != p._version or sh[1].stride() != p.stride() or sh[1].dtype != torch.bfloat16:
+            return None
+        return sh[1]
 
     def _derive_counts(self):
         steps = {id(p): int(float(st['step'])) for p, st in self.state.items() if 'step' in st}
@@ -74,13 +83,15 @@ class HipAdamW(torch.optim.AdamW):
             missed = self._missed[id(p)]
             if missed >= 1 << 23:
                 raise RuntimeError('HipAdamW: a tensor skipped too many steps')
-            desc[ti] = (p.data_ptr(), 0, st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), float(self.param_groups[gi]['weight_decay']),
-                        gi | (missed << 8), p.numel())
+            sh = self._shadow_of(p)
+            desc[ti] = (p.data_ptr(), 0, st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), 0 if sh is None else sh.data_ptr(),
+                        float(self.param_groups[gi]['weight_decay']), gi | (missed << 8), p.numel())
             blocks += [(ti, c) for c in range((p.numel() + chunk - 1) // chunk)]
         self._desc = desc
         self._dev_blocks = torch.tensor(blocks, dtype=torch.int32).view(-1).to(dev)
         self._nblocks = len(blocks)
         self._live_params = [p for _, p in live]
+        self._live_shadows = [self._shadow_of(p) for _, p in live]
         self._live_key = tuple((gi, float(self.param_groups[gi]['weight_decay'])) for gi, _ in live)
         self._live_grads = None
 
@@ -110,6 +121,7 @@ class HipAdamW(torch.optim.AdamW):
             self._derive_counts()
         self._global += 1
         same_set = (self._live_params is not None and len(live) == len(self._live_params) and all(p is q for (_, p), q in zip(live, self._live_params))
+                    and all(self._shadow_of(p) is s for (_, p), s in zip(live, self._live_shadows))
                     and self._live_key == tuple((gi, float(self.param_groups[gi]['weight_decay'])) for gi, _ in live))
         if same_set:
             for k in self._absent:      # tensors that sit this step out fall one step behind (torch counts steps per tensor)

@@ -76,6 +76,29 @@ def _bwd_data(dy2, weight):
     return None
 
 
+_SHADOWS = os.environ.get('SEGDISTILL_BF16_SHADOWS', '1') == '1'
+
+
+def lowp_copy(t, dt):
+    """t.to(dt) for a low-precision forward.  For a TRAINABLE fp32 parameter under bf16 storage the copy is kept on the parameter as its
+    shadow (`_sd_shadow` = (parameter version, tensor)): engine/optim.py::HipAdamW rewrites it together with the parameter, so the next
+    forward -- eager or a graph replay -- finds the cast already done instead of running one tiny kernel per weight and bias.  Any torch
+    op that writes the parameter (checkpoint load, another optimizer) bumps its version and the shadow is remade.  (A write through
+    `param.data` does NOT bump it: code that edits weights that way mid-training must delete `param._sd_shadow` or run with
+    SEGDISTILL_BF16_SHADOWS=0.)"""
+    if not (_SHADOWS and dt == torch.bfloat16 and isinstance(t, torch.nn.Parameter) and t.requires_grad and t.dtype == torch.float32 and t.is_cuda):
+        return t.to(dt)
+    sh = getattr(t, '_sd_shadow', None)
+    if sh is not None and sh[0] == t._version and sh[1].dtype == dt:
+        return sh[1]
+    if torch.cuda.is_current_stream_capturing():
+        return t.to(dt)                 # never created inside a capture: the warm-up passes before it make them
+    with torch.no_grad():
+        val = t.detach().to(dt)         # preserves the parameter's dense layout
+    t._sd_shadow = (t._version, val)
+    return val
+
+
 class _TokenLinear(torch.autograd.Function):
     """Under autocast the forward computes in the autocast dtype exactly as F.linear would (activations and a cast copy of
     the fp32 master weight in bf16); the bf16 activations are what is saved, so the split-K weight-gradient kernel reads half
@@ -88,8 +111,8 @@ class _TokenLinear(torch.autograd.Function):
             dt = torch.get_autocast_dtype('cuda')
             with torch.autocast('cuda', enabled=False):
                 xc = x.to(dt)
-                wc = weight.to(dt)
-                y = F.linear(xc, wc, None if bias is None else bias.to(dt))
+                wc = lowp_copy(weight, dt)
+                y = F.linear(xc, wc, None if bias is None else lowp_copy(bias, dt))
             ctx.save_for_backward(xc, wc)
         else:
             y = linear_forward(x, weight, bias)

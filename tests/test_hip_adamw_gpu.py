@@ -71,3 +71,30 @@ def test_one_launch_adamw_matches_torch():
     opt_c.step()
     for pa, pc in zip(a, c):
         assert torch.allclose(pa, pc, rtol=2e-6, atol=1e-7)
+
+
+def test_bf16_shadows_follow_the_parameters():
+    """linear.lowp_copy keeps a bf16 shadow on a trainable parameter; HipAdamW rewrites it with every step (csrc/optim.hip), so a bf16-autocast
+    forward never casts the weight again.  The shadow must equal the freshly cast parameter bit for bit, survive many steps, and be remade
+    after a torch op writes the parameter."""
+    from segdistill_amd.engine.optim import HipAdamW
+    from segdistill_amd.linear import lowp_copy
+    dev = torch.device('cuda:0')
+    ps = _params(dev, 11)
+    opt = HipAdamW([dict(params=ps, lr=1e-3, weight_decay=0.01)], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    shadowed = ps[:3] + ps[5:6]                                    # incl. the channels-last filter
+    shadows = [lowp_copy(p, torch.bfloat16) for p in shadowed]
+    assert all(s.dtype == torch.bfloat16 and s.stride() == p.stride() for s, p in zip(shadows, shadowed))
+    for step in range(4):
+        _grads(ps, step, False)
+        opt.step()
+        for p, s in zip(shadowed, shadows):
+            assert lowp_copy(p, torch.bfloat16) is s                # still the same tensor: nothing was cast again
+            assert torch.equal(s, p.detach().to(torch.bfloat16))
+    with torch.no_grad():
+        shadowed[0].mul_(2.0)                                        # a torch op bumps the version: the shadow is stale and is remade
+    s2 = lowp_copy(shadowed[0], torch.bfloat16)
+    assert s2 is not shadows[0] and torch.equal(s2, shadowed[0].detach().to(torch.bfloat16))
+    _grads(ps, 9, False)
+    opt.step()                                                       # the optimizer follows the new shadow
+    assert torch.equal(s2, shadowed[0].detach().to(torch.bfloat16))
