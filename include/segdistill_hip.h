@@ -492,12 +492,15 @@ int sd_linear_wgrad_partials(const void *dY, const void *X, int dtype, long toke
  * [B, out_features, P] planes the loss kernels read (sd_ce_up_*, sd_cgd_kl_up_*) and the gradient read from such planes: no
  * [B, P, out] <-> [B, out, P] transpose copy in either direction (2 x 79 MB per step at config 2).
  *   X  [B, P, in_features]   W [out_features, in_features]   bias [out_features] or NULL   Y / dY [B, out_features, P]
- * Arithmetic: split-bf16 (tunable align_split_bf16) or exact f32 MFMA.  bwd_weight: deterministic slab combine; dbias may be NULL.
+ * X, Y, dY, dX in `dtype` storage; W, bias, dW, dbias always fp32 (master weights).  Arithmetic: fp32 storage -- split-bf16 (tunable
+ * align_split_bf16) or exact f32 MFMA; bf16 storage -- bf16 MFMA with fp32 accumulation (the master weight is rounded on its way into LDS).
+ * bwd_weight: deterministic slab combine; dbias may be NULL.
  */
 size_t sd_linear_nchw_workspace_bytes(int B, long P, int in_features, int out_features);
-int sd_linear_nchw_fwd(const float *X, const float *W, const float *bias, float *Y, int B, long P, int in_features, int out_features, void *stream);
-int sd_linear_nchw_bwd_data(const float *dY, const float *W, float *dX, int B, long P, int in_features, int out_features, void *stream);
-int sd_linear_nchw_bwd_weight(const float *dY, const float *X, float *dW, float *dbias, int B, long P, int in_features, int out_features,
+int sd_linear_nchw_fwd(const void *X, const float *W, const float *bias, void *Y, int dtype, int B, long P, int in_features, int out_features,
+                       void *stream);
+int sd_linear_nchw_bwd_data(const void *dY, const float *W, void *dX, int dtype, int B, long P, int in_features, int out_features, void *stream);
+int sd_linear_nchw_bwd_weight(const void *dY, const void *X, float *dW, float *dbias, int dtype, int B, long P, int in_features, int out_features,
                               void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------

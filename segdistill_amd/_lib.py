@@ -28,9 +28,9 @@ SIGNATURES = {
     'sd_abi_version': (_i, []),
     'sd_error_string': (C.c_char_p, [_i]),
     'sd_linear_nchw_workspace_bytes': (_sz, [_i, C.c_long, _i, _i]),
-    'sd_linear_nchw_fwd': (_i, [_vp, _vp, _vp, _vp, _i, C.c_long, _i, _i, _vp]),
-    'sd_linear_nchw_bwd_data': (_i, [_vp, _vp, _vp, _i, C.c_long, _i, _i, _vp]),
-    'sd_linear_nchw_bwd_weight': (_i, [_vp, _vp, _vp, _vp, _i, C.c_long, _i, _i, _vp, _sz, _vp]),
+    'sd_linear_nchw_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_long, _i, _i, _vp]),
+    'sd_linear_nchw_bwd_data': (_i, [_vp, _vp, _vp, _i, _i, C.c_long, _i, _i, _vp]),
+    'sd_linear_nchw_bwd_weight': (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_long, _i, _i, _vp, _sz, _vp]),
     'sd_adamw_chunk': (_i, []),
     'sd_adamw_max_groups': (_i, []),
     'sd_adamw_multi': (_i, [_vp, _vp, _i, C.POINTER(C.c_float), _i, C.c_double, C.c_double, _f, _i, _vp]),

@@ -721,6 +721,60 @@ int sd_linear_patch_fwd(const float *X, const float *W, const float *bias, float
     return sd::gemm_nt_patch(X, W, bias, Y, workspace, workspace_bytes, B, H, Wd, channels, r, out_features, static_cast<hipStream_t>(stream));
 }
 
+size_t sd_linear_nchw_workspace_bytes(int B, long P, int in_features, int out_features) {
+    return sd::linear_nchw_workspace_bytes(B, P, in_features, out_features);
+}
+
+int sd_linear_nchw_fwd(const void *X, const float *W, const float *bias, void *Y, int dtype, int B, long P, int in_features, int out_features,
+                       void *stream) {
+    if (!X || !W || !Y) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0 || B > 65535) return SD_E_SHAPE;
+    if (dtype == SD_F32) return sd::linear_nchw_f32_fwd((const float *)X, W, bias, (float *)Y, B, P, in_features, out_features, stream);
+    // bf16 storage: A = W [m][k] (fp32 master, rounded on its way into LDS), B = tokens_b [n][k], C_b [m][n]
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((P + sd::BN - 1) / sd::BN), (out_features + sd::BM - 1) / sd::BM, B);
+    sd::launch_gemm<float, sd::bf16_t, sd::bf16_t, false, false>(grid, st, W, (const sd::bf16_t *)X, (sd::bf16_t *)Y, bias, out_features, (int)P, in_features,
+                                                                 (long)in_features, (long)in_features, P, 0L, P * in_features, P * out_features, 1, in_features);
+    return (int)hipGetLastError();
+}
+
+int sd_linear_nchw_bwd_data(const void *dY, const float *W, void *dX, int dtype, int B, long P, int in_features, int out_features, void *stream) {
+    if (!dY || !W || !dX) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0 || B > 65535) return SD_E_SHAPE;
+    if (dtype == SD_F32) return sd::linear_nchw_f32_bwd_data((const float *)dY, W, (float *)dX, B, P, in_features, out_features, stream);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((in_features + sd::BN - 1) / sd::BN, (unsigned)((P + sd::BM - 1) / sd::BM), B);
+    sd::launch_gemm<sd::bf16_t, float, sd::bf16_t, true, true>(grid, st, (const sd::bf16_t *)dY, W, (sd::bf16_t *)dX, nullptr, (int)P, in_features, out_features,
+                                                               P, (long)in_features, (long)in_features, P * out_features, 0L, P * in_features, 1, out_features);
+    return (int)hipGetLastError();
+}
+
+int sd_linear_nchw_bwd_weight(const void *dY, const void *X, float *dW, float *dbias, int dtype, int B, long P, int in_features, int out_features,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+    if (!dY || !X || !dW || !workspace) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0 || B > 65535) return SD_E_SHAPE;
+    if (dtype == SD_F32)
+        return sd::linear_nchw_f32_bwd_weight((const float *)dY, (const float *)X, dW, dbias, B, P, in_features, out_features, workspace, workspace_bytes, stream);
+    if (workspace_bytes < sd::linear_nchw_workspace_bytes(B, P, in_features, out_features) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return SD_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int nsplit = sd::pred_splits(B, P);
+    const int klen = (int)(((P + nsplit - 1) / nsplit + 63) / 64 * 64);
+    nsplit = (int)((P + klen - 1) / klen);
+    const long slab = (long)out_features * in_features;
+    float *slabs = static_cast<float *>(workspace);
+    // slab z = dY_b[:, chunk] . X_b[chunk, :]: A = dY_b [m][k] (pixels contiguous), B = tokens_b [k][n]
+    dim3 grid((in_features + sd::BN - 1) / sd::BN, (out_features + sd::BM - 1) / sd::BM, B * nsplit);
+    sd::launch_gemm<sd::bf16_t, sd::bf16_t, float, false, true>(grid, st, (const sd::bf16_t *)dY, (const sd::bf16_t *)X, slabs, nullptr, out_features, in_features,
+                                                                (int)P, P, (long)in_features, (long)in_features, P * out_features, P * in_features, slab, nsplit,
+                                                                klen);
+    hipLaunchKernelGGL((sd::slab_reduce<float>), dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, slabs, dW, slab, B * nsplit);
+    if (dbias) hipLaunchKernelGGL((sd::bias_grad<sd::bf16_t>), dim3(out_features), dim3(256), 0, st, (const sd::bf16_t *)dY, dbias, B, out_features, P);
+    return (int)hipGetLastError();
+}
+
 int sd_linear_wgrad_fuses_bias_dtype(int dtype, long tokens, int out_features, int in_features) {
     if (tokens <= 0 || out_features <= 0 || in_features <= 0) return 0;
     return sd::linear_wgrad_plan(tokens, out_features, in_features, dtype == SD_BF16).direct ? 1 : 0;

@@ -23,5 +23,12 @@ int cgd_tunable(const char *key, int set, int v);
 int cgd_up_tunable(const char *key, int set, int v);
 int sra_tunable(const char *key, int set, int v);
 int token_gemm_tunable(const char *key, int set, int v);
+// token-major -> class-planes Linear, fp32 (token_gemm.hip); the dtype-dispatching C entry points live in align1x1.hip
+size_t linear_nchw_workspace_bytes(int B, long P, int in_features, int out_features);
+int pred_splits(int B, long P);
+int linear_nchw_f32_fwd(const float *X, const float *W, const float *bias, float *Y, int B, long P, int in_features, int out_features, void *stream);
+int linear_nchw_f32_bwd_data(const float *dY, const float *W, float *dX, int B, long P, int in_features, int out_features, void *stream);
+int linear_nchw_f32_bwd_weight(const float *dY, const float *X, float *dW, float *dbias, int B, long P, int in_features, int out_features, void *workspace,
+                               size_t workspace_bytes, void *stream);
 
 }  // namespace sd

@@ -599,6 +599,62 @@ int token_gemm_tunable(const char *key, int set, int v) {
     return g_align_split_bf16;
 }
 
+size_t linear_nchw_workspace_bytes(int B, long P, int in_features, int out_features) {
+    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0) return 0;
+    const int nsplit = pred_splits(B, P);
+    return ((size_t)B * nsplit * out_features * in_features + (size_t)B * out_features) * sizeof(float) + 16;
+}
+
+int linear_nchw_f32_fwd(const float *X, const float *W, const float *bias, float *Y, int B, long P, int in_features, int out_features, void *stream) {
+    if (!X || !W || !Y) return SD_E_NULL;
+    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0 || B > 65535) return SD_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long sB = P * in_features, sC = P * out_features;
+    if (g_pred_split_bf16 && in_features % 32 == 0)
+        return launch_epi<128, 128, 2, 2, true, 0, true, true, true>(W, X, Y, bias, nullptr, out_features, (int)P, in_features, in_features, in_features, P,
+                                                                         st, B, 0L, sB, sC);
+    return launch_epi<128, 128, 2, 2, true, 0, true, true>(W, X, Y, bias, nullptr, out_features, (int)P, in_features, in_features, in_features, P, st, B,
+                                                               0L, sB, sC);
+}
+
+int linear_nchw_f32_bwd_data(const float *dY, const float *W, float *dX, int B, long P, int in_features, int out_features, void *stream) {
+    if (!dY || !W || !dX) return SD_E_NULL;
+    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0 || B > 65535) return SD_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // C_b [P x in] = A_b . B with A_b = dY_b read as [k = class][m = pixel], B = W [k = class][n = in]
+    if (g_pred_split_bf16)
+        return launch_epi<128, 128, 2, 2, false, 0, false, false, true>(dY, W, dX, nullptr, nullptr, P, in_features, out_features, P, in_features,
+                                                                            in_features, st, B, P * out_features, 0L, P * in_features);
+    return launch_epi<128, 128, 2, 2, false, 0, false, false>(dY, W, dX, nullptr, nullptr, P, in_features, out_features, P, in_features, in_features, st, B,
+                                                                  P * out_features, 0L, P * in_features);
+}
+
+int linear_nchw_f32_bwd_weight(const float *dY, const float *X, float *dW, float *dbias, int B, long P, int in_features, int out_features, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+    if (!dY || !X || !dW || !workspace) return SD_E_NULL;
+    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0 || B > 65535) return SD_E_SHAPE;
+    if (workspace_bytes < linear_nchw_workspace_bytes(B, P, in_features, out_features) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return SD_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int nsplit = pred_splits(B, P);
+    const int klen = (int)(((P + nsplit - 1) / nsplit + 31) / 32 * 32);
+    nsplit = (int)((P + klen - 1) / klen);
+    const long slab = (long)out_features * in_features;
+    float *slabs = static_cast<float *>(workspace);
+    float *bias_part = slabs + (size_t)B * pred_splits(B, P) * slab;
+    int rc;
+    if (g_pred_split_bf16 && klen % 32 == 0 && P % 32 == 0)
+        rc = launch_epi<128, 128, 2, 2, false, 0, true, false, true>(dY, X, slabs, nullptr, nullptr, out_features, in_features, (int)P, P, in_features,
+                                                                         in_features, st, B, P * out_features, P * in_features, slab, nsplit, klen);
+    else
+        rc = launch_epi<128, 128, 2, 2, false, 0, true, false>(dY, X, slabs, nullptr, nullptr, out_features, in_features, (int)P, P, in_features, in_features,
+                                                                   st, B, P * out_features, P * in_features, slab, nsplit, klen);
+    if (rc) return rc;
+    if (dbias) hipLaunchKernelGGL(plane_rowsum_partials, dim3(out_features, B), dim3(256), 0, st, dY, bias_part, out_features, P);
+    hipLaunchKernelGGL(pred_wgrad_reduce, dim3((unsigned)((slab + 255) / 256 + 1)), dim3(256), 0, st, slabs, dW, slab, B * nsplit, bias_part, dbias,
+                       out_features, B);
+    return (int)hipGetLastError();
+}
+
 }  // namespace sd
 
 extern "C" {
@@ -619,62 +675,6 @@ int sd_linear_fwd(const void *X, const float *W, long w_row_stride, const float 
     }
     return sd::dispatch<true>((const float *)X, W, (float *)Y, bias, (const float *)residual, tokens, out_features, in_features, in_features,
                               w_row_stride, out_features, act, static_cast<hipStream_t>(stream));
-}
-
-size_t sd_linear_nchw_workspace_bytes(int B, long P, int in_features, int out_features) {
-    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0) return 0;
-    const int nsplit = sd::pred_splits(B, P);
-    return ((size_t)B * nsplit * out_features * in_features + (size_t)B * out_features) * sizeof(float) + 16;
-}
-
-int sd_linear_nchw_fwd(const float *X, const float *W, const float *bias, float *Y, int B, long P, int in_features, int out_features, void *stream) {
-    if (!X || !W || !Y) return SD_E_NULL;
-    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0 || B > 65535) return SD_E_SHAPE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const long sB = P * in_features, sC = P * out_features;
-    if (sd::g_pred_split_bf16 && in_features % 32 == 0)
-        return sd::launch_epi<128, 128, 2, 2, true, 0, true, true, true>(W, X, Y, bias, nullptr, out_features, (int)P, in_features, in_features, in_features, P,
-                                                                         st, B, 0L, sB, sC);
-    return sd::launch_epi<128, 128, 2, 2, true, 0, true, true>(W, X, Y, bias, nullptr, out_features, (int)P, in_features, in_features, in_features, P, st, B,
-                                                               0L, sB, sC);
-}
-
-int sd_linear_nchw_bwd_data(const float *dY, const float *W, float *dX, int B, long P, int in_features, int out_features, void *stream) {
-    if (!dY || !W || !dX) return SD_E_NULL;
-    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0 || B > 65535) return SD_E_SHAPE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    // C_b [P x in] = A_b . B with A_b = dY_b read as [k = class][m = pixel], B = W [k = class][n = in]
-    if (sd::g_pred_split_bf16)
-        return sd::launch_epi<128, 128, 2, 2, false, 0, false, false, true>(dY, W, dX, nullptr, nullptr, P, in_features, out_features, P, in_features,
-                                                                            in_features, st, B, P * out_features, 0L, P * in_features);
-    return sd::launch_epi<128, 128, 2, 2, false, 0, false, false>(dY, W, dX, nullptr, nullptr, P, in_features, out_features, P, in_features, in_features, st, B,
-                                                                  P * out_features, 0L, P * in_features);
-}
-
-int sd_linear_nchw_bwd_weight(const float *dY, const float *X, float *dW, float *dbias, int B, long P, int in_features, int out_features, void *workspace,
-                              size_t workspace_bytes, void *stream) {
-    if (!dY || !X || !dW || !workspace) return SD_E_NULL;
-    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0 || B > 65535) return SD_E_SHAPE;
-    if (workspace_bytes < sd_linear_nchw_workspace_bytes(B, P, in_features, out_features) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return SD_E_WORKSPACE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    int nsplit = sd::pred_splits(B, P);
-    const int klen = (int)(((P + nsplit - 1) / nsplit + 31) / 32 * 32);
-    nsplit = (int)((P + klen - 1) / klen);
-    const long slab = (long)out_features * in_features;
-    float *slabs = static_cast<float *>(workspace);
-    float *bias_part = slabs + (size_t)B * sd::pred_splits(B, P) * slab;
-    int rc;
-    if (sd::g_pred_split_bf16 && klen % 32 == 0 && P % 32 == 0)
-        rc = sd::launch_epi<128, 128, 2, 2, false, 0, true, false, true>(dY, X, slabs, nullptr, nullptr, out_features, in_features, (int)P, P, in_features,
-                                                                         in_features, st, B, P * out_features, P * in_features, slab, nsplit, klen);
-    else
-        rc = sd::launch_epi<128, 128, 2, 2, false, 0, true, false>(dY, X, slabs, nullptr, nullptr, out_features, in_features, (int)P, P, in_features, in_features,
-                                                                   st, B, P * out_features, P * in_features, slab, nsplit, klen);
-    if (rc) return rc;
-    if (dbias) hipLaunchKernelGGL(sd::plane_rowsum_partials, dim3(out_features, B), dim3(256), 0, st, dY, bias_part, out_features, P);
-    hipLaunchKernelGGL(sd::pred_wgrad_reduce, dim3((unsigned)((slab + 255) / 256 + 1)), dim3(256), 0, st, slabs, dW, slab, B * nsplit, bias_part, dbias,
-                       out_features, B);
-    return (int)hipGetLastError();
 }
 
 int sd_linear_bwd_data(const void *dY, const float *W, long w_row_stride, void *dX, int dtype, long tokens, int in_features, int out_features,

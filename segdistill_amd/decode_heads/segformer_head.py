@@ -196,9 +196,10 @@ class SegFormerHead(BaseDecodeHead):
             # frozen network in fp32 (the teacher): W x tokens^T lands in contiguous NCHW planes directly -- no weight gradient to
             # care about, the faulty kernel is a bf16 one -- and the 79 MB transpose copy of the [8,16384,150] logits is saved
             out = torch.baddbmm(pred.bias.view(1, -1, 1), w2d.unsqueeze(0).expand(b, -1, -1), tokens.transpose(1, 2))
-        elif torch.is_grad_enabled() and linear_to_planes_supported(tokens, w2d, pred.bias):
-            # training in fp32: the swapped-role product writes the class planes directly and its backward reads the gradient planes
-            # (csrc/token_gemm.hip sd_linear_nchw_*): neither the 79 MB transpose of the logits nor that of their gradient
+        elif (torch.is_grad_enabled() or tokens.dtype == torch.bfloat16) and linear_to_planes_supported(tokens, w2d, pred.bias):
+            # training (fp32 or bf16 storage), and the frozen network under bf16 storage: the swapped-role product writes the class planes
+            # directly and its backward reads the gradient planes (csrc: sd_linear_nchw_*): neither the 39-79 MB transpose of the logits
+            # nor that of their gradient, and no library bf16 batched GEMM
             out = linear_to_planes(tokens, w2d, pred.bias)
         else:
             out = token_linear(tokens, w2d, pred.bias, defer_ok=True).transpose(1, 2).contiguous()   # w2d: a view of the leaf weight

@@ -234,19 +234,20 @@ class _LongKLinear(torch.autograd.Function):
 
 
 class _LinearToPlanes(torch.autograd.Function):
-    """y[b, :, p] = W . x[b, p, :] + bias: token-major input, contiguous class planes out (csrc/token_gemm.hip: sd_linear_nchw_*)."""
+    """y[b, :, p] = W . x[b, p, :] + bias: token-major input, contiguous class planes out (csrc: sd_linear_nchw_*).  fp32, or bf16 storage
+    with fp32 master weight / bias (what autocast computes: the weight is rounded to bf16 inside the kernel)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         x = x.contiguous()
-        w = weight.contiguous()
+        w = weight.detach().contiguous()
         B, P, K = x.shape
         N = w.shape[0]
         L = _lib.lib()
-        y = torch.empty(B, N, P, dtype=torch.float32, device=x.device)
-        b = None if bias is None else bias.detach().contiguous()
-        _lib.check(L.sd_linear_nchw_fwd(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), B, P, K, N, _stream_ptr()),
-                   'sd_linear_nchw_fwd')
+        y = torch.empty(B, N, P, dtype=x.dtype, device=x.device)
+        b = None if bias is None else bias.detach().float().contiguous()
+        _lib.check(L.sd_linear_nchw_fwd(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), _DT[x.dtype], B, P, K, N,
+                                        _stream_ptr()), 'sd_linear_nchw_fwd')
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         return y
@@ -258,23 +259,30 @@ class _LinearToPlanes(torch.autograd.Function):
         N = w.shape[0]
         L = _lib.lib()
         dy = dy.contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _lib.check(L.sd_linear_nchw_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, P, K, N, _stream_ptr()), 'sd_linear_nchw_bwd_data')
+            _lib.check(L.sd_linear_nchw_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), _DT[x.dtype], B, P, K, N, _stream_ptr()),
+                       'sd_linear_nchw_bwd_data')
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw = torch.empty_like(w)
+            dw = torch.empty(N, K, dtype=torch.float32, device=x.device)
             db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
             wsb = L.sd_linear_nchw_workspace_bytes(B, P, K, N)
             ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-            _lib.check(L.sd_linear_nchw_bwd_weight(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(), B, P, K, N,
+            _lib.check(L.sd_linear_nchw_bwd_weight(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), None if db is None else db.data_ptr(), _DT[x.dtype], B, P, K, N,
                                                    ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_nchw_bwd_weight')
         return dx, dw, db
 
 
 def linear_to_planes_supported(x, weight, bias):
-    return (x.is_cuda and x.dim() == 3 and x.dtype == torch.float32 and weight.dtype == torch.float32 and (bias is None or bias.dtype == torch.float32)
-            and not torch.is_autocast_enabled() and x.shape[-1] % 4 == 0 and x.shape[1] % 4 == 0 and os.environ.get('SEGDISTILL_PRED_PLANES', '1') == '1')
+    if not (x.is_cuda and x.dim() == 3 and weight.dtype == torch.float32 and (bias is None or bias.dtype == torch.float32)
+            and os.environ.get('SEGDISTILL_PRED_PLANES', '1') == '1'):
+        return False
+    if torch.is_autocast_enabled():
+        return (x.dtype == torch.bfloat16 and torch.get_autocast_dtype('cuda') == torch.bfloat16 and x.shape[-1] % 8 == 0 and x.shape[1] % 8 == 0)
+    return x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[1] % 4 == 0
 
 
 def linear_to_planes(x, weight, bias=None):

@@ -150,3 +150,32 @@ def test_linear_to_planes_matches_conv1x1(case, split):
     assert err(xd.grad, x64.grad) < 2e-6
     assert err(wd.grad, w64.grad) < 5e-6
     assert err(bd.grad, b64.grad) < 5e-6
+
+
+@pytest.mark.parametrize('case', [(2, 1024, 256, 150), (1, 4096, 64, 19), (2, 16384, 768, 150)])
+def test_linear_to_planes_bf16_storage(case):
+    """bf16 activations, fp32 master weight / bias (config 5): against fp64 on the bf16-rounded operands (the kernel rounds the master weight
+    to bf16 on its way into LDS, as autocast's cast does); outputs and input gradient are stored in bf16."""
+    from segdistill_amd import linear
+    B, P, K, N = case
+    g = torch.Generator().manual_seed(P + K + N)
+    x = torch.randn(B, P, K, generator=g).to(torch.bfloat16)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(B, N, P, generator=g).to(torch.bfloat16)
+    x64, w64, b64 = x.double().requires_grad_(True), w.to(torch.bfloat16).double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.einsum('bpk,nk->bnp', x64, w64) + b64[None, :, None]
+    ref.backward(dy.double())
+    dev = torch.device('cuda:0')
+    xd, wd, bd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        assert linear.linear_to_planes_supported(xd, wd, bd)
+        y = linear.linear_to_planes(xd, wd, bd)
+    y.backward(dy.to(dev))
+    def err(a, r):
+        return float((a.detach().double().cpu() - r).abs().max() / r.abs().max())
+    assert y.dtype == torch.bfloat16 and y.shape == (B, N, P) and y.is_contiguous()
+    assert err(y, ref.detach()) < 1e-2
+    assert xd.grad.dtype == torch.bfloat16 and err(xd.grad, x64.grad) < 1e-2
+    assert wd.grad.dtype == torch.float32 and err(wd.grad, w64.grad) < 2e-3
+    assert err(bd.grad, b64.grad) < 1e-4
