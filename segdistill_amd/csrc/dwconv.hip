@@ -33,10 +33,8 @@ template <typename T> struct CV;  // channel vector of 16 bytes
 template <> struct CV<float> {
     static constexpr int N = 4;
     typedef float raw_t __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ void load(const float *p, float (&o)[4]) {
-        raw_t v = *reinterpret_cast<const raw_t *>(p);
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-    }
+    static __device__ __forceinline__ void unpack(const raw_t &v, float (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    static __device__ __forceinline__ void load(const float *p, float (&o)[4]) { unpack(*reinterpret_cast<const raw_t *>(p), o); }
     static __device__ __forceinline__ void store(float *p, const float (&o)[4]) {
         raw_t v = {o[0], o[1], o[2], o[3]};
         *reinterpret_cast<raw_t *>(p) = v;
@@ -45,14 +43,14 @@ template <> struct CV<float> {
 template <> struct CV<bf16_t> {
     static constexpr int N = 8;
     typedef unsigned int raw_t __attribute__((ext_vector_type(4)));
-    static __device__ __forceinline__ void load(const bf16_t *p, float (&o)[8]) {
-        raw_t v = *reinterpret_cast<const raw_t *>(p);
+    static __device__ __forceinline__ void unpack(const raw_t &v, float (&o)[8]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             o[2 * i] = __uint_as_float(v[i] << 16);
             o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
         }
     }
+    static __device__ __forceinline__ void load(const bf16_t *p, float (&o)[8]) { unpack(*reinterpret_cast<const raw_t *>(p), o); }
     static __device__ __forceinline__ void store(bf16_t *p, const float (&o)[8]) {
         raw_t v;
 #pragma unroll
@@ -61,21 +59,30 @@ template <> struct CV<bf16_t> {
     }
 };
 
-template <int N>
-__device__ __forceinline__ void load_w(const float *__restrict__ w, int C, int c, int k, float (&o)[N]) {
-#pragma unroll
-    for (int i = 0; i < N; i += 4) {
-        o[i] = w[(size_t)(c + i) * 9 + k];          // conv layout [C][9]: 36 consecutive bytes per channel, L1/K$-resident
-        o[i + 1] = w[(size_t)(c + i + 1) * 9 + k];
-        o[i + 2] = w[(size_t)(c + i + 2) * 9 + k];
-        o[i + 3] = w[(size_t)(c + i + 3) * 9 + k];
-    }
-}
-
 // grid: (ceil(strips_per_row * (C/N) / 256), B*H).  A thread produces kStrip consecutive pixels of one row
 // for one channel vector; per input row it loads the kStrip+2 columns once (1.5 loads per tap-row-pixel).
 // exact (erf) GELU, the nn.GELU() default used by the Mix-FFN (mix_transformer.py:20, act_layer=nn.GELU)
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+//
+// erff() of the device library is two polynomial branches (|x| < 1, else an exp form) and the pre-activations straddle |x| = 1 in nearly
+// every wave, so both run: ~50 VALU slots per element against 9 FMAs of convolution -- the kernel was VALU-bound at twice its HBM floor.
+// One branch-free form instead (Abramowitz-Stegun 7.1.26 shape, refit to degree 6):
+//     erfc(a) = t P(t) exp(-a^2),  t = 1 / (1 + 0.39 a),  a = |v| / sqrt(2)          max |error| 8.3e-9 in exact arithmetic on [0, inf)
+//     1 + erf(v / sqrt 2) = erfc(a) for v < 0,  2 - erfc(a) otherwise
+// ~16 VALU + rcp + exp2.  The negative tail is computed without the 1 + erf cancellation, so it is MORE accurate there than the library
+// form; over v in [-12, 12] the f32 result is within 3.9e-7 (< 1 ulp of the value) of the f64 GELU, the library form within 4.5e-7
+// (tests/test_dwconv_gpu.py::test_gelu_error_bound holds the kernel to 6e-7).
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float a = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.39f, a, 1.f));
+    float p = -0.22753699123859406f;
+    p = fmaf(p, t, 0.8866638541221619f);
+    p = fmaf(p, t, -0.6353994011878967f);
+    p = fmaf(p, t, 0.6495586633682251f);
+    p = fmaf(p, t, 0.09138870239257812f);
+    p = fmaf(p, t, 0.2353251725435257f);
+    const float q = p * t * __builtin_amdgcn_exp2f(a * a * -1.4426950408889634f);   // erfc(a); exp2 underflows to 0 for |v| > ~14.4
+    return 0.5f * v * (v < 0.f ? q : 2.f - q);
+}
 
 template <typename T, bool FLIP, bool BIAS, bool GELU = false>
 __global__ __launch_bounds__(256) void dw3x3_fwd(const T *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
@@ -92,10 +99,25 @@ __global__ __launch_bounds__(256) void dw3x3_fwd(const T *__restrict__ x, const 
     const int spr = (W + kStrip - 1) / kStrip;
     if (t >= spr * cv) return;
     const int c = (t % cv) * N;
+    // The 9 taps of this lane's N channels: 9N consecutive floats of nn.Conv2d's [C][9] layout (16-byte aligned: N % 4 == 0), held in
+    // registers -- 9N/4 vector loads instead of the 9N scalar gathers (one per tap and channel) this kernel used to issue.  Every index
+    // below is a compile-time constant after unrolling.  (Staging them tap-major through LDS for the whole workgroup cost more VALU in
+    // index arithmetic than the gathers: 1217 instructions per wave against ~700, on a kernel that is VALU-bound -- SQ counters in
+    // profiles/r02_pmc_dw3x3.txt.)
+    float wreg[9 * N];
+#pragma unroll
+    for (int i = 0; i < 9 * N; i += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(w + (size_t)c * 9 + i);
+        wreg[i] = v.x; wreg[i + 1] = v.y; wreg[i + 2] = v.z; wreg[i + 3] = v.w;
+    }
     const int x0 = (t / cv) * kStrip;
     const int row = item / gridDim.x;  // b*H + yy
     const int yy = row % H;
     const size_t img = (size_t)(row - yy) * W;  // pixel index of (b, 0, 0)
+    // `inner`: all kStrip + 2 input columns and all kStrip outputs lie inside the row -- no bounds test, no zero fill.  Only the first
+    // and last strip of a row take the checked path (the halo tests and their zero fills were a quarter of this VALU-bound kernel).
+    // In-row offsets are 32-bit (the launcher rejects W * C >= 2^31); only the row origin is a 64-bit product.
+    const bool inner = x0 >= 1 && x0 + kStrip + 1 <= W;
 
     float acc[kStrip][N];
 #pragma unroll
@@ -114,45 +136,68 @@ __global__ __launch_bounds__(256) void dw3x3_fwd(const T *__restrict__ x, const 
 #pragma unroll
             for (int i = 0; i < N; ++i) acc[p][i] = bv[i];
     }
+    // All 3 x (kStrip + 2) input vectors are requested before the first one is used, from clamped (always valid) addresses and with no
+    // branch in between: a wave has 18 16-byte loads in flight instead of three dependent rounds of 6 (each round waited for the previous
+    // one: ~7 us per wave, 2.9 TB/s on an HBM-resident map with the VALU 14 % busy).  Out-of-image rows are skipped below (uniform per
+    // workgroup), out-of-row columns zeroed on the checked path.
+    typename CV<T>::raw_t raw[3][kStrip + 2];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = min(max(yy + ky - 1, 0), H - 1);
+        const T *xr = x + ((img + (size_t)iy * W) * C + c);
+#pragma unroll
+        for (int j = 0; j < kStrip + 2; ++j) {
+            raw[ky][j] = *reinterpret_cast<const typename CV<T>::raw_t *>(xr + min(max(x0 + j - 1, 0), W - 1) * C);
+        }
+    }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = yy + ky - 1;
         if (iy < 0 || iy >= H) continue;
         float col[kStrip + 2][N];
 #pragma unroll
-        for (int j = 0; j < kStrip + 2; ++j) {
-            const int ix = x0 + j - 1;
-            if (ix >= 0 && ix < W) CV<T>::load(x + (img + (size_t)iy * W + ix) * C + c, col[j]);
-            else {
+        for (int j = 0; j < kStrip + 2; ++j) CV<T>::unpack(raw[ky][j], col[j]);
+        if (!inner) {
 #pragma unroll
-                for (int i = 0; i < N; ++i) col[j][i] = 0.f;
+            for (int j = 0; j < kStrip + 2; ++j) {
+                const int ix = x0 + j - 1;
+                if (ix < 0 || ix >= W) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) col[j][i] = 0.f;
+                }
             }
         }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             float wv[N];
             const int k = FLIP ? 8 - (3 * ky + kx) : 3 * ky + kx;
-            load_w<N>(w, C, c, k, wv);
+#pragma unroll
+            for (int i = 0; i < N; ++i) wv[i] = wreg[9 * i + k];
 #pragma unroll
             for (int p = 0; p < kStrip; ++p)
 #pragma unroll
                 for (int i = 0; i < N; ++i) acc[p][i] = fmaf(wv[i], col[p + kx][i], acc[p][i]);
         }
     }
-    if constexpr (GELU) {  // epilogue GELU; the frozen teacher never needs the pre-activation, training keeps it in y_pre for the backward
-        if (y_pre) {
+    const size_t orow = (img + (size_t)yy * W) * C + c;
+    auto put = [&](T *dst) {
+        if (inner) {
+#pragma unroll
+            for (int p = 0; p < kStrip; ++p) CV<T>::store(dst + orow + (x0 + p) * C, acc[p]);
+        } else {
 #pragma unroll
             for (int p = 0; p < kStrip; ++p)
-                if (x0 + p < W) CV<T>::store(y_pre + (img + (size_t)yy * W + x0 + p) * C + c, acc[p]);
+                if (x0 + p < W) CV<T>::store(dst + orow + (x0 + p) * C, acc[p]);
         }
+    };
+    if constexpr (GELU) {  // epilogue GELU; the frozen teacher never needs the pre-activation, training keeps it in y_pre for the backward
+        if (y_pre) put(y_pre);
 #pragma unroll
         for (int p = 0; p < kStrip; ++p)
 #pragma unroll
             for (int i = 0; i < N; ++i) acc[p][i] = gelu_erf(acc[p][i]);
     }
-#pragma unroll
-    for (int p = 0; p < kStrip; ++p)
-        if (x0 + p < W) CV<T>::store(y + (img + (size_t)yy * W + x0 + p) * C + c, acc[p]);
+    put(y);
 }
 
 // Weight / bias gradient partials.  A "segment" is up to SEG consecutive pixels of one image row.
@@ -293,7 +338,7 @@ template <typename T> WgGeo wgrad_geo(int B, int H, int W, int C) {
 int check_dw(const void *a, const void *b, int dtype, int B, int H, int W, int C) {
     if (!a || !b) return SD_E_NULL;
     if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (long)B * H > 0x7fffffffL) return SD_E_SHAPE;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (long)B * H > 0x7fffffffL || (long)(W + 2) * C > 0x7fffffffL) return SD_E_SHAPE;   // in-row offsets are int
     if (C % (dtype == SD_F32 ? 4 : 8)) return SD_E_UNSUPPORTED;  // 16-byte channel vectors
     if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return SD_E_ALIGN;
     return SD_OK;
@@ -305,12 +350,15 @@ int fwd_launch(const void *x, const float *w, const float *bias, void *y, int B,
     const int cv = C / CV<T>::N;
     const int spr = (W + kStrip - 1) / kStrip;
     dim3 grid((spr * cv + 255) / 256, B * H);
-    if (gelu && bias) hipLaunchKernelGGL((dw3x3_fwd<T, false, true, true>), grid, dim3(256), 0, st, (const T *)x, w, bias, (T *)y, H, W, C, (T *)y_pre);
-    else if (gelu) hipLaunchKernelGGL((dw3x3_fwd<T, false, false, true>), grid, dim3(256), 0, st, (const T *)x, w, nullptr, (T *)y, H, W, C, (T *)y_pre);
-    else if (flip) hipLaunchKernelGGL((dw3x3_fwd<T, true, false>), grid, dim3(256), 0, st, (const T *)x, w, nullptr, (T *)y, H, W, C);
-    else if (bias) hipLaunchKernelGGL((dw3x3_fwd<T, false, true>), grid, dim3(256), 0, st, (const T *)x, w, bias, (T *)y, H, W, C);
-    else hipLaunchKernelGGL((dw3x3_fwd<T, false, false>), grid, dim3(256), 0, st, (const T *)x, w, nullptr, (T *)y, H, W, C);
-    return (int)hipGetLastError();
+    auto go = [&](auto kern, const float *b, void *pre) -> int {
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, (const T *)x, w, b, (T *)y, H, W, C, (T *)pre);
+        return (int)hipGetLastError();
+    };
+    if (gelu && bias) return go(dw3x3_fwd<T, false, true, true>, bias, y_pre);
+    if (gelu) return go(dw3x3_fwd<T, false, false, true>, nullptr, y_pre);
+    if (flip) return go(dw3x3_fwd<T, true, false>, nullptr, nullptr);
+    if (bias) return go(dw3x3_fwd<T, false, true>, bias, nullptr);
+    return go(dw3x3_fwd<T, false, false>, nullptr, nullptr);
 }
 
 template <typename T>

@@ -111,3 +111,24 @@ def test_dwconv_gelu_training_form(dtype, deferred_scope):
     assert wg.grad.shape == (C, 1, 3, 3) and wg.grad.is_contiguous()
     assert _err(wg.grad, w64.grad) < (2e-5 if dtype == torch.float32 else 2e-2)
     assert _err(bg.grad, b64.grad) < (2e-5 if dtype == torch.float32 else 2e-2)
+
+
+def test_gelu_error_bound():
+    """The branch-free erf of the fused GELU epilogue (csrc/dwconv.hip::gelu_erf) against the f64 GELU: a centre-tap-only filter turns the
+    kernel into an element-wise GELU.  Bound 6e-7 absolute over [-12, 12] (the f32 library form 0.5 v (1 + erff(v / sqrt 2)) sits at
+    4.5e-7), and the negative tail keeps its RELATIVE accuracy instead of flushing to zero where 1 + erf cancels."""
+    from segdistill_amd.dwconv import dwconv3x3_gelu_tokens_inference
+    dev = torch.device('cuda:0')
+    C = 64
+    v = torch.linspace(-12, 12, 64 * 64 * C, dtype=torch.float64)
+    x = v.float().reshape(1, 64 * 64, C).to(dev)
+    w = torch.zeros(C, 1, 3, 3, device=dev)
+    w[:, 0, 1, 1] = 1.0
+    y = dwconv3x3_gelu_tokens_inference(x, w, None, 64, 64).double().cpu().reshape(-1)
+    xv = x.double().cpu().reshape(-1)
+    ref = 0.5 * xv * torch.special.erfc(-xv / 2 ** 0.5)
+    assert float((y - ref).abs().max()) < 6e-7
+    tail = (xv < -3) & (xv > -9)
+    assert float(((y - ref).abs() / ref.abs())[tail].max()) < 2e-2     # erfc(6.4) = 1e-19: the library form returns exactly 0 here
+    mid = xv.abs() < 3
+    assert float(((y - ref).abs() / ref.abs().clamp_min(1e-6))[mid].max()) < 1e-5
