@@ -55,6 +55,8 @@ template <int G> __device__ __forceinline__ float group_sum(float v) {
 }
 
 // grid: ceil(rows / rows_per_block); rows_per_block = kLnThreads / G
+// (One row per row-group: batching 4 rows per group the way ln_bwd does measured 5-20 % SLOWER here -- 6.8 -> 8.0 us at 131072 x 32 f32 --
+// the forward has no accumulators to carry and the larger grid already keeps 8 waves per SIMD in flight.)
 // Residual form (res != nullptr): the row that is normalised is  xsum = x + scale * res  (scale = row_scale[row / rows_per_sample],
 // the stochastic-depth factor of that sample, or 1), and xsum is written out as well -- the block's "x = x + drop_path(f(x))"
 // followed by the next LayerNorm in ONE pass (reference mix_transformer.py:150-151).
