@@ -94,6 +94,9 @@ class KDTrainer:
         if not example_batch['img'].is_cuda:
             return False
         m = self.model
+        if getattr(m, 'log_grad', False):   # the gradient-angle diagnostic back-propagates twice inside train_step: eager only
+            warnings.warn('hipGraph capture skipped: distillation[0] asks for log_grad')
+            return False
         try:
             self._static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in example_batch.items()}
             has_kd = hasattr(m, 'distillation_loss') and bool(getattr(m, 'distillation', None))

@@ -19,14 +19,15 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
-def parse_losses(losses, want_host_values=True):
+def parse_losses(losses, want_host_values=True, extra=None):
     """-> (loss tensor, OrderedDict name -> float | 0-dim tensor).
 
     mean of every entry; ``loss`` = sum of the entries whose key contains 'loss'
     (so acc_seg is excluded and the KD keys are included).  With ``want_host_values=False`` (``defer_log_sync``) the
     returned 0-dim tensors are this RANK's values: nobody reads them until a log line is due, so their cross-rank mean
     is taken there (``KDTrainer.log_values`` -- one collective per log interval instead of one per step, and none
-    inside a captured step)."""
+    inside a captured step).  ``extra(log_vars) -> {name: 0-dim tensor}`` adds entries after the sum is formed (reference
+    SD_structure.py:124-134 puts `deg` there, in front of `loss`)."""
     log_vars = OrderedDict()
     for name, value in losses.items():
         if isinstance(value, torch.Tensor):
@@ -36,6 +37,8 @@ def parse_losses(losses, want_host_values=True):
         else:
             raise TypeError(f'{name} is not a tensor or list of tensors')
     loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+    if extra is not None:   # diagnostics computed from the per-key means (SDModule's `log_grad` angle): logged, never part of `loss`
+        log_vars.update(extra(log_vars))
     log_vars['loss'] = loss
     names = list(log_vars)
     packed = torch.stack([log_vars[n].detach().float().reshape(()) for n in names])

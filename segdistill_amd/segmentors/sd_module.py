@@ -150,6 +150,43 @@ class SDModule(BaseSegmentor):
         # batch that the allocator placed at the freed address, and the student would be distilled against another image's features
         self._prefetched = (img, img._version, taps, ev)
 
+    # ---- `log_grad` diagnostic (reference SD_structure.py:92-108 get_grads, :124-134) --------------------------------------------------
+    def get_grads(self, loss, params=None):
+        """Flattened gradient of `loss` w.r.t. the student's trainable parameters (the graph is kept).  The reference back-propagates
+        into `.grad`, concatenates the non-None ones and zeroes them; `torch.autograd.grad` gives the same vector without touching
+        `.grad` (so the real backward of the step still starts from clean gradients), with zeros where the loss does not reach."""
+        params = [p for p in self.student.parameters() if p.requires_grad] if params is None else params
+        grads = torch.autograd.grad(loss, params, retain_graph=True, allow_unused=True)
+        return [None if g is None else g.detach().flatten() for g in grads]
+
+    def _grad_angle(self, log_vars):
+        """`deg`: the angle, in degrees with the reference's pi = 3.1416, between the student gradients of the segmentation loss
+        (the LAST key containing 'loss_seg') and of the distillation loss (the LAST key containing 'channel')."""
+        loss_seg = loss_distill = None
+        for key, value in log_vars.items():
+            if 'loss_seg' in key:
+                loss_seg = value
+            elif 'channel' in key:
+                loss_distill = value
+        if loss_seg is None or loss_distill is None:   # the reference reads an unassigned local here
+            raise UnboundLocalError("log_grad needs a '*loss_seg*' and a '*channel*' entry among the losses (reference SD_structure.py:125-131)")
+        params = [p for p in self.student.parameters() if p.requires_grad]
+        g_seg, g_kd = self.get_grads(loss_seg, params), self.get_grads(loss_distill, params)
+        keep = [i for i in range(len(params)) if g_seg[i] is not None or g_kd[i] is not None]
+        cat = lambda gs: torch.cat([gs[i] if gs[i] is not None else torch.zeros(params[i].numel(), device=params[i].device, dtype=params[i].dtype)
+                                    for i in keep])
+        a, b = cat(g_seg), cat(g_kd)
+        cos = torch.sum(a * b) / (torch.norm(a) * torch.norm(b))
+        return {'deg': torch.acos(cos) * 180 / 3.1416}
+
+    def _parse_losses(self, losses):
+        if not self.log_grad:
+            return super()._parse_losses(losses)
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('log_grad runs two extra backward passes per step and cannot be captured into a hipGraph: train in eager mode')
+        from .base import parse_losses
+        return parse_losses(losses, want_host_values=not self.defer_log_sync, extra=self._grad_angle)
+
     def forward_train(self, img, img_metas=None, gt_semantic_seg=None):
         if not self.external_step:
             self.cnt += 1
