@@ -282,7 +282,8 @@ int sd_linear_patch_fwd(const float *X, const float *W, const float *bias /* or 
  * nn.Conv2d(dim, dim, 3, 1, 1, groups=dim) -> flatten/transpose back; called from Mlp.forward :48-55).
  * Replaces those two transposes plus the grouped conv and its two backward convs.  Weights are passed, and
  * weight gradients returned, in nn.Conv2d's own layout [C][9] fp32 (= [C,1,3,3] contiguous, k = 3*ky + kx):
- * no transpose on either side of the boundary; C % 4 == 0 (fp32) / C % 8 == 0 (bf16), 16-byte aligned pointers.
+ * no transpose on either side of the boundary; C % 4 == 0 (fp32) / C % 8 == 0 (bf16), 16-byte aligned pointers;
+ * SD_E_SHAPE when (W + 2) * C >= 2^31 (offsets inside an image row are 32-bit).
  * sd_dwconv3x3_bwd_weight with dw == NULL leaves its partials [slabs][9*C + C] (weight gradient in conv layout,
  * then the C bias sums) in the workspace for sd_multi_slab_reduce; slabs = sd_dwconv3x3_wgrad_slabs(...).
  */
@@ -292,7 +293,8 @@ int sd_dwconv3x3_wgrad_slabs(int dtype, int B, int H, int W, int C);
 int sd_dwconv3x3_fwd(const void *x, const float *w, const float *bias /* or NULL */, void *y,
                      int dtype, int B, int H, int W, int C, void *stream);
 
-/* inference-only: y = GELU(dwconv(x) + bias) (exact erf GELU), i.e. DWConv followed by the Mix-FFN activation
+/* inference-only: y = GELU(dwconv(x) + bias) (the erf GELU of nn.GELU(); erfc evaluated by one branch-free degree-6 form, f32 result within
+ * 3.9e-7 of the f64 value over [-12, 12], see csrc/dwconv.hip::gelu_erf), i.e. DWConv followed by the Mix-FFN activation
  * (mix_transformer.py:50-51) in one pass; used for the frozen teacher, which never needs the pre-activation */
 int sd_dwconv3x3_gelu_fwd(const void *x, const float *w, const float *bias /* or NULL */, void *y,
                           int dtype, int B, int H, int W, int C, void *stream);

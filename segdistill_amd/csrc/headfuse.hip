@@ -139,14 +139,15 @@ __device__ __forceinline__ void add_branch_strip(float (&acc)[4][HV<T>::N], cons
     const float ly = sy - (float)y0u;
     const int y0 = min(max(y0u, 0), h - 1), y1 = min(max(y0u + 1, 0), h - 1);
     const int base = (int)floorf((X0 + 0.5f) / F - 0.5f);          // un-clamped left tap of the strip's first pixel
-    const T *img = z + (size_t)b * h * w * E + c;
+    const T *img = z + (size_t)b * h * w * E + c;                  // offsets inside an image are 32-bit (the launcher checks H * W * E < 2^31)
+    const T *r0 = img + y0 * w * E, *r1 = img + y1 * w * E;
     float col[NC][N];                                               // vertically interpolated coarse columns base .. base+NC-1
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
         const int x = min(max(base + j, 0), w - 1);
         float a[N], d[N];
-        HV<T>::load(img + ((size_t)y0 * w + x) * E, a);
-        HV<T>::load(img + ((size_t)y1 * w + x) * E, d);
+        HV<T>::load(r0 + x * E, a);
+        HV<T>::load(r1 + x * E, d);
 #pragma unroll
         for (int i = 0; i < N; ++i) col[j][i] = fmaf(ly, d[i] - a[i], a[i]);
     }
@@ -169,18 +170,22 @@ __global__ __launch_bounds__(256) void upsum_fwd_strip(const T *__restrict__ z1,
                                                         T *__restrict__ y, int B, int H, int W, int E) {
     constexpr int N = HV<T>::N;
     const int ev = E / N, sw = W / 4;
-    const size_t t = xcd_item(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
-    if (t >= (size_t)B * H * sw * ev) return;
-    const int c = (int)(t % ev) * N;
-    const size_t strip = t / ev;
-    const int X0 = (int)(strip % sw) * 4;
-    const int Y = (int)((strip / sw) % H);
-    const int b = (int)(strip / ((size_t)sw * H));
-    const size_t pix = ((size_t)b * H + Y) * W + X0;
+    // grid (ceil(sw * ev / 256), B * H): the row index and everything derived from it is wave-uniform (scalar registers), a thread divides
+    // once by `ev`, and offsets inside an image are 32-bit.  (The 1-D form decomposed a 64-bit thread index with five runtime divisions:
+    // 754 vector instructions per thread, about as much vector-ALU time as the kernel's HBM time.)
+    const unsigned item = (unsigned)xcd_item(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const unsigned row = item / gridDim.x;                          // b * H + Y
+    const int t = (int)(item - row * gridDim.x) * 256 + threadIdx.x;
+    if (t >= sw * ev) return;
+    const int sx = t / ev;
+    const int c = (t - sx * ev) * N;
+    const int X0 = sx * 4;
+    const int b = (int)(row / (unsigned)H), Y = (int)(row - (unsigned)b * H);
+    const size_t pix = (size_t)row * W + X0;
     float acc[4][N];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        HV<T>::load(z1 + (pix + p) * E + c, acc[p]);
+        HV<T>::load(z1 + pix * E + c + p * E, acc[p]);
         if (bias) {
 #pragma unroll
             for (int i = 0; i < N; ++i) acc[p][i] += bias[c + i];
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(256) void upsum_fwd_strip(const T *__restrict__ z1,
                 if (relu) acc[p][i] = fmaxf(acc[p][i], 0.f);
             }
         }
-        HV<T>::store(y + (pix + p) * E + c, acc[p]);
+        HV<T>::store(y + pix * E + c + p * E, acc[p]);
     }
 }
 
@@ -343,14 +348,13 @@ static int upsum_fwd_impl(const void *z1, const void *z2, const void *z3, const 
     if (E % (dtype == SD_F32 ? 4 : 8)) return SD_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int N = dtype == SD_F32 ? 4 : 8;
-    if (f2 == 2 && f3 == 4 && f4 == 8 && W % 4 == 0) {          // the SegFormer geometry: strip kernel
-        const size_t strips = (size_t)B * H * (W / 4) * (E / N);
-        const unsigned g = (unsigned)((strips + 255) / 256);
+    if (f2 == 2 && f3 == 4 && f4 == 8 && W % 4 == 0 && (size_t)H * W * E < 0x7fffffffull && (size_t)B * H <= 65535) {   // the SegFormer geometry: strip kernel
+        const dim3 g((unsigned)(((size_t)(W / 4) * (E / N) + 255) / 256), (unsigned)(B * H));
         if (dtype == SD_F32)
-            hipLaunchKernelGGL((sd::upsum_fwd_strip<float>), dim3(g), dim3(256), 0, st, (const float *)z1, (const float *)z2, (const float *)z3,
+            hipLaunchKernelGGL((sd::upsum_fwd_strip<float>), g, dim3(256), 0, st, (const float *)z1, (const float *)z2, (const float *)z3,
                                (const float *)z4, bias, scale, shift, relu, (float *)y, B, H, W, E);
         else
-            hipLaunchKernelGGL((sd::upsum_fwd_strip<sd::bf16_t>), dim3(g), dim3(256), 0, st, (const sd::bf16_t *)z1, (const sd::bf16_t *)z2,
+            hipLaunchKernelGGL((sd::upsum_fwd_strip<sd::bf16_t>), g, dim3(256), 0, st, (const sd::bf16_t *)z1, (const sd::bf16_t *)z2,
                                (const sd::bf16_t *)z3, (const sd::bf16_t *)z4, bias, scale, shift, relu, (sd::bf16_t *)y, B, H, W, E);
         return (int)hipGetLastError();
     }
