@@ -173,7 +173,7 @@ def fused_leg(device, B, C=150, hw=128, F=4, g=8, tau=4.0, reps=20):
     return out
 
 
-def kernel_roofline_entries(groups=('r2', 'r1_bf16', 'tok', 'align', 'ce', 'pix', 'at', 'ifvd', 'sra', 'optim'), reps=10):
+def kernel_roofline_entries(groups=('r2', 'r1_bf16', 'tok', 'align', 'ce', 'pix', 'at', 'ifvd', 'sra', 'optim', 'dw', 'ln', 'upsum'), reps=10):
     import subprocess
     import tempfile
     out = []

@@ -341,6 +341,73 @@ def bench_ce(dev, reps, B=8, C=150, hw=128, F=4):
             _entry('ce_up bwd', 'ce_up_bwd', [B, C, hw, hw, '->', H, H], 'f32', tb, 'valu', N * (8 + 4), VALU, note)]
 
 
+def bench_dw(dev, reps, B=8):
+    """Depth-wise 3x3 (+ bias + erf GELU) of the Mix-FFN, token-major [B, H*W, 4*dim]: the frozen teacher's stage-1 map of config 2 and the
+    student's training forward / input gradient / weight-gradient partials at its stage-1 map."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    out = []
+    for tag, side, C, train in (('teacher stage 1 (frozen)', 128, 256, False), ('student stage 1 (training)', 128, 128, True)):
+        x = torch.randn(B, side * side, C, device=dev)
+        w = torch.randn(C, 9, device=dev) / 3
+        b = torch.randn(C, device=dev)
+        y, pre, dx = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        nb = x.numel() * 4
+        shape = [B, side, side, C]
+        if not train:
+            t = _time(lambda st: _ok(L.sd_dwconv3x3_gelu_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 0, B, side, side, C, st), 'dw gelu'), reps)
+            out.append(_entry(f'dw3x3 + GELU fwd, {tag}', 'dw3x3_fwd', shape, 'f32', t, 'hbm', 2 * nb, HBM))
+            continue
+        t = _time(lambda st: _ok(L.sd_dwconv3x3_gelu_fwd_train(x.data_ptr(), w.data_ptr(), b.data_ptr(), pre.data_ptr(), y.data_ptr(), 0, B, side, side, C, st),
+                                 'dw gelu train'), reps)
+        out.append(_entry(f'dw3x3 + GELU fwd keeping the pre-activation, {tag}', 'dw3x3_fwd', shape, 'f32', t, 'hbm', 3 * nb, HBM))
+        t = _time(lambda st: _ok(L.sd_dwconv3x3_bwd_data(y.data_ptr(), w.data_ptr(), dx.data_ptr(), 0, B, side, side, C, st), 'dw bwd data'), reps)
+        out.append(_entry(f'dw3x3 bwd_data, {tag}', 'dw3x3_fwd<flip>', shape, 'f32', t, 'hbm', 2 * nb, HBM))
+        wsb = L.sd_dwconv3x3_workspace_bytes(0, B, side, side, C)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        t = _time(lambda st: _ok(L.sd_dwconv3x3_bwd_weight(x.data_ptr(), y.data_ptr(), None, None, 0, B, side, side, C, ws.data_ptr(), wsb, st), 'dw bwd weight'), reps)
+        out.append(_entry(f'dw3x3 bwd_weight partials (combine deferred), {tag}', 'dw3x3_wgrad_partials', shape, 'f32', t, 'hbm', 2 * nb, HBM))
+    return out
+
+
+def bench_ln(dev, reps, rows=131072, C=64):
+    """LayerNorm over the channels of token-major activations at the teacher's stage-1 shape of config 2."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    x, dy = torch.randn(rows, C, device=dev), torch.randn(rows, C, device=dev)
+    g, b = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    y, dx = torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    wsb = L.sd_layernorm_workspace_bytes(rows, C)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    nb = x.numel() * 4
+    tf = _time(lambda st: _ok(L.sd_layernorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), 0, rows, C, 1e-6, st),
+                              'ln fwd'), reps)
+    tb = _time(lambda st: _ok(L.sd_layernorm_bwd(x.data_ptr(), dy.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), None, None, 0, rows, C,
+                                                 ws.data_ptr(), wsb, st), 'ln bwd'), reps)
+    return [_entry('layernorm fwd', 'ln_fwd', [rows, C], 'f32', tf, 'hbm', 2 * nb, HBM),
+            _entry('layernorm bwd (parameter-gradient combine deferred)', 'ln_bwd', [rows, C], 'f32', tb, 'hbm', 3 * nb, HBM)]
+
+
+def bench_upsum(dev, reps, B=8, E=256):
+    """y = z1 + up(z2) + up(z3) + up(z4) of the SegFormer head (student, E = 256) and its backward to the three coarse branches."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    sizes = [(128, 128), (64, 64), (32, 32), (16, 16)]
+    zs = [torch.randn(B, h * w, E, device=dev) for h, w in sizes]
+    y = torch.empty_like(zs[0])
+    dz = [torch.empty_like(z) for z in zs[1:]]
+    nb = [z.numel() * 4 for z in zs]
+    tf = _time(lambda st: _ok(L.sd_upsum_fwd(zs[0].data_ptr(), zs[1].data_ptr(), zs[2].data_ptr(), zs[3].data_ptr(), None, y.data_ptr(), 0, B, 128, 128, E, 2, 4, 8, st),
+                              'upsum fwd'), reps)
+    wsb = L.sd_upsum_bwd3_workspace_bytes(B, 128, 128, E)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    tb = _time(lambda st: _ok(L.sd_upsum_bwd3(y.data_ptr(), dz[0].data_ptr(), dz[1].data_ptr(), dz[2].data_ptr(), 0, B, 128, 128, E, ws.data_ptr(), wsb, st), 'upsum bwd3'), reps)
+    return [_entry('head up-sample + sum fwd', 'upsum_fwd_strip', [B, 128, 128, E], 'f32', tf, 'hbm', 2 * nb[0] + sum(nb[1:]), HBM),
+            _entry('head up-sample + sum bwd (three coarse branches, separable)', 'upsum_bwd_rows + upsum_bwd_cols', [B, 128, 128, E], 'f32', tb, 'hbm',
+                   nb[0] + sum(nb[1:]), HBM, 'algorithmic bytes: dy once + the three gradients; the fp32 row partials (7/8 of dy, written and re-read) are extra traffic')]
+
+
 GROUPS = {
     'r1': lambda dev, reps: bench_r1(dev, reps),
     'r1_bf16': lambda dev, reps: bench_r1(dev, reps, C=768, HW=128, dtype=torch.bfloat16),      # config 5 stage 1
@@ -357,6 +424,9 @@ GROUPS = {
     'optim': lambda dev, reps: bench_optim(dev, reps),
     'ifvd': lambda dev, reps: bench_ifvd(dev, reps),
     'ce': lambda dev, reps: bench_ce(dev, reps),
+    'dw': lambda dev, reps: bench_dw(dev, reps),
+    'ln': lambda dev, reps: bench_ln(dev, reps),
+    'upsum': lambda dev, reps: bench_upsum(dev, reps),
 }
 
 
