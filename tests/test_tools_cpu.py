@@ -1,0 +1,36 @@
+"""The measurement tools are part of the deliverable (profiles/ is produced by them on the GPU box): every Python tool must at least compile
+here, every shell tool must pass `bash -n` and only call tools that exist, and `bench.py`'s kernel-roofline groups must exist in
+tools/kernel_rooflines.py."""
+import ast
+import glob
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_python_tools_compile():
+    for path in sorted(glob.glob(os.path.join(ROOT, 'tools', '*.py'))) + [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')]:
+        with open(path) as f:
+            ast.parse(f.read(), filename=path)
+
+
+def test_shell_tools_parse_and_reference_existing_files():
+    for path in sorted(glob.glob(os.path.join(ROOT, 'tools', '*.sh'))):
+        assert subprocess.run(['bash', '-n', path]).returncode == 0, path
+        with open(path) as f:
+            text = f.read()
+        for rel in set(re.findall(r'\b(tools/[A-Za-z0-9_]+\.(?:py|sh))\b', text)):
+            assert os.path.isfile(os.path.join(ROOT, rel)), f'{path} calls {rel}, which does not exist'
+
+
+def test_bench_roofline_groups_exist():
+    with open(os.path.join(ROOT, 'bench.py')) as f:
+        m = re.search(r"def kernel_roofline_entries\(groups=\(([^)]*)\)", f.read())
+    assert m, 'bench.py::kernel_roofline_entries not found'
+    wanted = re.findall(r"'([a-z0-9_]+)'", m.group(1))
+    with open(os.path.join(ROOT, 'tools', 'kernel_rooflines.py')) as f:
+        src = f.read()
+    have = re.findall(r"^\s+'([a-z0-9_]+)': lambda dev, reps", src, re.M)
+    assert wanted and set(wanted) <= set(have), (wanted, have)
