@@ -214,14 +214,19 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int sra_slot(int r) { return 16 * (r >> 4) + 8 * ((r >> 2) & 1) + (r & 3) + 4 * ((r >> 3) & 1); }   // row of a 32-block -> k slot
 __device__ __forceinline__ float bf16_lane(const u32x4 &v, int e) { return (e & 1) ? __uint_as_float(v[e >> 1] & 0xffff0000u) : __uint_as_float(v[e >> 1] << 16); }
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+// on PAIRS of values: one v_cvt_pk_bf16_f32 per pair and plane, packed residual subtractions (see token_gemm.hip::split8; same bits)
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const __bf16 hh = static_cast<__bf16>(x[e]);
-        const float r1 = x[e] - static_cast<float>(hh);
-        const __bf16 mm = static_cast<__bf16>(r1);
-        const float r2 = r1 - static_cast<float>(mm);
-        h[e] = hh, m[e] = mm, l[e] = static_cast<__bf16>(r2);
+    for (int e = 0; e < 8; e += 2) {
+        const f32x2 v = {x[e], x[e + 1]};
+        const bf16x2 hh = __builtin_convertvector(v, bf16x2);
+        const f32x2 r1 = v - __builtin_convertvector(hh, f32x2);
+        const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
+        const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
+        const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
+        h[e] = hh[0], h[e + 1] = hh[1], m[e] = mm[0], m[e + 1] = mm[1], l[e] = ll[0], l[e + 1] = ll[1];
     }
 }
 // acc += A . B over 16 k with A = ah + am + al, B = bh + bm + bl

@@ -30,6 +30,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int BK = 32, KP = BK + 4;   // k-contiguous LDS rows: 36 floats = 144 B (16-byte aligned, conflict-free ds_read_b128 / ds_write_b128)
 
 __device__ __forceinline__ float gelu_exact(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
@@ -256,14 +258,19 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
                 for (int j = 0; j < TN; ++j) { f.b[j][e] = lo4.b[j][e]; f.b[j][4 + e] = hi4.b[j][e]; }
             }
         };
+        // Written on PAIRS of values (two-element vectors): the conversions become one v_cvt_pk_bf16_f32 per pair and the residuals one
+        // v_pk_add_f32 per pair.  The scalar form left that pairing to the SLP vectoriser, which packed 40 of the 128 subtractions of a
+        // k-step and emitted 128 instead of 96 conversions (383 vector instructions per k-step against 48 MFMAs).  Same operations, same bits.
         auto split8 = [&](const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const __bf16 hh = static_cast<__bf16>(x[e]);
-                const float r1 = x[e] - static_cast<float>(hh);
-                const __bf16 mm = static_cast<__bf16>(r1);
-                const float r2 = r1 - static_cast<float>(mm);
-                h[e] = hh, m[e] = mm, l[e] = static_cast<__bf16>(r2);
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 v = {x[e], x[e + 1]};
+                const bf16x2 hh = __builtin_convertvector(v, bf16x2);
+                const f32x2 r1 = v - __builtin_convertvector(hh, f32x2);
+                const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
+                const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
+                const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
+                h[e] = hh[0], h[e + 1] = hh[1], m[e] = mm[0], m[e + 1] = mm[1], l[e] = ll[0], l[e + 1] = ll[1];
             }
         };
         // The split of the NEXT fragments is independent of the MFMAs on the CURRENT planes: both are issued in one scheduling region so
