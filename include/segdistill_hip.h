@@ -67,8 +67,10 @@ const char *sd_error_string(int code);
  *       "sra_split_bf16" (0|1, default 1: fp32-storage attention products on the bf16 matrix pipe with every operand split exactly
  *       into three bf16 terms -- fp32-grade results; 0 = v_mfma_f32_32x32x2_f32), "sra_bf16_mfma" (0|1, default 1: bf16-storage
  *       attention forward and backward on the bf16 matrix pipe with P / dS rounded to bf16; 0 = the f32-input MFMA kernels), "align_split_bf16"
- *       (0|1, default 1: the three fp32 products of the 1x1 align projection in split-bf16 arithmetic).  The sra_* and align_* keys
- *       select arithmetic, not geometry: no workspace size depends on them. */
+ *       (0|1, default 1: the three fp32 products of the 1x1 align projection and of sd_linear_nchw_* in split-bf16 arithmetic),
+ *       "pred_tall_tile" (0|1, default 1: sd_linear_nchw_fwd / _bwd_weight use ONE 160-row tile for 129 ... 160 output planes -- the 150
+ *       classes -- instead of two 128-row tiles; same arithmetic).  The sra_*, align_* and pred_* keys select arithmetic or tiling, not
+ *       workspace geometry: no workspace size depends on them. */
 int sd_set_tunable(const char *key, int value);
 int sd_get_tunable(const char *key);
 

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import _lib
 from ..builder import HEADS, build_loss
 from ..layers import ConvModule, frozen_derived, resize, tokens_of
 from ..linear import call_linear, linear_forward, linear_to_planes, linear_to_planes_supported, token_linear
@@ -192,15 +193,17 @@ class SegFormerHead(BaseDecodeHead):
         # 131072 tokens -- then runs on the split-K kernel instead of a 20-workgroup library GEMM (0.39 ms at config 2);
         # (b) ROCm 7.0 hipBLASLt's bf16 kernel for the batched W x tokens^T form (E=768, HW=16384) reads out of bounds
         # (tools/gemm_fault_probe.py reproduces the GPU memory fault).
-        if not torch.is_grad_enabled() and tokens.dtype == torch.float32 and not torch.is_autocast_enabled() and pred.bias is not None:
-            # frozen network in fp32 (the teacher): W x tokens^T lands in contiguous NCHW planes directly -- no weight gradient to
-            # care about, the faulty kernel is a bf16 one -- and the 79 MB transpose copy of the [8,16384,150] logits is saved
-            out = torch.baddbmm(pred.bias.view(1, -1, 1), w2d.unsqueeze(0).expand(b, -1, -1), tokens.transpose(1, 2))
-        elif (torch.is_grad_enabled() or tokens.dtype == torch.bfloat16) and linear_to_planes_supported(tokens, w2d, pred.bias):
-            # training (fp32 or bf16 storage), and the frozen network under bf16 storage: the swapped-role product writes the class planes
-            # directly and its backward reads the gradient planes (csrc: sd_linear_nchw_*): neither the 39-79 MB transpose of the logits
-            # nor that of their gradient, and no library bf16 batched GEMM
+        frozen_f32 = not torch.is_grad_enabled() and tokens.dtype == torch.float32 and not torch.is_autocast_enabled()
+        if linear_to_planes_supported(tokens, w2d, pred.bias) and (not frozen_f32 or (e % 32 == 0 and _lib.get_tunable('align_split_bf16') == 1)):
+            # the swapped-role product writes the class planes directly and its backward reads the gradient planes (csrc: sd_linear_nchw_*):
+            # neither the 39-79 MB transpose of the logits nor that of their gradient, and no library bf16 batched GEMM.  Training (fp32 or
+            # bf16 storage), the frozen network under bf16 storage, and -- since the 160-row tile -- the frozen fp32 teacher as well
+            # (E = 768: 243 us against 299 us for the library's batched W x tokens^T; with 128-row tiles it was 307 us)
             out = linear_to_planes(tokens, w2d, pred.bias)
+        elif frozen_f32 and pred.bias is not None:
+            # frozen network in fp32 without the split-bf16 kernel (E % 32 != 0, or the mode switched off): the library's W x tokens^T also
+            # lands in contiguous NCHW planes directly -- no weight gradient to care about, the faulty library kernel is a bf16 one
+            out = torch.baddbmm(pred.bias.view(1, -1, 1), w2d.unsqueeze(0).expand(b, -1, -1), tokens.transpose(1, 2))
         else:
             out = token_linear(tokens, w2d, pred.bias, defer_ok=True).transpose(1, 2).contiguous()   # w2d: a view of the leaf weight
         out = out.view(b, pred.out_channels, h, w)

@@ -8,6 +8,7 @@ run SEGDISTILL_HIP_ADAMW=0
 run SEGDISTILL_SPLIT_BF16=0
 run SEGDISTILL_TOKEN_GEMM=0
 run SEGDISTILL_PRED_PLANES=0
+run SEGDISTILL_PRED_TALL_TILE=0
 run SEGDISTILL_UPSUM_BWD3=0
 run SEGDISTILL_BF16_SHADOWS=0
 run SEGDISTILL_SPLIT_BF16=0 SEGDISTILL_TOKEN_GEMM=0 SEGDISTILL_HIP_ADAMW=0

@@ -11,6 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tools.gemm_bench import timeit  # noqa: E402
+from segdistill_amd import _lib  # noqa: E402
 from segdistill_amd.linear import linear_to_planes  # noqa: E402
 
 
@@ -21,18 +22,22 @@ def main():
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     for B, P in ((8, 16384), (8, 4096)):
-        x = torch.randn(B, P, a.E, device=dev)
-        w = torch.randn(a.classes, a.E, device=dev) * 0.05
+      for E in sorted({a.E, 256}):
+        x = torch.randn(B, P, E, device=dev)
+        w = torch.randn(a.classes, E, device=dev) * 0.05
         b = torch.randn(a.classes, device=dev)
         with torch.no_grad():
             lib = timeit(lambda: torch.baddbmm(b.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), x.transpose(1, 2)))
+            _lib.set_tunable('pred_tall_tile', 0)
+            hip128 = timeit(lambda: linear_to_planes(x, w, b))
+            _lib.set_tunable('pred_tall_tile', 1)
             hip = timeit(lambda: linear_to_planes(x, w, b))
             ref = torch.baddbmm(b.view(1, -1, 1).double(), w.double().unsqueeze(0).expand(B, -1, -1), x.double().transpose(1, 2))
             e_lib = (torch.baddbmm(b.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), x.transpose(1, 2)).double() - ref).abs().max().item()
             e_hip = (linear_to_planes(x, w, b).double() - ref).abs().max().item()
-        gf = 2.0 * B * P * a.E * a.classes / 1e9
-        print(f'B={B} P={P} E={a.E} -> {a.classes}: library {lib:7.1f} us ({gf / lib / 1e3:5.1f} TF, max err {e_lib:.2e}) | '
-              f'class-plane kernel {hip:7.1f} us ({gf / hip / 1e3:5.1f} TF, max err {e_hip:.2e})')
+        gf = 2.0 * B * P * E * a.classes / 1e9
+        print(f'B={B} P={P} E={E} -> {a.classes}: library {lib:7.1f} us ({gf / lib * 1e3:5.1f} TF, max err {e_lib:.2e}) | class-plane kernel, 128-row tiles '
+              f'{hip128:7.1f} us | 160-row tile {hip:7.1f} us ({gf / hip * 1e3:5.1f} TF, max err {e_hip:.2e})')
 
 
 if __name__ == '__main__':
