@@ -122,6 +122,18 @@ __global__ __launch_bounds__(256) void multi_colsum_partials(const ColsumTable t
     for (int jj = j0; jj < cv; jj += cg) {
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f), u = make_float4(0.f, 0.f, 0.f, 0.f);
         long row = (long)blk * rpb + rg;
+        // eight rows requested before any is added (two were: the walk ran at the load latency -- 156 us for the ~280 MB of config 5's bf16
+        // gradients, 1.8 TB/s); even rows still go to `s` and odd rows to `u` in walk order, so the sums are bit-identical
+        for (; row + 7 * stride < rows; row += 8 * stride) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = CS<T>::load(x + (row + q * stride) * C + 4 * jj);
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                s.x += v[q].x; s.y += v[q].y; s.z += v[q].z; s.w += v[q].w;
+                u.x += v[q + 1].x; u.y += v[q + 1].y; u.z += v[q + 1].z; u.w += v[q + 1].w;
+            }
+        }
         for (; row + stride < rows; row += 2 * stride) {
             const float4 a = CS<T>::load(x + row * C + 4 * jj), b = CS<T>::load(x + (row + stride) * C + 4 * jj);
             s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
