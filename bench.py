@@ -10,11 +10,14 @@ student fwd + frozen-teacher fwd + distillation loss (HIP kernels) + supervised 
 flat-buffer gradient all-reduce (RCCL) + fused AdamW step + LR update.  Workload at N=1: BASELINE
 config 2 (Segformer-B0 <- B2, CGD group 8, T 4, bs 8, 512x512, 150 classes), fp32 as the reference.
 
-Rank 0 prints ONE JSON line with, besides the contract fields:
+Rank 0 prints ONE SHORT JSON line (< 3.5 KB: the driver keeps only the tail of stdout) with, besides the contract fields:
   roofline      the HBM-bound CGD kernels (R1 fwd+bwd) at the config-2 operand shape, timed with HIP
                 events in this same process: achieved = 5*N*4 bytes / (t_fwd + t_bwd);
   cpu_baseline  the whole KD step on host cores (networks on torch-CPU, criteria from oracle/), B=2,
-                a bounded sample (N=1 only).
+                a bounded sample (N=1 only);
+  config.arithmetic / config.value_exact_f32   the shipped fp32 mode computes its GEMM-shaped products as split-bf16
+                (fp32-grade by test); the same workload on exact-f32 MFMA is measured by a child run (N=1 only).
+--kernel-rooflines additionally writes the per-kernel-family table to a side file (roofline.kernels_file).
 """
 from __future__ import annotations
 
@@ -173,19 +176,45 @@ def fused_leg(device, B, C=150, hw=128, F=4, g=8, tau=4.0, reps=20):
     return out
 
 
+KERNEL_GROUPS = ('r2', 'r1_bf16', 'tok', 'align', 'ce', 'pix', 'at', 'ifvd', 'sra', 'optim', 'dw', 'ln', 'upsum')
+
+
 def kernel_roofline_entries(groups=('r2', 'r1_bf16', 'tok', 'align', 'ce', 'pix', 'at', 'ifvd', 'sra', 'optim', 'dw', 'ln', 'upsum'), reps=10):
+    """tools/kernel_rooflines.py, one CHILD process per kernel family.  Called only from a parent that has not touched the GPU yet
+    (main() runs it before init_distributed / any torch.cuda call) and only at N = 1.  A family that times out, dies or writes bad
+    JSON becomes one error entry; nothing here can take the bench line down."""
     import subprocess
     import tempfile
     out = []
     for g in groups:
-        with tempfile.NamedTemporaryFile(suffix='.json') as f:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'kernel_rooflines.py'), '--only', g, '--reps', str(reps), '--json', f.name],
-                               cwd=ROOT, capture_output=True, text=True, timeout=300)
-            if r.returncode != 0:
-                out.append({'name': g, 'error': f'kernel_rooflines.py --only {g} exited with {r.returncode}'})
-                continue
-            out += json.load(open(f.name))
+        try:
+            with tempfile.NamedTemporaryFile(suffix='.json') as f:
+                r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'kernel_rooflines.py'), '--only', g, '--reps', str(reps), '--json', f.name],
+                                   cwd=ROOT, capture_output=True, text=True, timeout=300)
+                if r.returncode != 0:
+                    out.append({'name': g, 'error': f'kernel_rooflines.py --only {g} exited with {r.returncode}'})
+                    continue
+                out += json.load(open(f.name))
+        except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+            out.append({'name': g, 'error': f'{type(e).__name__}: {str(e)[:120]}'})
     return out
+
+
+def exact_f32_child(argv_base, steps, warmup, timeout=420):
+    """The same workload with every split-bf16 product switched back to exact-f32 MFMA (SEGDISTILL_SPLIT_BF16=0), in a CHILD process started
+    before this one touches the GPU.  Returns (imgs/s or None, note)."""
+    import subprocess
+    env = dict(os.environ, SEGDISTILL_SPLIT_BF16='0', SEGDISTILL_BENCH_CHILD='1')
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv_base + ['--steps', str(steps), '--warmup', str(warmup), '--no-roofline',
+                                                                     '--no-cpu-baseline', '--no-exact-f32']
+    try:
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+        if r.returncode != 0 or not lines:
+            return None, f'child exited with {r.returncode}'
+        return float(json.loads(lines[-1])['value']), None
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
+        return None, f'{type(e).__name__}: {str(e)[:120]}'
 
 
 def _usable_cores():
@@ -233,8 +262,8 @@ def cpu_baseline_leg(cfg, batch=2, budget_s=25.0, max_threads=32):
         trainer.step(data.next())
     dt = time.perf_counter() - t0
     return {'value': round(batch * timed / dt, 4), 'unit': 'imgs/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{timed} KD train step(s) (after 1 warm-up of {warm:.1f} s) of the same config at batch {batch} on host cores: '
-                      f'networks on torch-CPU fp32, criteria from oracle/ (eager restatement of losses.py:95-113)',
+            'sample': f'{timed} KD step(s) of the same config at batch {batch} after 1 warm-up ({warm:.1f} s): networks on torch-CPU fp32, '
+                      f'criteria from oracle/ (losses.py:95-113 restated)',
             's_per_step': round(dt / timed, 3)}
 
 
@@ -260,6 +289,66 @@ def spawn_ranks(n, argv):
     return subprocess.run(cmd, env=env, cwd=ROOT).returncode
 
 
+def _newest_profile(pattern):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)), reverse=True)
+    return files[0] if files else None
+
+
+def compose_line(*, args, world, B, dt, rank_ms, graphed, segments, trainer_bf16, arithmetic, grad_bytes, ranks_seen, backend, rccl_version,
+                 logs, allreduce_ms=None, roofline=None, cpu_baseline=None, exact_f32=None, kernels_file=None, errors=None):
+    """The ONE JSON line of the contract, kept SHORT (the driver keeps only the tail of stdout: round 2's 24 KB line was lost).  Pure: the
+    CPU test tests/test_bench_line_cpu.py builds it from canned leg outputs and holds it under 3500 bytes."""
+    cfg_name = os.path.basename(args.config)
+    is_cfg2 = 'cfg2' in cfg_name
+    line = {
+        'metric': 'imgs/sec/node KD train_step, ' + ('Segformer-B2->B0 512x512' if is_cfg2 else cfg_name),
+        'value': round(world * B * args.steps / dt, 3), 'unit': 'imgs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16' if trainer_bf16 else 'f32', 'data': 'synthetic',
+        'config': {'workload': ('BASELINE configs[1]: Segformer-B0 student + B2 teacher, CGD group=8 T=4 alpha=3, 512x512, 150 classes'
+                                if is_cfg2 else cfg_name),
+                   'config_file': os.path.relpath(args.config, ROOT), 'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': f'dp{world}',
+                   'arithmetic': arithmetic, 'kd_path': args.kd_path, 'hip_graph': graphed, 'graph_segments': segments,
+                   'weights': 'random-init', 'grad_allreduce_bytes': grad_bytes, 'rccl_ranks': ranks_seen, 'dist_backend': backend,
+                   'rccl_version': rccl_version, 'rank_ms_per_step': rank_ms},
+        'final_log_vars': {k: round(v, 5) for k, v in list(logs.items())[:8]},
+    }
+    if allreduce_ms is not None:
+        line['config']['grad_allreduce_ms'] = allreduce_ms
+    if exact_f32 is not None:
+        line['config']['value_exact_f32'] = exact_f32
+    if roofline is not None:
+        line['roofline'] = roofline
+        if kernels_file:
+            line['roofline']['kernels_file'] = kernels_file
+    if cpu_baseline is not None:
+        line['cpu_baseline'] = cpu_baseline
+    if errors:
+        line['errors'] = [e[:160] for e in errors][:4]
+    return line
+
+
+def allreduce_probe(trainer, reps=10):
+    """Device time of the step's gradient exchange (pack + ONE all-reduce of the flat buffer), HIP events on the stream it runs on.
+    COLLECTIVE: every rank calls it."""
+    r = trainer.reducer
+    if not r.collective:
+        return None
+    for _ in range(2):
+        r.pack()
+        r.exchange()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        r.pack()
+        r.exchange()
+    e1.record()
+    torch.cuda.synchronize()
+    return round(e0.elapsed_time(e1) / reps, 4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -271,6 +360,11 @@ def main():
                     help="fused: bilinear resize fused into the CGD kernels (R2); r1: ATen resize + streaming kernels")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-exact-f32', action='store_true', help='skip the exact-f32 A/B child run (config.value_exact_f32)')
+    ap.add_argument('--kernel-rooflines', action='store_true',
+                    help='N=1 only: also time every hand-written kernel family against its own bound (tools/kernel_rooflines.py, child processes '
+                         'started before this process touches the GPU); the table goes to a SIDE FILE named by roofline.kernels_file')
+    ap.add_argument('--kernels-out', default=os.path.join(ROOT, 'gpurun_out', 'bench_kernels.json'))
     ap.add_argument('--cpu-threads', type=int, default=32)
     ap.add_argument('--graph', choices=['auto', 'on', 'hybrid', 'off'], default='auto',
                     help='on: capture the whole forward+backward as hipGraphs (cut at the SyncBN collectives when ranks > 1); hybrid: '
@@ -278,6 +372,28 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    # ---- child processes first: nothing above or below this block has touched the GPU in THIS process yet ------------------------------
+    errors = []
+    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    single = world_env == 1 and args.gpus == 1 and os.environ.get('SEGDISTILL_BENCH_CHILD') != '1'
+    kernels_file = None
+    if single and args.kernel_rooflines and not args.no_roofline:
+        try:
+            entries = kernel_roofline_entries()
+            os.makedirs(os.path.dirname(args.kernels_out), exist_ok=True)
+            with open(args.kernels_out, 'w') as f:
+                json.dump(entries, f, indent=0)
+            kernels_file = os.path.relpath(args.kernels_out, ROOT)
+        except Exception as e:  # noqa: BLE001
+            errors.append(f'kernel rooflines: {type(e).__name__}: {e}')
+    exact_f32 = None
+    split_on = os.environ.get('SEGDISTILL_SPLIT_BF16', '1') == '1'
+    if single and split_on and not args.no_exact_f32:
+        base = ['--config', args.config, '--kd-path', args.kd_path, '--graph', args.graph] + (['--batch', str(args.batch)] if args.batch else [])
+        exact_f32, err = exact_f32_child(base, args.steps, args.warmup)
+        if err:
+            errors.append('exact-f32 A/B: ' + err)
 
     from segdistill_amd.config import Config
     from segdistill_amd.engine import KDTrainer, SyntheticADE, init_distributed
@@ -317,9 +433,14 @@ def main():
         graphed = 'hybrid' if trainer.enable_hybrid_graph(data.next()) else False
     for _ in range(args.warmup - n_eager_warm):
         trainer.step(data.next())
-    dt = timed_steps(trainer, data, args.steps, world)
-    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    dt_local = timed_steps(trainer, data, args.steps, world)
+    t = torch.tensor([dt_local], device=device, dtype=torch.float64)
+    rank_ms = None
     if dist.is_initialized():
+        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, t)
+        per = [float(x.item()) / args.steps * 1e3 for x in every]
+        rank_ms = {'min': round(min(per), 3), 'max': round(max(per), 3)}
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     logs = trainer.log_values()
@@ -334,33 +455,36 @@ def main():
         rccl_version = '.'.join(str(v) for v in torch.cuda.nccl.version()) if backend == 'nccl' else None
     except Exception:  # noqa: BLE001
         rccl_version = None
+    allreduce_ms = allreduce_probe(trainer) if dist.is_initialized() else None       # collective: all ranks
+    if rank == 0 and allreduce_ms is not None:
+        print(f'[bench] gradient exchange (pack + one all-reduce of {trainer.reducer.nbytes} bytes over {ranks_seen} ranks, {backend}): '
+              f'{allreduce_ms} ms per step by HIP events; step {dt / args.steps * 1e3:.3f} ms; hip_graph={graphed}', file=sys.stderr)
 
     if rank == 0:
-        line = {
-            'metric': 'imgs/sec/node KD train_step, ' + ('Segformer-B2->B0 512x512' if 'cfg2' in os.path.basename(args.config)
-                                                          else os.path.basename(args.config)), 'value': round(world * B * args.steps / dt, 3),
-            'unit': 'imgs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if trainer.bf16 else 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: Segformer-B0 student + B2 teacher, CGD group=8 T=4 alpha=3, 512x512, 150 classes'
-                       if 'cfg2' in os.path.basename(args.config) else os.path.basename(args.config),
-                       'config_file': os.path.relpath(args.config, ROOT), 'per_gpu_batch': B, 'global_batch': B * world,
-                       'parallelism': f'dp{world}', 'kd_path': args.kd_path, 'hip_graph': graphed, 'weights': 'random-init (no checkpoints offline)',
-                       'grad_allreduce_bytes': trainer.reducer.nbytes, 'rccl_ranks': ranks_seen, 'dist_backend': backend, 'rccl_version': rccl_version,
-                       'cpu_baseline_batch': 2,
-                       'graph_segments': (len([g for g in trainer._seg.items if isinstance(g, torch.cuda.CUDAGraph)])
-                                          if graphed == 'full' else None)},
-            'final_log_vars': {k: round(v, 5) for k, v in logs.items()},
-        }
-        if not args.no_roofline:
-            torch.cuda.empty_cache()
-            line['roofline'] = roofline_leg(device, B)
-            line['roofline']['fused_r2'] = fused_leg(device, B)
-            # every other hand-written kernel of the path at its BASELINE shape against ITS bound (HBM / MFMA / VALU): tools/kernel_rooflines.py,
-            # one child process per kernel family (each captures and replays its own hipGraphs; isolation keeps a fault in one family from
-            # taking the bench line down with it)
-            line['roofline']['kernels'] = kernel_roofline_entries()
-        if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline_leg(cfg, max_threads=args.cpu_threads)
+        segs = (len([g for g in trainer._seg.items if isinstance(g, torch.cuda.CUDAGraph)]) if graphed == 'full' else None)
+        arithmetic = ('bf16 storage, fp32 accumulate' if trainer.bf16 else
+                      ('split-bf16 (bf16x3 on the bf16 MFMA pipe, fp32-grade: tests/test_token_gemm_gpu.py)' if split_on else 'exact-f32 MFMA'))
+        roofline = cpu = None
+        try:
+            if not args.no_roofline:
+                torch.cuda.empty_cache()
+                roofline = roofline_leg(device, B)
+                roofline['fused_r2'] = fused_leg(device, B)
+                top = _newest_profile('r*_step_top5.json')
+                if top:
+                    roofline['step_top5'] = {'source': 'stored: ' + os.path.relpath(top, ROOT), 'kernels': json.load(open(top))[:5]}
+        except Exception as e:  # noqa: BLE001 -- an optional leg never costs the headline
+            errors.append(f'roofline leg: {type(e).__name__}: {e}')
+        try:
+            if world == 1 and not args.no_cpu_baseline:
+                cpu = cpu_baseline_leg(cfg, max_threads=args.cpu_threads)
+        except Exception as e:  # noqa: BLE001
+            errors.append(f'cpu baseline leg: {type(e).__name__}: {e}')
+        line = compose_line(args=args, world=world, B=B, dt=dt, rank_ms=rank_ms, graphed=graphed, segments=segs, trainer_bf16=trainer.bf16,
+                            arithmetic=arithmetic, grad_bytes=trainer.reducer.nbytes, ranks_seen=ranks_seen, backend=backend,
+                            rccl_version=rccl_version, logs=logs, allreduce_ms=allreduce_ms, roofline=roofline, cpu_baseline=cpu,
+                            exact_f32=exact_f32, kernels_file=kernels_file, errors=errors)
+        sys.stderr.flush()
         print(json.dumps(line))
         sys.stdout.flush()
     if dist.is_initialized():

@@ -440,7 +440,11 @@ int launch_epi(const float *A, const float *Bm, float *C, const float *bias, con
     if (klen <= 0 || nsplit <= 1) { nsplit = 1; klen = K; }
     // two staging buffers, or ONE when the whole reduction is a single k-step (K <= 32: the stage-1 products -- HBM-bound, so what matters
     // there is how many workgroups, i.e. bytes in flight, a CU holds)
-    const size_t lds_bytes = (klen > BK ? 2 : 1) * (size_t)((AKC ? BM * KP : BK * (BM + 4)) + (BT ? BN * KP : BK * (BN + 4))) * sizeof(float);
+    // The row-major epilogue parks 4 waves x 32 rows x (TN*32 + 4) floats in the same LDS: with ONE staging buffer of two [k][m] / [k][n]
+    // operands (bwd-data of the class-plane Linear with <= 32 classes: 33792 B) that image (34816 B) is the larger of the two.
+    constexpr size_t epi_bytes = (size_t)4 * 32 * ((BN / (32 * WAVES_N)) * 32 + 4) * sizeof(float);
+    const size_t stage_bytes = (klen > BK ? 2 : 1) * (size_t)((AKC ? BM * KP : BK * (BM + 4)) + (BT ? BN * KP : BK * (BN + 4))) * sizeof(float);
+    const size_t lds_bytes = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     const long tiles_m = (M + BM - 1) / BM;
     const int tiles_n = (N + BN - 1) / BN;
     const long nblk = tiles_m * tiles_n;

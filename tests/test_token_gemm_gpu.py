@@ -119,7 +119,10 @@ def test_patch_linear_gathers_inside_the_gemm(case):
     assert not linear.patch_linear_supported(xd.clone().requires_grad_(True), (H, W), r, wd, enabled=True)     # a graph to build: the copy route
 
 
-@pytest.mark.parametrize('case', [(2, 1024, 256, 150), (1, 4096, 64, 19), (3, 260, 32, 150), (8, 16384, 256, 150)])
+# (.., 256 / 768, 19): <= 32 classes is ONE k-step of the input-gradient product = a single LDS staging buffer, smaller than the row-major
+# epilogue image of wave 3 (round-2 advisor finding: rows 28-31 of its blocks were dropped when in_features > 64)
+@pytest.mark.parametrize('case', [(2, 1024, 256, 150), (1, 4096, 64, 19), (3, 260, 32, 150), (8, 16384, 256, 150), (2, 1024, 256, 19), (1, 512, 768, 19),
+                                  (2, 384, 128, 32)])
 @pytest.mark.parametrize('split', [1, 0])
 def test_linear_to_planes_matches_conv1x1(case, split):
     """sd_linear_nchw_* (the head's linear_pred on a token-major map, logits written as class planes, gradient read from planes) against

@@ -11,6 +11,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 @pytest.mark.parametrize('config,batch,mode,segments', [
@@ -18,8 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ])
 def test_bench_two_ranks_on_one_gpu(config, batch, mode, segments):
     env = dict(os.environ, SEGDISTILL_DIST_BACKEND='gloo', SEGDISTILL_FORCE_DEVICE='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import bench
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29547', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '4', '--batch', str(batch),
+           '--master-port', str(bench._free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '4', '--batch', str(batch),
            '--no-roofline', '--config', os.path.join(ROOT, 'configs', 'kd', config)]
     res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
@@ -30,6 +32,8 @@ def test_bench_two_ranks_on_one_gpu(config, batch, mode, segments):
     assert d['config']['hip_graph'] == mode and d['config']['graph_segments'] == segments and d['scaling'] == 'weak' and d['value'] > 0
     assert all(v == v and abs(v) < 1e6 for v in d['final_log_vars'].values())
     assert 'cpu_baseline' not in d                       # N=1 only
+    assert len(lines[0]) < 2500 and d['config']['rank_ms_per_step']['min'] <= d['config']['rank_ms_per_step']['max']
+    assert d['config']['grad_allreduce_ms'] > 0 and 'gradient exchange' in res.stderr
 
 
 def test_bench_spawns_its_own_ranks():

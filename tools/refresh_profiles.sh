@@ -1,6 +1,7 @@
 #!/bin/bash
 # Regenerate the round's measurement artifacts on an MI355X box (run from the repo root; writes under gpurun_out/refresh/).
-#   1 bench.json              the default `python bench.py` line (roofline + roofline.kernels + cpu_baseline)
+#   1 bench.json              the `python bench.py --kernel-rooflines` line (roofline + cpu_baseline + exact-f32 A/B) and bench_kernels.json,
+#                             the per-kernel-family table (child processes started before bench.py touches the GPU)
 #   2 bench_kernel_stats.csv  rocprofv3 --kernel-trace --stats of the same command (+ the line it printed under the profiler)
 #   3 train_step_kernels.txt  per-step kernel table of the steady-state steps (tools/prof_summary.py)
 #   4 other_configs.txt       the other BASELINE configs, graph and hybrid mode
@@ -22,17 +23,17 @@ want() { [[ " $STEPS " == *" $1 "* ]]; }
 echo "start $(date +%T) steps: $STEPS" | tee $OUT/progress.txt
 if want 1; then
 echo "[1] bench" | tee -a $OUT/progress.txt
-python bench.py 2>$OUT/bench.err | tail -1 > $OUT/bench.json
+python bench.py --kernel-rooflines --kernels-out $OUT/bench_kernels.json 2>$OUT/bench.err | tail -1 > $OUT/bench.json
 fi
 if want 2; then
 echo "[2] bench under rocprof" | tee -a $OUT/progress.txt
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python3 $R/bench.py --no-cpu-baseline > /tmp/bench_prof.out 2>/dev/null )
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python3 $R/bench.py --no-cpu-baseline --no-exact-f32 > /tmp/bench_prof.out 2>/dev/null )
 tail -1 /tmp/bench_prof.out > $OUT/bench_under_rocprof.json
 cp $(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1) $OUT/bench_kernel_stats.csv 2>/dev/null
 fi
 if want 3; then
 echo "[3] per-step table" | tee -a $OUT/progress.txt
-( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_step -o step -- python3 $R/bench.py --no-cpu-baseline --no-roofline > /dev/null 2>&1 )
+( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_step -o step -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-exact-f32 > /dev/null 2>&1 )
 python tools/prof_summary.py /tmp/prof_step --skip 8 --top 70 --out $OUT/train_step_kernels.txt > /dev/null
 fi
 if want 4; then
@@ -41,7 +42,7 @@ echo "[4] other configs" | tee -a $OUT/progress.txt
 CONFIGS=${CONFIGS:-"cfg3_segformer_b2_b0_cgd_cd cfg5_segformer_b4_b1_multistage_bf16 cfg1_pspnet_r101_r18_cd cfg4_pspnet_r18_swin_b_cgd_align"}
 for c in $CONFIGS; do
   for g in on hybrid; do
-    timeout 900 python bench.py --config configs/kd/$c.py --steps 10 --warmup 4 --graph $g --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | \
+    timeout 900 python bench.py --config configs/kd/$c.py --steps 10 --warmup 4 --graph $g --no-cpu-baseline --no-roofline --no-exact-f32 2>/dev/null | tail -1 | \
       python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$c', 'graph=$g', d['config']['hip_graph'], d['value'], 'imgs/s', d['ms_per_step'], 'ms/step', d['dtype'], 'B=%d' % d['config']['per_gpu_batch'])" >> $OUT/other_configs.txt 2>&1
     echo "   $c $g done" | tee -a $OUT/progress.txt
   done
