@@ -69,8 +69,9 @@ const char *sd_error_string(int code);
  *       attention forward and backward on the bf16 matrix pipe with P / dS rounded to bf16; 0 = the f32-input MFMA kernels), "align_split_bf16"
  *       (0|1, default 1: the three fp32 products of the 1x1 align projection and of sd_linear_nchw_* in split-bf16 arithmetic),
  *       "pred_tall_tile" (0|1, default 1: sd_linear_nchw_fwd / _bwd_weight use ONE 160-row tile for 129 ... 160 output planes -- the 150
- *       classes -- instead of two 128-row tiles; same arithmetic).  The sra_*, align_* and pred_* keys select arithmetic or tiling, not
- *       workspace geometry: no workspace size depends on them. */
+ *       classes -- instead of two 128-row tiles; same arithmetic), "ce_bwd_multiclass" (0|1, default 1: sd_ce_up_bwd handles 4 (2 at
+ *       factor 8) class planes per workgroup with the pixel maps loaded once per group; 0 = one class per workgroup, rounds 1-2).
+ *       The sra_*, align_*, pred_* and ce_* keys select arithmetic or tiling, not workspace geometry: no workspace size depends on them. */
 int sd_set_tunable(const char *key, int value);
 int sd_get_tunable(const char *key);
 
@@ -455,7 +456,7 @@ int sd_bn_act_bwd_elemt(const void *x, const void *dy, const float *mean, const 
  * Deferred combination of partial slabs.  The parameter-gradient kernels (sd_layernorm_bwd / sd_add_layernorm_bwd with
  * dgamma == dbeta == NULL, sd_linear_wgrad_partials) leave their per-workgroup partials in the caller's workspace instead
  * of launching their own combine pass; nothing reads a parameter gradient before the optimizer, so the caller collects the
- * jobs of a whole backward and combines them in ONE launch per 24 jobs:  out[i] = sum_{s < nslabs} partials[s*n + i].
+ * jobs of a whole backward and combines them in ONE launch per 80 jobs:  out[i] = sum_{s < nslabs} partials[s*n + i].
  * `jobs` is a HOST array (its contents travel as kernel arguments: nothing is copied, safe under hipGraph capture).
  *   sd_layernorm_bwd_blocks(rows, C)           slabs the LayerNorm backward leaves: partials [nblk][2][C] (dgamma row, dbeta row)
  *   sd_linear_wgrad_slabs(dtype, T, M, N)      slabs of the tall-skinny weight-gradient plan (0: the shape does not take that plan);
@@ -482,7 +483,7 @@ typedef struct sd_colsum_job {
 } sd_colsum_job;
 
 int sd_colsum_blocks(long rows, int C);
-/* the partials of MANY matrices in one launch per 24 jobs (host array, by-value kernel arguments like sd_multi_slab_reduce) */
+/* the partials of MANY matrices in one launch per 80 jobs (host array, by-value kernel arguments like sd_multi_slab_reduce) */
 int sd_multi_colsum_partials(const sd_colsum_job *jobs, int njobs, int dtype, void *stream);
 int sd_colsum_partials(const void *x, int dtype, long rows, int C, float *partials, size_t partials_bytes, void *stream);
 int sd_layernorm_bwd_blocks(long rows, int C);

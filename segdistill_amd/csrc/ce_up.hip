@@ -17,6 +17,7 @@
 //             SAME pixels for consecutive channels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "cgd_device.h"
 #include "up_device.h"
@@ -271,6 +272,181 @@ __global__ void ce_up_bwd(const T *__restrict__ s, const int32_t *__restrict__ l
     }
 }
 
+// ---- round 3: the same backward with CPW class planes per workgroup and every load requested one tap row ahead ---------------------------
+// The one-class kernel above re-reads the per-pixel maps (label, log-partition, upstream) once PER CLASS -- 150 x 8 B x 2.1 M pixels = 2.5 GB
+// of L2 traffic per launch at config 2, as 4-byte loads issued right in front of their use: 216 us against ~52 us of vector issue.  Here a
+// workgroup owns CPW consecutive classes of a band: the pixel maps are loaded once per CPW classes as F-wide vectors (the F pixels a thread
+// owns in an output row are contiguous and F*4-byte aligned), and the maps of gap j+1 as well as the taps of tap row j+1 are requested
+// BEFORE gap j is computed (asm volatile loads, explicit wait: the compiler would otherwise sink them to their first use, as in the
+// forward).  Same arithmetic per (pixel, class) as above, operation for operation.
+template <int N> struct PinRow;   // N consecutive dwords, N*4-byte aligned
+template <> struct PinRow<2> {
+    typedef unsigned v2 __attribute__((ext_vector_type(2)));
+    v2 r;
+    __device__ __forceinline__ void request(const void *p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(p) : "memory"); }
+    __device__ __forceinline__ unsigned operator[](int i) const { return r[i]; }
+};
+template <> struct PinRow<4> {
+    typedef unsigned v4 __attribute__((ext_vector_type(4)));
+    v4 r;
+    __device__ __forceinline__ void request(const void *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory"); }
+    __device__ __forceinline__ unsigned operator[](int i) const { return r[i]; }
+};
+template <> struct PinRow<8> {
+    typedef unsigned v4 __attribute__((ext_vector_type(4)));
+    v4 lo, hi;
+    __device__ __forceinline__ void request(const void *p) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lo) : "v"(p) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(hi) : "v"(p) : "memory");
+    }
+    __device__ __forceinline__ unsigned operator[](int i) const { return i < 4 ? lo[i] : hi[i - 4]; }
+};
+
+// grid.x = B*nband*ngrp with the class group fastest; block: round64(w) threads; dynamic LDS CPW*2*F*blockDim floats.
+// PF: the pixel maps of gap j+1 are requested while gap j is computed (F <= 4; at F = 8 the second set of 8 x 8 x 2..3 registers does not fit
+// and the maps are requested at the top of their own gap, still as vectors and still once per CPW classes).
+template <typename T, int F, bool GMAP, int CPW, bool PF>
+__global__ __launch_bounds__(256) void ce_up_bwd_mc(const T *__restrict__ s, const int32_t *__restrict__ label, const float *__restrict__ lse2,
+                             const float *__restrict__ upstream, float gscale, T *__restrict__ ds, int C, int h, int w, int R, int nband,
+                             int ngrp, int ignore_index) {
+    extern __shared__ float rowbuf[];   // [CPW][2][F * blockDim]
+    const int wg = blockIdx.x;
+    const int grp = wg % ngrp;
+    const int k = (wg / ngrp) % nband;
+    const int b = wg / (ngrp * nband);
+    const int kx = threadIdx.x;
+    const bool active = kx < w;
+    const int kxc = min(kx, w - 1);
+    const int H = F * h, W = F * w;
+    const size_t plane = (size_t)h * w;
+    const int c0 = grp * CPW;
+    const T *pc[CPW];
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) pc[i] = s + ((size_t)b * C + min(c0 + i, C - 1)) * plane;   // classes beyond C: clamped here, never stored
+    const size_t pix0 = (size_t)b * H * W;
+    const float guni = GMAP ? 0.f : gscale * upstream[0];
+    const int y0 = k * R, y1 = min(h, y0 + R);
+    const int bufstride = F * blockDim.x;
+    const int xl0 = max(kxc - 1, 0), xr0 = min(kxc + 1, w - 1);
+
+    struct Taps { unsigned a[CPW], b[CPW], c[CPW]; };
+    struct Pix { PinRow<F> lab[F], lse[F], up[GMAP ? F : 1]; };
+    auto request_taps = [&](Taps &t, int row) {
+        const size_t ro = (size_t)row * w;
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            t.a[i] = pinned_load1<T>(pc[i] + ro + xl0);
+            t.b[i] = pinned_load1<T>(pc[i] + ro + kxc);
+            t.c[i] = pinned_load1<T>(pc[i] + ro + xr0);
+        }
+    };
+    auto request_pix = [&](Pix &px, int j) {
+#pragma unroll
+        for (int q = 0; q < F; ++q) {
+            const int Y = min(max(F * j - F / 2 + q, 0), H - 1);            // rows outside the image (half gaps): clamped, never used
+            const size_t o = pix0 + (size_t)Y * W + F * kxc;
+            px.lab[q].request(label + o);
+            px.lse[q].request(lse2 + o);
+            if (GMAP) px.up[q].request(upstream + o);
+        }
+    };
+    auto hrow_raw = [&](const Taps &t, int i, float (&o)[F]) {             // up_device.h::hrow on already-loaded taps
+        const float a = raw_to_float<T>(t.a[i]), bb = raw_to_float<T>(t.b[i]), c = raw_to_float<T>(t.c[i]);
+        const float dl = bb - a, dr = c - bb;
+#pragma unroll
+        for (int rx = 0; rx < F; ++rx) {
+            if (rx < F / 2) o[rx] = fmaf((rx + F / 2 + 0.5f) / F, dl, a);
+            else o[rx] = fmaf((rx - F / 2 + 0.5f) / F, dr, bb);
+        }
+    };
+
+    float sp[CPW][F], accA[CPW][F];
+    Taps tcur, tnxt;
+    Pix pcur, pnxt;
+    request_taps(tcur, max(y0 - 1, 0));
+    request_taps(tnxt, min(y0, h - 1));
+    if (PF) request_pix(pcur, y0);
+    wait_pinned_loads();
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        hrow_raw(tcur, i, sp[i]);
+#pragma unroll
+        for (int rx = 0; rx < F; ++rx) accA[i][rx] = 0.f;
+    }
+    tcur = tnxt;
+    int parity = 0;
+    for (int j = y0; j <= y1; ++j) {
+        if (!PF) {
+            request_pix(pcur, j);
+            wait_pinned_loads();
+        }
+        request_taps(tnxt, min(j + 1, h - 1));      // the last iteration's requests re-read valid (clamped) addresses and are dropped
+        if (PF) request_pix(pnxt, j + 1);
+        float sc[CPW][F], accB[CPW][F];
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            hrow_raw(tcur, i, sc[i]);
+#pragma unroll
+            for (int rx = 0; rx < F; ++rx) accB[i][rx] = 0.f;
+        }
+        const bool top = (j == 0), bot = (j == h);
+#pragma unroll
+        for (int q = 0; q < F; ++q) {
+            if ((top && q < F / 2) || (bot && q >= F / 2)) continue;
+            const float lam = (q + 0.5f) / F;
+            const float wa = top ? 0.f : (bot ? 1.f : 1.f - lam);
+            const float wb = top ? 1.f : (bot ? 0.f : lam);
+#pragma unroll
+            for (int rx = 0; rx < F; ++rx) {
+                const int lab = (int)pcur.lab[q][rx];
+                const float nl = -__uint_as_float(pcur.lse[q][rx]);
+                const float gp = (lab == ignore_index) ? 0.f : (GMAP ? gscale * __uint_as_float(pcur.up[q][rx]) : guni);
+#pragma unroll
+                for (int i = 0; i < CPW; ++i) {
+                    const float p = ex2(fmaf(fmaf(lam, sc[i][rx] - sp[i][rx], sp[i][rx]), kLog2e, nl));
+                    const float D = gp * (p - (lab == c0 + i ? 1.f : 0.f));
+                    accA[i][rx] = fmaf(wa, D, accA[i][rx]);
+                    accB[i][rx] = fmaf(wb, D, accB[i][rx]);
+                }
+            }
+        }
+        if (j > y0) {
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) {
+                float *buf = rowbuf + (2 * i + parity) * bufstride;
+#pragma unroll
+                for (int rx = 0; rx < F; ++rx) buf[F * kx + rx] = accA[i][rx];
+            }
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < CPW; ++i) {
+                    if (c0 + i >= C) continue;
+                    const float *buf = rowbuf + (2 * i + parity) * bufstride;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int q = 0; q < F; ++q) {
+                        const float lam = (q + 0.5f) / F;
+                        const int xl = F * kx - F / 2 + q;
+                        const int xr = F * kx + F / 2 + q;
+                        if (xl >= 0) sum = fmaf(kx == 0 ? 1.f : lam, buf[xl], sum);
+                        if (xr < W) sum = fmaf(kx == w - 1 ? 1.f : 1.f - lam, buf[xr], sum);
+                    }
+                    VecIO<T>::store1(ds + ((size_t)b * C + c0 + i) * plane + (size_t)(j - 1) * w + kx, sum);
+                }
+            }
+            parity ^= 1;
+        }
+#pragma unroll
+        for (int i = 0; i < CPW; ++i)
+#pragma unroll
+            for (int rx = 0; rx < F; ++rx) { accA[i][rx] = accB[i][rx]; sp[i][rx] = sc[i][rx]; }
+        wait_pinned_loads();
+        tcur = tnxt;
+        if (PF) pcur = pnxt;
+    }
+}
+
 // Zero the hit counter with a kernel, not hipMemsetAsync: inside a captured hipGraph a memset becomes a memset NODE, and when two
 // graphs are replayed concurrently on different streams (teacher graph || student-step graph, engine/trainer.py) the fill value of
 // such nodes was observed to be taken from the OTHER graph's memset (counter came back as 0x01010101 + hits on ROCm 7.2 / gfx950).
@@ -285,6 +461,20 @@ int ce_factor(int h, int w, int H, int W) {
 }
 
 constexpr int kCeBand = 8;  // tap rows per workgroup
+
+}  // namespace
+
+int g_ce_bwd_multiclass = 1;   // tunable "ce_bwd_multiclass": 0 = the one-class-per-workgroup backward of rounds 1-2 (A/B, tests)
+
+int ce_tunable(const char *key, int set, int v) {
+    if (strcmp(key, "ce_bwd_multiclass")) return SD_E_UNSUPPORTED;
+    if (!set) return g_ce_bwd_multiclass;
+    if (v != 0 && v != 1) return SD_E_SHAPE;
+    g_ce_bwd_multiclass = v;
+    return SD_OK;
+}
+
+namespace {
 
 }  // namespace
 }  // namespace sd
@@ -330,6 +520,35 @@ int sd_ce_up_bwd(const void *logits, const int32_t *label, const float *pix_lse2
     if (!F) return SD_E_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int R = sd::kCeBand < h ? sd::kCeBand : h, nband = (h + R - 1) / R, threads = (w + 63) / 64 * 64;
+    // multi-class form (round 3): needs F*4-byte aligned pixel maps (16 bytes covers every F) -- torch allocations always are
+    const bool aligned = ((reinterpret_cast<uintptr_t>(label) | reinterpret_cast<uintptr_t>(pix_lse2) |
+                           (upstream_is_map ? reinterpret_cast<uintptr_t>(upstream) : 0)) & 15) == 0;
+    if (aligned && threads <= 256 && sd::g_ce_bwd_multiclass) {
+#define SD_CE_BWD_MC(TT, FF, CC, PP)                                                                                                   \
+    do {                                                                                                                             \
+        const int ngrp = (C + CC - 1) / CC;                                                                                          \
+        const long nwg = (long)B * nband * ngrp;                                                                                     \
+        if (nwg > 0x7fffffffL) return SD_E_SHAPE;                                                                                    \
+        const size_t lds = 2ull * CC * FF * threads * sizeof(float);                                                                 \
+        if (upstream_is_map)                                                                                                         \
+            hipLaunchKernelGGL((sd::ce_up_bwd_mc<TT, FF, true, CC, PP>), dim3((unsigned)nwg), dim3(threads), lds, st, (const TT *)logits, label, \
+                               pix_lse2, upstream, gscale, (TT *)dlogits, C, h, w, R, nband, ngrp, ignore_index);                    \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((sd::ce_up_bwd_mc<TT, FF, false, CC, PP>), dim3((unsigned)nwg), dim3(threads), lds, st, (const TT *)logits, label, \
+                               pix_lse2, upstream, gscale, (TT *)dlogits, C, h, w, R, nband, ngrp, ignore_index);                    \
+    } while (0)
+        if (dtype == SD_F32) {
+            if (F == 2) SD_CE_BWD_MC(float, 2, 4, true);
+            else if (F == 4) SD_CE_BWD_MC(float, 4, 4, true);
+            else SD_CE_BWD_MC(float, 8, 2, false);
+        } else {
+            if (F == 2) SD_CE_BWD_MC(sd::bf16_t, 2, 4, true);
+            else if (F == 4) SD_CE_BWD_MC(sd::bf16_t, 4, 4, true);
+            else SD_CE_BWD_MC(sd::bf16_t, 8, 2, false);
+        }
+#undef SD_CE_BWD_MC
+        return (int)hipGetLastError();
+    }
     const long nwg = (long)B * nband * C;
     if (nwg > 0x7fffffffL) return SD_E_SHAPE;
     const size_t lds = 2ull * F * threads * sizeof(float);

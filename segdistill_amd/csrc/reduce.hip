@@ -5,7 +5,7 @@
 // csrc/align1x1.hip).  Each used to be its own ~10 us launch behind its producer; inside a replayed hipGraph a dependent launch
 // costs about that much whatever it does, so they added up to ~0.6 ms of a 14 ms step.  Nothing reads these parameter gradients
 // before the optimizer, so the binding (segdistill_amd/deferred.py) collects the jobs during the backward and issues them here in
-// one launch per 24 jobs: out[i] = sum_s partials[s*n + i].  Deterministic (fixed summation order), no float atomics.
+// one launch per 80 jobs: out[i] = sum_s partials[s*n + i].  Deterministic (fixed summation order), no float atomics.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -14,7 +14,7 @@
 namespace sd {
 namespace {
 
-constexpr int kMaxJobs = 24;
+constexpr int kMaxJobs = 80;   // 80 x 36 bytes + 81 block offsets = 3.2 KB of the 4 KB kernel-argument segment (24 until round 3: four launches per step)
 
 struct JobTable {   // passed BY VALUE as the kernel argument: no device-side table, nothing to copy, safe under graph capture
     const float *part[kMaxJobs];
@@ -25,11 +25,25 @@ struct JobTable {   // passed BY VALUE as the kernel argument: no device-side ta
     int njobs;
 };
 
-// block = 4 slab groups x 64 consecutive outputs (256-byte rows per wave: coalesced)
+// wave-uniform binary search of the job a workgroup belongs to (the table sits in the kernel-argument segment: scalar loads)
+template <typename Table>
+__device__ __forceinline__ int find_job(const Table &t, int blk) {
+    int lo = 0, hi = t.njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (blk >= t.blk_begin[mid]) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+// block = 4 slab groups x 64 consecutive outputs (256-byte rows per wave: coalesced).  Slab group `grp` walks slabs grp, grp + 4, ... with
+// four accumulators (slab s goes to accumulator (s / 4) % 4).  Round 3: SIXTEEN slab rows are requested before any is added (four were: one
+// dword per lane per request, the walk ran at the load latency -- 0.12 ms per step for ~100 MB); each accumulator still receives its slabs in
+// walk order, so the sums are bit-identical to the four-in-flight form (tests/test_deferred_gpu.py emulates that order in torch).
 __global__ __launch_bounds__(256) void multi_slab_reduce(const JobTable t) {
     __shared__ float red[4][64];
-    int j = 0;
-    while (j + 1 < t.njobs && (int)blockIdx.x >= t.blk_begin[j + 1]) ++j;   // wave-uniform
+    const int j = find_job(t, (int)blockIdx.x);
     const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const long i = (long)((int)blockIdx.x - t.blk_begin[j]) * 64 + o;
     const long n = t.n[j];
@@ -38,11 +52,24 @@ __global__ __launch_bounds__(256) void multi_slab_reduce(const JobTable t) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < n) {
         int s = grp;
+        for (; s + 60 < ns; s += 64) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = p[(long)(s + 4 * q) * n + i];
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) {
+                s0 += v[q];
+                s1 += v[q + 1];
+                s2 += v[q + 2];
+                s3 += v[q + 3];
+            }
+        }
         for (; s + 12 < ns; s += 16) {
-            s0 += p[(long)s * n + i];
-            s1 += p[(long)(s + 4) * n + i];
-            s2 += p[(long)(s + 8) * n + i];
-            s3 += p[(long)(s + 12) * n + i];
+            const float a = p[(long)s * n + i], b = p[(long)(s + 4) * n + i], c = p[(long)(s + 8) * n + i], d = p[(long)(s + 12) * n + i];
+            s0 += a;
+            s1 += b;
+            s2 += c;
+            s3 += d;
         }
         for (; s < ns; s += 4) s0 += p[(long)s * n + i];
     }
@@ -110,8 +137,7 @@ struct ColsumTable {
 template <typename T>
 __global__ __launch_bounds__(256) void multi_colsum_partials(const ColsumTable t) {
     extern __shared__ float red[];   // [rpb][C] of the widest job
-    int j = 0;
-    while (j + 1 < t.njobs && (int)blockIdx.x >= t.blk_begin[j + 1]) ++j;   // wave-uniform
+    const int j = find_job(t, (int)blockIdx.x);
     const T *__restrict__ x = static_cast<const T *>(t.x[j]);
     float *__restrict__ part = t.part[j];
     const long rows = t.rows[j];

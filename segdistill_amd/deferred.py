@@ -2,7 +2,7 @@
 
 The LayerNorm and Linear weight-gradient kernels produce per-workgroup partial slabs and used to combine them with one small
 launch each (~65 per backward of Segformer-B0).  Inside ``scope()`` they leave the slabs in their workspace and register a job
-here; the scope's exit combines ALL jobs in one launch per 24 (``sd_multi_slab_reduce``).  Valid because nothing reads those
+here; the scope's exit combines ALL jobs in one launch per 80 (``sd_multi_slab_reduce``).  Valid because nothing reads those
 gradients before the optimizer: a call site opts in only when its result goes straight to a leaf parameter's ``.grad`` (no cast,
 no stacking, no accumulation into an existing gradient).  Outside a scope every op combines its partials at once, as before."""
 from __future__ import annotations

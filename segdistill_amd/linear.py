@@ -1,7 +1,8 @@
-"""nn.Linear on token-major activations with the weight gradient computed by the split-K MFMA kernel
-(csrc/align1x1.hip: sd_linear_wgrad).  Forward and the input gradient stay on hipBLASLt (they are well-shaped
-GEMMs); only dW = dY^T . X -- tall-skinny at the high-resolution MiT stages, where the library kernels run
-30x off the HBM roofline (profiles/r01_train_step_kernels_*.txt) -- is replaced."""
+"""nn.Linear on token-major activations.  Forward and input gradient: the measured three-way dispatch of `_gemm_mode` below (csrc/token_gemm.hip
+in split-bf16 or exact-f32 arithmetic, or the library GEMM); weight gradient dW = dY^T . X -- tall-skinny at the high-resolution MiT stages,
+where the library kernels ran 30x off the HBM roofline (profiles/r01_train_step_kernels_*.txt) -- by the split-K MFMA kernel
+(csrc/align1x1.hip: sd_linear_wgrad) with its slabs combined by the deferred batched reduction; the class-plane `linear_pred`
+(sd_linear_nchw_*) and the optional long-K / patch forms live here too."""
 from __future__ import annotations
 
 import os

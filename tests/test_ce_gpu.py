@@ -76,3 +76,33 @@ def test_fused_ce_uniform_upstream_and_head_integration():
     assert float((g_fused - logits.grad).norm() / logits.grad.norm()) < 1e-4
     acc_ref = 100.0 * float((up.argmax(1) == lab.squeeze(1)).sum()) / lab.numel()
     assert float(out['acc_seg']) == pytest.approx(acc_ref, abs=100.0 * 4 / lab.numel())
+
+
+@pytest.mark.parametrize('case', [(2, 150, 16, 16, 4), (1, 19, 8, 8, 8), (2, 7, 5, 12, 2), (1, 150, 33, 20, 4), (2, 150, 64, 64, 8), (1, 3, 40, 130, 4)])
+@pytest.mark.parametrize('uniform', [False, True])
+def test_multiclass_backward_agrees_with_the_one_class_kernel(case, uniform):
+    """Round 3's sd_ce_up_bwd (4 / 2 class planes per workgroup, vector map loads, requests one tap row ahead) performs the same operations
+    per (pixel, class) as the one-class kernel it replaces (tunable ce_bwd_multiclass = 0): bit-identical gradients, with a per-pixel and
+    with a uniform upstream gradient, including class counts that are not a multiple of the group (150, 19, 7, 3)."""
+    from segdistill_amd import _lib
+    from segdistill_amd.ce import fused_ce_up
+    B, C, h, w, Fk = case
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(C + h + w)
+    x = (3 * torch.randn(B, C, h, w, generator=g)).to(dev)
+    lab = torch.randint(0, C, (B, 1, h * Fk, w * Fk), generator=g)
+    lab[torch.rand(lab.shape, generator=g) < 0.07] = 255
+    lab = lab.to(dev)
+    g_map = torch.rand(B, h * Fk, w * Fk, generator=g).to(dev)
+    grads = []
+    for mode in (1, 0):
+        _lib.set_tunable('ce_bwd_multiclass', mode)
+        try:
+            xg = x.clone().requires_grad_(True)
+            loss, _ = fused_ce_up(xg, lab, 255)
+            (loss.mean() if uniform else (loss * g_map).sum()).backward()
+            grads.append(xg.grad.clone())
+        finally:
+            _lib.set_tunable('ce_bwd_multiclass', 1)
+    assert torch.isfinite(grads[0]).all()
+    assert torch.equal(grads[0], grads[1])

@@ -12,7 +12,9 @@ restated in fp64 by oracle/kd_ref.py (itself pinned to the reference's losses.py
 Per distillation entry:
  * every image slice b goes through the product modules again (align + criterion, B = 1): the step's logged KD value must equal the
    mean of the slice values (rows scale with B: a size-independent property that ties the full-size launch to the slices);
- * slices 0 and B-1: loss, gradient w.r.t. the raw student tap and w.r.t. the align weight / bias against the oracle.
+ * slices 0 and B-1: loss, gradient w.r.t. the raw student tap and w.r.t. the align weight / bias against the oracle;
+ * the entry launched at the step's own batch size: its tap / align gradients against the concatenated slice gradients / B
+   (fp32 1e-4 rel-L2; bf16-stored gradients 1e-2).
 Bars: fp32 1e-3 relative on the loss (held: 1e-4) and 1e-3 rel-L2 on gradients.  bf16 storage (config 5): the oracle is fed the same
 bf16-rounded operands (taps, the align weight as the MFMA kernel rounds it, the aligned feature as it is stored) -- loss 1e-3; the
 gradients pass through a bf16-stored dS, so their bar is 1e-2 rel-L2 (measured values are printed).
@@ -135,7 +137,7 @@ def test_kd_entries_match_oracle_on_gpu_taps(tag):
             with torch.no_grad():
                 align.weight.copy_(w0[str(i)][0])
                 align.bias.copy_(w0[str(i)][1])
-        slice_vals = []
+        slice_vals, slice_dx, slice_dw = [], [], []
         for b in range(B):
             xs_b = xs[b:b + 1].clone().requires_grad_(True)
             if align is not None:
@@ -143,8 +145,11 @@ def test_kd_entries_match_oracle_on_gpu_taps(tag):
             # the product's own per-entry flow on the RAW taps (token-major taps stay token-major: csrc/cgd_tok.hip + the token Linear)
             val = dl.entry_loss(i, xs_b, xt[b:b + 1], gt_dummy, seen['step'])
             slice_vals.append(float(val))
+            val.backward()
+            slice_dx.append(xs_b.grad.detach().double())
+            if align is not None:
+                slice_dw.append((align.weight.grad.detach().double().clone(), align.bias.grad.detach().double().clone()))
             if b in (0, B - 1):
-                val.backward()
                 ref = _oracle_entry(crit, xs[b:b + 1], xt[b:b + 1], None if align is None else align.weight, None if align is None else align.bias,
                                     seen['gt_hw'], bf16)
                 assert float(val) == pytest.approx(ref['loss'], rel=loss_tol), (tag, key, b)
@@ -158,5 +163,22 @@ def test_kd_entries_match_oracle_on_gpu_taps(tag):
                     assert e <= grad_tol, (tag, key, b, name, e)
         # the full-size launch of the step against the slices: rows scale with B, so the batch loss is the mean of the image losses
         assert logged[key] == pytest.approx(sum(slice_vals) / B, rel=2e-3 if bf16 else 1e-4), (tag, key)
+        # ... and the full-size GRADIENT: the same entry launched once more at the step's own batch size (the launch geometry of the step)
+        # must hand back, per image, 1/B of that image's slice gradient (which the oracle pinned above for slices 0 and B-1)
+        xs_full = xs.clone().requires_grad_(True)
+        if align is not None:
+            align.weight.grad = align.bias.grad = None
+        full = dl.entry_loss(i, xs_full, xt, gt_dummy, seen['step'])
+        assert float(full) == pytest.approx(logged[key], rel=2e-3 if bf16 else 1e-5), (tag, key)
+        full.backward()
+        full_tol = 1e-2 if bf16 else 1e-4
+        e_dx = _rel_l2(xs_full.grad.double().cpu().numpy(), (torch.cat(slice_dx, 0) / B).cpu().numpy())
+        full_errs = {'dx': e_dx}
+        if align is not None:
+            full_errs['dW'] = _rel_l2(align.weight.grad.double().cpu().numpy(), (sum(w for w, _ in slice_dw) / B).cpu().numpy())
+            full_errs['db'] = _rel_l2(align.bias.grad.double().cpu().numpy(), (sum(bb for _, bb in slice_dw) / B).cpu().numpy())
+        report.append((key[-40:], f'B={B} vs slices', abs(float(full) - logged[key]) / abs(logged[key]), full_errs))
+        for name, e in full_errs.items():
+            assert e <= full_tol, (tag, key, 'full-size gradient', name, e)
     for r in report:
         print(f'{tag} {r[0]} slice {r[1]}: loss rel {r[2]:.2e}; grad rel-L2 ' + ', '.join(f'{k} {v:.2e}' for k, v in r[3].items()))

@@ -13,7 +13,7 @@ def test_multi_slab_reduce_matches_sums():
     from segdistill_amd import _lib, deferred
     torch.manual_seed(0)
     dev = 'cuda:0'
-    shapes = [(1, 1), (3, 64), (16, 65), (17, 4096), (256, 512), (5, 65792), (64, 100)] * 5      # 35 jobs: two launches (24 + 11)
+    shapes = [(1, 1), (3, 64), (16, 65), (17, 4096), (256, 512), (5, 65792), (64, 100)] * 5      # 35 jobs
     parts = [torch.randn(ns, n, device=dev) for ns, n in shapes]
     outs = [torch.full((n,), float('nan'), device=dev) for _, n in shapes]
     with deferred.scope():
@@ -32,6 +32,53 @@ def test_multi_slab_reduce_matches_sums():
     bad = (deferred._Job * 1)()
     bad[0].partials, bad[0].out, bad[0].n, bad[0].nslabs = parts[0].data_ptr(), outs[0].data_ptr(), 0, 1
     assert L.sd_multi_slab_reduce(C.cast(bad, C.c_void_p), 1, None) != 0
+
+
+def _four_in_flight_order(p):
+    """The summation order of the round-2 kernel, operation for operation in fp32: slab group g = slabs g, g+4, ...; inside a group slab
+    s goes to accumulator (s // 4) % 4 while at least four more rounds remain (the `s + 12 < ns` loop), the tail to accumulator 0;
+    group result (s0 + s1) + (s2 + s3); output (g0 + g1) + (g2 + g3)."""
+    ns, n = p.shape
+    groups = []
+    for g in range(4):
+        acc = [torch.zeros(n, device=p.device) for _ in range(4)]
+        s = g
+        while s + 12 < ns:
+            for q in range(4):
+                acc[q] = acc[q] + p[s + 4 * q]
+            s += 16
+        while s < ns:
+            acc[0] = acc[0] + p[s]
+            s += 4
+        groups.append((acc[0] + acc[1]) + (acc[2] + acc[3]))
+    return (groups[0] + groups[1]) + (groups[2] + groups[3])
+
+
+@pytest.mark.parametrize('ns', [1, 4, 13, 16, 17, 61, 64, 65, 127, 128, 200, 333])
+def test_multi_slab_reduce_sixteen_in_flight_is_bit_identical_to_the_round_2_order(ns):
+    """Round 3 requests sixteen slab rows before adding any; every accumulator must still receive its slabs in the old order."""
+    from segdistill_amd import deferred
+    torch.manual_seed(ns)
+    for n in (64, 1000, 65536 + 7):
+        p = torch.randn(ns, n, device='cuda:0') * torch.logspace(-3, 3, ns, device='cuda:0')[:, None]     # order-sensitive sums
+        out = torch.empty(n, device='cuda:0')
+        with deferred.scope():
+            deferred.add(p, out, n, ns)
+        assert torch.equal(out, _four_in_flight_order(p)), (ns, n)
+
+
+def test_multi_slab_reduce_many_jobs_one_launch_table():
+    """80 jobs per launch table (24 until round 3): 170 jobs of mixed sizes = three launches, job lookup by binary search."""
+    from segdistill_amd import deferred
+    torch.manual_seed(3)
+    shapes = [((k * 7) % 70 + 1, (k * 131) % 3000 + 1) for k in range(170)]
+    parts = [torch.randn(ns, n, device='cuda:0') for ns, n in shapes]
+    outs = [torch.full((n,), float('nan'), device='cuda:0') for _, n in shapes]
+    with deferred.scope():
+        for p, o, (ns, n) in zip(parts, outs, shapes):
+            deferred.add(p, o, n, ns)
+    for p, o in zip(parts, outs):
+        assert torch.equal(o, _four_in_flight_order(p))
 
 
 def _student():
