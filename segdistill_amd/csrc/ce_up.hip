@@ -47,6 +47,9 @@ __device__ __forceinline__ void wait_pinned_loads() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+template <typename T> __device__ __forceinline__ unsigned plain_load1(const T *p);          // the same raw bits through a load hipcc counts
+template <> __device__ __forceinline__ unsigned plain_load1<float>(const float *p) { return __float_as_uint(*p); }
+template <> __device__ __forceinline__ unsigned plain_load1<bf16_t>(const bf16_t *p) { return p->bits; }
 template <typename T> __device__ __forceinline__ float raw_to_float(unsigned v);
 template <> __device__ __forceinline__ float raw_to_float<float>(unsigned v) { return __uint_as_float(v); }
 template <> __device__ __forceinline__ float raw_to_float<bf16_t>(unsigned v) { return __uint_as_float(v << 16); }
@@ -284,12 +287,14 @@ template <> struct PinRow<2> {
     typedef unsigned v2 __attribute__((ext_vector_type(2)));
     v2 r;
     __device__ __forceinline__ void request(const void *p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(r) : "v"(p) : "memory"); }
+    __device__ __forceinline__ void load(const void *p) { r = *reinterpret_cast<const v2 *>(p); }      // a load hipcc counts
     __device__ __forceinline__ unsigned operator[](int i) const { return r[i]; }
 };
 template <> struct PinRow<4> {
     typedef unsigned v4 __attribute__((ext_vector_type(4)));
     v4 r;
     __device__ __forceinline__ void request(const void *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory"); }
+    __device__ __forceinline__ void load(const void *p) { r = *reinterpret_cast<const v4 *>(p); }
     __device__ __forceinline__ unsigned operator[](int i) const { return r[i]; }
 };
 template <> struct PinRow<8> {
@@ -298,6 +303,10 @@ template <> struct PinRow<8> {
     __device__ __forceinline__ void request(const void *p) {
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(lo) : "v"(p) : "memory");
         asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(hi) : "v"(p) : "memory");
+    }
+    __device__ __forceinline__ void load(const void *p) {
+        lo = reinterpret_cast<const v4 *>(p)[0];
+        hi = reinterpret_cast<const v4 *>(p)[1];
     }
     __device__ __forceinline__ unsigned operator[](int i) const { return i < 4 ? lo[i] : hi[i - 4]; }
 };
@@ -335,9 +344,15 @@ __global__ __launch_bounds__(256) void ce_up_bwd_mc(const T *__restrict__ s, con
         const size_t ro = (size_t)row * w;
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
-            t.a[i] = pinned_load1<T>(pc[i] + ro + xl0);
-            t.b[i] = pinned_load1<T>(pc[i] + ro + kxc);
-            t.c[i] = pinned_load1<T>(pc[i] + ro + xr0);
+            if (PF) {
+                t.a[i] = pinned_load1<T>(pc[i] + ro + xl0);
+                t.b[i] = pinned_load1<T>(pc[i] + ro + kxc);
+                t.c[i] = pinned_load1<T>(pc[i] + ro + xr0);
+            } else {      // counted loads only (see request_pix)
+                t.a[i] = plain_load1<T>(pc[i] + ro + xl0);
+                t.b[i] = plain_load1<T>(pc[i] + ro + kxc);
+                t.c[i] = plain_load1<T>(pc[i] + ro + xr0);
+            }
         }
     };
     auto request_pix = [&](Pix &px, int j) {
@@ -345,9 +360,18 @@ __global__ __launch_bounds__(256) void ce_up_bwd_mc(const T *__restrict__ s, con
         for (int q = 0; q < F; ++q) {
             const int Y = min(max(F * j - F / 2 + q, 0), H - 1);            // rows outside the image (half gaps): clamped, never used
             const size_t o = pix0 + (size_t)Y * W + F * kxc;
-            px.lab[q].request(label + o);
-            px.lse[q].request(lse2 + o);
-            if (GMAP) px.up[q].request(upstream + o);
+            if (PF) {
+                px.lab[q].request(label + o);
+                px.lse[q].request(lse2 + o);
+                if (GMAP) px.up[q].request(upstream + o);
+            } else {
+                // no prefetch: ordinary loads, which hipcc counts and waits for itself.  (A pinned load's destination counts as written when
+                // the asm statement ends; at factor 8 -- ~300 registers -- the compiler parked such registers in AGPRs before the data had
+                // landed and a late return overwrote an address: a memory fault.  tools/asm_pending_audit.py scans for exactly that.)
+                px.lab[q].load(label + o);
+                px.lse[q].load(lse2 + o);
+                if (GMAP) px.up[q].load(upstream + o);
+            }
         }
     };
     auto hrow_raw = [&](const Taps &t, int i, float (&o)[F]) {             // up_device.h::hrow on already-loaded taps
@@ -366,7 +390,7 @@ __global__ __launch_bounds__(256) void ce_up_bwd_mc(const T *__restrict__ s, con
     request_taps(tcur, max(y0 - 1, 0));
     request_taps(tnxt, min(y0, h - 1));
     if (PF) request_pix(pcur, y0);
-    wait_pinned_loads();
+    if (PF) wait_pinned_loads();
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
         hrow_raw(tcur, i, sp[i]);
@@ -376,10 +400,7 @@ __global__ __launch_bounds__(256) void ce_up_bwd_mc(const T *__restrict__ s, con
     tcur = tnxt;
     int parity = 0;
     for (int j = y0; j <= y1; ++j) {
-        if (!PF) {
-            request_pix(pcur, j);
-            wait_pinned_loads();
-        }
+        if (!PF) request_pix(pcur, j);
         request_taps(tnxt, min(j + 1, h - 1));      // the last iteration's requests re-read valid (clamped) addresses and are dropped
         if (PF) request_pix(pnxt, j + 1);
         float sc[CPW][F], accB[CPW][F];
@@ -441,7 +462,7 @@ __global__ __launch_bounds__(256) void ce_up_bwd_mc(const T *__restrict__ s, con
         for (int i = 0; i < CPW; ++i)
 #pragma unroll
             for (int rx = 0; rx < F; ++rx) { accA[i][rx] = accB[i][rx]; sp[i][rx] = sc[i][rx]; }
-        wait_pinned_loads();
+        if (PF) wait_pinned_loads();
         tcur = tnxt;
         if (PF) pcur = pnxt;
     }

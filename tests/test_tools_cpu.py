@@ -34,3 +34,17 @@ def test_bench_roofline_groups_exist():
         src = f.read()
     have = re.findall(r"^\s+'([a-z0-9_]+)': lambda dev, reps", src, re.M)
     assert wanted and set(wanted) <= set(have), (wanted, have)
+
+
+def test_no_compiler_instruction_touches_a_register_with_a_pinned_load_pending():
+    """tools/asm_pending_audit.py over the kernels that use asm-volatile global loads (ce_up.hip, token_gemm.hip): between such a load and
+    its explicit wait the compiler must not copy, spill or reuse the destination registers (round 3: a factor-8 CE backward at ~300
+    registers parked them in AGPRs before the data had landed -- a GPU memory fault).  Cross-compiles for gfx950; no GPU needed."""
+    import shutil
+    import sys
+    import pytest
+    if not (shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc')):
+        pytest.skip('hipcc not available')
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'asm_pending_audit.py')], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert 'ce_up.hip: 0 compiler' in res.stdout and 'token_gemm.hip: 0 compiler' in res.stdout, res.stdout
