@@ -492,6 +492,34 @@ int sd_linear_wgrad_partials(const void *dY, const void *X, int dtype, long toke
                              int with_bias, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Split-bf16 Linear products with the WEIGHT operand split beforehand (round 3).  The mode-1 kernels above split both operands in
+ * registers inside the multiply loop; a weight changes once per optimizer step (never, for the frozen teacher), so its three bf16 planes are
+ * written once -- sd_presplit_multi: ONE launch for any number of weights -- in the order the matrix cores consume them (one contiguous
+ * 1 KB run per 32-column block, 16-deep k-step and plane) and the GEMM loads them straight into registers: no LDS and no vector
+ * arithmetic for that operand.  Same six bf16 products, same planes bit for bit, hence the same results as mode 1
+ * (tests/test_token_gemm_gpu.py).  Replaces the same reference ops as sd_linear_fwd / sd_linear_bwd_data (mix_transformer.py:24-27,48-55,
+ * 75-84,107-133; segformer_head.py:22-33,75-98).
+ *   sd_presplit_bytes(n_cols, k_depth)  bytes of one planes buffer: forward planes (out_features, in_features), bwd planes (in_features,
+ *                                       out_features); k_depth % 16 == 0, else 0.  Buffers 16-byte aligned, caller-owned.
+ *   job: W [out_features][w_row_stride >= in_features] fp32; fwd_planes and / or bwd_planes (NULL = not wanted)
+ *   sd_linear_fwd_planes       Y  [tokens][out] = X [tokens][in] . W^T + bias (+ residual); in_features % 32 == 0, X rows 16-byte aligned
+ *   sd_linear_bwd_data_planes  dX [tokens][in]  = dY [tokens][out] . W;                     out_features % 32 == 0
+ */
+typedef struct sd_presplit_job {
+    const float *W;
+    long w_row_stride;
+    int out_features, in_features;
+    void *fwd_planes;
+    void *bwd_planes;
+} sd_presplit_job;
+size_t sd_presplit_bytes(int n_cols, int k_depth);
+int sd_presplit_multi(const sd_presplit_job *jobs, int njobs, void *stream);
+int sd_linear_fwd_planes(const void *X, const void *fwd_planes, const float *bias, const void *residual, void *Y, int dtype, long tokens,
+                         int in_features, int out_features, void *stream);
+int sd_linear_bwd_data_planes(const void *dY, const void *bwd_planes, void *dX, int dtype, long tokens, int in_features, int out_features,
+                              void *stream);
+
+/* ---------------------------------------------------------------------------
  * A Linear from TOKEN-MAJOR features to contiguous class planes (fp32): the SegFormer head's `linear_pred` 1x1 conv
  * (mmseg/models/decode_heads/segformer_head.py:73,96) on the token-major fused feature map, with the logits landing directly in the
  * [B, out_features, P] planes the loss kernels read (sd_ce_up_*, sd_cgd_kl_up_*) and the gradient read from such planes: no

@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libsegdistill_hip.so')
+LIB_PATH = os.environ.get('SEGDISTILL_LIB') or os.path.join(_HERE, 'lib', 'libsegdistill_hip.so')   # SEGDISTILL_LIB: an A/B build of the SAME library
 
 SD_F32, SD_BF16 = 0, 1
 ABI_VERSION = 1
@@ -61,6 +61,10 @@ SIGNATURES = {
     'sd_align1x1_bwd_weight': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'sd_linear_fwd': (_i, [_vp, _vp, C.c_long, _vp, _vp, _vp, _i, C.c_long, _i, _i, _i, _i, _vp]),
     'sd_linear_bwd_data': (_i, [_vp, _vp, C.c_long, _vp, _i, C.c_long, _i, _i, _i, _vp]),
+    'sd_presplit_bytes': (_sz, [_i, _i]),
+    'sd_presplit_multi': (_i, [_vp, _i, _vp]),
+    'sd_linear_fwd_planes': (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_long, _i, _i, _vp]),
+    'sd_linear_bwd_data_planes': (_i, [_vp, _vp, _vp, _i, C.c_long, _i, _i, _vp]),
     'sd_linear_wgrad_workspace_bytes': (_sz, [C.c_long, _i, _i]),
     'sd_linear_longk_workspace_bytes': (_sz, [_i, _i, _i]),
     'sd_linear_longk_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -56,7 +56,7 @@ __device__ __forceinline__ void wait_loads() {
 }
 
 template <int ROWS, bool VEC, bool FULLK>
-__device__ __forceinline__ void load_ktile(KTile<ROWS> &f, const float *__restrict__ src, long ld, long r0, long rmax, int k0, int K) {
+__device__ __forceinline__ void load_ktile(KTile<ROWS> &f, const float *__restrict__ src, long ld, long r0, long rmax, int k0, int K, bool live = true) {
     const int t = threadIdx.x, c = (t & 7) * 4;
 #pragma unroll
     for (int i = 0; i < ROWS / 32; ++i) {
@@ -64,7 +64,9 @@ __device__ __forceinline__ void load_ktile(KTile<ROWS> &f, const float *__restri
         row = row < rmax ? row : rmax - 1;
         // branch-free: the address is clamped into the row, the value of an out-of-range k is zeroed by a select afterwards
         if (VEC && FULLK) {
-            f.v[i] = pinned_load16(src + row * ld + k0 + c);                          // K % 32 == 0: every chunk of every k-step exists
+            // K % 32 == 0: every chunk of every k-step exists.  !live (block-uniform): a placeholder request of one shared line, so that the
+            // count of outstanding operations -- the hand-counted vmcnt waits -- is the same in every round
+            f.v[i] = pinned_load16(live ? src + row * ld + k0 + c : src);
         } else if (VEC) {
             const bool in = k0 + c < K;                                   // K % 4 == 0: a chunk is entirely in or out
             const float4 v = *reinterpret_cast<const float4 *>(src + row * ld + (in ? k0 + c : 0));
@@ -125,7 +127,12 @@ __device__ __forceinline__ void store_ntile(const NTile<COLS> &f, float *dst /* 
 // C_z[M x N] = epilogue( A_z[M x K] . B_z ),  z = blockIdx.y (operand strides sA / sB / sC elements, 0 = shared),
 //   A(m, k) = AKC ? A[m * lda + k] : A[k * lda + m],   B(k, n) = BT ? Bm[n * ldb + k] : Bm[k * ldb + n].
 // EPI: bit 0 = + residual (C-shaped), bit 1 = exact GELU.  bias optional: per column n, or per row m when BIAS_ROW (the NCHW 1x1 projection).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, bool VEC, bool FULLK, int EPI, bool AKC = true, bool BIAS_ROW = false, bool X3 = false>
+// BFRAG (round 3; X3 + FULLK + AKC only): the B operand arrives PRE-SPLIT -- three bf16 planes in the fragment-contiguous layout written by
+// presplit_planes below (one 1 KB run per (32-column block, 16-deep k-step, plane): lane l's 16 bytes ARE its MFMA B fragment) -- and is
+// loaded straight from global memory / L2 into registers, one k16 step ahead: no LDS for B, no split arithmetic for B.  `Bm` is then the
+// planes buffer and `ldb` its number of 32-column blocks.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, bool VEC, bool FULLK, int EPI, bool AKC = true, bool BIAS_ROW = false, bool X3 = false,
+          bool BFRAG = false>
 __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ A, const float *__restrict__ Bm, float *__restrict__ C,
                                                        const float *__restrict__ bias, const float *__restrict__ residual, long M, int N, int K,
                                                        long lda, long ldb, long ldc, int tiles_n, int vec_out, long sA, long sB, long sC,
@@ -133,7 +140,8 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
     static_assert(WAVES_M * WAVES_N == 4, "four waves");
     constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
     constexpr int A_ELEMS = AKC ? BM * KP : BK * (BM + 4);
-    constexpr int B_ELEMS = BT ? BN * KP : BK * (BN + 4);
+    constexpr int B_ELEMS = BFRAG ? 0 : (BT ? BN * KP : BK * (BN + 4));
+    static_assert(!BFRAG || (X3 && FULLK && VEC && AKC), "pre-split B planes: split-bf16 mode, whole k-steps, k-contiguous A");
     extern __shared__ __attribute__((aligned(16))) float lds[];        // [2][A_ELEMS + B_ELEMS]
     // z = batch * nsplit + split: a split covers k in [split * klen, min(K, (split + 1) * klen)) and writes its own C slab (split-K)
     {
@@ -176,22 +184,26 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
     KTile<BN> fbt;
     NTile<BN> fbn;
     const int nk = (K + BK - 1) / BK;
-    auto load_tiles = [&](int k0) {
-        if (AKC) load_ktile<BM, VEC, FULLK>(fa, A, lda, m0, M, k0, K);
+    auto load_tiles = [&](int k0, bool live = true) {
+        if (AKC) load_ktile<BM, VEC, FULLK>(fa, A, lda, m0, M, k0, K, live);
         else load_ntile<BM, VEC, FULLK>(fan, A, lda, (int)m0, (int)M, k0, K);
+        if (BFRAG) return;
         if (BT) load_ktile<BN, VEC, FULLK>(fbt, Bm, ldb, n0, N, k0, K);
         else load_ntile<BN, VEC, FULLK>(fbn, Bm, ldb, n0, N, k0, K);
     };
     auto store_tiles = [&](float *buf) {
         if (AKC) store_ktile<BM>(fa, buf);
         else store_ntile<BM>(fan, buf);
+        if (BFRAG) return;
         if (BT) store_ktile<BN>(fbt, buf + A_ELEMS);
         else store_ntile<BN>(fbn, buf + A_ELEMS);
     };
     load_tiles(0);
-    if (FULLK) wait_loads();
-    store_tiles(lds);
-    __syncthreads();
+    if (FULLK && !BFRAG) wait_loads();
+    if (!BFRAG) {
+        store_tiles(lds);
+        __syncthreads();
+    }
     // Fragments of one quad (8 consecutive k): per lane 4 k-values of TM A rows and TN B columns.
     struct Frag { float a[TM][4], b[TN][4]; };
     auto read_frag = [&](Frag &f, const float *As, const float *Bs, int q4) {
@@ -233,7 +245,138 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
     //            | read sit behind 16 MFMAs (1024 cycles) instead of in front of them.  One barrier per k-step.
     // Two co-resident workgroups run this same program nearly in lockstep, so a bubble in one is not filled by the other (measured: 68 % MFMA
     // utilisation with the plain load / multiply / store / barrier order).
-    if constexpr (X3) {
+    if constexpr (BFRAG) {
+        // ---- split-bf16 products with a PRE-SPLIT B operand ------------------------------------------------------------------------------
+        // Per k32 tile and wave: 2 x TM fragments of A are read from LDS (eight CONSECUTIVE k per lane: k = 16 s + 8 (lane >> 5) .. + 7, the
+        // k order of the planes) and split in registers (the only vector arithmetic left: ~170 instructions against 48 MFMAs), 2 x 3 TN
+        // B fragments come from global memory as 16-byte loads.  vmcnt is counted by hand (asm loads are invisible to hipcc): the A tile
+        // of step kt+1 (NA loads) is requested first, then B(kt, 1) (NB loads); B(kt+1, 0) follows the LDS stores.
+        constexpr int NA = BM / 32, NB = 3 * TN;
+        struct APl { bf16x8 h[TM], m[TM], l[TM]; };
+        struct BPl { bf16x8 h[TN], m[TN], l[TN]; };
+        const int KS = K / 16, nblocks = (int)ldb;
+        const char *bbase[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nb = min((n0 + wn) / 32 + j, nblocks - 1);                 // blocks beyond N: clamped (their columns are never stored)
+            bbase[j] = reinterpret_cast<const char *>(Bm) + ((size_t)nb * KS) * 3072 + lane * 16;
+        }
+        auto load_b = [&](BPl &b, int ks) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const char *q = bbase[j] + (size_t)ks * 3072;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b.h[j]) : "v"(q) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(b.m[j]) : "v"(q) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(b.l[j]) : "v"(q) : "memory");
+            }
+        };
+        // Conversions in pairs (one v_cvt_pk_bf16_f32 per two values); residuals as one packed subtraction per pair.  (Measured and dropped,
+        // same box: the residuals as scalar v_sub_f32 kept apart by opaque asm operands -- a packed f32 instruction beside MFMAs is priced
+        // ~13 cycles above the two scalar ones it replaces, MI355X_MICROARCH.md -- 106.8 vs 105.1 / 107.1 us at 256 -> 256 over 131072
+        // tokens, no shape moved by more than the run-to-run noise: the asm operands cost s_nop pads and scheduling freedom.)
+        auto split8 = [&](const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 v = {x[e], x[e + 1]};
+                const bf16x2 hh = __builtin_convertvector(v, bf16x2);
+                const f32x2 r1 = v - __builtin_convertvector(hh, f32x2);
+                const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
+                const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
+                const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
+                h[e] = hh[0], h[e + 1] = hh[1], m[e] = mm[0], m[e + 1] = mm[1], l[e] = ll[0], l[e + 1] = ll[1];
+            }
+        };
+        auto read_split_a = [&](APl &P, const float *As, int s2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float *q = As + (wm + 32 * i + r) * KP + 16 * s2 + 8 * kh;
+                const float4 v0 = *reinterpret_cast<const float4 *>(q), v1 = *reinterpret_cast<const float4 *>(q + 4);
+                const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                split8(x, P.h[i], P.m[i], P.l[i]);
+            }
+        };
+        auto mfma_planes = [&](const APl &A_, const BPl &B_) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_.m[i], B_.m[j], c, 0, 0, 0);      // small terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_.l[i], B_.h[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_.h[i], B_.l[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_.m[i], B_.h[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_.h[i], B_.m[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_.h[i], B_.h[j], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        };
+        auto wait_vm = [&](auto n) {       // all but the n youngest vector-memory operations of this wave are done
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(n)::value) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // One scheduling region = the LDS reads + split of the NEXT A fragments and the 6 TM TN MFMAs on the CURRENT planes, interleaved by
+        // sched_group_barrier: an MFMA holds the SIMD's vector issue for 8 of its 32 cycles, so ~4 vector instructions ride in each gap.
+        auto interleave = [&]() {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM, 0);      // the fragment reads first: their latency hides behind the first MFMAs
+#pragma unroll
+            for (int q = 0; q < 6 * TM * TN; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+        };
+        // Schedule of k-step kt (tile kt in LDS stage kt & 1; B0 = B(kt, 0) and B1 = B(kt, 1) are register sets):
+        //   top     request B(kt, 1)                                   wait B(kt, 0)      [queue: B(kt,0), A(kt+1) | B(kt,1)]
+        //   half 0  { read + split A(kt, half 1) -> PA1  ||  MFMAs on (PA0, B0) }
+        //   middle  wait A(kt+1) (requested one whole step ago), store it to the other stage, request B(kt+1, 0) then A(kt+2); barrier
+        //   half 1  wait B(kt, 1)  { read + split A(kt+1, half 0) -> PA0  ||  MFMAs on (PA1, B1) }
+        // vmcnt retires in order, so B(kt+1, 0) is requested BEFORE A(kt+2): the wait for it at the next top does not drag the A tile along,
+        // which keeps its full step of flight time (the round-2 order -- A requested at the top, consumed half a step later -- ran each
+        // k-step at the HBM latency: 3.2 us against 1.3 us of matrix work).
+        APl PA0, PA1;
+        BPl B0, B1;
+        load_b(B0, 0);                                  // (the A tile of step 0 was requested above)
+        wait_vm(std::integral_constant<int, 0>{});
+        store_tiles(lds);
+        if (nk > 1) load_tiles(BK);                     // A(1): consumed in the middle of step 0
+        __syncthreads();
+        read_split_a(PA0, lds, 0);
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const float *cur = lds + (kt & 1) * A_ELEMS;
+            float *nxt = lds + ((kt + 1) & 1) * A_ELEMS;
+            load_b(B1, 2 * kt + 1);                     // NB
+            wait_vm(std::integral_constant<int, NA + NB>{});     // B0 = B(kt, 0) landed; A(kt+1) and B(kt, 1) may still fly
+            read_split_a(PA1, cur, 1);
+            mfma_planes(PA0, B0);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vm(std::integral_constant<int, NB>{});          // A(kt+1) landed
+            store_tiles(nxt);
+            load_b(B0, 2 * kt + 2);                     // NB; B0's registers were last read by the MFMAs above
+            load_tiles((kt + 2) * BK, kt + 2 < nk);             // NA; past the last tile: placeholder requests (no branch: one basic block)
+            __syncthreads();
+            wait_vm(std::integral_constant<int, NA + NB>{});     // B1 = B(kt, 1) landed
+            read_split_a(PA0, nxt, 0);
+            mfma_planes(PA1, B1);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            const float *cur = lds + ((nk - 1) & 1) * A_ELEMS;
+            load_b(B1, 2 * nk - 1);
+            wait_vm(std::integral_constant<int, NB>{});          // B0 landed (and everything older)
+            // the last round's placeholder A requests are dead values to the compiler, which would hand their registers out while the loads
+            // were still in flight (tools/asm_pending_audit.py): keep them alive up to this wait
+#pragma unroll
+            for (int i = 0; i < NA; ++i) asm volatile("" ::"v"(fa.v[i].x), "v"(fa.v[i].y), "v"(fa.v[i].z), "v"(fa.v[i].w));
+            read_split_a(PA1, cur, 1);
+            mfma_planes(PA0, B0);
+            interleave();
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vm(std::integral_constant<int, 0>{});
+            mfma_planes(PA1, B1);
+            __syncthreads();
+        }
+    } else if constexpr (X3) {
         // ---- split-bf16 products ("bf16x3"): every fp32 operand value is split EXACTLY into three bf16 terms x = hi + mid + lo (8 + 8 + 8
         // significand bits; each residual of a round-to-nearest is exactly representable), and a product a.b is formed from the six
         // bf16 x bf16 products whose weight is >= 2^-16 of the leading one -- hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid -- on
@@ -434,7 +577,7 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, int EPI, bool AKC = true, bool BIAS_ROW = false, bool X3 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, int EPI, bool AKC = true, bool BIAS_ROW = false, bool X3 = false, bool BFRAG = false>
 int launch_epi(const float *A, const float *Bm, float *C, const float *bias, const float *residual, long M, int N, int K, long lda, long ldb,
                long ldc, hipStream_t st, int batch = 1, long sA = 0, long sB = 0, long sC = 0, int nsplit = 1, int klen = 0) {
     if (klen <= 0 || nsplit <= 1) { nsplit = 1; klen = K; }
@@ -443,7 +586,7 @@ int launch_epi(const float *A, const float *Bm, float *C, const float *bias, con
     // The row-major epilogue parks 4 waves x 32 rows x (TN*32 + 4) floats in the same LDS: with ONE staging buffer of two [k][m] / [k][n]
     // operands (bwd-data of the class-plane Linear with <= 32 classes: 33792 B) that image (34816 B) is the larger of the two.
     constexpr size_t epi_bytes = (size_t)4 * 32 * ((BN / (32 * WAVES_N)) * 32 + 4) * sizeof(float);
-    const size_t stage_bytes = (klen > BK ? 2 : 1) * (size_t)((AKC ? BM * KP : BK * (BM + 4)) + (BT ? BN * KP : BK * (BN + 4))) * sizeof(float);
+    const size_t stage_bytes = (klen > BK ? 2 : 1) * (size_t)((AKC ? BM * KP : BK * (BM + 4)) + (BFRAG ? 0 : (BT ? BN * KP : BK * (BN + 4)))) * sizeof(float);
     const size_t lds_bytes = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     const long tiles_m = (M + BM - 1) / BM;
     const int tiles_n = (N + BN - 1) / BN;
@@ -454,6 +597,28 @@ int launch_epi(const float *A, const float *Bm, float *C, const float *bias, con
                      sA % 4 == 0 && sB % 4 == 0 && ((AKC || BT) ? klen % 4 == 0 : true) && (AKC ? K % 4 == 0 : M % 4 == 0) && (BT ? K % 4 == 0 : N % 4 == 0);
     // (a k-contiguous operand needs k origins on 16-byte boundaries; [k][m] / [k][n] operands vectorise along m / n whatever K is)
     const bool fullk = vec && K % BK == 0 && klen % BK == 0 && (AKC || M >= 4) && (BT || N >= 4);
+    if constexpr (BFRAG) {
+        // pre-split planes: A alone decides alignment; whole k-steps, no split-K
+        const bool ok = (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bm) & 15) == 0 && lda % 4 == 0 && K % BK == 0 &&
+                        nsplit == 1 && batch == 1 && ldb > 0;
+        if (!ok) return SD_E_UNSUPPORTED;
+        auto kernf = token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, true, EPI, AKC, BIAS_ROW, true, true>;
+        if (lds_bytes > 64 * 1024) {      // the row-major epilogue image of a 256-column tile: 66 KB
+            static bool raised = false;   // per instantiation; idempotent, so a race is harmless
+            if (!raised) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                if (e != hipSuccess) return (int)e;
+                raised = true;
+            }
+        }
+        const int vo = ((reinterpret_cast<uintptr_t>(C) & 15) == 0 && ldc % 4 == 0 && N % 4 == 0 &&
+                        (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0) &&
+                        (BIAS_ROW || !bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0)) ? 1 : 0;
+        hipLaunchKernelGGL(kernf, dim3((unsigned)nblk, 1), dim3(256), lds_bytes, st, A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, tiles_n, vo, 0L, 0L,
+                           0L, 1, K);
+        return (int)hipGetLastError();
+    }
+    else {
     auto kern = fullk ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, true, EPI, AKC, BIAS_ROW, X3>
                       : (vec ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, false, EPI, AKC, BIAS_ROW, X3>
                              : token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, false, false, EPI, AKC, BIAS_ROW, X3>);
@@ -473,6 +638,7 @@ int launch_epi(const float *A, const float *Bm, float *C, const float *bias, con
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)(batch * nsplit)), dim3(256), lds_bytes, st, A, Bm, C, bias, residual, M, N, K, lda, ldb,
                        ldc, tiles_n, vec_out, sA, sB, sC, nsplit, klen);
     return (int)hipGetLastError();
+    }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT>
@@ -499,6 +665,75 @@ int dispatch_x3(const float *A, const float *Bm, float *C, const float *bias, co
                 long ldc, hipStream_t st) {
     if (residual) return launch_epi<128, 128, 2, 2, BT, 1, true, false, true>(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, st);
     return launch_epi<128, 128, 2, 2, BT, 0, true, false, true>(A, Bm, C, bias, nullptr, M, N, K, lda, ldb, ldc, st);
+}
+
+// ---- pre-split weights (round 3) -------------------------------------------------------------------------------------------------------
+// B(k, n) of a Linear product as three bf16 planes (hi = rn(x), mid = rn(x - hi), lo = rn(x - hi - mid): the split of the X3 kernels, the same
+// bits) in FRAGMENT-CONTIGUOUS order: for every (32-column block nb, 16-deep k-step ks, plane) one 1 KB run whose lane-l 16 bytes hold
+// B(16 ks + 8 (l >> 5) + e, 32 nb + (l & 31)), e = 0..7 -- exactly lane l's B operand of v_mfma_f32_32x32x16_bf16.  Columns beyond the
+// matrix are zero.   dir 1 (forward):  B(k, n) = W[n][k]   (Nd = out_features, Kd = in_features)
+//                    dir 0 (bwd-data): B(k, n) = W[k][n]   (Nd = in_features,  Kd = out_features)
+constexpr int kMaxPresplit = 64;
+struct PresplitTable {   // by value in the kernel arguments (no device-side table: safe under graph capture)
+    const float *W[kMaxPresplit];
+    uint16_t *out[kMaxPresplit];
+    int ldw[kMaxPresplit], Nd[kMaxPresplit], Kd[kMaxPresplit], dir[kMaxPresplit];
+    int blk_begin[kMaxPresplit + 1];
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void presplit_planes(const PresplitTable t) {
+    int lo = 0, hi = t.njobs - 1;
+    while (lo < hi) {        // wave-uniform binary search
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= t.blk_begin[mid]) lo = mid;
+        else hi = mid - 1;
+    }
+    const int j = lo;
+    const int KS = t.Kd[j] / 16, NBk = (t.Nd[j] + 31) / 32;
+    const long f = (long)((int)blockIdx.x - t.blk_begin[j]) * 4 + (threadIdx.x >> 6);      // fragment = (nb, ks)
+    if (f >= (long)NBk * KS) return;
+    const int lane = threadIdx.x & 63;
+    const int nb = (int)(f / KS), ks = (int)(f - (long)nb * KS);
+    const int n = 32 * nb + (lane & 31), k0 = 16 * ks + 8 * (lane >> 5);
+    const float *__restrict__ W = t.W[j];
+    const long ldw = t.ldw[j];
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = 0.f;
+    if (n < t.Nd[j]) {
+        if (t.dir[j]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = W[(long)n * ldw + k0 + e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = W[(long)(k0 + e) * ldw + n];
+        }
+    }
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hh = static_cast<__bf16>(x[e]);
+        const float r1 = x[e] - static_cast<float>(hh);
+        const __bf16 mm = static_cast<__bf16>(r1);
+        const float r2 = r1 - static_cast<float>(mm);
+        h[e] = hh, m[e] = mm, l[e] = static_cast<__bf16>(r2);
+    }
+    bf16x8 *dst = reinterpret_cast<bf16x8 *>(t.out[j]) + (size_t)f * 3 * 64 + lane;
+    dst[0] = h;
+    dst[64] = m;
+    dst[128] = l;
+}
+
+// X3 products on a pre-split B operand (planes: `nblocks` 32-column blocks x K/16 k-steps)
+int dispatch_planes(const float *A, const void *planes, int nblocks, float *C, const float *bias, const float *residual, long M, int N, int K,
+                    hipStream_t st) {
+    const float *Bp = static_cast<const float *>(planes);
+    // 128 x 128 tiles, two workgroups per CU.  (Measured and dropped: 128 x 256 tiles -- each wave 64 x 128, 96 MFMAs per k-step against the
+    // same A split, ~330 registers, ONE workgroup per CU -- 109.7 vs 105.1 us at 256 -> 256 over 131072 tokens, 47.3 vs 43.6 us at 64 -> 256,
+    // 55.7 vs 45.4 us at 320 -> 1280 over 8192: PMC shows the same ~50 % matrix-pipe occupancy with less co-resident work to cover the waits.)
+    if (residual) return launch_epi<128, 128, 2, 2, true, 1, true, false, true, true>(A, Bp, C, bias, residual, M, N, K, K, nblocks, N, st);
+    return launch_epi<128, 128, 2, 2, true, 0, true, false, true, true>(A, Bp, C, bias, nullptr, M, N, K, K, nblocks, N, st);
 }
 
 template <bool BT>
@@ -719,6 +954,75 @@ int sd_linear_bwd_data(const void *dY, const float *W, long w_row_stride, void *
                                       in_features, static_cast<hipStream_t>(stream));
     return sd::dispatch<false>((const float *)dY, W, (float *)dX, nullptr, nullptr, tokens, in_features, out_features, out_features, w_row_stride,
                                in_features, 0, static_cast<hipStream_t>(stream));
+}
+
+size_t sd_presplit_bytes(int n_cols, int k_depth) {
+    if (n_cols <= 0 || k_depth <= 0 || k_depth % 16) return 0;
+    return (size_t)((n_cols + 31) / 32) * (k_depth / 16) * 3 * 1024;
+}
+
+int sd_presplit_multi(const sd_presplit_job *jobs, int njobs, void *stream) {
+    if (njobs < 0) return SD_E_SHAPE;
+    if (njobs == 0) return SD_OK;
+    if (!jobs) return SD_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    sd::PresplitTable t{};
+    int cnt = 0;
+    long blocks = 0;
+    auto flush = [&]() {
+        if (!cnt) return;
+        t.blk_begin[cnt] = (int)blocks;
+        t.njobs = cnt;
+        hipLaunchKernelGGL(sd::presplit_planes, dim3((unsigned)blocks), dim3(256), 0, st, t);
+        cnt = 0;
+        blocks = 0;
+    };
+    for (int q = 0; q < njobs; ++q) {
+        const sd_presplit_job &jb = jobs[q];
+        if (!jb.W || (!jb.fwd_planes && !jb.bwd_planes)) return SD_E_NULL;
+        if (jb.out_features <= 0 || jb.in_features <= 0 || jb.w_row_stride < jb.in_features) return SD_E_SHAPE;
+        if ((reinterpret_cast<uintptr_t>(jb.fwd_planes) | reinterpret_cast<uintptr_t>(jb.bwd_planes)) & 15) return SD_E_ALIGN;
+        for (int dir = 1; dir >= 0; --dir) {
+            void *out = dir ? jb.fwd_planes : jb.bwd_planes;
+            if (!out) continue;
+            const int Nd = dir ? jb.out_features : jb.in_features, Kd = dir ? jb.in_features : jb.out_features;
+            if (Kd % 16) return SD_E_UNSUPPORTED;
+            if (cnt == sd::kMaxPresplit) flush();
+            t.W[cnt] = jb.W;
+            t.out[cnt] = static_cast<uint16_t *>(out);
+            t.ldw[cnt] = (int)jb.w_row_stride;
+            t.Nd[cnt] = Nd;
+            t.Kd[cnt] = Kd;
+            t.dir[cnt] = dir;
+            t.blk_begin[cnt] = (int)blocks;
+            blocks += ((long)((Nd + 31) / 32) * (Kd / 16) + 3) / 4;
+            if (blocks > 0x7fffffffL) return SD_E_SHAPE;
+            ++cnt;
+        }
+    }
+    flush();
+    return (int)hipGetLastError();
+}
+
+int sd_linear_fwd_planes(const void *X, const void *fwd_planes, const float *bias, const void *residual, void *Y, int dtype, long tokens,
+                         int in_features, int out_features, void *stream) {
+    if (!X || !fwd_planes || !Y) return SD_E_NULL;
+    if (dtype != SD_F32) return SD_E_DTYPE;
+    if (tokens <= 0 || in_features <= 0 || out_features <= 0) return SD_E_SHAPE;
+    if (in_features % 32) return SD_E_UNSUPPORTED;
+    return sd::dispatch_planes((const float *)X, fwd_planes, (out_features + 31) / 32, (float *)Y, bias, (const float *)residual, tokens, out_features,
+                               in_features, static_cast<hipStream_t>(stream));
+}
+
+int sd_linear_bwd_data_planes(const void *dY, const void *bwd_planes, void *dX, int dtype, long tokens, int in_features, int out_features,
+                              void *stream) {
+    if (!dY || !bwd_planes || !dX) return SD_E_NULL;
+    if (dtype != SD_F32) return SD_E_DTYPE;
+    if (tokens <= 0 || in_features <= 0 || out_features <= 0) return SD_E_SHAPE;
+    if (out_features % 32) return SD_E_UNSUPPORTED;
+    // C[T x in] = dY[T x out] . B,  B(k, n) = W[k][n]: K = out_features, N = in_features
+    return sd::dispatch_planes((const float *)dY, bwd_planes, (in_features + 31) / 32, (float *)dX, nullptr, nullptr, tokens, in_features, out_features,
+                               static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -40,6 +40,7 @@ class HipAdamW(torch.optim.AdamW):
         self._desc = None
         self._dev_tensors = self._dev_blocks = None
         self._nblocks = 0
+        self._planes = None         # planes.Refresher, created at the first step
 
     @staticmethod
     def _shadow_of(p):
@@ -147,6 +148,12 @@ class HipAdamW(torch.optim.AdamW):
         lrs = (ctypes.c_float * len(self.param_groups))(*[float(g['lr']) for g in self.param_groups])
         _lib.check(L.sd_adamw_multi(self._dev_tensors.data_ptr(), self._dev_blocks.data_ptr(), self._nblocks, lrs, len(self.param_groups), float(b1),
                                     float(b2), float(eps), self._global, _stream_ptr()), 'sd_adamw_multi')
+        # the parameters were written through raw pointers (no version bump): rewrite, in ONE launch, the pre-split bf16 planes that the
+        # split-bf16 GEMMs keep of them (segdistill_amd/planes.py; buffers stay where they are, so a captured graph keeps reading them)
+        if self._planes is None:
+            from ..planes import Refresher
+            self._planes = Refresher()
+        self._planes.refresh(self._live_params)
         return loss
 
 

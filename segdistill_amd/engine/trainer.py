@@ -383,10 +383,26 @@ class KDTrainer:
         else:
             m.load_state_dict(weights)
         self.optimizer.load_state_dict(sd['optimizer'])
+        self._sync_derived_weights()
         meta = sd.get('meta', sd)
         self.iter = int(meta['iter'])
         if hasattr(m, 'cnt'):
             m.cnt = int(meta['cnt'])
+
+    def _sync_derived_weights(self):
+        """Copies of the weights that kernels read instead of the fp32 parameter -- pre-split bf16 planes (planes.py), bf16 shadows
+        (linear.lowp_copy) -- are rewritten IN PLACE now: a captured graph has their addresses baked in and a replay runs no Python forward
+        that would notice the parameters' new versions."""
+        from .. import planes
+        params = self.reducer.params
+        if params and params[0].is_cuda:
+            planes.sync(params)
+            with torch.no_grad():
+                for p in params:
+                    sh = getattr(p, '_sd_shadow', None)
+                    if sh is not None:
+                        sh[1].copy_(p)
+                        p._sd_shadow = (p._version, sh[1])
 
     def save(self, path):
         import os

@@ -10,7 +10,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import _lib, deferred, token_gemm
+from . import _lib, deferred, planes, token_gemm
 from .ops import _DT, _stream_ptr
 
 MIN_TOKENS = 1     # every training Linear: below 8192 tokens dW is the library's GEMM, but the bias gradient still avoids ATen's
@@ -54,6 +54,9 @@ def linear_forward(x, weight, bias):
     """x . W^T + bias without autograd bookkeeping (frozen networks, and the forward of _TokenLinear): the measured three-way dispatch."""
     if x.dtype == torch.float32 and token_gemm.supported(x, weight):
         mode = _gemm_mode(x.numel() // x.shape[-1], x.shape[-1], weight.shape[0])
+        if mode == 'x3' and planes.supported(weight):
+            # the weight's bf16 planes are split ONCE per optimizer step (never, for a frozen weight), not in every k-step (planes.py)
+            return token_gemm.linear_fwd_planes(x, weight, planes.get(weight, 'fwd'), bias)
         if mode != 'lib':
             return token_gemm.linear_fwd(x, weight, bias, split_bf16=(mode == 'x3'))
     if x.is_cuda and weight.dtype == torch.float32 and not weight.requires_grad and (bias is None or not bias.requires_grad):
@@ -72,6 +75,8 @@ def _bwd_data(dy2, weight):
     """dy2 [T, N] . W [N, K] -> [T, K] (None: not ours, use the library)."""
     if dy2.dtype == torch.float32 and weight.dtype == torch.float32 and dy2.is_cuda and weight.dim() == 2:
         mode = _gemm_mode(dy2.shape[0], weight.shape[0], weight.shape[1])
+        if mode == 'x3' and planes.supported(weight):
+            return token_gemm.linear_bwd_data_planes(dy2, weight, planes.get(weight, 'bwd'))
         if mode != 'lib':
             return token_gemm.linear_bwd_data(dy2, weight, split_bf16=(mode == 'x3'))
     return None

@@ -56,3 +56,32 @@ def linear_bwd_data(dy, weight, split_bf16=False):
     rc = _lib.lib().sd_linear_bwd_data(d2.data_ptr(), w.data_ptr(), ldw, dx.data_ptr(), _lib.SD_F32, T, K, N, 1 if split_bf16 else 0, _stream_ptr())
     _lib.check(rc, 'sd_linear_bwd_data')
     return dx.reshape(*dy.shape[:-1], K)
+
+
+def linear_fwd_planes(x, weight, planes, bias=None, residual=None):
+    """x . W^T + bias (+ residual) in split-bf16 arithmetic with the weight's pre-split forward planes (segdistill_amd/planes.py)."""
+    x2 = _rows(x)
+    T, K = x2.shape
+    N = weight.shape[0]
+    y = torch.empty(T, N, dtype=torch.float32, device=x.device)
+    r2 = None
+    if residual is not None:
+        r2 = _rows(residual)
+        if r2.shape != y.shape or r2.dtype != torch.float32:
+            raise ValueError('residual must be fp32 of the output shape')
+    b = None if bias is None else (bias if bias.dtype == torch.float32 and bias.is_contiguous() else bias.float().contiguous())
+    rc = _lib.lib().sd_linear_fwd_planes(x2.data_ptr(), planes.data_ptr(), None if b is None else b.data_ptr(), None if r2 is None else r2.data_ptr(),
+                                         y.data_ptr(), _lib.SD_F32, T, K, N, _stream_ptr())
+    _lib.check(rc, 'sd_linear_fwd_planes')
+    return y.reshape(*x.shape[:-1], N)
+
+
+def linear_bwd_data_planes(dy, weight, planes):
+    """dy . W with the weight's pre-split bwd planes."""
+    d2 = _rows(dy)
+    T, N = d2.shape
+    K = weight.shape[1]
+    dx = torch.empty(T, K, dtype=torch.float32, device=dy.device)
+    rc = _lib.lib().sd_linear_bwd_data_planes(d2.data_ptr(), planes.data_ptr(), dx.data_ptr(), _lib.SD_F32, T, K, N, _stream_ptr())
+    _lib.check(rc, 'sd_linear_bwd_data_planes')
+    return dx.reshape(*dy.shape[:-1], K)

@@ -182,3 +182,117 @@ def test_linear_to_planes_bf16_storage(case):
     assert xd.grad.dtype == torch.bfloat16 and err(xd.grad, x64.grad) < 1e-2
     assert wd.grad.dtype == torch.float32 and err(wd.grad, w64.grad) < 2e-3
     assert err(bd.grad, b64.grad) < 1e-4
+
+
+# ---- round 3: split-bf16 products on a PRE-SPLIT weight (planes in the order the matrix cores consume them) ----------------------------------
+PLANE_SHAPES = [  # tokens, in_features (K), out_features (N); K % 32 == 0 (forward), N % 32 == 0 for the input gradient
+    (4096, 32, 128), (1000, 64, 256), (4099, 256, 256), (777, 160, 640), (512, 640, 160), (300, 256, 150), (2048, 512, 2048), (16384, 64, 256),
+    (131, 1280, 320), (128, 32, 32), (5000, 128, 96),
+]
+
+
+@pytest.mark.parametrize('T,K,N', PLANE_SHAPES)
+def test_planes_gemm_matches_fp64_at_the_split_mode_bound(T, K, N):
+    """sd_presplit_multi + sd_linear_fwd_planes / sd_linear_bwd_data_planes: the same six bf16 products as mode 1 with the weight's planes
+    written beforehand -- the SAME error bound as the exact-f32 path, error within 2x of it; ragged token counts, column counts that are not
+    a multiple of the 32-column block (150, 160) or of the 128-column tile, bias, residual, a single k-step (K = 32)."""
+    from segdistill_amd import planes, token_gemm
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(T * 5 + K * 3 + N)
+    x = torch.randn(T, K, device=dev, generator=g)
+    w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
+    b = torch.randn(N, device=dev, generator=g)
+    r = torch.randn(T, N, device=dev, generator=g)
+    dy = torch.randn(T, N, device=dev, generator=g)
+    x64, w64, b64 = x.double(), w.double(), b.double()
+    ref = x64 @ w64.t() + b64
+    tol = 3e-7 * max(8.0, K ** 0.5)
+    pf = planes.get(w, 'fwd')
+    y = token_gemm.linear_fwd_planes(x, w, pf, b)
+    assert _rel(y, ref) < tol
+    assert _rel(token_gemm.linear_fwd_planes(x, w, pf), x64 @ w64.t()) < tol
+    assert _rel(token_gemm.linear_fwd_planes(x, w, pf, b, residual=r), ref + r.double()) < tol
+    e3, e1 = float((y.double() - ref).norm() / ref.norm()), float((token_gemm.linear_fwd(x, w, b).double() - ref).norm() / ref.norm())
+    assert e3 < 2.0 * e1 + 1e-8, (e3, e1)
+    if N % 32 == 0:
+        pb = planes.get(w, 'bwd')
+        assert _rel(token_gemm.linear_bwd_data_planes(dy, w, pb), dy.double() @ w64) < 3e-7 * max(8.0, N ** 0.5)
+
+
+def test_planes_hold_the_exact_three_way_split_in_fragment_order():
+    """The planes buffer, decoded on the host: hi + mid + lo == w exactly (fp32 values whose 24 significand bits fit three bf16 terms) and
+    element (block nb, k-step ks, plane, lane l, e) is W[32 nb + (l & 31)][16 ks + 8 (l >> 5) + e]; columns beyond the matrix are zero."""
+    from segdistill_amd import planes
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(11)
+    N, K = 150, 96
+    w = torch.randn(N, K, device=dev, generator=g)
+    buf = planes.get(w, 'fwd').view(torch.bfloat16).reshape((N + 31) // 32, K // 16, 3, 64, 8).float().cpu()
+    wc = w.cpu()
+    lane = torch.arange(64)
+    for nb in range(buf.shape[0]):
+        for ks in range(buf.shape[1]):
+            n = 32 * nb + (lane & 31)
+            k = 16 * ks + 8 * (lane >> 5)
+            want = torch.zeros(64, 8)
+            ok = n < N
+            want[ok] = torch.stack([wc[n[ok], k[ok] + e] for e in range(8)], 1)
+            hi, mid, lo = buf[nb, ks, 0], buf[nb, ks, 1], buf[nb, ks, 2]
+            assert torch.equal(hi, want.to(torch.bfloat16).float())
+            assert torch.equal((hi.double() + mid.double() + lo.double()).float(), want)
+    # bwd planes: B(k, n) = W[k][n]
+    wb = torch.randn(64, 40, device=dev, generator=g)
+    bb = planes.get(wb, 'bwd').view(torch.bfloat16).reshape(2, 4, 3, 64, 8).float().cpu()
+    for nb in range(2):
+        for ks in range(4):
+            n, k = 32 * nb + (lane & 31), 16 * ks + 8 * (lane >> 5)
+            want = torch.zeros(64, 8)
+            ok = n < 40
+            want[ok] = torch.stack([wb.cpu()[k[ok] + e, n[ok]] for e in range(8)], 1)
+            assert torch.equal((bb[nb, ks, 0].double() + bb[nb, ks, 1].double() + bb[nb, ks, 2].double()).float(), want)
+
+
+def test_planes_follow_the_weight_through_optimizer_steps_checkpoint_loads_and_views():
+    """planes.py's one freshness rule: (a) HipAdamW writes parameters through raw pointers and rewrites the planes IN PLACE in the same step
+    (same buffer address, new contents); (b) a torch-side write (copy_) bumps the version and the next use recomputes; (c) the column blocks
+    of one wide parameter (linear_fuse) are separate entries of the same base and are all refreshed; (d) planes.sync rewrites at once."""
+    from segdistill_amd import planes, token_gemm
+    from segdistill_amd.engine.optim import HipAdamW
+    from segdistill_amd.linear import token_linear
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(2)
+    wide = torch.nn.Parameter(torch.randn(128, 256, device=dev, generator=g) / 16)
+    w2 = torch.nn.Parameter(torch.randn(256, 64, device=dev, generator=g) / 8)
+    opt = HipAdamW([wide, w2], lr=1e-2, weight_decay=0.01)
+    x = torch.randn(40000, 64, device=dev, generator=g)        # 313 x 2 tiles of 128 x 128: the split-bf16 dispatch of linear.py
+    x2 = torch.randn(40000, 128, device=dev, generator=g)
+
+    def run():
+        y = token_linear(x, w2)                                 # [T, 256]
+        a, b = wide[:, :128], wide[:, 128:]
+        z = token_linear(x2, a) + token_linear(x2, b)
+        return y, z
+
+    def check(y, z):
+        assert _rel(y, x.double() @ w2.detach().double().t()) < 3e-6
+        assert _rel(z, x2.double() @ (wide.detach()[:, :128] + wide.detach()[:, 128:]).double().t()) < 3e-6
+
+    y, z = run()
+    check(y, z)
+    ents = [e for e in planes._ENTRIES.values() if e.base() is wide or e.base() is w2]
+    assert len(ents) == 3 and all(e.fwd is not None for e in ents)
+    ptrs = [e.fwd.data_ptr() for e in ents]
+    before = [e.fwd.clone() for e in ents]
+    (y.sum() + z.sum()).backward()
+    opt.step()                                                  # raw-pointer update + in-place refresh
+    assert [e.fwd.data_ptr() for e in ents] == ptrs
+    assert all(not torch.equal(e.fwd, b0) for e, b0 in zip(ents, before))
+    with torch.no_grad():
+        check(*run())
+    with torch.no_grad():
+        w2.copy_(torch.randn(256, 64, device=dev, generator=g) / 8)       # a checkpoint load: version bump -> recomputed at next use
+        check(*run())
+        wide.data.mul_(0.5)                                      # behind torch's back: no version bump ...
+        assert planes.sync([wide]) == 2                          # ... sync rewrites its entries now
+        check(*run())
+    assert [e.fwd.data_ptr() for e in ents] == ptrs

@@ -32,39 +32,53 @@ def regs_of(text):
 
 
 def audit(asm_path):
+    """`pending`: the wave's outstanding vector-memory operations in issue order -- asm loads with their destination registers, everything
+    else (compiler loads / stores, asm stores) as anonymous slots so that a counted `s_waitcnt vmcnt(N)` retires the right ones (all but
+    the N youngest)."""
     lines = open(asm_path).read().splitlines()
-    findings, kernel, in_asm, pending = [], None, False, {}
+    findings, kernel, in_asm, pending = [], None, False, []
+    VM = re.compile(r'(global|buffer|flat|scratch)_(load|store|atomic)')
+
+    def retire(text):
+        nonlocal pending
+        m = re.search(r'vmcnt\((\d+)\)', text)
+        if m:
+            n = int(m.group(1))
+            pending = pending[len(pending) - n:] if n and n < len(pending) else ([] if n == 0 else pending)
+
     for ln, raw in enumerate(lines, 1):
-        l = raw.split(';')[0].strip() if not raw.strip().startswith(';;#') else raw.strip()
+        st = raw.strip()
+        l = st if st.startswith(';;#') else raw.split(';')[0].strip()
         m = re.match(r'^(_Z\S+):', raw)
         if m:
-            kernel, pending, in_asm = m.group(1), {}, False
+            kernel, pending, in_asm = m.group(1), [], False
             continue
-        if raw.strip().startswith(';;#ASMSTART'):
+        if st.startswith(';;#ASMSTART'):
             in_asm = True
             continue
-        if raw.strip().startswith(';;#ASMEND'):
+        if st.startswith(';;#ASMEND'):
             in_asm = False
             continue
         if not l or l.endswith(':') or l.startswith('.'):
             continue
-        if in_asm:
-            if re.match(r'(global|buffer|flat)_load', l) and ' lds' not in l:
-                dst = l.split(None, 1)[1].split(',')[0]
-                for r in regs_of(dst):
-                    pending[r] = ln
-            m = re.match(r's_waitcnt\s+.*vmcnt\((\d+)\)', l)
-            if m and int(m.group(1)) == 0:
-                pending = {}
-            # counted waits (vmcnt(N), N > 0) retire the oldest loads; keeping them pending errs on the side of reporting
-            continue
         if l.startswith('s_endpgm'):
-            pending = {}
+            pending = []
             continue
-        if pending:
-            hit = regs_of(l) & set(pending)
+        if l.startswith('s_waitcnt'):
+            retire(l)
+            continue
+        if in_asm:
+            if VM.match(l):
+                is_load = '_load' in l and ' lds' not in l
+                pending.append((regs_of(l.split(None, 1)[1].split(',')[0]) if is_load else set(), ln))
+            continue
+        live = set().union(*[r for r, _ in pending]) if pending else set()
+        if live:
+            hit = regs_of(l) & live
             if hit:
                 findings.append((kernel, ln, l, sorted(hit)[:4]))
+        if VM.match(l):
+            pending.append((set(), ln))
     return findings
 
 

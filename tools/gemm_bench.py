@@ -87,7 +87,7 @@ def main():
         if a.only and key != a.only:
             continue
         print(f'== {title}, {a.dtype}; us per call; roofline = max(flops/{peak_f / 1e12:.0f} TF, bytes/6.3 TB/s)')
-        print(f'{"shape":<14} {"T":>7} {"K":>5} {"N":>5} {"n":>3} | {"roof":>7} {"lib fwd":>8} {"hip fwd":>8} {"x3 fwd":>8} | {"lib dX":>8} {"hip dX":>8} {"x3 dX":>8}')
+        print(f'{"shape":<14} {"T":>7} {"K":>5} {"N":>5} {"n":>3} | {"roof":>7} {"lib fwd":>8} {"hip fwd":>8} {"x3 fwd":>8} {"pl fwd":>8} | {"lib dX":>8} {"hip dX":>8} {"x3 dX":>8} {"pl dX":>8}   (pl = x3 on pre-split weight planes)')
         s_lib = s_hip = s_roof = s_best = 0.0
         for tag, T, K, N, cnt in shapes:
             x = torch.randn(T, K, device=dev).to(dt)
@@ -99,18 +99,27 @@ def main():
             lib_f = timeit(lambda: F.linear(x, w, b), a.reps)
             hip_f = timeit(lambda: token_gemm.linear_fwd(x, w, b), a.reps) if token_gemm else float('nan')
             x3_f = timeit(lambda: token_gemm.linear_fwd(x, w, b, split_bf16=True), a.reps) if token_gemm and dt == torch.float32 else float('nan')
+            pl_f = pl_b = float('nan')
+            if token_gemm and dt == torch.float32 and K % 32 == 0:
+                from segdistill_amd import planes
+                pf = planes.get(w, 'fwd')
+                pl_f = timeit(lambda: token_gemm.linear_fwd_planes(x, w, pf, b), a.reps)
             lib_b = hip_b = x3_b = float('nan')
             if with_bwd:
                 lib_b = timeit(lambda: dy @ w, a.reps)
                 hip_b = timeit(lambda: token_gemm.linear_bwd_data(dy, w), a.reps) if token_gemm else float('nan')
                 x3_b = timeit(lambda: token_gemm.linear_bwd_data(dy, w, split_bf16=True), a.reps) if token_gemm and dt == torch.float32 else float('nan')
-            print(f'{tag:<14} {T:>7} {K:>5} {N:>5} {cnt:>3} | {roof:7.1f} {lib_f:8.1f} {hip_f:8.1f} {x3_f:8.1f} | {lib_b:8.1f} {hip_b:8.1f} {x3_b:8.1f}')
-            s_best += cnt * (min(lib_f, hip_f, x3_f) + (min(lib_b, hip_b, x3_b) if with_bwd else 0))
+                if token_gemm and dt == torch.float32 and N % 32 == 0:
+                    pb = planes.get(w, 'bwd')
+                    pl_b = timeit(lambda: token_gemm.linear_bwd_data_planes(dy, w, pb), a.reps)
+            print(f'{tag:<14} {T:>7} {K:>5} {N:>5} {cnt:>3} | {roof:7.1f} {lib_f:8.1f} {hip_f:8.1f} {x3_f:8.1f} {pl_f:8.1f} | {lib_b:8.1f} {hip_b:8.1f} {x3_b:8.1f} {pl_b:8.1f}')
+            nn = lambda *v: min(t for t in v if t == t)
+            s_best += cnt * (nn(lib_f, hip_f, x3_f, pl_f) + (nn(lib_b, hip_b, x3_b, pl_b) if with_bwd else 0))
             s_roof += cnt * roof * (2 if with_bwd else 1)
             s_lib += cnt * (lib_f + (lib_b if with_bwd else 0))
             s_hip += cnt * (hip_f + (hip_b if with_bwd else 0))
             del x, w, dy
-        print(f'   sum over the network: roofline(f32 MFMA) {s_roof / 1e3:.3f} ms, library {s_lib / 1e3:.3f} ms, hip f32 {s_hip / 1e3:.3f} ms, best of the three per shape {s_best / 1e3:.3f} ms')
+        print(f'   sum over the network: roofline(f32 MFMA) {s_roof / 1e3:.3f} ms, library {s_lib / 1e3:.3f} ms, hip f32 {s_hip / 1e3:.3f} ms, best per shape {s_best / 1e3:.3f} ms')
         tot[key] = (s_roof, s_lib, s_hip)
 
 
