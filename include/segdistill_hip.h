@@ -520,6 +520,17 @@ int sd_linear_bwd_data_planes(const void *dY, const void *bwd_planes, void *dX, 
                               void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Weight gradient of a token-major nn.Linear for the shapes sd_linear_wgrad's tall-skinny plan does not take (fewer than 8192 tokens, or a
+ * weight of more than 16 regions of 64 x 64: the stage 3-4 Linears of the MiT encoders, mix_transformer.py:24-27,75-84): split-K over the
+ * tokens on the pipelined MFMA kernel (round 3; replaces the library's `dY^T @ X`, which ran these on ~100 workgroups).  fp32 only.
+ *   sd_linear_wgrad_splitk_slabs  number of [out x in] slabs the launch writes (0: shape not supported -- out, in must be multiples of 4)
+ *   sd_linear_wgrad_splitk        slabs[z] = dY[chunk z]^T . X[chunk z]; the caller sums them (sd_multi_slab_reduce), at once or deferred
+ */
+int sd_linear_wgrad_splitk_slabs(long tokens, int out_features, int in_features);
+int sd_linear_wgrad_splitk(const float *dY, const float *X, float *slabs, size_t slabs_bytes, long tokens, int out_features, int in_features,
+                           void *stream);
+
+/* ---------------------------------------------------------------------------
  * A Linear from TOKEN-MAJOR features to contiguous class planes (fp32): the SegFormer head's `linear_pred` 1x1 conv
  * (mmseg/models/decode_heads/segformer_head.py:73,96) on the token-major fused feature map, with the logits landing directly in the
  * [B, out_features, P] planes the loss kernels read (sd_ce_up_*, sd_cgd_kl_up_*) and the gradient read from such planes: no

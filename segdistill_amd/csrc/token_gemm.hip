@@ -1025,4 +1025,47 @@ int sd_linear_bwd_data_planes(const void *dY, const void *bwd_planes, void *dX, 
                                static_cast<hipStream_t>(stream));
 }
 
+/* dW [out x in] = dY^T . X over FEW tokens (< 8192) or a LARGE weight (more than 16 regions of 64 x 64): the products for which
+ * sd_linear_wgrad's direct tall-skinny plan does not apply and the library picks un-split 32 x 32 tiles on ~100 workgroups (63 us for
+ * 1024 x 256 over 2048 tokens against ~7 us of matrix work).  Split-K over the tokens on the pipelined kernel above (A = dY read as [k][m],
+ * B = X as [k][n], split-bf16 arithmetic when the shapes allow whole k-steps, exact f32 MFMA otherwise); the caller combines the slabs
+ * (sd_multi_slab_reduce: deterministic, and deferrable to the end of the backward like every other parameter gradient). */
+static int wgrad_splitk_plan(long tokens, int M, int N, int *klen_out) {
+    if (tokens <= 0 || M <= 0 || N <= 0 || tokens > 0x7fffffffL || M % 4 || N % 4) return 0;
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    // where it pays (tools/wgrad_splitk_bench.py, us library / split-K kernel, MI355X): 8192 tokens 640 x 160: 52 / 36; 2048 tokens 256 x 256:
+    // 14.8 / 9.2, 512 x 256: 15.3 / 10.9, 128 x 64: 18.7 / 9.1 -- but 1024 x 256: 15.7 / 19.3, 32 x 2048: 15.3 / 19.0 (16 tiles x 22 slabs of
+    // two k-steps each: all prologue, and 22 MB of slabs): few tokens AND many tiles stay with the library
+    if (tokens < 8192 && tiles > 8) return 0;
+    long nsplit = (384 + tiles - 1) / tiles;                    // ~1.5 workgroups per CU
+    if (nsplit > tokens / 64) nsplit = tokens / 64;             // at least two k-steps per slab
+    if (nsplit < 1) nsplit = 1;
+    long klen = ((tokens + nsplit - 1) / nsplit + 31) / 32 * 32;
+    nsplit = (tokens + klen - 1) / klen;
+    if (nsplit > 512) return 0;
+    *klen_out = (int)klen;
+    return (int)nsplit;
+}
+
+int sd_linear_wgrad_splitk_slabs(long tokens, int out_features, int in_features) {
+    int klen;
+    return wgrad_splitk_plan(tokens, out_features, in_features, &klen);
+}
+
+int sd_linear_wgrad_splitk(const float *dY, const float *X, float *slabs, size_t slabs_bytes, long tokens, int out_features, int in_features,
+                           void *stream) {
+    if (!dY || !X || !slabs) return SD_E_NULL;
+    int klen = 0;
+    const int nsplit = wgrad_splitk_plan(tokens, out_features, in_features, &klen);
+    if (!nsplit) return SD_E_UNSUPPORTED;
+    const long slab = (long)out_features * in_features;
+    if (slabs_bytes < (size_t)nsplit * slab * sizeof(float) || (reinterpret_cast<uintptr_t>(slabs) & 15)) return SD_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int M = out_features, N = in_features, K = (int)tokens;
+    if (sd::g_align_split_bf16 && K % 32 == 0)
+        return sd::launch_epi<128, 128, 2, 2, false, 0, false, false, true>(dY, X, slabs, nullptr, nullptr, M, N, K, M, N, N, st, 1, 0L, 0L, slab, nsplit,
+                                                                            klen);
+    return sd::launch_epi<128, 128, 2, 2, false, 0, false, false>(dY, X, slabs, nullptr, nullptr, M, N, K, M, N, N, st, 1, 0L, 0L, slab, nsplit, klen);
+}
+
 }  // extern "C"

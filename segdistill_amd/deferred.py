@@ -41,6 +41,13 @@ def add(partials, out, n, nslabs):
     _jobs.append((partials, out, int(n), int(nslabs)))
 
 
+def reduce_now(partials, out, n, nslabs):
+    """out[i] = sum_s partials[s*n + i] at once (one launch of the batched kernel with a single job)."""
+    job = (_Job * 1)()
+    job[0].partials, job[0].out, job[0].n, job[0].nslabs = partials.data_ptr(), out.data_ptr(), int(n), int(nslabs)
+    _lib.check(_lib.lib().sd_multi_slab_reduce(C.cast(job, C.c_void_p), 1, _stream_ptr()), 'sd_multi_slab_reduce')
+
+
 def side_launch(fn, *operands):
     """Inside a scope: run `fn` (kernel launches whose results nobody reads before the scope ends -- weight-gradient partials) on a SIDE
     stream, ordered behind everything enqueued so far on the current stream, so that they overlap the backward's critical chain

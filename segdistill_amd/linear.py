@@ -83,6 +83,7 @@ def _bwd_data(dy2, weight):
 
 
 _SHADOWS = os.environ.get('SEGDISTILL_BF16_SHADOWS', '1') == '1'
+_SPLITK_WGRAD = os.environ.get('SEGDISTILL_SPLITK_WGRAD', '1') == '1'      # A/B: 0 = the library's dY^T @ X for the non-tall-skinny weight gradients
 
 
 def lowp_copy(t, dt):
@@ -147,9 +148,22 @@ class _TokenLinear(torch.autograd.Function):
             L = _lib.lib()
             direct = bool(L.sd_linear_wgrad_fuses_bias_dtype(_DT[x.dtype], T, M, N))
             if not direct and x.dtype == torch.float32:
-                # fewer than 8192 tokens or a weight of more than 16 64x64 regions: no longer tall-skinny, and the library's GEMM beats
-                # the generic split-K kernel 2-2.7x there (tools/wgrad_bench.py: T=8192 640x160 51 vs 107 us, T=4096 512x256 26 vs 67 us)
-                dw = (dyc.t() @ x2).to(ctx.w_dtype)
+                # fewer than 8192 tokens or a weight of more than 16 64x64 regions: no longer tall-skinny.  Round 3: split-K over the tokens
+                # on the pipelined MFMA kernel (sd_linear_wgrad_splitk), slabs combined by the deferred batched pass -- the library ran
+                # these on ~100 workgroups of 32 x 32 tiles (63 us for 1024 x 256 over 2048 tokens; profiles/r03_step_shapes.txt)
+                ns = L.sd_linear_wgrad_splitk_slabs(T, M, N) if _SPLITK_WGRAD and ctx.w_dtype == torch.float32 else 0
+                if ns:
+                    ws = torch.empty(ns, M * N, dtype=torch.float32, device=x.device)
+                    _lib.check(L.sd_linear_wgrad_splitk(dyc.data_ptr(), x2.data_ptr(), ws.data_ptr(), ws.numel() * 4, T, M, N, _stream_ptr()),
+                               'sd_linear_wgrad_splitk')
+                    buf = torch.empty(M * N, dtype=torch.float32, device=x.device)
+                    if ctx.defer_ok and deferred.enabled():
+                        deferred.add(ws, buf, M * N, ns)
+                    else:
+                        deferred.reduce_now(ws, buf, M * N, ns)
+                    dw = buf.view(M, N)
+                else:
+                    dw = (dyc.t() @ x2).to(ctx.w_dtype)
                 db = deferred.column_sum(dyc, ctx.defer_bias_ok and ctx.w_dtype == torch.float32).to(ctx.w_dtype) if want_db else None
                 return dx, dw, db, None, None
             fuse_b = want_db and direct

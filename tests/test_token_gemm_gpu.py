@@ -296,3 +296,57 @@ def test_planes_follow_the_weight_through_optimizer_steps_checkpoint_loads_and_v
         assert planes.sync([wide]) == 2                          # ... sync rewrites its entries now
         check(*run())
     assert [e.fwd.data_ptr() for e in ents] == ptrs
+
+
+@pytest.mark.parametrize('T,M,N', [(2048, 512, 256), (2048, 256, 512), (8192, 640, 160), (2048, 64, 1024), (2048, 64, 32), (4000, 160, 320),
+                                   (1000, 20, 36), (96, 256, 256), (8192, 160, 640), (8192, 1024, 256)])
+def test_splitk_weight_gradient_matches_fp64(T, M, N):
+    """sd_linear_wgrad_splitk (round 3): dW = dY^T . X for few tokens / large weights, split-K slabs + the batched combine; both arithmetic
+    modes (split-bf16 when tokens % 32 == 0, exact f32 MFMA otherwise); error bound of a T-term fp32 dot product."""
+    import ctypes as C
+    from segdistill_amd import _lib, deferred
+    from segdistill_amd.ops import _stream_ptr
+    L = _lib.lib()
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(T + M + N)
+    dy = torch.randn(T, M, device=dev, generator=g)
+    x = torch.randn(T, N, device=dev, generator=g)
+    ref = dy.double().t() @ x.double()
+    ns = L.sd_linear_wgrad_splitk_slabs(T, M, N)
+    assert ns >= 1
+    for split in (1, 0):
+        _lib.set_tunable('align_split_bf16', split)
+        try:
+            ws = torch.full((ns, M * N), float('nan'), device=dev)
+            _lib.check(L.sd_linear_wgrad_splitk(dy.data_ptr(), x.data_ptr(), ws.data_ptr(), ws.numel() * 4, T, M, N, _stream_ptr()), 'splitk')
+        finally:
+            _lib.set_tunable('align_split_bf16', 1)
+        out = torch.empty(M * N, device=dev)
+        deferred.reduce_now(ws, out, M * N, ns)
+        assert _rel(out.view(M, N), ref) < 3e-7 * max(8.0, T ** 0.5), (split, ns)
+    assert L.sd_linear_wgrad_splitk_slabs(T, M + 1, N) == 0 and L.sd_linear_wgrad_splitk(dy.data_ptr(), x.data_ptr(), ws.data_ptr(), 16, T, M, N, None) != 0
+    assert L.sd_linear_wgrad_splitk_slabs(2048, 1024, 256) == 0        # few tokens and 16 tiles: the library's turf (measured)
+
+
+def test_token_linear_few_tokens_takes_the_splitk_weight_gradient():
+    """The autograd op at a stage-4 shape (2048 tokens, 256 -> 512 with bias): the weight gradient goes through sd_linear_wgrad_splitk --
+    immediately outside a deferred scope, through the batched combine inside one -- and matches fp64."""
+    from segdistill_amd import deferred
+    from segdistill_amd.linear import token_linear
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn(8, 256, 256, device=dev, generator=g, requires_grad=True)
+    w = (torch.randn(512, 256, device=dev, generator=g) / 16).requires_grad_(True)
+    b = torch.randn(512, device=dev, generator=g).requires_grad_(True)
+    up = torch.randn(8, 256, 512, device=dev, generator=g)
+    x64, w64, b64 = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    torch.nn.functional.linear(x64, w64, b64).backward(up.double())
+    for scoped in (False, True):
+        x.grad = w.grad = b.grad = None
+        y = token_linear(x, w, b, defer_ok=True)
+        if scoped:
+            with deferred.scope():
+                y.backward(up)
+        else:
+            y.backward(up)
+        assert _rel(w.grad, w64.grad) < 3e-5 and _rel(b.grad, b64.grad) < 3e-5 and _rel(x.grad, x64.grad) < 3e-6, scoped
