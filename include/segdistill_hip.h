@@ -511,8 +511,15 @@ typedef struct sd_presplit_job {
     int out_features, in_features;
     void *fwd_planes;
     void *bwd_planes;
+    void *row_planes;   /* [3][out_features][in_features] bf16, row-major: the A operand of sd_linear_nchw_fwd_planes (in_features % 8 == 0) */
 } sd_presplit_job;
 size_t sd_presplit_bytes(int n_cols, int k_depth);
+size_t sd_presplit_rows_bytes(int out_features, int in_features);
+/* sd_linear_nchw_fwd with the weight's pre-split row planes (fp32 storage, out_features <= 160, in_features % 32 == 0): the class-plane
+ * linear_pred of the SegFormer head (segformer_head.py:73,96) whose 160-row tile needs every weight row in every wave -- its A fragments become
+ * plain LDS reads of the planes instead of 5/6 of the kernel's split arithmetic. */
+int sd_linear_nchw_fwd_planes(const void *X, const void *w_row_planes, const float *bias, void *Y, int dtype, int B, long P, int in_features,
+                              int out_features, void *stream);
 int sd_presplit_multi(const sd_presplit_job *jobs, int njobs, void *stream);
 int sd_linear_fwd_planes(const void *X, const void *fwd_planes, const float *bias, const void *residual, void *Y, int dtype, long tokens,
                          int in_features, int out_features, void *stream);

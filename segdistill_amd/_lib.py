@@ -63,6 +63,8 @@ SIGNATURES = {
     'sd_linear_bwd_data': (_i, [_vp, _vp, C.c_long, _vp, _i, C.c_long, _i, _i, _i, _vp]),
     'sd_presplit_bytes': (_sz, [_i, _i]),
     'sd_presplit_multi': (_i, [_vp, _i, _vp]),
+    'sd_presplit_rows_bytes': (_sz, [_i, _i]),
+    'sd_linear_nchw_fwd_planes': (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_long, _i, _i, _vp]),
     'sd_linear_fwd_planes': (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_long, _i, _i, _vp]),
     'sd_linear_bwd_data_planes': (_i, [_vp, _vp, _vp, _i, C.c_long, _i, _i, _vp]),
     'sd_linear_wgrad_splitk_slabs': (_i, [C.c_long, _i, _i]),

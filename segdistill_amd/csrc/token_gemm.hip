@@ -131,16 +131,22 @@ __device__ __forceinline__ void store_ntile(const NTile<COLS> &f, float *dst /* 
 // presplit_planes below (one 1 KB run per (32-column block, 16-deep k-step, plane): lane l's 16 bytes ARE its MFMA B fragment) -- and is
 // loaded straight from global memory / L2 into registers, one k16 step ahead: no LDS for B, no split arithmetic for B.  `Bm` is then the
 // planes buffer and `ldb` its number of 32-column blocks.
+// APL (round 3; X3 + FULLK + AKC + BT only): the A operand arrives PRE-SPLIT as three ROW-MAJOR bf16 planes [plane][M][K] (presplit_planes, dir 2)
+// and is staged through LDS as planes (rows of 32 k = 64 bytes, pitch 80: conflict-free ds_read_b128), so its MFMA fragments are plain 16-byte LDS
+// reads -- for a tile whose every wave needs ALL of A's rows (the 160-class-row tile of linear_pred: five row blocks per wave) this removes 5/6 of
+// the split arithmetic, which was 2040 vector-issue cycles per k-step against 1920 of matrix work.  `A` is then the planes buffer.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, bool VEC, bool FULLK, int EPI, bool AKC = true, bool BIAS_ROW = false, bool X3 = false,
-          bool BFRAG = false>
+          bool BFRAG = false, bool APL = false>
 __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ A, const float *__restrict__ Bm, float *__restrict__ C,
                                                        const float *__restrict__ bias, const float *__restrict__ residual, long M, int N, int K,
                                                        long lda, long ldb, long ldc, int tiles_n, int vec_out, long sA, long sB, long sC,
                                                        int nsplit, int klen) {
     static_assert(WAVES_M * WAVES_N == 4, "four waves");
     constexpr int TM = BM / (32 * WAVES_M), TN = BN / (32 * WAVES_N);
-    constexpr int A_ELEMS = AKC ? BM * KP : BK * (BM + 4);
+    constexpr int APITCH = 20;                                   // APL: one plane row = 32 bf16 + 16 bytes of pad = 20 floats
+    constexpr int A_ELEMS = APL ? 3 * BM * APITCH : (AKC ? BM * KP : BK * (BM + 4));
     constexpr int B_ELEMS = BFRAG ? 0 : (BT ? BN * KP : BK * (BN + 4));
+    static_assert(!APL || (X3 && FULLK && VEC && AKC && BT && !BFRAG), "pre-split A planes: split-bf16 mode, whole k-steps, k-contiguous operands");
     static_assert(!BFRAG || (X3 && FULLK && VEC && AKC), "pre-split B planes: split-bf16 mode, whole k-steps, k-contiguous A");
     extern __shared__ __attribute__((aligned(16))) float lds[];        // [2][A_ELEMS + B_ELEMS]
     // z = batch * nsplit + split: a split covers k in [split * klen, min(K, (split + 1) * klen)) and writes its own C slab (split-K)
@@ -184,15 +190,35 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
     KTile<BN> fbt;
     NTile<BN> fbn;
     const int nk = (K + BK - 1) / BK;
+    // APL staging: 3 planes x BM rows x 4 chunks of 16 bytes per k-step; chunk q -> (plane, row, c); the surplus threads of the last round
+    // repeat the last chunk (same address, same data: no branch)
+    constexpr int NAPL = APL ? (3 * BM * 4 + 255) / 256 : 1;
+    f32x4 fap[NAPL];
     auto load_tiles = [&](int k0, bool live = true) {
-        if (AKC) load_ktile<BM, VEC, FULLK>(fa, A, lda, m0, M, k0, K, live);
+        if constexpr (APL) {
+#pragma unroll
+            for (int i = 0; i < NAPL; ++i) {
+                const int q = min((int)threadIdx.x + 256 * i, 3 * BM * 4 - 1);
+                const int pl = q / (BM * 4), rem = q - pl * (BM * 4), row = rem >> 2, c = rem & 3;
+                const long gr = min(m0 + row, M - 1);
+                const char *src = reinterpret_cast<const char *>(A) + (((long)pl * M + gr) * K + k0) * 2 + c * 16;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fap[i]) : "v"(src) : "memory");
+            }
+        } else if (AKC) load_ktile<BM, VEC, FULLK>(fa, A, lda, m0, M, k0, K, live);
         else load_ntile<BM, VEC, FULLK>(fan, A, lda, (int)m0, (int)M, k0, K);
         if (BFRAG) return;
         if (BT) load_ktile<BN, VEC, FULLK>(fbt, Bm, ldb, n0, N, k0, K);
         else load_ntile<BN, VEC, FULLK>(fbn, Bm, ldb, n0, N, k0, K);
     };
     auto store_tiles = [&](float *buf) {
-        if (AKC) store_ktile<BM>(fa, buf);
+        if constexpr (APL) {
+#pragma unroll
+            for (int i = 0; i < NAPL; ++i) {
+                const int q = min((int)threadIdx.x + 256 * i, 3 * BM * 4 - 1);
+                const int pl = q / (BM * 4), rem = q - pl * (BM * 4), row = rem >> 2, c = rem & 3;
+                *reinterpret_cast<f32x4 *>(buf + (pl * BM + row) * APITCH + c * 4) = fap[i];
+            }
+        } else if (AKC) store_ktile<BM>(fa, buf);
         else store_ntile<BM>(fan, buf);
         if (BFRAG) return;
         if (BT) store_ktile<BN>(fbt, buf + A_ELEMS);
@@ -374,6 +400,109 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
             __builtin_amdgcn_sched_barrier(0);
             wait_vm(std::integral_constant<int, 0>{});
             mfma_planes(PA1, B1);
+            __syncthreads();
+        }
+    } else if constexpr (APL) {
+        // ---- split-bf16 products, A from pre-split LDS planes, B (fp32 in LDS) split in registers --------------------------------------------
+        struct Pl { bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN]; };
+        auto split8 = [&](const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 v = {x[e], x[e + 1]};
+                const bf16x2 hh = __builtin_convertvector(v, bf16x2);
+                const f32x2 r1 = v - __builtin_convertvector(hh, f32x2);
+                const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
+                const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
+                const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
+                h[e] = hh[0], h[e + 1] = hh[1], m[e] = mm[0], m[e + 1] = mm[1], l[e] = ll[0], l[e + 1] = ll[1];
+            }
+        };
+        auto fetch = [&](Pl &P, const float *As, const float *Bs, int s2) {       // k = 16 s2 + 8 kh .. + 7 for both operands
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float *q = As + (wm + 32 * i + r) * APITCH + 8 * s2 + 4 * kh;
+                P.ah[i] = *reinterpret_cast<const bf16x8 *>(q);
+                P.am[i] = *reinterpret_cast<const bf16x8 *>(q + BM * APITCH);
+                P.al[i] = *reinterpret_cast<const bf16x8 *>(q + 2 * BM * APITCH);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float *q = Bs + (wn + 32 * j + r) * KP + 16 * s2 + 8 * kh;
+                const float4 v0 = *reinterpret_cast<const float4 *>(q), v1 = *reinterpret_cast<const float4 *>(q + 4);
+                const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                split8(x, P.bh[j], P.bm[j], P.bl[j]);
+            }
+        };
+        auto mfma_planes = [&](const Pl &P) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.am[i], P.bm[j], c, 0, 0, 0);      // small terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.al[i], P.bh[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.ah[i], P.bl[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.am[i], P.bh[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.ah[i], P.bm[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.ah[i], P.bh[j], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        };
+        // One workgroup per CU (113 KB of LDS) = one wave per SIMD: nobody covers a wait, so the tile of step kt+2 is requested as soon as the
+        // staging registers are free (right after tile kt+1 went to LDS) and has a whole k-step -- 60 MFMAs, ~0.9 us -- to arrive; requested at
+        // the top of its own step (round-2 order) it had half of that and every k-step stalled on HBM latency (250 -> see profiles/).
+        auto keep_alive = [&]() {      // pending requests whose values nobody reads are dead to the compiler: pin their registers up to the wait
+#pragma unroll
+            for (int i = 0; i < NAPL; ++i) asm volatile("" ::"v"(fap[i]));
+#pragma unroll
+            for (int i = 0; i < BN / 32; ++i) asm volatile("" ::"v"(fbt.v[i].x), "v"(fbt.v[i].y), "v"(fbt.v[i].z), "v"(fbt.v[i].w));
+        };
+        Pl P0, P1;
+        if (nk > 1) load_tiles(BK);
+        fetch(P0, lds, lds + A_ELEMS, 0);
+        // staging instructions of one k-step per thread: LDS stores, then the global requests of the tile after next
+        constexpr int NST = NAPL + BN / 32;
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            const float *cur = lds + (kt & 1) * (A_ELEMS + B_ELEMS);
+            float *nxt = lds + ((kt + 1) & 1) * (A_ELEMS + B_ELEMS);
+            wait_loads();                               // tile kt+1 has had a whole k-step to land
+            // ONE scheduling region: the MFMAs on the current planes with, in their gaps, the fragment reads + split of the next planes, the LDS
+            // stores of tile kt+1 and the requests of tile kt+2 -- a wave alone on its SIMD cannot afford a phase in which the matrix pipe waits
+            // for its stores and requests (that phase structure ran at 39 % of the matrix-pipe time)
+            fetch(P1, cur, cur + A_ELEMS, 1);
+            mfma_planes(P0);
+            store_tiles(nxt);
+            load_tiles(min(kt + 2, nk - 1) * BK);       // past the end: a repeat of the last tile (1 / nk of the traffic), dropped below
+            __builtin_amdgcn_sched_group_barrier(0x100, 3 * TM + 2 * TN, 0);
+#pragma unroll
+            for (int q = 0; q < 6 * TM * TN; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (q < NST) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                else if (q < 2 * NST) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            fetch(P0, nxt, nxt + A_ELEMS, 0);
+            mfma_planes(P1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3 * TM + 2 * TN, 0);
+#pragma unroll
+            for (int q = 0; q < 6 * TM * TN; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            const float *cur = lds + ((nk - 1) & 1) * (A_ELEMS + B_ELEMS);
+            fetch(P1, cur, cur + A_ELEMS, 1);
+            mfma_planes(P0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (nk > 1) {
+                wait_loads();
+                keep_alive();
+            }
+            mfma_planes(P1);
             __syncthreads();
         }
     } else if constexpr (X3) {
@@ -577,7 +706,8 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, int EPI, bool AKC = true, bool BIAS_ROW = false, bool X3 = false, bool BFRAG = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool BT, int EPI, bool AKC = true, bool BIAS_ROW = false, bool X3 = false, bool BFRAG = false,
+          bool APL = false>
 int launch_epi(const float *A, const float *Bm, float *C, const float *bias, const float *residual, long M, int N, int K, long lda, long ldb,
                long ldc, hipStream_t st, int batch = 1, long sA = 0, long sB = 0, long sC = 0, int nsplit = 1, int klen = 0) {
     if (klen <= 0 || nsplit <= 1) { nsplit = 1; klen = K; }
@@ -586,7 +716,7 @@ int launch_epi(const float *A, const float *Bm, float *C, const float *bias, con
     // The row-major epilogue parks 4 waves x 32 rows x (TN*32 + 4) floats in the same LDS: with ONE staging buffer of two [k][m] / [k][n]
     // operands (bwd-data of the class-plane Linear with <= 32 classes: 33792 B) that image (34816 B) is the larger of the two.
     constexpr size_t epi_bytes = (size_t)4 * 32 * ((BN / (32 * WAVES_N)) * 32 + 4) * sizeof(float);
-    const size_t stage_bytes = (klen > BK ? 2 : 1) * (size_t)((AKC ? BM * KP : BK * (BM + 4)) + (BFRAG ? 0 : (BT ? BN * KP : BK * (BN + 4)))) * sizeof(float);
+    const size_t stage_bytes = (klen > BK ? 2 : 1) * (size_t)((APL ? 3 * BM * 20 : (AKC ? BM * KP : BK * (BM + 4))) + (BFRAG ? 0 : (BT ? BN * KP : BK * (BN + 4)))) * sizeof(float);
     const size_t lds_bytes = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
     const long tiles_m = (M + BM - 1) / BM;
     const int tiles_n = (N + BN - 1) / BN;
@@ -619,9 +749,18 @@ int launch_epi(const float *A, const float *Bm, float *C, const float *bias, con
         return (int)hipGetLastError();
     }
     else {
-    auto kern = fullk ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, true, EPI, AKC, BIAS_ROW, X3>
-                      : (vec ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, false, EPI, AKC, BIAS_ROW, X3>
-                             : token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, false, false, EPI, AKC, BIAS_ROW, X3>);
+    // (pre-split A planes: the B operand alone decides the alignment; the caller guarantees whole k-steps and no split-K)
+    if (APL && !((reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Bm) & 15) == 0 && ldb % 4 == 0 && sB % 4 == 0 && K % BK == 0 &&
+                 nsplit == 1 && sA == 0))
+        return SD_E_UNSUPPORTED;
+    auto pick = [&]() {
+        if constexpr (APL) return token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, true, EPI, AKC, BIAS_ROW, X3, false, true>;
+        else
+            return fullk ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, true, EPI, AKC, BIAS_ROW, X3>
+                         : (vec ? token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, true, false, EPI, AKC, BIAS_ROW, X3>
+                                : token_gemm_f32<BM, BN, WAVES_M, WAVES_N, BT, false, false, EPI, AKC, BIAS_ROW, X3>);
+    };
+    auto kern = pick();
     if (lds_bytes > 64 * 1024) {
         static bool raised[3] = {false, false, false};   // per instantiation (this function template) and load flavour; idempotent, so a race is harmless
         const int flavour = fullk ? 2 : (vec ? 1 : 0);
@@ -690,6 +829,29 @@ __global__ __launch_bounds__(256) void presplit_planes(const PresplitTable t) {
         else hi = mid - 1;
     }
     const int j = lo;
+    if (t.dir[j] == 2) {
+        // ROW-MAJOR planes [plane][Nd rows][Kd] of W [Nd][ldw]: the A operand of the APL kernels (staged through LDS as plain 2-D tiles)
+        const int kc = t.Kd[j] / 8;
+        const long g = (long)((int)blockIdx.x - t.blk_begin[j]) * 256 + threadIdx.x;
+        if (g >= (long)t.Nd[j] * kc) return;
+        const int row = (int)(g / kc), c8 = (int)(g - (long)row * kc);
+        const float *src = t.W[j] + (long)row * t.ldw[j] + 8 * c8;
+        bf16x8 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = src[e];
+            const __bf16 hh = static_cast<__bf16>(x);
+            const float r1 = x - static_cast<float>(hh);
+            const __bf16 mm = static_cast<__bf16>(r1);
+            h[e] = hh, m[e] = mm, l[e] = static_cast<__bf16>(r1 - static_cast<float>(mm));
+        }
+        const size_t plane = (size_t)t.Nd[j] * t.Kd[j];
+        uint16_t *dst = t.out[j] + (size_t)row * t.Kd[j] + 8 * c8;
+        *reinterpret_cast<bf16x8 *>(dst) = h;
+        *reinterpret_cast<bf16x8 *>(dst + plane) = m;
+        *reinterpret_cast<bf16x8 *>(dst + 2 * plane) = l;
+        return;
+    }
     const int KS = t.Kd[j] / 16, NBk = (t.Nd[j] + 31) / 32;
     const long f = (long)((int)blockIdx.x - t.blk_begin[j]) * 4 + (threadIdx.x >> 6);      // fragment = (nb, ks)
     if (f >= (long)NBk * KS) return;
@@ -877,6 +1039,18 @@ int linear_nchw_f32_fwd(const float *X, const float *W, const float *bias, float
                                                                0L, sB, sC);
 }
 
+// the same forward with W given as pre-split ROW-MAJOR planes (sd_presplit_multi, row_planes): the 160-row tile, A fragments from LDS planes
+int linear_nchw_f32_fwd_planes(const float *X, const void *w_row_planes, const float *bias, float *Y, int B, long P, int in_features, int out_features,
+                               void *stream) {
+    if (!X || !w_row_planes || !Y) return SD_E_NULL;
+    if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0 || B > 65535) return SD_E_SHAPE;
+    if (in_features % 32 || out_features > 160) return SD_E_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long sB = P * in_features, sC = P * out_features;
+    return launch_epi<160, 128, 1, 4, true, 0, true, true, true, false, true>(static_cast<const float *>(w_row_planes), X, Y, bias, nullptr, out_features, (int)P,
+                                                                                  in_features, in_features, in_features, P, st, B, 0L, sB, sC);
+}
+
 int linear_nchw_f32_bwd_data(const float *dY, const float *W, float *dX, int B, long P, int in_features, int out_features, void *stream) {
     if (!dY || !W || !dX) return SD_E_NULL;
     if (B <= 0 || P <= 0 || in_features <= 0 || out_features <= 0 || B > 65535) return SD_E_SHAPE;
@@ -979,13 +1153,23 @@ int sd_presplit_multi(const sd_presplit_job *jobs, int njobs, void *stream) {
     };
     for (int q = 0; q < njobs; ++q) {
         const sd_presplit_job &jb = jobs[q];
-        if (!jb.W || (!jb.fwd_planes && !jb.bwd_planes)) return SD_E_NULL;
+        if (!jb.W || (!jb.fwd_planes && !jb.bwd_planes && !jb.row_planes)) return SD_E_NULL;
         if (jb.out_features <= 0 || jb.in_features <= 0 || jb.w_row_stride < jb.in_features) return SD_E_SHAPE;
-        if ((reinterpret_cast<uintptr_t>(jb.fwd_planes) | reinterpret_cast<uintptr_t>(jb.bwd_planes)) & 15) return SD_E_ALIGN;
-        for (int dir = 1; dir >= 0; --dir) {
-            void *out = dir ? jb.fwd_planes : jb.bwd_planes;
+        if ((reinterpret_cast<uintptr_t>(jb.fwd_planes) | reinterpret_cast<uintptr_t>(jb.bwd_planes) | reinterpret_cast<uintptr_t>(jb.row_planes)) & 15)
+            return SD_E_ALIGN;
+        for (int dir = 2; dir >= 0; --dir) {
+            void *out = dir == 2 ? jb.row_planes : (dir ? jb.fwd_planes : jb.bwd_planes);
             if (!out) continue;
             const int Nd = dir ? jb.out_features : jb.in_features, Kd = dir ? jb.in_features : jb.out_features;
+            if (dir == 2) {
+                if (Kd % 8 || (reinterpret_cast<uintptr_t>(jb.W) & 3)) return SD_E_UNSUPPORTED;
+                if (cnt == sd::kMaxPresplit) flush();
+                t.W[cnt] = jb.W; t.out[cnt] = static_cast<uint16_t *>(out); t.ldw[cnt] = (int)jb.w_row_stride;
+                t.Nd[cnt] = Nd; t.Kd[cnt] = Kd; t.dir[cnt] = 2; t.blk_begin[cnt] = (int)blocks;
+                blocks += ((long)Nd * (Kd / 8) + 255) / 256;
+                ++cnt;
+                continue;
+            }
             if (Kd % 16) return SD_E_UNSUPPORTED;
             if (cnt == sd::kMaxPresplit) flush();
             t.W[cnt] = jb.W;
@@ -1002,6 +1186,17 @@ int sd_presplit_multi(const sd_presplit_job *jobs, int njobs, void *stream) {
     }
     flush();
     return (int)hipGetLastError();
+}
+
+size_t sd_presplit_rows_bytes(int out_features, int in_features) {
+    if (out_features <= 0 || in_features <= 0 || in_features % 8) return 0;
+    return (size_t)out_features * in_features * 3 * 2;
+}
+
+int sd_linear_nchw_fwd_planes(const void *X, const void *w_row_planes, const float *bias, void *Y, int dtype, int B, long P, int in_features,
+                              int out_features, void *stream) {
+    if (dtype != SD_F32) return SD_E_DTYPE;
+    return sd::linear_nchw_f32_fwd_planes((const float *)X, w_row_planes, bias, (float *)Y, B, P, in_features, out_features, stream);
 }
 
 int sd_linear_fwd_planes(const void *X, const void *fwd_planes, const float *bias, const void *residual, void *Y, int dtype, long tokens,

@@ -83,6 +83,7 @@ def _bwd_data(dy2, weight):
 
 
 _SHADOWS = os.environ.get('SEGDISTILL_BF16_SHADOWS', '1') == '1'
+_PRED_PLANES_A = os.environ.get('SEGDISTILL_PRED_PLANES_A', '1') == '1'    # A/B: 0 = linear_pred's forward splits W in registers (round 2)
 _SPLITK_WGRAD = os.environ.get('SEGDISTILL_SPLITK_WGRAD', '1') == '1'      # A/B: 0 = the library's dY^T @ X for the non-tall-skinny weight gradients
 
 
@@ -266,8 +267,16 @@ class _LinearToPlanes(torch.autograd.Function):
         L = _lib.lib()
         y = torch.empty(B, N, P, dtype=x.dtype, device=x.device)
         b = None if bias is None else bias.detach().float().contiguous()
-        _lib.check(L.sd_linear_nchw_fwd(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), _DT[x.dtype], B, P, K, N,
-                                        _stream_ptr()), 'sd_linear_nchw_fwd')
+        if (x.dtype == torch.float32 and _SPLIT_BF16 and _PRED_PLANES_A and N <= 160 and K % 32 == 0 and planes.supported(weight) and weight.is_contiguous()
+                and L.sd_get_tunable(b'align_split_bf16') == 1):
+            # the weight's row-major bf16 planes, split once per optimizer step (never, for the frozen teacher): every wave of the 160-row tile
+            # needs all class rows, so splitting W in registers was 5/6 of the kernel's vector work (290 -> see profiles/r03_kernels.txt)
+            pr = planes.get(weight, 'rows')
+            _lib.check(L.sd_linear_nchw_fwd_planes(x.data_ptr(), pr.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), _DT[x.dtype], B, P, K, N,
+                                                   _stream_ptr()), 'sd_linear_nchw_fwd_planes')
+        else:
+            _lib.check(L.sd_linear_nchw_fwd(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), _DT[x.dtype], B, P, K, N,
+                                            _stream_ptr()), 'sd_linear_nchw_fwd')
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         return y

@@ -28,16 +28,17 @@ ENABLED = os.environ.get('SEGDISTILL_PRESPLIT', '1') == '1'
 
 class _Job(C.Structure):
     _fields_ = [('W', C.c_void_p), ('w_row_stride', C.c_long), ('out_features', C.c_int), ('in_features', C.c_int), ('fwd_planes', C.c_void_p),
-                ('bwd_planes', C.c_void_p)]
+                ('bwd_planes', C.c_void_p), ('row_planes', C.c_void_p)]
 
 
 class Entry:
-    __slots__ = ('base', 'key', 'w_ptr', 'ldw', 'out', 'inp', 'fwd', 'bwd', 'version', '__weakref__')
+    __slots__ = ('base', 'key', 'w_ptr', 'ldw', 'out', 'inp', 'fwd', 'bwd', 'rows', 'version', '__weakref__')
 
     def fill(self, job):
         job.W, job.w_row_stride, job.out_features, job.in_features = self.w_ptr, self.ldw, self.out, self.inp
         job.fwd_planes = None if self.fwd is None else self.fwd.data_ptr()
         job.bwd_planes = None if self.bwd is None else self.bwd.data_ptr()
+        job.row_planes = None if self.rows is None else self.rows.data_ptr()
 
 
 _ENTRIES = {}      # key -> Entry (trainable weights)
@@ -55,6 +56,13 @@ def _launch(entries):
     for j, e in zip(arr, entries):
         e.fill(j)
     _lib.check(_lib.lib().sd_presplit_multi(C.cast(arr, C.c_void_p), len(entries), _stream_ptr()), 'sd_presplit_multi')
+
+
+def _alloc_rows(out, inp, device):
+    nbytes = _lib.lib().sd_presplit_rows_bytes(int(out), int(inp))
+    if nbytes == 0:
+        raise ValueError(f'row planes need in_features % 8 == 0 (got {inp})')
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
 def _alloc(n_cols, k_depth, device):
@@ -77,8 +85,9 @@ def _drop(key, base_id):
 
 
 def get(weight, direction):
-    """-> the uint8 planes tensor of `weight` [out, in] for direction 'fwd' (y = x . W^T, reduction over in) or 'bwd' (dx = dy . W, reduction
-    over out), fresh for the weight's current values."""
+    """-> the uint8 planes tensor of `weight` [out, in] for direction 'fwd' (y = x . W^T, reduction over in), 'bwd' (dx = dy . W, reduction
+    over out) -- both in fragment order -- or 'rows' (row-major planes [3][out][in]: the weight as the LDS-staged A operand of
+    sd_linear_nchw_fwd_planes), fresh for the weight's current values."""
     global _GEN
     out, inp = weight.shape
     if not weight.requires_grad:
@@ -89,8 +98,9 @@ def get(weight, direction):
             e.w_ptr, e.ldw, e.out, e.inp = weight.data_ptr(), weight.stride(0), out, inp
             e.fwd = _alloc(out, inp, weight.device) if direction == 'fwd' else None
             e.bwd = _alloc(inp, out, weight.device) if direction == 'bwd' else None
+            e.rows = _alloc_rows(out, inp, weight.device) if direction == 'rows' else None
             _launch([e])
-            return e.fwd if direction == 'fwd' else e.bwd
+            return getattr(e, direction)
         root = weight._base if weight._base is not None else weight        # a view object may be new on every call: cache on its base
         return frozen_derived(root, ('planes', direction, weight.data_ptr(), out, inp, weight.stride(0)), make)
     base = weight._base if weight._base is not None else weight
@@ -102,20 +112,23 @@ def get(weight, direction):
     if e is None:
         e = Entry()
         e.base = weakref.ref(base, lambda _, k=key, b=id(base): _drop(k, b))
-        e.key, e.w_ptr, e.ldw, e.out, e.inp, e.fwd, e.bwd, e.version = key, weight.data_ptr(), weight.stride(0), out, inp, None, None, None
+        e.key, e.w_ptr, e.ldw, e.out, e.inp, e.fwd, e.bwd, e.rows, e.version = key, weight.data_ptr(), weight.stride(0), out, inp, None, None, None, None
         _ENTRIES[key] = e
         _BY_BASE.setdefault(id(base), []).append(e)
         _GEN += 1
-    want = e.fwd if direction == 'fwd' else e.bwd
+    want = getattr(e, direction)
     if want is None:
-        # both directions of a trainable weight are written together (one launch now, one launch per step from the optimizer)
-        if inp % 16 == 0 and e.fwd is None:
-            e.fwd = _alloc(out, inp, weight.device)
-        if out % 16 == 0 and e.bwd is None:
-            e.bwd = _alloc(inp, out, weight.device)
+        if direction == 'rows':
+            e.rows = _alloc_rows(out, inp, weight.device)
+        else:
+            # both fragment-order directions of a trainable weight are written together (one launch now, one per step from the optimizer)
+            if inp % 16 == 0 and e.fwd is None:
+                e.fwd = _alloc(out, inp, weight.device)
+            if out % 16 == 0 and e.bwd is None:
+                e.bwd = _alloc(inp, out, weight.device)
         e.version = None
         _GEN += 1
-        want = e.fwd if direction == 'fwd' else e.bwd
+        want = getattr(e, direction)
         if want is None:
             raise ValueError(f'no {direction} planes for a weight of shape {tuple(weight.shape)}')
     if e.version != weight._version:
@@ -134,7 +147,7 @@ def sync(params=None):
     """Recompute NOW, in place, the planes of `params` (all when None) and mark them fresh -- for code that has just changed weights behind a
     captured graph's back (KDTrainer.load_state_dict after enable_graph: a replay runs no Python forward that could notice the stale version)."""
     ents = list(_ENTRIES.values()) if params is None else [e for p in params for e in _BY_BASE.get(id(p), ())]
-    ents = [e for e in ents if e.base() is not None and (e.fwd is not None or e.bwd is not None)]
+    ents = [e for e in ents if e.base() is not None and (e.fwd is not None or e.bwd is not None or e.rows is not None)]
     if ents:
         _launch(ents)
         for e in ents:
@@ -155,7 +168,7 @@ class Refresher:
             return 0
         ids = tuple(id(p) for p in params)
         if self._gen != _GEN or self._ids != ids:
-            ents = [e for pid in ids for e in _BY_BASE.get(pid, ()) if e.base() is not None and (e.fwd is not None or e.bwd is not None)]
+            ents = [e for pid in ids for e in _BY_BASE.get(pid, ()) if e.base() is not None and (e.fwd is not None or e.bwd is not None or e.rows is not None)]
             # entries that are STALE by the shared rule stay stale (their next forward recomputes them); fresh ones are kept fresh
             self._ents = ents
             self._arr = (_Job * max(1, len(ents)))()

@@ -350,3 +350,29 @@ def test_token_linear_few_tokens_takes_the_splitk_weight_gradient():
         else:
             y.backward(up)
         assert _rel(w.grad, w64.grad) < 3e-5 and _rel(b.grad, b64.grad) < 3e-5 and _rel(x.grad, x64.grad) < 3e-6, scoped
+
+
+@pytest.mark.parametrize('case', [(2, 1024, 256, 150), (1, 4096, 64, 19), (8, 16384, 768, 150), (3, 260, 32, 150), (2, 512, 96, 160), (1, 384, 128, 33)])
+def test_linear_to_planes_forward_on_row_planes(case):
+    """sd_linear_nchw_fwd_planes (round 3): W as pre-split row-major planes staged through LDS; against fp64 and against the round-2 forward
+    (same six products per term: both within the split-mode bound), class counts that are not a multiple of 32, ragged pixel counts."""
+    from segdistill_amd import _lib, planes
+    from segdistill_amd.ops import _stream_ptr
+    B, P, K, N = case
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(P + K + N)
+    x = torch.randn(B, P, K, device=dev, generator=g)
+    w = torch.randn(N, K, device=dev, generator=g) * K ** -0.5
+    b = torch.randn(N, device=dev, generator=g)
+    ref = torch.einsum('bpk,nk->bnp', x.double(), w.double()) + b.double()[None, :, None]
+    L = _lib.lib()
+    y = torch.full((B, N, P), float('nan'), device=dev)
+    pr = planes.get(w, 'rows')
+    _lib.check(L.sd_linear_nchw_fwd_planes(x.data_ptr(), pr.data_ptr(), b.data_ptr(), y.data_ptr(), 0, B, P, K, N, _stream_ptr()), 'fwd_planes')
+    y0 = torch.empty_like(y)
+    _lib.check(L.sd_linear_nchw_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y0.data_ptr(), 0, B, P, K, N, _stream_ptr()), 'fwd')
+    tol = 3e-7 * max(8.0, K ** 0.5)
+    assert _rel(y, ref) < tol and _rel(y0, ref) < tol
+    # the row planes themselves: hi + mid + lo == w exactly, plane-major
+    pl = pr.view(torch.bfloat16).reshape(3, N, K).double()
+    assert torch.equal((pl[0] + pl[1] + pl[2]).float(), w) and torch.equal(pl[0].float(), w.to(torch.bfloat16).float())

@@ -4,6 +4,7 @@
 set -u
 R=$(pwd)
 OUT=$1; shift
+case $OUT in /*) ;; *) OUT=$R/$OUT ;; esac
 mkdir -p $OUT
 export TMPDIR=/tmp
 TAG=$(echo "$*" | tr -c 'A-Za-z0-9' '_')
