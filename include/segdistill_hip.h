@@ -555,6 +555,32 @@ int sd_linear_nchw_bwd_weight(const void *dY, const void *X, float *dW, float *d
                               void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Bilinear resize of contiguous NCHW maps, forward and backward (round 3).
+ * Replaces F.interpolate(x, size, mode='bilinear', align_corners) as the reference's networks call it through
+ * mmseg/ops/wrappers.py:6-28 -- PSPHead's pooled branches (psp_head.py:52-58), UPerHead's top-down path and level fusion
+ * (uper_head.py:101-121), `resize_concat` (decode_head.py:130-139) -- and KLDLoss.resize (losses.py:25-33) for the sizes the fused
+ * up-sample kernels do not take.  Any input / output size, align_corners 0 | 1, ATen's index arithmetic.  planes = B * C.
+ * Backward: deterministic gather (no atomics): din[y][x] = sum of weight * dout over the outputs whose taps touch (y, x).
+ */
+int sd_resize_bilinear_fwd(const void *in, void *out, int dtype, long planes, int h, int w, int H, int W, int align_corners, void *stream);
+int sd_resize_bilinear_bwd(const void *dout, void *din, int dtype, long planes, int h, int w, int H, int W, int align_corners, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * LayerNorm / residual-add + LayerNorm (the two entry points above) whose output feeds a spatial-reduction attention (round 3): the
+ * normalised tokens are ALSO written in the patch order [B, (H/r)(W/r), r*r*C] that the SR conv -- a Linear over non-overlapping r x r
+ * patches, mix_transformer.py:75-84,121-124 -- multiplies, and the backward gathers the gradient that returns in patch order and adds it to
+ * the token-order gradient.  Replaces, per SR block, one gather copy forward and one scatter copy + one add backward.  H, W, r powers of
+ * two, r >= 2 (sd_layernorm_patch_supported).  res == NULL: plain LayerNorm (xsum, row_scale unused).  dy_patches may be NULL.
+ */
+int sd_layernorm_patch_supported(int H, int W, int r);
+int sd_add_layernorm_patch_fwd(const void *x, const void *res, const float *row_scale, long rows_per_sample, void *xsum, const float *gamma,
+                               const float *beta, void *y, void *y_patches, float *mean, float *rstd, int dtype, long rows, int C, float eps, int H,
+                               int W, int r, void *stream);
+int sd_add_layernorm_patch_bwd(const void *xsum, const void *dy, const void *dy_patches, const float *gamma, const float *mean, const float *rstd,
+                               const void *dres, const float *row_scale, long rows_per_sample, void *dx, void *dr, float *dgamma, float *dbeta,
+                               int dtype, long rows, int C, int H, int W, int r, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Optimizer step: AdamW over every trainable tensor in ONE launch.
  * Replaces torch.optim.AdamW.step() as the reference runs it through mmcv's OptimizerHook (mmseg/apis/train.py:89 builds the
  * optimizer; the KD configs use AdamW lr 6e-5, betas (0.9, 0.999), weight_decay 0.01 with paramwise_cfg lr / decay multipliers,

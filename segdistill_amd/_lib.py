@@ -93,6 +93,9 @@ SIGNATURES = {
     'sd_sra_bwd': (_i, [_vp] * 7 + [_i] * 6 + [_f, _vp, _sz, _vp]),
     'sd_add_layernorm_fwd': (_i, [_vp] * 3 + [C.c_long] + [_vp] * 6 + [_i, C.c_long, _i, _f, _vp]),
     'sd_add_layernorm_bwd': (_i, [_vp] * 7 + [C.c_long] + [_vp] * 4 + [_i, C.c_long, _i, _vp, _sz, _vp]),
+    'sd_layernorm_patch_supported': (_i, [_i, _i, _i]),
+    'sd_add_layernorm_patch_fwd': (_i, [_vp, _vp, _vp, C.c_long] + [_vp] * 7 + [_i, C.c_long, _i, _f, _i, _i, _i, _vp]),
+    'sd_add_layernorm_patch_bwd': (_i, [_vp] * 8 + [C.c_long] + [_vp] * 4 + [_i, C.c_long, _i, _i, _i, _i, _vp, _sz, _vp]),
     'sd_upsum_fwd': (_i, [_vp] * 6 + [_i] * 8 + [_vp]),
     'sd_upsum_affine_fwd': (_i, [_vp] * 7 + [_i] + [_vp] + [_i] * 8 + [_vp]),
     'sd_upsum_bwd': (_i, [_vp, _vp] + [_i] * 6 + [_vp]),
@@ -111,6 +114,8 @@ SIGNATURES = {
     'sd_bn_act_fwd': (_i, [_vp] * 6 + [C.c_long, _i, _vp, _i, C.c_long, _i, _vp]),
     'sd_bn_act_bwd_reduce': (_i, [_vp] * 7 + [C.c_long, _i, _vp, _vp, _i, C.c_long, _i, _vp, _sz, _vp]),
     'sd_bn_act_bwd_elemt': (_i, [_vp] * 7 + [C.c_long, _i, _vp, _vp, _f, _vp, _vp, _i, C.c_long, _i, _vp]),
+    'sd_resize_bilinear_fwd': (_i, [_vp, _vp, _i, C.c_long, _i, _i, _i, _i, _i, _vp]),
+    'sd_resize_bilinear_bwd': (_i, [_vp, _vp, _i, C.c_long, _i, _i, _i, _i, _i, _vp]),
     'sd_ce_up_supported': (_i, [_i, _i, _i, _i]),
     'sd_ce_up_fwd': (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     'sd_ce_up_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp] + [_i] * 8 + [_vp]),

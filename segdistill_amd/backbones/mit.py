@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from ..builder import BACKBONES
 from ..layers import DropPath, frozen_derived, nchw_view_of_tokens, tokens_of, trunc_normal_
-from ..layernorm import HipLayerNorm, add_layernorm, add_layernorm_supported
+from ..layernorm import (HipLayerNorm, add_layernorm, add_layernorm_patches, add_layernorm_supported, layernorm_patches, patch_supported)
 from ..linear import call_linear, longk_linear, patch_linear_forward, patch_linear_supported
 
 
@@ -42,6 +42,9 @@ def _mit_init(m):
         m.weight.data.normal_(0, math.sqrt(2.0 / fan_out))
         if m.bias is not None:
             m.bias.data.zero_()
+
+
+_LN_PATCHES = os.environ.get('SEGDISTILL_LN_PATCHES', '1') == '1'      # A/B: 0 = the SR path gathers its patches with a copy (round 2)
 
 
 class Tap(nn.Identity):
@@ -113,7 +116,15 @@ class SRAttention(nn.Module):
             if os.environ.get('SEGDISTILL_CL_WEIGHTS', '1') == '1':
                 self.sr.weight.data = self.sr.weight.data.contiguous(memory_format=torch.channels_last)
 
-    def _spatial_reduce(self, x, hw):
+    def takes_patches(self, x, hw):
+        """True when forward() can take the LayerNorm output ALSO in patch order (`patches=`): the producing LayerNorm kernel then writes it
+        (csrc/layernorm.hip, patch form) and its backward gathers the patch-order gradient -- no gather copy, no scatter copy + add."""
+        conv = getattr(self, 'sr', None)
+        return (_LN_PATCHES and self.sr_ratio > 1 and not (conv._forward_hooks or conv._forward_pre_hooks)
+                and conv.weight.is_contiguous(memory_format=torch.channels_last) and patch_supported(x, hw, self.sr_ratio)
+                and not patch_linear_supported(x, hw, self.sr_ratio, conv.weight))
+
+    def _spatial_reduce(self, x, hw, patches=None):
         """The SR conv has kernel == stride == r, i.e. it is a Linear over non-overlapping r x r patches.  On token-major
         input that is ONE gather of the patches ([B, H/r, W/r, r*r*C]) and a GEMM; the reference's NCHW route costs a
         transpose copy in, an (often poorly supported) strided conv, and a transpose copy out."""
@@ -123,6 +134,8 @@ class SRAttention(nn.Module):
         if conv._forward_hooks or H % r or W % r:
             return conv(x.transpose(1, 2).reshape(b, c, H, W)).flatten(2).transpose(1, 2)
         cl = conv.weight.is_contiguous(memory_format=torch.channels_last)
+        if patches is not None:          # already gathered by the LayerNorm that produced x
+            return longk_linear(patches, conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c), conv.bias, weight_is_view=True)
         if cl and patch_linear_supported(x, hw, r, conv.weight):
             # frozen network: the gather happens inside the GEMM's operand staging (csrc/align1x1.hip: gemm_nt_patch), no patch copy
             return patch_linear_forward(x, hw, r, conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c), conv.bias)
@@ -134,14 +147,14 @@ class SRAttention(nn.Module):
         w2 = frozen_derived(conv.weight, 'sr_patch', lambda: conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c).contiguous())
         return longk_linear(patches, w2, conv.bias)
 
-    def forward(self, x, hw):
+    def forward(self, x, hw, patches=None):
         from .. import sra as hip_sra
         b, n, c = x.shape
         h, d = self.num_heads, c // self.num_heads
         q_lin = call_linear(self.q, x)
         src = x
         if self.sr_ratio > 1:
-            src = self.norm(self._spatial_reduce(x, hw))
+            src = self.norm(self._spatial_reduce(x, hw, patches))
         kv_lin = call_linear(self.kv, src)
         observed = any(t._forward_hooks or t._forward_pre_hooks for t in (self.ATTN, self.Q, self.K, self.V))
         dropping = self.training and self.attn_drop.p > 0
@@ -207,10 +220,20 @@ def _run_stage(x, hw, blocks, stage_norm):
         for blk in blocks:
             x = blk(x, hw)
         return stage_norm(x)
-    n = blocks[0].norm1(x)
-    for blk, nxt in zip(blocks, norms):
-        x, n = add_layernorm(x, blk.attn(n, hw), blk.norm2, blk._scale(x))
-        x, n = add_layernorm(x, blk.mlp(n, hw), nxt, blk._scale(x))
+    # a LayerNorm whose output feeds a spatial-reduction attention also writes it in the SR conv's patch order (layernorm.py, patch form)
+    want = [blk.attn.takes_patches(x, hw) for blk in blocks]
+    pt = None
+    if want[0]:
+        n, pt = layernorm_patches(x, blocks[0].norm1, hw, blocks[0].attn.sr_ratio)
+    else:
+        n = blocks[0].norm1(x)
+    for i, (blk, nxt) in enumerate(zip(blocks, norms)):
+        x, n = add_layernorm(x, blk.attn(n, hw, patches=pt) if pt is not None else blk.attn(n, hw), blk.norm2, blk._scale(x))
+        if i + 1 < len(blocks) and want[i + 1]:
+            x, n, pt = add_layernorm_patches(x, blk.mlp(n, hw), nxt, hw, blocks[i + 1].attn.sr_ratio, blk._scale(x))
+        else:
+            x, n = add_layernorm(x, blk.mlp(n, hw), nxt, blk._scale(x))
+            pt = None
     return n
 
 

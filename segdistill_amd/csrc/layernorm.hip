@@ -54,6 +54,20 @@ template <int G> __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// Patch geometry of the spatial-reduction attention that consumes a LayerNorm output (round 3): token row (b, yy, xx) of a [B, H*W, C] map goes
+// to row ((b, yy / r, xx / r), (yy % r, xx % r)) of the [B, (H/r)(W/r), r*r*C] patch matrix that the SR conv multiplies as a Linear
+// (mix_transformer.py:75-84,121-124).  H, W, r powers of two (every MiT stage at 512 x 512): shifts only.  lr < 0: no patch output.
+struct PatchGeom {
+    int lw, lhw, lr;      // log2 W, log2 (H W), log2 r
+};
+__device__ __forceinline__ long patch_row(long row, const PatchGeom g) {
+    const long b = row >> g.lhw;
+    const int rem = (int)(row & ((1L << g.lhw) - 1)), yy = rem >> g.lw, xx = rem & ((1 << g.lw) - 1);
+    const int lh = g.lhw - g.lw;
+    return ((((b << (lh - g.lr)) + (yy >> g.lr)) << (g.lw - g.lr)) + (xx >> g.lr)) * (1L << (2 * g.lr)) + ((yy & ((1 << g.lr) - 1)) << g.lr) +
+           (xx & ((1 << g.lr) - 1));
+}
+
 // grid: ceil(rows / rows_per_block); rows_per_block = kLnThreads / G
 // (One row per row-group: batching 4 rows per group the way ln_bwd does measured 5-20 % SLOWER here -- 6.8 -> 8.0 us at 131072 x 32 f32 --
 // the forward has no accumulators to carry and the larger grid already keeps 8 waves per SIMD in flight.)
@@ -64,7 +78,8 @@ template <typename T, int G, int V>
 __global__ __launch_bounds__(kLnThreads) void ln_fwd(const T *__restrict__ x, const T *__restrict__ res, const float *__restrict__ row_scale,
                                                       long rows_per_sample, T *__restrict__ xsum, const float *__restrict__ gamma,
                                                       const float *__restrict__ beta, T *__restrict__ y, float *__restrict__ mean_out,
-                                                      float *__restrict__ rstd_out, long rows, int C, float eps) {
+                                                      float *__restrict__ rstd_out, long rows, int C, float eps, T *__restrict__ y2,
+                                                      PatchGeom pg) {
     const int gl = threadIdx.x % G;
     const long row = (long)blockIdx.x * (kLnThreads / G) + threadIdx.x / G;
     const bool live = row < rows;
@@ -96,6 +111,7 @@ __global__ __launch_bounds__(kLnThreads) void ln_fwd(const T *__restrict__ x, co
     }
     const float rstd = rsqrtf(group_sum<G>(q) / C + eps);
     if (!live) return;
+    const long prow = y2 ? patch_row(row, pg) : 0;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
         const int j = gl + i * G;
@@ -107,6 +123,7 @@ __global__ __launch_bounds__(kLnThreads) void ln_fwd(const T *__restrict__ x, co
             o.z = (v[i].z - mean) * rstd * g.z + b.z;
             o.w = (v[i].w - mean) * rstd * g.w + b.w;
             LV<T>::store(y + row * C + 4 * j, o);
+            if (y2) LV<T>::store(y2 + prow * C + 4 * j, o);       // the same values in patch order: the SR path's gather copy, folded in
         }
     }
     if (gl == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
@@ -120,7 +137,8 @@ template <typename T, int G, int V>
 __global__ __launch_bounds__(kLnThreads) void ln_bwd(const T *__restrict__ x, const T *__restrict__ dy, const float *__restrict__ gamma,
                                                       const float *__restrict__ mean_in, const float *__restrict__ rstd_in,
                                                       const T *__restrict__ dres, const float *__restrict__ row_scale, long rows_per_sample,
-                                                      T *__restrict__ dx, T *__restrict__ dr, float *__restrict__ part, long rows, int C) {
+                                                      T *__restrict__ dx, T *__restrict__ dr, float *__restrict__ part, long rows, int C,
+                                                      const T *__restrict__ dy2, PatchGeom pg) {
     extern __shared__ float red[];  // [RPB][2][C]
     constexpr int RPB = kLnThreads / G;
     const int gl = threadIdx.x % G, rg = threadIdx.x / G;
@@ -153,6 +171,10 @@ __global__ __launch_bounds__(kLnThreads) void ln_bwd(const T *__restrict__ x, co
                 const bool on = live && j < cv;
                 xr[u][i] = on ? LV<T>::load(x + row * C + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
                 dr_in[u][i] = on ? LV<T>::load(dy + row * C + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (dy2 && on) {      // the gradient that arrives in PATCH order from the SR path: gathered and added here (was a scatter copy + an add)
+                    const float4 d2 = LV<T>::load(dy2 + patch_row(row, pg) * C + 4 * j);
+                    dr_in[u][i].x += d2.x; dr_in[u][i].y += d2.y; dr_in[u][i].z += d2.z; dr_in[u][i].w += d2.w;
+                }
                 er[u][i] = (on && dres) ? LV<T>::load(dres + row * C + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
@@ -268,11 +290,13 @@ int ln_bwd_blocks(long rows, int G) {
 
 template <typename T>
 int ln_fwd_launch(const void *x, const void *res, const float *row_scale, long rows_per_sample, void *xsum, const float *gamma,
-                  const float *beta, void *y, float *mean, float *rstd, long rows, int C, float eps, hipStream_t st) {
+                  const float *beta, void *y, float *mean, float *rstd, long rows, int C, float eps, hipStream_t st, void *y2 = nullptr,
+                  PatchGeom pg = PatchGeom{0, 0, -1}) {
     const LnPlan p = ln_plan(C);
 #define SD_CALL(GG, VV)                                                                                                              \
     hipLaunchKernelGGL((ln_fwd<T, GG, VV>), dim3((unsigned)((rows + kLnThreads / GG - 1) / (kLnThreads / GG))), dim3(kLnThreads), 0, st, \
-                       (const T *)x, (const T *)res, row_scale, rows_per_sample, (T *)xsum, gamma, beta, (T *)y, mean, rstd, rows, C, eps)
+                       (const T *)x, (const T *)res, row_scale, rows_per_sample, (T *)xsum, gamma, beta, (T *)y, mean, rstd, rows, C, eps,  \
+                       (T *)y2, pg)
     SD_LN_DISPATCH(SD_CALL);
 #undef SD_CALL
     return (int)hipGetLastError();
@@ -281,7 +305,7 @@ int ln_fwd_launch(const void *x, const void *res, const float *row_scale, long r
 template <typename T>
 int ln_bwd_launch(const void *x, const void *dy, const float *gamma, const float *mean, const float *rstd, const void *dres,
                   const float *row_scale, long rows_per_sample, void *dx, void *dr, float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
-                  long rows, int C, hipStream_t st) {
+                  long rows, int C, hipStream_t st, const void *dy2 = nullptr, PatchGeom pg = PatchGeom{0, 0, -1}) {
     const LnPlan p = ln_plan(C);
     const int nblk = ln_bwd_blocks(rows, p.G);
     if (ws_bytes < (size_t)nblk * 2 * C * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
@@ -290,7 +314,7 @@ int ln_bwd_launch(const void *x, const void *dy, const float *gamma, const float
     if (lds > 64 * 1024) return SD_E_UNSUPPORTED;
 #define SD_CALL(GG, VV)                                                                                                              \
     hipLaunchKernelGGL((ln_bwd<T, GG, VV>), dim3(nblk), dim3(kLnThreads), lds, st, (const T *)x, (const T *)dy, gamma, mean, rstd,      \
-                       (const T *)dres, row_scale, rows_per_sample, (T *)dx, (T *)dr, part, rows, C)
+                       (const T *)dres, row_scale, rows_per_sample, (T *)dx, (T *)dr, part, rows, C, (const T *)dy2, pg)
     SD_LN_DISPATCH(SD_CALL);
 #undef SD_CALL
     // dgamma == dbeta == NULL: the partials [nblk][2][C] stay in the workspace for a deferred combine (sd_multi_slab_reduce)
@@ -307,10 +331,63 @@ int check_ln(const void *a, const void *b, int dtype, long rows, int C) {
     return SD_OK;
 }
 
+// H, W, r powers of two, r | H, r | W, rows a multiple of H*W
+int patch_geom(long rows, int H, int W, int r, PatchGeom *g) {
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    const int lh = lg(H), lw = lg(W), lr = lg(r);
+    if (H <= 0 || W <= 0 || r <= 1 || lh < 0 || lw < 0 || lr < 0 || lr > lh || lr > lw) return SD_E_UNSUPPORTED;
+    if (rows % ((long)H * W)) return SD_E_SHAPE;
+    g->lw = lw; g->lhw = lh + lw; g->lr = lr;
+    return SD_OK;
+}
+
 }  // namespace
 }  // namespace sd
 
 extern "C" {
+
+int sd_layernorm_patch_supported(int H, int W, int r) {
+    sd::PatchGeom g;
+    return sd::patch_geom((long)H * W, H, W, r, &g) == SD_OK ? 1 : 0;
+}
+
+/* LayerNorm (res == NULL) or residual-add + LayerNorm whose output is ALSO written in the patch order of the spatial-reduction attention
+ * that consumes it, and the matching backward that gathers the patch-order gradient (dy_patches, may be NULL) into dy. */
+int sd_add_layernorm_patch_fwd(const void *x, const void *res, const float *row_scale, long rows_per_sample, void *xsum, const float *gamma,
+                               const float *beta, void *y, void *y_patches, float *mean, float *rstd, int dtype, long rows, int C, float eps, int H,
+                               int W, int r, void *stream) {
+    int rc = sd::check_ln(x, y, dtype, rows, C);
+    if (rc) return rc;
+    if (res && (rc = sd::check_ln(res, xsum, dtype, rows, C))) return rc;
+    if (!gamma || !beta || !mean || !rstd || !y_patches) return SD_E_NULL;
+    if (reinterpret_cast<uintptr_t>(y_patches) & 15) return SD_E_ALIGN;
+    if (res && row_scale && (rows_per_sample <= 0 || rows % rows_per_sample)) return SD_E_SHAPE;
+    sd::PatchGeom g;
+    if ((rc = sd::patch_geom(rows, H, W, r, &g))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32)
+        return sd::ln_fwd_launch<float>(x, res, row_scale, rows_per_sample, xsum, gamma, beta, y, mean, rstd, rows, C, eps, st, y_patches, g);
+    return sd::ln_fwd_launch<sd::bf16_t>(x, res, row_scale, rows_per_sample, xsum, gamma, beta, y, mean, rstd, rows, C, eps, st, y_patches, g);
+}
+
+int sd_add_layernorm_patch_bwd(const void *xsum, const void *dy, const void *dy_patches, const float *gamma, const float *mean, const float *rstd,
+                               const void *dres, const float *row_scale, long rows_per_sample, void *dx, void *dr, float *dgamma, float *dbeta,
+                               int dtype, long rows, int C, int H, int W, int r, void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = sd::check_ln(xsum, dy, dtype, rows, C);
+    if (rc) return rc;
+    if (!gamma || !mean || !rstd || !dx || !workspace || (!dgamma != !dbeta)) return SD_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dres) | reinterpret_cast<uintptr_t>(dr) | reinterpret_cast<uintptr_t>(dy_patches)) & 15)
+        return SD_E_ALIGN;
+    if (row_scale && (rows_per_sample <= 0 || rows % rows_per_sample)) return SD_E_SHAPE;
+    sd::PatchGeom g{0, 0, -1};
+    if (dy_patches && (rc = sd::patch_geom(rows, H, W, r, &g))) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32)
+        return sd::ln_bwd_launch<float>(xsum, dy, gamma, mean, rstd, dres, row_scale, rows_per_sample, dx, dr, dgamma, dbeta, workspace,
+                                        workspace_bytes, rows, C, st, dy_patches, g);
+    return sd::ln_bwd_launch<sd::bf16_t>(xsum, dy, gamma, mean, rstd, dres, row_scale, rows_per_sample, dx, dr, dgamma, dbeta, workspace,
+                                         workspace_bytes, rows, C, st, dy_patches, g);
+}
 
 int sd_layernorm_supported(int C) { return (C > 0 && C % 4 == 0 && C <= 1024) ? 1 : 0; }
 

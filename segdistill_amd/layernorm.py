@@ -128,3 +128,111 @@ def add_layernorm(x, res, norm, scale=None):
         dt = torch.promote_types(x.dtype, res.dtype)
         x, res = x.to(dt), res.to(dt)
     return _AddLayerNormFn.apply(x, res, scale, norm.weight, norm.bias, norm.eps)
+
+
+# ---- LayerNorm whose consumer is a spatial-reduction attention: the output is also produced in the SR conv's patch order (round 3) -------------
+def patch_supported(x, hw, r):
+    return (x.is_cuda and x.dtype in _DT and x.dim() == 3 and r > 1 and x.shape[1] == hw[0] * hw[1]
+            and bool(_lib.lib().sd_layernorm_patch_supported(int(hw[0]), int(hw[1]), int(r))))
+
+
+def _patch_fwd(x, res, sc, rps, w, b, eps, H, W, r):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    yp = torch.empty(x.shape[0], (H // r) * (W // r), r * r * C, dtype=x.dtype, device=x.device)
+    xsum = None if res is None else torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().sd_add_layernorm_patch_fwd(x.data_ptr(), None if res is None else res.data_ptr(), None if sc is None else sc.data_ptr(), rps,
+                                               None if xsum is None else xsum.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), yp.data_ptr(),
+                                               mean.data_ptr(), rstd.data_ptr(), _DT[x.dtype], rows, C, float(eps), H, W, r, _stream_ptr())
+    _lib.check(rc, 'sd_add_layernorm_patch_fwd')
+    return xsum, y, yp, mean, rstd
+
+
+def _patch_bwd(ctx, xn, w, mean, rstd, sc, g_xsum, g_y, g_p, with_res):
+    """shared backward: dx (and dr) of the normalised row from the token-order gradient g_y plus the patch-order gradient g_p."""
+    C = xn.shape[-1]
+    rows = xn.numel() // C
+    L = _lib.lib()
+    dy = torch.zeros_like(xn) if g_y is None else g_y.contiguous()
+    dp = None if g_p is None else g_p.contiguous()
+    dres = None if g_xsum is None else g_xsum.contiguous()
+    dx = torch.empty_like(xn)
+    dr = None if (sc is None or not with_res) else torch.empty_like(xn)
+    dgb = torch.empty(2, C, dtype=torch.float32, device=xn.device)
+    wsb = L.sd_layernorm_workspace_bytes(rows, C)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=xn.device)
+    later = _defer(ctx.pdtype)
+    H, W, r = ctx.geom
+    rc = L.sd_add_layernorm_patch_bwd(xn.data_ptr(), dy.data_ptr(), None if dp is None else dp.data_ptr(), w.data_ptr(), mean.data_ptr(),
+                                      rstd.data_ptr(), None if dres is None else dres.data_ptr(), None if sc is None else sc.data_ptr(), ctx.rps,
+                                      dx.data_ptr(), None if dr is None else dr.data_ptr(), None if later else dgb[0].data_ptr(),
+                                      None if later else dgb[1].data_ptr(), _DT[xn.dtype], rows, C, H, W, r, ws.data_ptr(), wsb, _stream_ptr())
+    _lib.check(rc, 'sd_add_layernorm_patch_bwd')
+    if later:
+        deferred.add(ws, dgb, 2 * C, L.sd_layernorm_bwd_blocks(rows, C))
+    return dx, dr, dgb
+
+
+class _LayerNormPatchFn(torch.autograd.Function):
+    """(y, y_patches) = LayerNorm(x) in token order and in the r x r patch order of the SR conv that reads it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, H, W, r):
+        xc = x.contiguous()
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        _, y, yp, mean, rstd = _patch_fwd(xc, None, None, 1, w, b, eps, H, W, r)
+        ctx.save_for_backward(xc, w, mean, rstd)
+        ctx.pdtype, ctx.rps, ctx.geom = weight.dtype, 1, (H, W, r)
+        ctx.set_materialize_grads(False)
+        return y, yp
+
+    @staticmethod
+    def backward(ctx, g_y, g_p):
+        xc, w, mean, rstd = ctx.saved_tensors
+        if g_y is None and g_p is None:
+            return (None,) * 7
+        dx, _, dgb = _patch_bwd(ctx, xc, w, mean, rstd, None, None, g_y, g_p, False)
+        return dx, dgb[0].to(ctx.pdtype), dgb[1].to(ctx.pdtype), None, None, None, None
+
+
+class _AddLayerNormPatchFn(torch.autograd.Function):
+    """(xsum, y, y_patches) = (x + s*res, LayerNorm(x + s*res) in token order and in patch order)."""
+
+    @staticmethod
+    def forward(ctx, x, res, scale, weight, bias, eps, H, W, r):
+        xc, rc_ = x.contiguous(), res.contiguous()
+        w, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        sc = None if scale is None else scale.detach().float().contiguous()
+        rps = (xc.numel() // xc.shape[-1]) // xc.shape[0]
+        xsum, y, yp, mean, rstd = _patch_fwd(xc, rc_, sc, rps, w, b, eps, H, W, r)
+        ctx.save_for_backward(xsum, w, mean, rstd, sc)
+        ctx.pdtype, ctx.rps, ctx.geom = weight.dtype, rps, (H, W, r)
+        ctx.set_materialize_grads(False)
+        return xsum, y, yp
+
+    @staticmethod
+    def backward(ctx, g_xsum, g_y, g_p):
+        xsum, w, mean, rstd, sc = ctx.saved_tensors
+        if g_y is None and g_p is None:
+            if g_xsum is None:
+                return (None,) * 9
+            g_res = g_xsum if sc is None else g_xsum * sc.view(-1, *([1] * (g_xsum.dim() - 1))).to(g_xsum.dtype)
+            return (g_xsum, g_res) + (None,) * 7
+        dx, dr, dgb = _patch_bwd(ctx, xsum, w, mean, rstd, sc, g_xsum, g_y, g_p, True)
+        return dx, (dx if dr is None else dr), None, dgb[0].to(ctx.pdtype), dgb[1].to(ctx.pdtype), None, None, None, None
+
+
+def layernorm_patches(x, norm, hw, r):
+    """norm(x) -> (normed tokens, the same values as [B, (H/r)(W/r), r*r*C] patches)."""
+    return _LayerNormPatchFn.apply(x, norm.weight, norm.bias, norm.eps, int(hw[0]), int(hw[1]), int(r))
+
+
+def add_layernorm_patches(x, res, norm, hw, r, scale=None):
+    """add_layernorm with the patch-order copy of the normalised output: -> (xsum, normed, patches)."""
+    if res.dtype != x.dtype:
+        dt = torch.promote_types(x.dtype, res.dtype)
+        x, res = x.to(dt), res.to(dt)
+    return _AddLayerNormPatchFn.apply(x, res, scale, norm.weight, norm.bias, norm.eps, int(hw[0]), int(hw[1]), int(r))

@@ -177,6 +177,12 @@ def resize(input, size=None, scale_factor=None, mode='nearest', align_corners=No
             warnings.warn(f'align_corners={align_corners}: sizes {(ih, iw)} -> {(oh, ow)} are not of the form x+1 -> nx+1')
     if isinstance(size, torch.Size):
         size = tuple(int(v) for v in size)
+    if scale_factor is None and size is not None:
+        from . import resize as hip_resize
+        if hip_resize.supported(input, size, mode, align_corners):
+            if tuple(input.shape[2:]) == tuple(int(v) for v in size):
+                return input                                   # F.interpolate would copy; every caller only reads the result
+            return hip_resize.bilinear(input, size, bool(align_corners))     # csrc/resize.hip: contiguous NCHW maps on the GPU
     return F.interpolate(input, size, scale_factor, mode, align_corners)
 
 

@@ -129,3 +129,92 @@ def test_fused_stage_loop_equals_block_by_block():
         assert _err(a, b2) < 1e-5
     bad = [(n, _err(g_fused[n], p.grad)) for n, p in net.named_parameters() if not _err(g_fused[n], p.grad) < 2e-4]
     assert not bad, (len(bad), bad[:12])
+
+
+# ---- round 3: LayerNorm output also in the SR conv's patch order, backward gathering the patch-order gradient ---------------------------------
+def _gather_patches(t, H, W, r):
+    b, n, c = t.shape
+    return t.reshape(b, H // r, r, W // r, r, c).permute(0, 1, 3, 2, 4, 5).reshape(b, (H // r) * (W // r), r * r * c)
+
+
+@pytest.mark.parametrize('case', [(2, 16, 16, 32, 8), (1, 32, 64, 64, 4), (3, 8, 8, 160, 2), (2, 128, 128, 32, 8), (1, 16, 32, 320, 2)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('residual', [False, True])
+def test_layernorm_patch_form_matches_norm_then_gather(case, dtype, residual):
+    """sd_add_layernorm_patch_fwd / _bwd against fp64 LayerNorm followed by the r x r patch gather (mix_transformer.py:75-84,121-124), with
+    gradients arriving in BOTH orders (token order from the q Linear, patch order from the SR conv) and, in the residual form, on the sum."""
+    from segdistill_amd.layernorm import HipLayerNorm, add_layernorm_patches, layernorm_patches, patch_supported
+    B, H, W, C, r = case
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(H * W + C + r)
+    x = torch.randn(B, H * W, C, device=dev, generator=g).to(dtype)
+    res = torch.randn(B, H * W, C, device=dev, generator=g).to(dtype)
+    sc = torch.tensor([1.0, 0.0, 1.25][:B], device=dev) if residual else None
+    norm = HipLayerNorm(C, eps=1e-6).to(dev)
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.3 * torch.randn(C, device=dev, generator=g))
+        norm.bias.copy_(0.2 * torch.randn(C, device=dev, generator=g))
+    gy = torch.randn(B, H * W, C, device=dev, generator=g).to(dtype)
+    gp = torch.randn(B, (H // r) * (W // r), r * r * C, device=dev, generator=g).to(dtype)
+    gs = torch.randn(B, H * W, C, device=dev, generator=g).to(dtype)
+    assert patch_supported(x, (H, W), r)
+    xg, rg = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    if residual:
+        xsum, y, yp = add_layernorm_patches(xg, rg, norm, (H, W), r, sc)
+        torch.autograd.backward([xsum, y, yp], [gs, gy, gp])
+    else:
+        y, yp = layernorm_patches(xg, norm, (H, W), r)
+        torch.autograd.backward([y, yp], [gy, gp])
+    assert torch.equal(yp, _gather_patches(y, H, W, r))                    # the patch output is the token output, re-ordered
+    # fp64 composition
+    x64, r64 = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    w64, b64 = norm.weight.detach().double().requires_grad_(True), norm.bias.detach().double().requires_grad_(True)
+    s64 = x64 + (sc.double().view(-1, 1, 1) * r64 if sc is not None else r64) if residual else x64
+    if residual and dtype == torch.bfloat16:
+        s64 = s64 + (s64.detach().to(torch.bfloat16).double() - s64.detach())      # the stored sum is what is normalised
+    y64 = torch.nn.functional.layer_norm(s64, (C,), w64, b64, 1e-6)
+    outs, grads = [y64, _gather_patches(y64, H, W, r)], [gy.double(), gp.double()]
+    if residual:
+        outs, grads = [s64] + outs, [gs.double()] + grads
+    torch.autograd.backward(outs, grads)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+
+    def rel(a, b):
+        return float((a.double() - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    assert rel(y, y64.detach()) < tol
+    assert rel(xg.grad, x64.grad) < tol
+    if residual:
+        assert rel(xsum, s64.detach()) < tol and rel(rg.grad, r64.grad) < tol
+    assert rel(norm.weight.grad, w64.grad) < (1e-4 if dtype == torch.float32 else 5e-2) and rel(norm.bias.grad, b64.grad) < (1e-4 if dtype == torch.float32 else 5e-2)
+
+
+def test_mit_stage_with_patch_fused_norms_matches_the_gather_copy_path():
+    """MiT-B0 forward + backward with the SR paths fed by the patch-form LayerNorms against the same network with the round-2 gather copies."""
+    import copy
+    import segdistill_amd
+    from segdistill_amd.backbones import mit
+    from segdistill_amd.builder import BACKBONES
+    from segdistill_amd.registry import build_from_cfg
+    segdistill_amd.register_all()
+    torch.manual_seed(3)
+    a = build_from_cfg(dict(type='mit_b0'), BACKBONES).cuda().train()
+    a.reset_drop_path(0.)
+    b = copy.deepcopy(a)
+    img = torch.randn(2, 3, 256, 256, device='cuda:0')
+    ups = None
+    outs = {}
+    for tag, net, flag in (('fused', a, True), ('copy', b, False)):
+        mit._LN_PATCHES = flag
+        try:
+            feats = net(img)
+            if ups is None:
+                ups = [torch.randn_like(f) for f in feats]
+            torch.autograd.backward(list(feats), ups)
+        finally:
+            mit._LN_PATCHES = True
+        outs[tag] = [f.detach() for f in feats]
+    for fa, fb in zip(outs['fused'], outs['copy']):
+        assert float((fa - fb).abs().max()) <= 1e-5 * float(fb.abs().max())
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert pa.grad is not None and pb.grad is not None, n
+        assert float((pa.grad - pb.grad).norm()) <= 2e-5 * float(pb.grad.norm()) + 1e-8, n
