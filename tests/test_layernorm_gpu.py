@@ -106,13 +106,15 @@ def test_fused_stage_loop_equals_block_by_block():
     net.reset_drop_path(0.)
     net.train()
     img = torch.randn(2, 3, 128, 128, device='cuda')
-    calls, real = [], layernorm._AddLayerNormFn.apply
+    calls, real, real_p = [], layernorm._AddLayerNormFn.apply, layernorm._AddLayerNormPatchFn.apply
     layernorm._AddLayerNormFn.apply = lambda *a: (calls.append(1), real(*a))[1]
+    layernorm._AddLayerNormPatchFn.apply = lambda *a: (calls.append(2), real_p(*a))[1]     # round 3: the form that also feeds an SR conv
     try:
         outs = net(img)
     finally:
-        layernorm._AddLayerNormFn.apply = real
-    assert len(calls) == 2 * sum(net.depths)          # every residual add of every block went through the fused kernel
+        layernorm._AddLayerNormFn.apply, layernorm._AddLayerNormPatchFn.apply = real, real_p
+    assert len(calls) == 2 * sum(net.depths)          # every residual add of every block went through a fused kernel
+    assert calls.count(2) == 3                        # block 2 of stages 1-3: its norm1 output also goes out in patch order
     # A loss WITH a gradient: sum of mean(o^2) would not do -- the stage outputs are LayerNorm outputs with gamma = 1, beta = 0, whose mean
     # square is 1 whatever the input, so every gradient would be rounding noise and the comparison below would hold only while the library
     # GEMMs happen to round identically in both passes (they stop doing so once earlier tests have given hipBLASLt a workspace).
