@@ -281,7 +281,8 @@ __global__ void ce_up_bwd(const T *__restrict__ s, const int32_t *__restrict__ l
 // workgroup owns CPW consecutive classes of a band: the pixel maps are loaded once per CPW classes as F-wide vectors (the F pixels a thread
 // owns in an output row are contiguous and F*4-byte aligned), and the maps of gap j+1 as well as the taps of tap row j+1 are requested
 // BEFORE gap j is computed (asm volatile loads, explicit wait: the compiler would otherwise sink them to their first use, as in the
-// forward).  Same arithmetic per (pixel, class) as above, operation for operation.
+// forward).  The upstream factor is folded into the two row weights per pixel (one multiply per pixel instead of one per pixel and class), so
+// results agree with the one-class kernel to rounding, not bit for bit.
 template <int N> struct PinRow;   // N consecutive dwords, N*4-byte aligned
 template <> struct PinRow<2> {
     typedef unsigned v2 __attribute__((ext_vector_type(2)));
@@ -403,12 +404,12 @@ __global__ __launch_bounds__(256) void ce_up_bwd_mc(const T *__restrict__ s, con
         if (!PF) request_pix(pcur, j);
         request_taps(tnxt, min(j + 1, h - 1));      // the last iteration's requests re-read valid (clamped) addresses and are dropped
         if (PF) request_pix(pnxt, j + 1);
-        float sc[CPW][F], accB[CPW][F];
+        float sc[CPW][F], dv[CPW][F], accB[CPW][F];
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             hrow_raw(tcur, i, sc[i]);
 #pragma unroll
-            for (int rx = 0; rx < F; ++rx) accB[i][rx] = 0.f;
+            for (int rx = 0; rx < F; ++rx) { accB[i][rx] = 0.f; dv[i][rx] = sc[i][rx] - sp[i][rx]; }
         }
         const bool top = (j == 0), bot = (j == h);
 #pragma unroll
@@ -422,12 +423,15 @@ __global__ __launch_bounds__(256) void ce_up_bwd_mc(const T *__restrict__ s, con
                 const int lab = (int)pcur.lab[q][rx];
                 const float nl = -__uint_as_float(pcur.lse[q][rx]);
                 const float gp = (lab == ignore_index) ? 0.f : (GMAP ? gscale * __uint_as_float(pcur.up[q][rx]) : guni);
+                // per pixel, shared by the CPW classes: the row weights with the upstream factor folded in, and the label relative to this group
+                const float ga = wa * gp, gb = wb * gp;
+                const int rel = lab - c0;
 #pragma unroll
                 for (int i = 0; i < CPW; ++i) {
-                    const float p = ex2(fmaf(fmaf(lam, sc[i][rx] - sp[i][rx], sp[i][rx]), kLog2e, nl));
-                    const float D = gp * (p - (lab == c0 + i ? 1.f : 0.f));
-                    accA[i][rx] = fmaf(wa, D, accA[i][rx]);
-                    accB[i][rx] = fmaf(wb, D, accB[i][rx]);
+                    const float p = ex2(fmaf(fmaf(lam, dv[i][rx], sp[i][rx]), kLog2e, nl));
+                    const float D = p - (rel == i ? 1.f : 0.f);           // softmax - onehot: 7 vector issues + 1 exponential per (pixel, class)
+                    accA[i][rx] = fmaf(ga, D, accA[i][rx]);
+                    accB[i][rx] = fmaf(gb, D, accB[i][rx]);
                 }
             }
         }
@@ -462,7 +466,17 @@ __global__ __launch_bounds__(256) void ce_up_bwd_mc(const T *__restrict__ s, con
         for (int i = 0; i < CPW; ++i)
 #pragma unroll
             for (int rx = 0; rx < F; ++rx) { accA[i][rx] = accB[i][rx]; sp[i][rx] = sc[i][rx]; }
-        if (PF) wait_pinned_loads();
+        if (PF) {
+            // The requests of this iteration are OLDER than its gradient stores (vmcnt retires in order): where the wave is known to have issued
+            // exactly CPW stores, wait for all but those -- vmcnt(0) made every tap row wait for its own stores to be acknowledged (~1 us, nine
+            // times per workgroup).  Wave-uniform conditions: a stored row (j > y0), a full class group, at least one active lane in the wave.
+            if (j > y0 && c0 + CPW <= C && (int)(threadIdx.x & ~63u) < w) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                wait_pinned_loads();
+            }
+        }
         tcur = tnxt;
         if (PF) pcur = pnxt;
     }
@@ -545,28 +559,32 @@ int sd_ce_up_bwd(const void *logits, const int32_t *label, const float *pix_lse2
     const bool aligned = ((reinterpret_cast<uintptr_t>(label) | reinterpret_cast<uintptr_t>(pix_lse2) |
                            (upstream_is_map ? reinterpret_cast<uintptr_t>(upstream) : 0)) & 15) == 0;
     if (aligned && threads <= 256 && sd::g_ce_bwd_multiclass) {
-#define SD_CE_BWD_MC(TT, FF, CC, PP)                                                                                                   \
+#define SD_CE_BWD_MC1(TT, FF, GG, CC, PP)                                                                                            \
     do {                                                                                                                             \
         const int ngrp = (C + CC - 1) / CC;                                                                                          \
         const long nwg = (long)B * nband * ngrp;                                                                                     \
         if (nwg > 0x7fffffffL) return SD_E_SHAPE;                                                                                    \
         const size_t lds = 2ull * CC * FF * threads * sizeof(float);                                                                 \
-        if (upstream_is_map)                                                                                                         \
-            hipLaunchKernelGGL((sd::ce_up_bwd_mc<TT, FF, true, CC, PP>), dim3((unsigned)nwg), dim3(threads), lds, st, (const TT *)logits, label, \
-                               pix_lse2, upstream, gscale, (TT *)dlogits, C, h, w, R, nband, ngrp, ignore_index);                    \
-        else                                                                                                                         \
-            hipLaunchKernelGGL((sd::ce_up_bwd_mc<TT, FF, false, CC, PP>), dim3((unsigned)nwg), dim3(threads), lds, st, (const TT *)logits, label, \
-                               pix_lse2, upstream, gscale, (TT *)dlogits, C, h, w, R, nband, ngrp, ignore_index);                    \
+        hipLaunchKernelGGL((sd::ce_up_bwd_mc<TT, FF, GG, CC, PP>), dim3((unsigned)nwg), dim3(threads), lds, st, (const TT *)logits, label,  \
+                           pix_lse2, upstream, gscale, (TT *)dlogits, C, h, w, R, nband, ngrp, ignore_index);                        \
+    } while (0)
+    // classes per workgroup: as many as fit 256 registers with nothing parked in AGPRs while loads are pending (tools/asm_pending_audit.py):
+    // 6 with a uniform upstream gradient (the training step: 25 groups for 150 classes), 4 with a per-pixel one, 2 at factor 8
+#define SD_CE_BWD_MC(TT, FF, CMAP, CUNI, PP)                                                                                       \
+    do {                                                                                                                             \
+        if (upstream_is_map) SD_CE_BWD_MC1(TT, FF, true, CMAP, PP);                                                                  \
+        else SD_CE_BWD_MC1(TT, FF, false, CUNI, PP);                                                                                 \
     } while (0)
         if (dtype == SD_F32) {
-            if (F == 2) SD_CE_BWD_MC(float, 2, 4, true);
-            else if (F == 4) SD_CE_BWD_MC(float, 4, 4, true);
-            else SD_CE_BWD_MC(float, 8, 2, false);
+            if (F == 2) SD_CE_BWD_MC(float, 2, 4, 4, true);
+            else if (F == 4) SD_CE_BWD_MC(float, 4, 4, 6, true);
+            else SD_CE_BWD_MC(float, 8, 2, 2, false);
         } else {
-            if (F == 2) SD_CE_BWD_MC(sd::bf16_t, 2, 4, true);
-            else if (F == 4) SD_CE_BWD_MC(sd::bf16_t, 4, 4, true);
-            else SD_CE_BWD_MC(sd::bf16_t, 8, 2, false);
+            if (F == 2) SD_CE_BWD_MC(sd::bf16_t, 2, 4, 4, true);
+            else if (F == 4) SD_CE_BWD_MC(sd::bf16_t, 4, 4, 6, true);
+            else SD_CE_BWD_MC(sd::bf16_t, 8, 2, 2, false);
         }
+#undef SD_CE_BWD_MC1
 #undef SD_CE_BWD_MC
         return (int)hipGetLastError();
     }

@@ -81,8 +81,8 @@ def test_fused_ce_uniform_upstream_and_head_integration():
 @pytest.mark.parametrize('case', [(2, 150, 16, 16, 4), (1, 19, 8, 8, 8), (2, 7, 5, 12, 2), (1, 150, 33, 20, 4), (2, 150, 64, 64, 8), (1, 3, 40, 130, 4)])
 @pytest.mark.parametrize('uniform', [False, True])
 def test_multiclass_backward_agrees_with_the_one_class_kernel(case, uniform):
-    """Round 3's sd_ce_up_bwd (4 / 2 class planes per workgroup, vector map loads, requests one tap row ahead) performs the same operations
-    per (pixel, class) as the one-class kernel it replaces (tunable ce_bwd_multiclass = 0): bit-identical gradients, with a per-pixel and
+    """Round 3's sd_ce_up_bwd (4 / 2 class planes per workgroup, vector map loads, requests one tap row ahead) computes the same sum
+    per (pixel, class) as the one-class kernel it replaces (tunable ce_bwd_multiclass = 0): gradients equal to rounding, with a per-pixel and
     with a uniform upstream gradient, including class counts that are not a multiple of the group (150, 19, 7, 3)."""
     from segdistill_amd import _lib
     from segdistill_amd.ce import fused_ce_up
@@ -105,4 +105,5 @@ def test_multiclass_backward_agrees_with_the_one_class_kernel(case, uniform):
         finally:
             _lib.set_tunable('ce_bwd_multiclass', 1)
     assert torch.isfinite(grads[0]).all()
-    assert torch.equal(grads[0], grads[1])
+    # same products, re-associated (upstream factor folded into the row weights): agreement to rounding
+    assert float((grads[0] - grads[1]).abs().max()) <= 2e-6 * float(grads[1].abs().max())
