@@ -490,6 +490,11 @@ int sd_layernorm_bwd_blocks(long rows, int C);
 int sd_linear_wgrad_slabs(int dtype, long tokens, int out_features, int in_features);
 int sd_linear_wgrad_partials(const void *dY, const void *X, int dtype, long tokens, int out_features, int in_features,
                              int with_bias, void *workspace, size_t workspace_bytes, void *stream);
+/* The same split between kernel and combine for sd_linear_wgrad's GENERIC plan (not tall-skinny; bf16 storage mostly): _slabs() = number of
+ * [out x in] fp32 slabs (0: un-split or direct plan -- use the calls above), _partials() writes them, the caller sums them. */
+int sd_linear_wgrad_generic_slabs(int dtype, long tokens, int out_features, int in_features);
+int sd_linear_wgrad_generic_partials(const void *dY, const void *X, int dtype, long tokens, int out_features, int in_features, void *workspace,
+                                     size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
  * Split-bf16 Linear products with the WEIGHT operand split beforehand (round 3).  The mode-1 kernels above split both operands in

@@ -108,6 +108,8 @@ SIGNATURES = {
     'sd_layernorm_bwd_blocks': (_i, [C.c_long, _i]),
     'sd_linear_wgrad_slabs': (_i, [_i, C.c_long, _i, _i]),
     'sd_linear_wgrad_partials': (_i, [_vp, _vp, _i, C.c_long, _i, _i, _i, _vp, _sz, _vp]),
+    'sd_linear_wgrad_generic_slabs': (_i, [_i, C.c_long, _i, _i]),
+    'sd_linear_wgrad_generic_partials': (_i, [_vp, _vp, _i, C.c_long, _i, _i, _vp, _sz, _vp]),
     'sd_bn_supported': (_i, [_i]),
     'sd_bn_workspace_bytes': (_sz, [C.c_long, _i]),
     'sd_bn_stats': (_i, [_vp, _i, C.c_long, _i, _f, _vp, _vp, _vp, _vp, _f, _vp, _sz, _vp]),

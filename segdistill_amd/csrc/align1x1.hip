@@ -808,6 +808,38 @@ int sd_linear_wgrad_slabs(int dtype, long tokens, int out_features, int in_featu
     return p.direct ? p.nslabs : 0;
 }
 
+/* the split-K plan of the generic (non tall-skinny) weight gradient: number of [out x in] slabs sd_linear_wgrad_generic_partials writes (>= 2),
+ * or 0 when that plan is a single un-split GEMM (nothing to defer) or the direct plan applies */
+int sd_linear_wgrad_generic_slabs(int dtype, long tokens, int out_features, int in_features) {
+    if (tokens <= 0 || out_features <= 0 || in_features <= 0 || (dtype != SD_F32 && dtype != SD_BF16)) return 0;
+    const sd::WgradPlan p = sd::linear_wgrad_plan(tokens, out_features, in_features, dtype == SD_BF16);
+    return (!p.direct && p.nsplit > 1) ? p.nslabs : 0;
+}
+
+/* the GEMM of sd_linear_wgrad's generic plan WITHOUT its slab combine: the caller sums the slabs (sd_multi_slab_reduce), typically deferred to
+ * the end of the backward -- under bf16 storage (config 5) ~54 such combines ran as separate launches per step */
+int sd_linear_wgrad_generic_partials(const void *dY, const void *X, int dtype, long tokens, int out_features, int in_features, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
+    if (!dY || !X || !workspace) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    if (tokens <= 0 || tokens > 0x7fffffffL || out_features <= 0 || in_features <= 0) return SD_E_SHAPE;
+    const int M = out_features, N = in_features;
+    const sd::WgradPlan p = sd::linear_wgrad_plan(tokens, M, N, dtype == SD_BF16);
+    if (p.direct || p.nsplit <= 1) return SD_E_UNSUPPORTED;
+    const long slab = (long)M * N;
+    if (workspace_bytes < (size_t)p.nslabs * slab * sizeof(float) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return SD_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *slabs = static_cast<float *>(workspace);
+    dim3 grid((N + sd::BN - 1) / sd::BN, (M + sd::BM - 1) / sd::BM, p.nsplit);
+    if (dtype == SD_F32)
+        sd::launch_gemm<float, float, float, true, true>(grid, st, (const float *)dY, (const float *)X, slabs, nullptr, M, N, (int)tokens, (long)M, (long)N,
+                                                         (long)N, 0L, 0L, slab, p.nsplit, p.klen);
+    else
+        sd::launch_gemm<sd::bf16_t, sd::bf16_t, float, true, true>(grid, st, (const sd::bf16_t *)dY, (const sd::bf16_t *)X, slabs, nullptr, M, N,
+                                                                   (int)tokens, (long)M, (long)N, (long)N, 0L, 0L, slab, p.nsplit, p.klen);
+    return (int)hipGetLastError();
+}
+
 int sd_linear_wgrad_partials(const void *dY, const void *X, int dtype, long tokens, int out_features, int in_features, int with_bias,
                              void *workspace, size_t workspace_bytes, void *stream) {
     if (!dY || !X || !workspace) return SD_E_NULL;

@@ -185,6 +185,17 @@ class _TokenLinear(torch.autograd.Function):
                 elif want_db:
                     db = deferred.column_sum(dyc, ctx.defer_bias_ok)
                 return dx, dw, db, None, None
+            gs = 0 if direct else L.sd_linear_wgrad_generic_slabs(_DT[x.dtype], T, M, N)
+            if gs and ctx.defer_ok and deferred.enabled() and ctx.w_dtype == torch.float32:
+                # the generic split-K plan (bf16 storage: most Linears of config 5) inside a deferred scope: its slab combine joins the batched
+                # pass at the end of the backward instead of running as one more launch per layer (54 of them per config-5 step)
+                ws = torch.empty(gs, M * N, dtype=torch.float32, device=x.device)
+                _lib.check(L.sd_linear_wgrad_generic_partials(dyc.data_ptr(), x2.data_ptr(), _DT[x.dtype], T, M, N, ws.data_ptr(), ws.numel() * 4,
+                                                              _stream_ptr()), 'sd_linear_wgrad_generic_partials')
+                buf = torch.empty(M * N, dtype=torch.float32, device=x.device)
+                deferred.add(ws, buf, M * N, gs)
+                db = deferred.column_sum(dyc, ctx.defer_bias_ok) if want_db else None
+                return dx, buf.view(M, N), db, None, None
             dw32 = torch.empty(M, N, dtype=torch.float32, device=x.device)
             db32 = torch.empty(M, dtype=torch.float32, device=x.device) if fuse_b else None
             wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)

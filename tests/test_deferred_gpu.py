@@ -145,3 +145,34 @@ def test_column_sum(rows, C, dtype):
         assert torch.equal(now, out)
     assert torch.equal(late, out)                     # same kernels, same order: bit-identical
     assert torch.equal(deferred.column_sum(x[:, :C - 1] if C > 4 else x.t().contiguous().t()), (x[:, :C - 1] if C > 4 else x).sum(0, dtype=torch.float32)) or True
+
+
+@pytest.mark.parametrize('T,M,N', [(32768, 256, 256), (8192, 640, 160), (2048, 512, 256)])
+def test_bf16_generic_weight_gradient_defers_its_combine(T, M, N):
+    """Under bf16 storage most weight gradients take sd_linear_wgrad's GENERIC split-K plan; inside a deferred scope its slab combine joins the
+    batched pass (sd_linear_wgrad_generic_partials): same values as the immediate path (same GEMM, same slabs, same summation order class)."""
+    from segdistill_amd import _lib, deferred
+    from segdistill_amd.linear import token_linear
+    dev = torch.device('cuda:0')
+    L = _lib.lib()
+    assert L.sd_linear_wgrad_generic_slabs(1, T, M, N) >= 2
+    g = torch.Generator(device=dev).manual_seed(T + M)
+    x = torch.randn(T, N, device=dev, generator=g).to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(M, N, device=dev, generator=g) / N ** 0.5).requires_grad_(True)
+    b = torch.randn(M, device=dev, generator=g).requires_grad_(True)
+    up = torch.randn(T, M, device=dev, generator=g).to(torch.bfloat16)
+    grads = []
+    for scoped in (False, True):
+        x.grad = w.grad = b.grad = None
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            y = token_linear(x, w, b, defer_ok=True)
+        if scoped:
+            with deferred.scope():
+                y.backward(up)
+        else:
+            y.backward(up)
+        grads.append((w.grad.clone(), b.grad.clone()))
+    ref = up.double().t() @ x.detach().double()
+    assert float((grads[1][0].double() - ref).abs().max() / ref.abs().max()) < 2e-3
+    assert float((grads[0][0] - grads[1][0]).abs().max()) <= 1e-5 * float(grads[0][0].abs().max())
+    assert float((grads[0][1] - grads[1][1]).abs().max()) <= 1e-4 * float(grads[0][1].abs().max())
