@@ -408,6 +408,64 @@ def bench_upsum(dev, reps, B=8, E=256):
                    nb[0] + sum(nb[1:]), HBM, 'algorithmic bytes: dy once + the three gradients; the fp32 row partials (7/8 of dy, written and re-read) are extra traffic')]
 
 
+def bench_resize(dev, reps):
+    """csrc/resize.hip at the shapes of the config-4 teacher's UPerHead (level fusion [8,512,64,64] -> 128^2) and of the PSPNet student's
+    pooled branches ([8,128,6,6] -> 64^2), forward and gather backward."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    out = []
+    for (B, C, h, H, tag) in ((8, 512, 64, 128, 'UPerHead level fusion'), (8, 512, 16, 128, 'UPerHead coarsest level x8'), (8, 128, 6, 64, 'PPM branch 6x6 -> 64x64')):
+        x = torch.randn(B, C, h, h, device=dev)
+        y = torch.empty(B, C, H, H, device=dev)
+        dx = torch.empty_like(x)
+        tf = _time(lambda st: _ok(L.sd_resize_bilinear_fwd(x.data_ptr(), y.data_ptr(), 0, B * C, h, h, H, H, 0, st), 'resize fwd'), reps)
+        tb = _time(lambda st: _ok(L.sd_resize_bilinear_bwd(y.data_ptr(), dx.data_ptr(), 0, B * C, h, h, H, H, 0, st), 'resize bwd'), reps)
+        nb_in, nb_out = x.numel() * 4, y.numel() * 4
+        out += [_entry(f'bilinear resize fwd ({tag})', 'resize_bilinear_fwd', [B, C, h, h, H, H], 'f32', tf, 'hbm', nb_in + nb_out, HBM),
+                _entry(f'bilinear resize bwd ({tag})', 'resize_bilinear_bwd', [B, C, h, h, H, H], 'f32', tb, 'hbm', nb_in + nb_out, HBM,
+                       'gather form: every dOut element is read by ~4 input pixels (L2)')]
+    return out
+
+
+def bench_gemm_planes(dev, reps):
+    """Token Linear products on pre-split weight planes (sd_linear_fwd_planes / _bwd_data_planes) at the largest shapes of config 2, priced
+    against the split-bf16 matrix-pipe bound (dense bf16 / 6 cross products) and, for the HBM-bound ones, against 8 TB/s."""
+    from segdistill_amd import planes, token_gemm
+    out = []
+    for (T, K, N, tag) in ((131072, 256, 256, 'head fuse1 256->256'), (131072, 64, 256, 'teacher s1 fc1 64->256'), (32768, 128, 512, 'teacher s2 fc1'),
+                           (8192, 320, 1280, 'teacher s3 fc1'), (8192, 1280, 320, 'teacher s3 fc2')):
+        x = torch.randn(T, K, device=dev)
+        w = torch.randn(N, K, device=dev) * 0.05
+        b = torch.randn(N, device=dev)
+        pf = planes.get(w, 'fwd')
+        t = _time(lambda st: token_gemm.linear_fwd_planes(x, w, pf, b), reps)
+        flops, nbytes = 2.0 * T * K * N, (T * K + T * N) * 4.0
+        if flops / (MFMA_BF16 / 6 * 1e12) >= nbytes / (HBM * 1e9):
+            out.append(_entry(f'token Linear fwd on weight planes ({tag})', 'token_gemm_f32<..., BFRAG>', [T, K, N], 'f32 (split-bf16)', t, 'mfma', flops,
+                              MFMA_BF16 / 6, 'bound: dense bf16 peak / 6 cross products'))
+        else:
+            out.append(_entry(f'token Linear fwd on weight planes ({tag})', 'token_gemm_f32<..., BFRAG>', [T, K, N], 'f32 (split-bf16)', t, 'hbm', nbytes, HBM))
+    return out
+
+
+def bench_pred(dev, reps):
+    """linear_pred as class planes (sd_linear_nchw_fwd_planes: W as pre-split row planes through LDS) for the teacher (E = 768) and the student."""
+    from segdistill_amd import _lib, planes
+    L = _lib.lib()
+    out = []
+    for E in (768, 256):
+        B, P, N = 8, 16384, 150
+        x = torch.randn(B, P, E, device=dev)
+        w = torch.randn(N, E, device=dev) * 0.05
+        b = torch.randn(N, device=dev)
+        y = torch.empty(B, N, P, device=dev)
+        pr = planes.get(w, 'rows')
+        t = _time(lambda st: _ok(L.sd_linear_nchw_fwd_planes(x.data_ptr(), pr.data_ptr(), b.data_ptr(), y.data_ptr(), 0, B, P, E, N, st), 'pred'), reps)
+        out.append(_entry(f'linear_pred -> class planes, E = {E}', 'token_gemm_f32<160, 128, 1, 4, ..., APL>', [B, P, E, N], 'f32 (split-bf16)', t, 'mfma',
+                          2.0 * B * P * E * N, MFMA_BF16 / 6, 'bound: dense bf16 peak / 6 cross products'))
+    return out
+
+
 GROUPS = {
     'r1': lambda dev, reps: bench_r1(dev, reps),
     'r1_bf16': lambda dev, reps: bench_r1(dev, reps, C=768, HW=128, dtype=torch.bfloat16),      # config 5 stage 1
@@ -427,6 +485,9 @@ GROUPS = {
     'dw': lambda dev, reps: bench_dw(dev, reps),
     'ln': lambda dev, reps: bench_ln(dev, reps),
     'upsum': lambda dev, reps: bench_upsum(dev, reps),
+    'resize': lambda dev, reps: bench_resize(dev, reps),
+    'gemm': lambda dev, reps: bench_gemm_planes(dev, reps),
+    'pred': lambda dev, reps: bench_pred(dev, reps),
 }
 
 

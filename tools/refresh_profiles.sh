@@ -34,7 +34,9 @@ fi
 if want 3; then
 echo "[3] per-step table" | tee -a $OUT/progress.txt
 ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_step -o step -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-exact-f32 > /dev/null 2>&1 )
-python tools/prof_summary.py /tmp/prof_step --skip 8 --top 70 --out $OUT/train_step_kernels.txt > /dev/null
+python tools/prof_summary.py /tmp/prof_step --skip 8 --top 90 --gaps 12 --out $OUT/train_step_kernels.txt > /dev/null
+python tools/step_kernel_shapes.py /tmp/prof_step "" > $OUT/step_shapes.txt 2>/dev/null
+python tools/step_top5.py $OUT/train_step_kernels.txt $OUT/bench_kernels.json > $OUT/step_top5.json 2>/dev/null
 fi
 if want 4; then
 echo "[4] other configs" | tee -a $OUT/progress.txt
@@ -50,7 +52,7 @@ done
 fi
 if want 5; then
 echo "[5] kernel rooflines: trace + PMC passes" | tee -a $OUT/progress.txt
-for g in r1 tok r2 ce align sra optim dw ln upsum; do
+for g in r1 tok r2 ce align sra optim dw ln upsum resize gemm pred; do
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kr_$g -o k -- python3 $R/tools/kernel_rooflines.py --only $g > $OUT/kernels_$g.txt 2>/dev/null )
   cp $(find /tmp/kr_$g -name '*kernel_stats.csv' | head -1) $OUT/kernels_${g}_stats.csv 2>/dev/null
 done
@@ -68,6 +70,9 @@ fi
 if want 6; then
 echo "[6] gemm bench" | tee -a $OUT/progress.txt
 python tools/gemm_bench.py 2>/dev/null | grep -v amdgpu.ids > $OUT/gemm_bench.txt
+python tools/wgrad_splitk_bench.py 2>/dev/null | grep -v amdgpu.ids > $OUT/wgrad_splitk_bench.txt
+python tools/pred_bench.py 2>/dev/null | grep -v amdgpu.ids > $OUT/pred_bench.txt
+tools/gemm_pmc.sh $OUT --mode pl > $OUT/gemm_pmc_planes.txt 2>&1
 fi
 ls -la $OUT | tee -a $OUT/progress.txt
 [ -f $OUT/bench.json ] && cut -c1-600 $OUT/bench.json
