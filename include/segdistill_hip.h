@@ -565,10 +565,13 @@ int sd_linear_nchw_bwd_weight(const void *dY, const void *X, float *dW, float *d
  * mmseg/ops/wrappers.py:6-28 -- PSPHead's pooled branches (psp_head.py:52-58), UPerHead's top-down path and level fusion
  * (uper_head.py:101-121), `resize_concat` (decode_head.py:130-139) -- and KLDLoss.resize (losses.py:25-33) for the sizes the fused
  * up-sample kernels do not take.  Any input / output size, align_corners 0 | 1, ATen's index arithmetic.  planes = B * C.
- * Backward: deterministic gather (no atomics): din[y][x] = sum of weight * dout over the outputs whose taps touch (y, x).
+ * Backward: deterministic separable gather (no atomics): din[y][x] = sum of weight * dout over the outputs whose taps touch (y, x), rows first
+ * (fp32 workspace of sd_resize_bilinear_bwd_workspace_bytes(planes, h, W) bytes, 16-byte aligned), then columns.
  */
 int sd_resize_bilinear_fwd(const void *in, void *out, int dtype, long planes, int h, int w, int H, int W, int align_corners, void *stream);
-int sd_resize_bilinear_bwd(const void *dout, void *din, int dtype, long planes, int h, int w, int H, int W, int align_corners, void *stream);
+size_t sd_resize_bilinear_bwd_workspace_bytes(long planes, int h, int W);
+int sd_resize_bilinear_bwd(const void *dout, void *din, int dtype, long planes, int h, int w, int H, int W, int align_corners, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
  * LayerNorm / residual-add + LayerNorm (the two entry points above) whose output feeds a spatial-reduction attention (round 3): the

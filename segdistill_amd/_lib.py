@@ -117,7 +117,8 @@ SIGNATURES = {
     'sd_bn_act_bwd_reduce': (_i, [_vp] * 7 + [C.c_long, _i, _vp, _vp, _i, C.c_long, _i, _vp, _sz, _vp]),
     'sd_bn_act_bwd_elemt': (_i, [_vp] * 7 + [C.c_long, _i, _vp, _vp, _f, _vp, _vp, _i, C.c_long, _i, _vp]),
     'sd_resize_bilinear_fwd': (_i, [_vp, _vp, _i, C.c_long, _i, _i, _i, _i, _i, _vp]),
-    'sd_resize_bilinear_bwd': (_i, [_vp, _vp, _i, C.c_long, _i, _i, _i, _i, _i, _vp]),
+    'sd_resize_bilinear_bwd_workspace_bytes': (_sz, [C.c_long, _i, _i]),
+    'sd_resize_bilinear_bwd': (_i, [_vp, _vp, _i, C.c_long, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'sd_ce_up_supported': (_i, [_i, _i, _i, _i]),
     'sd_ce_up_fwd': (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 8 + [_vp]),
     'sd_ce_up_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp] + [_i] * 8 + [_vp]),

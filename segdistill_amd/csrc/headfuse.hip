@@ -11,6 +11,7 @@
 // (transposed interpolation, no atomics).  HBM-bound byte work.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "cgd_device.h"
 
@@ -289,6 +290,150 @@ __global__ __launch_bounds__(256) void upsum_bwd_cols(const float *__restrict__ 
     HV<T>::store(dz + tap * E + c, acc);
 }
 
+// ---- round 3: the same three gradients in ONE pass, no global partials (W = 128 maps: every SegFormer head at 512 x 512) ---------------------
+// The two-pass form above writes the fp32 row partials (7/8 of the dy bytes) and reads them back: 412 MB of traffic for 178 MB of algorithmic
+// bytes (58 + 31 us at config 2).  Here a workgroup owns a band of 16 output rows x all 128 columns x 32 channels and produces the COMPLETE
+// taps of that band -- 8 / 4 / 2 tap rows of the x2 / x4 / x8 branches -- by walking the 24 output rows their supports touch (rows
+// [16 m - 4, 16 m + 20): the halo is re-read, mostly from L2, by the neighbouring band): each dy row is staged in LDS once (double-buffered,
+// requested one row ahead), reduced along x for all three factors from LDS with per-thread weight tables, and added into per-tap-row
+// accumulators that live in registers (static indices: the row loop is unrolled, only the weights are data).  thread = (4-channel vector
+// c4 = tid & 7, column group xg = tid >> 3): taps kx = xg and xg + 32 of the x2 branch, kx = xg of the x4 branch, kx = xg < 16 of the x8 branch.
+__global__ __launch_bounds__(256) void upsum_bwd3_band(const float *__restrict__ dy, float *__restrict__ dz2, float *__restrict__ dz3,
+                                                        float *__restrict__ dz4, int H, int E) {
+    constexpr int W = 128, CP = 36, R = 16;
+    __shared__ __attribute__((aligned(16))) float row_tile[2][W * CP];
+    const int c4 = threadIdx.x & 7, xg = threadIdx.x >> 3;
+    const int nband = H / R, ncs = E / 32;
+    const int cs = blockIdx.x % ncs, band = (blockIdx.x / ncs) % nband, b = blockIdx.x / (ncs * nband);
+    const int c0 = cs * 32 + c4 * 4, Y0 = band * R;
+    // x weights of this thread's taps: output column X = F kx - F/2 + t, t < 2F (clamped; weight 0 outside the image)
+    float wx2[2][4], wx4[8], wx8[16];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int X = 2 * (xg + 32 * k) - 1 + t;
+            wx2[k][t] = (X >= 0 && X < W) ? tap_weight(X, 2, W / 2, xg + 32 * k) : 0.f;
+        }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int X = 4 * xg - 2 + t;
+        wx4[t] = (X >= 0 && X < W) ? tap_weight(X, 4, W / 4, xg) : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int X = 8 * xg - 4 + t;
+        wx8[t] = (xg < 16 && X >= 0 && X < W) ? tap_weight(X, 8, W / 8, xg) : 0.f;
+    }
+    float4 a2[2][8], a4[4], a8[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a2[k][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    a8[0] = a8[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *img = dy + (size_t)b * H * W * E + cs * 32;
+    // staging: thread -> pixels X = (tid >> 3) + 32 i, its own 4-channel vector
+    float4 st[4];
+    auto request = [&](int Y) {
+        const float *src = img + (size_t)Y * W * E + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st[i] = *reinterpret_cast<const float4 *>(src + (size_t)(xg + 32 * i) * E);
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4 *>(&row_tile[buf][(xg + 32 * i) * CP + c4 * 4]) = st[i];
+    };
+    auto axpy = [](float4 &a, float w, const float4 v) { a.x = fmaf(w, v.x, a.x); a.y = fmaf(w, v.y, a.y); a.z = fmaf(w, v.z, a.z); a.w = fmaf(w, v.w, a.w); };
+    const int ylo = max(Y0 - 4, 0), yhi = min(Y0 + R + 4, H);      // rows [ylo, yhi)
+    request(ylo);
+    int buf = 0;
+    for (int Y = ylo; Y < yhi; ++Y) {
+        park(buf);
+        if (Y + 1 < yhi) request(Y + 1);       // lands while this row is reduced
+        __syncthreads();
+        const float *row = row_tile[buf];
+        // ---- x2 branch: tap rows 8 m .. 8 m + 7
+        {
+            int i0, i1;
+            float lam;
+            src_of(Y, 2, H / 2, i0, i1, lam);
+            const int q0 = i0 - (Y0 >> 1), q1 = i1 - (Y0 >> 1);
+            if ((q0 >= 0 && q0 < 8) || (q1 >= 0 && q1 < 8)) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    float4 hsum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int X = min(max(2 * (xg + 32 * k) - 1 + t, 0), W - 1);
+                        axpy(hsum, wx2[k][t], *reinterpret_cast<const float4 *>(row + X * CP + c4 * 4));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float wy = (q == q0 ? 1.f - lam : 0.f) + (q == q1 ? lam : 0.f);
+                        if (wy != 0.f) axpy(a2[k][q], wy, hsum);
+                    }
+                }
+            }
+        }
+        // ---- x4 branch: tap rows 4 m .. 4 m + 3
+        {
+            int i0, i1;
+            float lam;
+            src_of(Y, 4, H / 4, i0, i1, lam);
+            const int q0 = i0 - (Y0 >> 2), q1 = i1 - (Y0 >> 2);
+            if ((q0 >= 0 && q0 < 4) || (q1 >= 0 && q1 < 4)) {
+                float4 hsum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int X = min(max(4 * xg - 2 + t, 0), W - 1);
+                    axpy(hsum, wx4[t], *reinterpret_cast<const float4 *>(row + X * CP + c4 * 4));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float wy = (q == q0 ? 1.f - lam : 0.f) + (q == q1 ? lam : 0.f);
+                    if (wy != 0.f) axpy(a4[q], wy, hsum);
+                }
+            }
+        }
+        // ---- x8 branch: tap rows 2 m, 2 m + 1 (threads xg < 16: whole waves 0 and 1)
+        if (xg < 16) {
+            int i0, i1;
+            float lam;
+            src_of(Y, 8, H / 8, i0, i1, lam);
+            const int q0 = i0 - (Y0 >> 3), q1 = i1 - (Y0 >> 3);
+            if ((q0 >= 0 && q0 < 2) || (q1 >= 0 && q1 < 2)) {
+                float4 hsum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int X = min(max(8 * xg - 4 + t, 0), W - 1);
+                    axpy(hsum, wx8[t], *reinterpret_cast<const float4 *>(row + X * CP + c4 * 4));
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float wy = (q == q0 ? 1.f - lam : 0.f) + (q == q1 ? lam : 0.f);
+                    if (wy != 0.f) axpy(a8[q], wy, hsum);
+                }
+            }
+        }
+        buf ^= 1;
+    }
+    // ---- store the band's taps
+    const int h2 = H / 2, h4 = H / 4, h8 = H / 8;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            *reinterpret_cast<float4 *>(dz2 + (((size_t)b * h2 + (Y0 >> 1) + q) * (W / 2) + xg + 32 * k) * E + c0) = a2[k][q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(dz3 + (((size_t)b * h4 + (Y0 >> 2) + q) * (W / 4) + xg) * E + c0) = a4[q];
+    if (xg < 16) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<float4 *>(dz4 + (((size_t)b * h8 + (Y0 >> 3) + q) * (W / 8) + xg) * E + c0) = a8[q];
+    }
+}
+
 // dz[b,ky,kx,:] = sum over the outputs that use tap (ky,kx) of weight * dy.  grid: ceil(B*h*w*(E/N) / 256)
 template <typename T>
 __global__ __launch_bounds__(256) void upsum_bwd(const T *__restrict__ dy, T *__restrict__ dz, int B, int h, int w, int E, int F) {
@@ -332,6 +477,19 @@ __global__ __launch_bounds__(256) void upsum_bwd(const T *__restrict__ dy, T *__
 
 bool ok_factor(int f) { return f == 2 || f == 4 || f == 8; }
 
+}  // namespace
+
+int g_upsum_bwd_band = 1;     // tunable "upsum_bwd_band" (A/B, tests): 0 = the two-pass form with global row partials (round 2)
+
+int headfuse_tunable(const char *key, int set, int v) {
+    if (strcmp(key, "upsum_bwd_band")) return SD_E_UNSUPPORTED;
+    if (!set) return g_upsum_bwd_band;
+    if (v != 0 && v != 1) return SD_E_SHAPE;
+    g_upsum_bwd_band = v;
+    return SD_OK;
+}
+
+namespace {
 }  // namespace
 }  // namespace sd
 
@@ -398,6 +556,12 @@ int sd_upsum_bwd3(const void *dy, void *dz2, void *dz3, void *dz4, int dtype, in
     float *r8 = r4 + (size_t)B * H * (W / 4) * E;
     const size_t lds = (size_t)W * 68 * sizeof(float);
     const size_t taps = (size_t)B * ((size_t)(H / 2) * (W / 2) + (size_t)(H / 4) * (W / 4) + (size_t)(H / 8) * (W / 8));
+    if (dtype == SD_F32 && W == 128 && H % 16 == 0 && E % 32 == 0 && sd::g_upsum_bwd_band) {
+        // one pass, no global partials (round 3)
+        hipLaunchKernelGGL(sd::upsum_bwd3_band, dim3((unsigned)((size_t)B * (H / 16) * (E / 32))), dim3(256), 0, st, (const float *)dy, (float *)dz2,
+                           (float *)dz3, (float *)dz4, H, E);
+        return (int)hipGetLastError();
+    }
     if (dtype == SD_F32) {
         static bool raised = false;
         if (lds > 64 * 1024 && !raised) {

@@ -35,7 +35,10 @@ class _Bilinear(torch.autograd.Function):
         B, C, h, w, H, W, align = ctx.geom
         dy = dy.contiguous()
         dx = torch.empty(B, C, h, w, dtype=dy.dtype, device=dy.device)
-        _lib.check(_lib.lib().sd_resize_bilinear_bwd(dy.data_ptr(), dx.data_ptr(), _DT[dy.dtype], B * C, h, w, H, W, align, _stream_ptr()),
+        L = _lib.lib()
+        wsb = L.sd_resize_bilinear_bwd_workspace_bytes(B * C, h, W)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dy.device)
+        _lib.check(L.sd_resize_bilinear_bwd(dy.data_ptr(), dx.data_ptr(), _DT[dy.dtype], B * C, h, w, H, W, align, ws.data_ptr(), wsb, _stream_ptr()),
                    'sd_resize_bilinear_bwd')
         return dx, None, None, None
 

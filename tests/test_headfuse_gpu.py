@@ -103,3 +103,37 @@ def test_frozen_head_folds_norm_and_relu_into_the_sum(dtype):
     assert len(calls) == 1
     tol = 1e-4 if dtype == torch.float32 else 3e-2
     assert _err(out_fused, out_plain) < tol and _err(out_fused, out_cpu) < (1e-4 if dtype == torch.float32 else 5e-2)
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 128, 64), (1, 32, 128, 64), (8, 128, 128, 256), (3, 16, 128, 192)])
+def test_upsum_bwd3_band_kernel_matches_the_two_pass_form_and_fp64(shape):
+    """Round 3's one-pass sd_upsum_bwd3 (bands of 16 output rows, per-tap-row accumulators in registers, no global partials; W = 128, fp32)
+    against the two-pass form it replaces (tunable upsum_bwd_band = 0) and against the fp64 transpose of the three bilinear up-samplings;
+    band borders (first / last band: clamped taps), a single band (H = 16), channel counts of 2, 3, 6, 8 slices of 32."""
+    from segdistill_amd import _lib
+    from segdistill_amd.ops import _stream_ptr
+    B, H, W, E = shape
+    dev = torch.device('cuda:0')
+    L = _lib.lib()
+    g = torch.Generator(device=dev).manual_seed(H + E)
+    dy = torch.randn(B, H * W, E, device=dev, generator=g)
+    outs = {}
+    for mode in (1, 0):
+        _lib.set_tunable('upsum_bwd_band', mode)
+        try:
+            dz = [torch.full((B, (H // f) * (W // f), E), float('nan'), device=dev) for f in (2, 4, 8)]
+            wsb = L.sd_upsum_bwd3_workspace_bytes(B, H, W, E)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            _lib.check(L.sd_upsum_bwd3(dy.data_ptr(), dz[0].data_ptr(), dz[1].data_ptr(), dz[2].data_ptr(), 0, B, H, W, E, ws.data_ptr(), wsb,
+                                       _stream_ptr()), 'sd_upsum_bwd3')
+            outs[mode] = dz
+        finally:
+            _lib.set_tunable('upsum_bwd_band', 1)
+    dy64 = dy.double().reshape(B, H, W, E).permute(0, 3, 1, 2)
+    for k, f in enumerate((2, 4, 8)):
+        z = torch.zeros(B, E, H // f, W // f, dtype=torch.float64, device=dev, requires_grad=True)
+        F.interpolate(z, size=(H, W), mode='bilinear', align_corners=False).backward(dy64)
+        ref = z.grad.permute(0, 2, 3, 1).reshape(B, -1, E)
+        for mode in (1, 0):
+            err = float((outs[mode][k].double() - ref).abs().max() / ref.abs().max())
+            assert err < 2e-6, (f, mode, err)

@@ -419,11 +419,13 @@ def bench_resize(dev, reps):
         y = torch.empty(B, C, H, H, device=dev)
         dx = torch.empty_like(x)
         tf = _time(lambda st: _ok(L.sd_resize_bilinear_fwd(x.data_ptr(), y.data_ptr(), 0, B * C, h, h, H, H, 0, st), 'resize fwd'), reps)
-        tb = _time(lambda st: _ok(L.sd_resize_bilinear_bwd(y.data_ptr(), dx.data_ptr(), 0, B * C, h, h, H, H, 0, st), 'resize bwd'), reps)
+        wsb = L.sd_resize_bilinear_bwd_workspace_bytes(B * C, h, H)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        tb = _time(lambda st: _ok(L.sd_resize_bilinear_bwd(y.data_ptr(), dx.data_ptr(), 0, B * C, h, h, H, H, 0, ws.data_ptr(), wsb, st), 'resize bwd'), reps)
         nb_in, nb_out = x.numel() * 4, y.numel() * 4
         out += [_entry(f'bilinear resize fwd ({tag})', 'resize_bilinear_fwd', [B, C, h, h, H, H], 'f32', tf, 'hbm', nb_in + nb_out, HBM),
                 _entry(f'bilinear resize bwd ({tag})', 'resize_bilinear_bwd', [B, C, h, h, H, H], 'f32', tb, 'hbm', nb_in + nb_out, HBM,
-                       'gather form: every dOut element is read by ~4 input pixels (L2)')]
+                       'separable gather: rows then columns through an fp32 workspace of B*C*h*W elements (extra traffic)')]
     return out
 
 
