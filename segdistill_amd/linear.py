@@ -84,6 +84,7 @@ def _bwd_data(dy2, weight):
 
 _SHADOWS = os.environ.get('SEGDISTILL_BF16_SHADOWS', '1') == '1'
 _PRED_PLANES_A = os.environ.get('SEGDISTILL_PRED_PLANES_A', '1') == '1'    # A/B: 0 = linear_pred's forward splits W in registers (round 2)
+_BF16_WGRAD_LIB = os.environ.get('SEGDISTILL_BF16_WGRAD_LIB', '0') == '1'
 _SPLITK_WGRAD = os.environ.get('SEGDISTILL_SPLITK_WGRAD', '1') == '1'      # A/B: 0 = the library's dY^T @ X for the non-tall-skinny weight gradients
 
 
@@ -184,6 +185,11 @@ class _TokenLinear(torch.autograd.Function):
                     db = buf[M * N:]
                 elif want_db:
                     db = deferred.column_sum(dyc, ctx.defer_bias_ok)
+                return dx, dw, db, None, None
+            if not direct and _BF16_WGRAD_LIB and x.dtype == torch.bfloat16:
+                # A/B switch: the library's bf16 GEMM for the generic (not tall-skinny) weight gradients under bf16 storage
+                dw = (dyc.t() @ x2).to(ctx.w_dtype)
+                db = deferred.column_sum(dyc, ctx.defer_bias_ok and ctx.w_dtype == torch.float32).to(ctx.w_dtype) if want_db else None
                 return dx, dw, db, None, None
             gs = 0 if direct else L.sd_linear_wgrad_generic_slabs(_DT[x.dtype], T, M, N)
             if gs and ctx.defer_ok and deferred.enabled() and ctx.w_dtype == torch.float32:
