@@ -14,13 +14,39 @@ attention adds (relative-position bias + mask) as one additive term of SDPA.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ..builder import BACKBONES
 from ..layernorm import HipLayerNorm          # nn.LayerNorm subclass: same keys, HIP kernels on CUDA tokens (ATen's ran 3.9 ms of a config-4 step)
-from ..layers import DropPath, to_2tuple, trunc_normal_
+from ..layers import DropPath, frozen_derived, to_2tuple, trunc_normal_
+
+
+_GATHER_WINDOWS = os.environ.get('SEGDISTILL_SWIN_GATHER', '1') == '1'
+_TABLES = {}
+
+
+def _window_tables(h, w, ws, shift, device):
+    """(fwd, inv) int64 index tables of one image: fwd[j] = token that lands at window-ordered position j of the padded, cyclically shifted
+    map (h*w = the appended zero row for padded positions); inv[t] = window-ordered position of token t.  Built from the module's own
+    pad / roll / window_partition on an index map, so the gather IS that composition."""
+    key = (h, w, ws, shift, str(device))
+    hit = _TABLES.get(key)
+    if hit is None:
+        pad_r, pad_b = (ws - w % ws) % ws, (ws - h % ws) % ws
+        idx = torch.arange(h * w).view(1, h, w, 1)
+        idx = F.pad(idx, (0, 0, 0, pad_r, 0, pad_b), value=h * w)
+        if shift > 0:
+            idx = torch.roll(idx, shifts=(-shift, -shift), dims=(1, 2))
+        fwd = window_partition(idx, ws).reshape(-1)
+        inv = torch.empty(h * w + 1, dtype=torch.long)
+        inv[fwd] = torch.arange(fwd.numel())
+        hit = (fwd.to(device), inv[:h * w].contiguous().to(device))
+        _TABLES[key] = hit
+    return hit
 
 
 def window_partition(x, ws):
@@ -72,13 +98,23 @@ class WindowAttention(nn.Module):
         bw, n, c = x.shape
         h = self.num_heads
         q, k, v = self.qkv(x).reshape(bw, n, 3, h, c // h).permute(2, 0, 3, 1, 4)
-        bias = self.relative_position_bias_table[self.relative_position_index.view(-1)].view(n, n, h).permute(2, 0, 1)  # [h,N,N]
-        add = bias.unsqueeze(0)
-        if mask is not None:
-            nw = mask.shape[0]
-            add = (add + mask.unsqueeze(1)).repeat(bw // nw, 1, 1, 1)  # windows of one image are contiguous
+        def additive():
+            bias = self.relative_position_bias_table[self.relative_position_index.view(-1)].view(n, n, h).permute(2, 0, 1)  # [h,N,N]
+            add = bias.unsqueeze(0)
+            if mask is not None:
+                nw = mask.shape[0]
+                add = (add + mask.unsqueeze(1)).repeat(bw // nw, 1, 1, 1)  # windows of one image are contiguous
+            return add.to(q.dtype)
+        if torch.is_grad_enabled() and self.relative_position_bias_table.requires_grad:
+            add = additive()
+        else:
+            # frozen network (the config-4 teacher): bias gather + mask add + the repeat over the batch -- a 111 MB copy per stage-1 block --
+            # are the same tensor every step: cached per (mask identity, windows, dtype), invalidated by a checkpoint load like every
+            # derived weight (layers.frozen_derived)
+            key = ('swin_bias', None if mask is None else (mask.data_ptr(), mask._version), bw, q.dtype)
+            add = frozen_derived(self.relative_position_bias_table, key, additive) if not self.relative_position_bias_table.requires_grad else additive()
         drop = self.attn_drop.p if self.training else 0.
-        out = F.scaled_dot_product_attention(q, k, v, attn_mask=add.to(q.dtype), dropout_p=drop, scale=self.scale)
+        out = F.scaled_dot_product_attention(q, k, v, attn_mask=add, dropout_p=drop, scale=self.scale)
         return self.proj_drop(self.proj(out.transpose(1, 2).reshape(bw, n, c)))
 
 
@@ -100,8 +136,20 @@ class SwinTransformerBlock(nn.Module):
         h, w = self.H, self.W
         assert n == h * w, 'input feature has wrong size'
         ws = self.window_size
-        y = self.norm1(x).view(b, h, w, c)
         pad_r, pad_b = (ws - w % ws) % ws, (ws - h % ws) % ws
+        if x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad) and _GATHER_WINDOWS:
+            # no autograd graph to build (the frozen teacher): pad + cyclic shift + window partition are ONE row gather (they were three
+            # copies), window reverse + un-shift + un-pad another (index tables cached per geometry; padded positions read an appended
+            # zero row, exactly what F.pad produced)
+            fwd_idx, inv_idx = _window_tables(h, w, ws, self.shift_size, x.device)
+            y = self.norm1(x)
+            y = torch.cat([y, y.new_zeros(b, 1, c)], 1) if (pad_r or pad_b) else y
+            win = y.index_select(1, fwd_idx).view(-1, ws * ws, c)
+            win = self.attn(win, mask=mask_matrix if self.shift_size > 0 else None)
+            y = win.reshape(b, -1, c).index_select(1, inv_idx)
+            x = x + self.drop_path(y)
+            return x + self.drop_path(self.mlp(self.norm2(x)))
+        y = self.norm1(x).view(b, h, w, c)
         if pad_r or pad_b:
             y = F.pad(y, (0, 0, 0, pad_r, 0, pad_b))
         hp, wp = h + pad_b, w + pad_r
