@@ -6,8 +6,6 @@ extract_feat :77-82, encode_decode :84-94, forward_train :136-166); loss keys ar
 """
 from __future__ import annotations
 
-import os
-
 import torch
 import torch.nn as nn
 
@@ -15,9 +13,6 @@ from .. import builder
 from ..builder import SEGMENTORS
 from ..layers import add_prefix, resize
 from .base import BaseSegmentor
-
-
-_CL_RESNET = os.environ.get('SEGDISTILL_CL_RESNET', '0') == '1'
 
 
 @SEGMENTORS.register_module()
@@ -47,18 +42,7 @@ class EncoderDecoder(BaseSegmentor):
             for h in heads:
                 h.init_weights()
 
-    def _maybe_channels_last(self, img):
-        """EXPERIMENT (SEGDISTILL_CL_RESNET=1, off by default): ResNet backbones + conv heads in channels-last storage, so that MIOpen's NHWC
-        implicit-GEMM kernels -- which it picks anyway -- run without their NCHW <-> NHWC `batched_transpose` launches (148 per config-1 step)."""
-        if not _CL_RESNET or not img.is_cuda or type(self.backbone).__name__ not in ('ResNet', 'ResNetV1c', 'ResNetV1d'):
-            return img
-        if not getattr(self, '_cl_done', False):
-            self.to(memory_format=torch.channels_last)
-            object.__setattr__(self, '_cl_done', True)
-        return img.contiguous(memory_format=torch.channels_last)
-
     def extract_feat(self, img):
-        img = self._maybe_channels_last(img)
         graphed = getattr(self, '_graphed_backbone', None)   # set by KDTrainer.enable_hybrid_graph
         if graphed is not None and self.training and torch.is_grad_enabled() and img.is_cuda:
             x = graphed(img)
