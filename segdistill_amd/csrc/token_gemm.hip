@@ -149,6 +149,9 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
     static_assert(!APL || (X3 && FULLK && VEC && AKC && BT && !BFRAG), "pre-split A planes: split-bf16 mode, whole k-steps, k-contiguous operands");
     static_assert(!BFRAG || (X3 && FULLK && VEC && AKC), "pre-split B planes: split-bf16 mode, whole k-steps, k-contiguous A");
     extern __shared__ __attribute__((aligned(16))) float lds[];        // [2][A_ELEMS + B_ELEMS]
+#ifdef SD_GEMM_STAMPS
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
     // z = batch * nsplit + split: a split covers k in [split * klen, min(K, (split + 1) * klen)) and writes its own C slab (split-K)
     {
         const int zb = blockIdx.y / nsplit, sp = blockIdx.y - zb * nsplit;
@@ -350,6 +353,11 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             }
         };
+        // (Measured and dropped, round 3: the A fragments straight from global memory as well -- every wave requests its own rows a whole k-step
+        // ahead into two register sets; no LDS, no barrier in the main loop, 252 registers, audit clean.  Same box, planes forward: 123.4 vs
+        // 103.9 us at 256 -> 256 over 131072 tokens, 20.9 vs 17.2 us at 32 -> 32, 22.9 vs 18.7 at 160 -> 640 over 8192 -- slower on all 47 shapes
+        // of tools/gemm_bench.py.  Each row of A is then fetched by both waves of a tile row, 16 bytes per lane from 32 different lines per
+        // instruction: the vector-memory path, not the barrier, becomes the limit.)
         // Schedule of k-step kt (tile kt in LDS stage kt & 1; B0 = B(kt, 0) and B1 = B(kt, 1) are register sets):
         //   top     request B(kt, 1)                                   wait B(kt, 0)      [queue: B(kt,0), A(kt+1) | B(kt,1)]
         //   half 0  { read + split A(kt, half 1) -> PA1  ||  MFMAs on (PA0, B0) }
@@ -366,26 +374,57 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
         if (nk > 1) load_tiles(BK);                     // A(1): consumed in the middle of step 0
         __syncthreads();
         read_split_a(PA0, lds, 0);
+        // -DSD_GEMM_STAMPS (diagnostic A/B build only, tools/gemm_stamps.py): s_memtime at the phase boundaries of every k-step, summed per
+        // phase; wave 0 of every 64th workgroup writes its sums to the buffer that build's launcher passes in `residual` (unused by EPI = 0)
+#ifdef SD_GEMM_STAMPS
+        unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime(), tbegin = tlast;
+#define SD_STAMP(i)                                                    \
+    do {                                                               \
+        const unsigned long long tnow = __builtin_amdgcn_s_memtime();  \
+        tph[i] += tnow - tlast;                                        \
+        tlast = tnow;                                                  \
+    } while (0)
+#else
+#define SD_STAMP(i)
+#endif
         for (int kt = 0; kt + 1 < nk; ++kt) {
             const float *cur = lds + (kt & 1) * A_ELEMS;
             float *nxt = lds + ((kt + 1) & 1) * A_ELEMS;
             load_b(B1, 2 * kt + 1);                     // NB
             wait_vm(std::integral_constant<int, NA + NB>{});     // B0 = B(kt, 0) landed; A(kt+1) and B(kt, 1) may still fly
+            SD_STAMP(0);
             read_split_a(PA1, cur, 1);
             mfma_planes(PA0, B0);
             interleave();
             __builtin_amdgcn_sched_barrier(0);
+            SD_STAMP(1);
             wait_vm(std::integral_constant<int, NB>{});          // A(kt+1) landed
+            SD_STAMP(2);
             store_tiles(nxt);
             load_b(B0, 2 * kt + 2);                     // NB; B0's registers were last read by the MFMAs above
             load_tiles((kt + 2) * BK, kt + 2 < nk);             // NA; past the last tile: placeholder requests (no branch: one basic block)
             __syncthreads();
+            SD_STAMP(3);
             wait_vm(std::integral_constant<int, NA + NB>{});     // B1 = B(kt, 1) landed
+            SD_STAMP(4);
             read_split_a(PA0, nxt, 0);
             mfma_planes(PA1, B1);
             interleave();
             __builtin_amdgcn_sched_barrier(0);
+            SD_STAMP(5);
         }
+#ifdef SD_GEMM_STAMPS
+        if (residual && (blockIdx.x & 63) == 0 && threadIdx.x == 0) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(residual)) + (blockIdx.x >> 6) * 12;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o[i] = tph[i];
+            o[6] = __builtin_amdgcn_s_memtime() - tbegin;
+            o[7] = (unsigned long long)(nk - 1);
+            o[8] = tbegin - t_entry;                                  // prologue: first requests -> first fragments split
+            o[9] = t_entry;                                           // absolute, for the workgroup timeline
+        }
+#endif
+#undef SD_STAMP
         {
             const float *cur = lds + ((nk - 1) & 1) * A_ELEMS;
             load_b(B1, 2 * nk - 1);
@@ -681,6 +720,12 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
             else rows_out(std::false_type{});
             __syncthreads();
         }
+#ifdef SD_GEMM_STAMPS
+        if (BFRAG && EPI == 0 && residual && (blockIdx.x & 63) == 0 && threadIdx.x == 0) {
+            unsigned long long *o = reinterpret_cast<unsigned long long *>(const_cast<float *>(residual)) + (blockIdx.x >> 6) * 12;
+            o[10] = __builtin_amdgcn_s_memtime();                     // absolute end (stores issued, not necessarily drained)
+        }
+#endif
         return;
     }
     // unaligned output (N % 4 != 0: the 150 classes of linear_pred): element stores in the accumulator layout -- col = lane & 31,
@@ -887,6 +932,10 @@ __global__ __launch_bounds__(256) void presplit_planes(const PresplitTable t) {
     dst[128] = l;
 }
 
+#ifdef SD_GEMM_STAMPS
+const float *g_gemm_stamp_buf = nullptr;     // diagnostic build: device buffer of 8 x u64 per 64 workgroups (sd_debug_gemm_stamps)
+#endif
+
 // X3 products on a pre-split B operand (planes: `nblocks` 32-column blocks x K/16 k-steps)
 int dispatch_planes(const float *A, const void *planes, int nblocks, float *C, const float *bias, const float *residual, long M, int N, int K,
                     hipStream_t st) {
@@ -895,7 +944,11 @@ int dispatch_planes(const float *A, const void *planes, int nblocks, float *C, c
     // same A split, ~330 registers, ONE workgroup per CU -- 109.7 vs 105.1 us at 256 -> 256 over 131072 tokens, 47.3 vs 43.6 us at 64 -> 256,
     // 55.7 vs 45.4 us at 320 -> 1280 over 8192: PMC shows the same ~50 % matrix-pipe occupancy with less co-resident work to cover the waits.)
     if (residual) return launch_epi<128, 128, 2, 2, true, 1, true, false, true, true>(A, Bp, C, bias, residual, M, N, K, K, nblocks, N, st);
+#ifdef SD_GEMM_STAMPS
+    return launch_epi<128, 128, 2, 2, true, 0, true, false, true, true>(A, Bp, C, bias, g_gemm_stamp_buf, M, N, K, K, nblocks, N, st);
+#else
     return launch_epi<128, 128, 2, 2, true, 0, true, false, true, true>(A, Bp, C, bias, nullptr, M, N, K, K, nblocks, N, st);
+#endif
 }
 
 template <bool BT>
@@ -1198,6 +1251,13 @@ int sd_linear_nchw_fwd_planes(const void *X, const void *w_row_planes, const flo
     if (dtype != SD_F32) return SD_E_DTYPE;
     return sd::linear_nchw_f32_fwd_planes((const float *)X, w_row_planes, bias, (float *)Y, B, P, in_features, out_features, stream);
 }
+
+#ifdef SD_GEMM_STAMPS
+int sd_debug_gemm_stamps(const void *buf) {      // diagnostic A/B build only (not in the header): where sd_linear_fwd_planes writes its phase sums
+    sd::g_gemm_stamp_buf = static_cast<const float *>(buf);
+    return SD_OK;
+}
+#endif
 
 int sd_linear_fwd_planes(const void *X, const void *fwd_planes, const float *bias, const void *residual, void *Y, int dtype, long tokens,
                          int in_features, int out_features, void *stream) {
