@@ -361,11 +361,17 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
         // Schedule of k-step kt (tile kt in LDS stage kt & 1; B0 = B(kt, 0) and B1 = B(kt, 1) are register sets):
         //   top     request B(kt, 1)                                   wait B(kt, 0)      [queue: B(kt,0), A(kt+1) | B(kt,1)]
         //   half 0  { read + split A(kt, half 1) -> PA1  ||  MFMAs on (PA0, B0) }
-        //   middle  wait A(kt+1) (requested one whole step ago), store it to the other stage, request B(kt+1, 0) then A(kt+2); barrier
+        //   middle  wait A(kt+1) (requested one whole step ago), store it to the other stage, request B(kt+1, 0); barrier; request A(kt+2)
         //   half 1  wait B(kt, 1)  { read + split A(kt+1, half 0) -> PA0  ||  MFMAs on (PA1, B1) }
         // vmcnt retires in order, so B(kt+1, 0) is requested BEFORE A(kt+2): the wait for it at the next top does not drag the A tile along,
         // which keeps its full step of flight time (the round-2 order -- A requested at the top, consumed half a step later -- ran each
         // k-step at the HBM latency: 3.2 us against 1.3 us of matrix work).
+        // tools/gemm_stamps.py (256 -> 256 over 131072 tokens, cycles per k-step and wave): wait B(kt, 0) 614 | half 0 1058 | wait A 48 | store +
+        // requests + barrier 1294 | wait B(kt, 1) 63 | half 1 1039 = 4117 against 1536 of MFMA issue, two waves per SIMD; prologue 5500 and
+        // last step + epilogue 9300 of a 43900-cycle workgroup lifetime.  The fragment loads hit in L2 yet take ~3000 cycles: the vector L1
+        // returns a CU's loads in order, so they queue behind the other waves' A-tile loads from HBM.  (Tried and dropped: a THIRD B register
+        // set, every request a whole step ahead -- the rotation needs the k-loop unrolled by three and hipcc then allocates > 256 registers
+        // (200 AGPRs as spill space at one workgroup per CU, 357-635 scratch spills when held to two), pending loads among the spilled.)
         APl PA0, PA1;
         BPl B0, B1;
         load_b(B0, 0);                                  // (the A tile of step 0 was requested above)
@@ -402,8 +408,11 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
             SD_STAMP(2);
             store_tiles(nxt);
             load_b(B0, 2 * kt + 2);                     // NB; B0's registers were last read by the MFMAs above
-            load_tiles((kt + 2) * BK, kt + 2 < nk);             // NA; past the last tile: placeholder requests (no branch: one basic block)
+            // the A tile is requested BEHIND the barrier: all four waves' fragment requests (L2 hits) are then in the CU's in-order return
+            // queue ahead of the workgroup's HBM requests instead of interleaved with them (same box, 47 shapes of tools/gemm_bench.py: 3-7 %
+            // on the latency-bound products -- 2048 x 1024 -> 256: 37.0 vs 39.5 us, 4096 -> 64: 133 vs 144 -- and +-1 % on the wide ones)
             __syncthreads();
+            load_tiles((kt + 2) * BK, kt + 2 < nk);             // NA; past the last tile: placeholder requests (no branch: one basic block)
             SD_STAMP(3);
             wait_vm(std::integral_constant<int, NA + NB>{});     // B1 = B(kt, 1) landed
             SD_STAMP(4);
@@ -693,7 +702,8 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) img[((e & 3) + 8 * (e >> 2) + 4 * kh) * WP + 32 * j + r] = acc[i][j][e];
-            __syncthreads();
+            // (no workgroup barrier: the image is private to the wave and a wave's LDS operations execute in order; the main loop's last
+            // barrier has already retired every other wave's reads of the staging buffers this image overlays)
             auto rows_out = [&](auto inner) {
                 constexpr bool IN = decltype(inner)::value;          // interior tile: no per-row / per-column predicate at all
 #pragma unroll
@@ -718,7 +728,6 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
             };
             if (m0 + BM <= M && n0 + BN <= N) rows_out(std::true_type{});
             else rows_out(std::false_type{});
-            __syncthreads();
         }
 #ifdef SD_GEMM_STAMPS
         if (BFRAG && EPI == 0 && residual && (blockIdx.x & 63) == 0 && threadIdx.x == 0) {
