@@ -392,6 +392,60 @@ def test_at_kl_fused_matches_oracle(shape, dtype):
     assert _rel_l2(sg.grad.float().cpu().numpy(), s64.grad.numpy()) < gtol
 
 
+@pytest.mark.parametrize('B,HW,K', [(3, 63, 5), (2, 16384, 150), (1, 5000, 700), (2, 1024, 1)])
+def test_ifvd_group_is_a_stable_sort_by_class(B, HW, K):
+    """sd_ifvd_group (one workgroup per image: per-wave counts, prefix, scatter) against torch's stable argsort: same order, run offsets
+    and inverse permutation -- labels outside [0, K) go last; ragged sizes, one class only, and K large enough for the > 48 KB LDS image."""
+    from segdistill_amd import _lib
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * HW + K)
+    cls = torch.randint(-2, K + 3, (B, HW), generator=g, dtype=torch.int32)
+    cls[:, : HW // 3] = torch.randint(0, K, (1,), generator=g).item()          # one long run: cut by several wave ranges
+    d = cls.to(dev)
+    order, pos = torch.empty(B, HW, dtype=torch.int32, device=dev), torch.empty(B, HW, dtype=torch.int32, device=dev)
+    offsets, skey = torch.empty(B, K + 1, dtype=torch.int32, device=dev), torch.empty(B, HW, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().sd_ifvd_group(d.data_ptr(), B, HW, K, order.data_ptr(), offsets.data_ptr(), pos.data_ptr(), skey.data_ptr(), None), 'sd_ifvd_group')
+    key = torch.where((cls >= 0) & (cls < K), cls, torch.full_like(cls, K)).long()
+    ref = key.argsort(dim=1, stable=True)
+    assert torch.equal(order.cpu().long(), ref)
+    assert torch.equal(skey.cpu().long(), torch.gather(key, 1, ref))
+    counts = torch.stack([torch.bincount(key[b], minlength=K + 1) for b in range(B)])
+    ref_off = torch.zeros(B, K + 1, dtype=torch.long)
+    ref_off[:, 1:] = counts[:, :K].cumsum(1)
+    assert torch.equal(offsets.cpu().long(), ref_off)
+    assert torch.equal(torch.gather(pos.cpu().long(), 1, ref), torch.arange(HW).expand(B, HW))
+
+
+@pytest.mark.parametrize('shape,dominant', [((2, 8, 200, 200), True), ((1, 5, 96, 96), True), ((2, 7, 33, 31), False)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_ifvd_class_sums_large_planes_and_dominant_classes(shape, dominant, dtype):
+    """Class means / coefficient sums where a class is cut by the waves' ranges of the sorted index (one class holds most pixels) and where
+    the channel plane no longer fits the LDS image (200 x 200 > 36864 pixels: gathers from global memory), against the fp64 oracle."""
+    from segdistill_amd.distillation import IFVDLoss
+    (B, C, h, w), dom = shape, dominant
+    g = torch.Generator().manual_seed(sum(shape) + int(dom))
+    s = (torch.randn(B, C, h, w, generator=g) + 0.5).to(dtype)
+    t = (torch.randn(B, C, h, w, generator=g) + 0.5).to(dtype)
+    lab = torch.randint(0, C, (B, 1, h, w), generator=g)
+    if dom:
+        lab[torch.rand(B, 1, h, w, generator=g) < 0.8] = 1
+    lab[torch.rand(B, 1, h, w, generator=g) < 0.05] = 255
+    s64 = s.double().requires_grad_(True)
+    ref = kd_ref.eager_ifvd(s64, t.double(), lab)
+    (0.7 * ref).backward()
+    sg = s.to(_dev()).requires_grad_(True)
+    loss = IFVDLoss()(sg, t.to(_dev()), lab.to(_dev()), 1)
+    (0.7 * loss).backward()
+    ltol, gtol = (LOSS_RTOL, GRAD_RL2) if dtype == torch.float32 else (3e-3, 2e-2)
+    assert float(loss) == pytest.approx(float(ref), rel=ltol)
+    assert _rel_l2(sg.grad.float().cpu().numpy(), s64.grad.numpy()) < gtol
+    # deterministic: a second run reproduces loss and gradient bit for bit
+    sg2 = s.to(_dev()).requires_grad_(True)
+    loss2 = IFVDLoss()(sg2, t.to(_dev()), lab.to(_dev()), 1)
+    (0.7 * loss2).backward()
+    assert torch.equal(loss, loss2) and torch.equal(sg.grad, sg2.grad)
+
+
 @pytest.mark.parametrize('shape', [(2, 19, 16, 16), (1, 150, 32, 32), (3, 6, 7, 9)])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_ifvd_kernels_match_oracle(shape, dtype):

@@ -309,14 +309,16 @@ def bench_ifvd(dev, reps, B=8, C=150, hw=128):
     S = (2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)).requires_grad_(True)
     T = 2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)
     cls = torch.randint(0, C, (B, hw, hw), device=dev, generator=gen, dtype=torch.int32)
-    # through the autograd binding (host-side sort / allocations inside): timed eagerly, not captured
-    tf = _time(lambda st: ops.ifvd_term(S.detach(), T, cls, C), reps, graph=False)
+    # through the autograd binding, captured and replayed like every other entry (round 3: no host-side sort any more); random labels are
+    # the worst case for the class sums (150 runs of ~109 pixels scattered over the whole plane)
+    tf = _time(lambda st: ops.ifvd_term(S.detach(), T, cls, C), reps)
     loss = ops.ifvd_term(S, T, cls, C)
-    tb = _time(lambda st: torch.autograd.grad(loss, S, retain_graph=True), reps, graph=False)
+    tb = _time(lambda st: torch.autograd.grad(loss, S, retain_graph=True), reps)
     N = S.numel()
-    note = 'through the autograd binding (includes the per-image class sort and small allocations); L2/Infinity-Cache resident at this size'
-    return [_entry('ifvd fwd (class means + cosine pass, both networks)', 'ifvd_seg_sum x2 + ifvd_cos x2', [B, C, hw, hw], 'f32', tf, 'hbm', 4 * N * 4, HBM, note),
-            _entry('ifvd bwd', 'ifvd_seg_sum x2 + ifvd_bwd', [B, C, hw, hw], 'f32', tb, 'hbm', 3 * N * 4, HBM, note)]
+    note = 'through the autograd binding; L2/Infinity-Cache resident at this size; round 2 (sort chain + one launch per network): 0.72 / 0.40 ms'
+    return [_entry('ifvd fwd (grouping + class means + cosine pass, both networks)', 'ifvd_group + ifvd_class_sums + ifvd_cos + ifvd_loss', [B, C, hw, hw],
+                   'f32', tf, 'hbm', 4 * N * 4, HBM, note),
+            _entry('ifvd bwd', 'ifvd_class_sums (weighted) + ifvd_bwd', [B, C, hw, hw], 'f32', tb, 'hbm', 3 * N * 4, HBM, note)]
 
 
 def bench_ce(dev, reps, B=8, C=150, hw=128, F=4):
