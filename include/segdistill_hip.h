@@ -167,31 +167,29 @@ int sd_at_kl_bwd(const void *S, const void *T, int dtype, int B, int C, int H, i
  * IFVDLoss, intra-class feature-variation term (losses.py:221-235): cosine similarity of every pixel's feature to the mean
  * feature of its class (per image), matched between student and teacher: 10 * mean_p (sim_S - sim_T)^2, and its gradient
  * with respect to the student feature INCLUDING the path through the class means (as the reference's autograd does).
- * cls [B][HW] int32 is the class of each pixel (-1 / >= K: no class); K < 1024.  Call order, forward: group, class_means, cos;
- * backward: coef_sums, bwd.
- *   sd_ifvd_group        stable grouping of every image's pixels by class: order [B][HW] (pixel indices, classes 0..K-1 first, then the
- *                        pixels without a class), offsets [B][K+1] (run starts; offsets[K] = pixels with a class), pos [B][HW] (inverse
- *                        of order), skey [B][HW] (class at each sorted position, K = none)
- *   sd_ifvd_class_means  mean_x[b,c,k] = sum_{p in run k} X[b,c,p] / (n_k + 1e-6) for both networks in one launch (T, mean_t may be NULL);
+ * cls [B][HW] int32 is the class of each pixel (-1 / >= K: no class).  Call order, forward: counts, class_means, cos; backward:
+ * coef_sums, bwd.  A class sum is a product with the one-hot label matrix, run on the bf16 matrix pipe with the features split exactly
+ * into three bf16 terms (fp32-grade): no sort of the pixels, no gathers, deterministic.
+ *   sd_ifvd_counts       counts[b,k] = number of pixels of image b with class k
+ *   sd_ifvd_class_means  mean_x[b,c,k] = sum_{p: cls = k} X[b,c,p] / (n_k + 1e-6) for both networks in one launch (T, mean_t may be NULL);
  *                        tables are [B][C][K]: the per-pixel passes read one channel's K values per wave
  *   sd_ifvd_cos          per pixel cos(X[b,:,p], mean_x[b,:,cls]) (eps 1e-8 per norm, F.cosine_similarity) for both networks,
- *                        loss = 10 * mean (sim_S - sim_T)^2, and the backward's coefficients: coef_px [2][B*HW] = alpha, gamma in pixel
- *                        order, coef_sorted [2][B*HW] = alpha, beta in the order of `order`.  Workspace: sd_ifvd_workspace_bytes.
- *   sd_ifvd_coef_sums    A[b,c,k] = sum_{p in run k} alpha_p S[b,c,p],  Bk[b,k] = sum_{p in run k} beta_p   (one launch)
+ *                        loss = 10 * mean (sim_S - sim_T)^2, and coefs [3][B*HW] = alpha, beta, gamma for the backward
+ *   sd_ifvd_coef_sums    A[b,c,k] = sum_{p: cls = k} alpha_p S[b,c,p],  Bk[b,k] = sum_{p: cls = k} beta_p
  *   sd_ifvd_bwd          dS = upstream * (alpha*mu_k - gamma*S + (A_k - mu_k*B_k)/(n_k + 1e-6))
- * Deterministic (no float atomics).  S, T, dS: [B,C,HW] in `dtype`; everything else fp32 / int32.
+ * Workspace (class_means, cos, coef_sums; 16-byte aligned): sd_ifvd_workspace_bytes.  S, T, dS: [B,C,HW] in `dtype`; everything else
+ * fp32 / int32.
  */
-size_t sd_ifvd_workspace_bytes(int B, int HW);
-int sd_ifvd_group(const int *cls, int B, int HW, int K, int *order, int *offsets, int *pos, int *skey, void *stream);
-int sd_ifvd_class_means(const void *S, const void *T /* or NULL */, int dtype, const int *order, const int *skey, const int *offsets,
-                        float *mean_s, float *mean_t, int B, int C, int HW, int K, void *stream);
-int sd_ifvd_cos(const void *S, const void *T, int dtype, const int *cls, const int *pos, const float *mean_s, const float *mean_t,
-                float *coef_px, float *coef_sorted, float *loss, void *workspace, size_t workspace_bytes,
-                int B, int C, int HW, int K, void *stream);
-int sd_ifvd_coef_sums(const void *S, int dtype, const int *order, const int *skey, const int *offsets, const float *coef_sorted,
-                      float *A, float *Bk, int B, int C, int HW, int K, void *stream);
-int sd_ifvd_bwd(const void *X, int dtype, const int *cls, const float *mean, const float *coef_px, const float *A, const float *Bk,
-                const int *offsets, const float *upstream /* device scalar or NULL */, void *dS,
+size_t sd_ifvd_workspace_bytes(int B, int C, int HW, int K);
+int sd_ifvd_counts(const int *cls, int B, int HW, int K, int *counts, void *stream);
+int sd_ifvd_class_means(const void *S, const void *T /* or NULL */, int dtype, const int *cls, const int *counts, float *mean_s, float *mean_t,
+                        void *workspace, size_t workspace_bytes, int B, int C, int HW, int K, void *stream);
+int sd_ifvd_cos(const void *S, const void *T, int dtype, const int *cls, const float *mean_s, const float *mean_t, float *coefs, float *loss,
+                void *workspace, size_t workspace_bytes, int B, int C, int HW, int K, void *stream);
+int sd_ifvd_coef_sums(const void *S, int dtype, const int *cls, const int *counts, const float *coefs, float *A, float *Bk,
+                      void *workspace, size_t workspace_bytes, int B, int C, int HW, int K, void *stream);
+int sd_ifvd_bwd(const void *X, int dtype, const int *cls, const float *mean, const float *coefs, const float *A, const float *Bk,
+                const int *counts, const float *upstream /* device scalar or NULL */, void *dS,
                 int B, int C, int HW, int K, void *stream);
 
 /* ---------------------------------------------------------------------------

@@ -301,38 +301,38 @@ class _IFVDFunction(torch.autograd.Function):
         HW, K = H * W, int(n_cls)
         cls = cls.reshape(B, HW).to(torch.int32).contiguous()
         L, dt, st = _lib.lib(), _DT[S.dtype], _stream_ptr()
-        i32 = dict(dtype=torch.int32, device=S.device)
         f32 = dict(dtype=torch.float32, device=S.device)
-        # pixels grouped by class, once for all channels and both networks (csrc/ifvd.hip: a stable counting sort, one workgroup per image)
-        order, pos, skey, offsets = torch.empty(B, HW, **i32), torch.empty(B, HW, **i32), torch.empty(B, HW, **i32), torch.empty(B, K + 1, **i32)
-        _lib.check(L.sd_ifvd_group(cls.data_ptr(), B, HW, K, order.data_ptr(), offsets.data_ptr(), pos.data_ptr(), skey.data_ptr(), st), 'sd_ifvd_group')
-        mean_s, mean_t = torch.empty(B, Cc, K, **f32), torch.empty(B, Cc, K, **f32)         # [B][C][K] (csrc/ifvd.hip)
-        _lib.check(L.sd_ifvd_class_means(S.data_ptr(), T.data_ptr(), dt, order.data_ptr(), skey.data_ptr(), offsets.data_ptr(), mean_s.data_ptr(),
-                                         mean_t.data_ptr(), B, Cc, HW, K, st), 'sd_ifvd_class_means')
-        coef_px, coef_sorted = torch.empty(2, B * HW, **f32), torch.empty(2, B * HW, **f32)
-        loss = torch.empty((), **f32)
-        wsb = L.sd_ifvd_workspace_bytes(B, HW)
+        counts = torch.empty(B, K, dtype=torch.int32, device=S.device)
+        _lib.check(L.sd_ifvd_counts(cls.data_ptr(), B, HW, K, counts.data_ptr(), st), 'sd_ifvd_counts')
+        wsb = L.sd_ifvd_workspace_bytes(B, Cc, HW, K)
         ws = torch.empty(wsb, dtype=torch.uint8, device=S.device)
-        _lib.check(L.sd_ifvd_cos(S.data_ptr(), T.data_ptr(), dt, cls.data_ptr(), pos.data_ptr(), mean_s.data_ptr(), mean_t.data_ptr(),
-                                 coef_px.data_ptr(), coef_sorted.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, B, Cc, HW, K, st), 'sd_ifvd_cos')
-        ctx.save_for_backward(S, cls, mean_s, coef_px, coef_sorted, order, skey, offsets)
+        mean_s, mean_t = torch.empty(B, Cc, K, **f32), torch.empty(B, Cc, K, **f32)         # [B][C][K] (csrc/ifvd.hip)
+        _lib.check(L.sd_ifvd_class_means(S.data_ptr(), T.data_ptr(), dt, cls.data_ptr(), counts.data_ptr(), mean_s.data_ptr(), mean_t.data_ptr(),
+                                         ws.data_ptr(), wsb, B, Cc, HW, K, st), 'sd_ifvd_class_means')
+        coefs = torch.empty(3, B * HW, **f32)
+        loss = torch.empty((), **f32)
+        _lib.check(L.sd_ifvd_cos(S.data_ptr(), T.data_ptr(), dt, cls.data_ptr(), mean_s.data_ptr(), mean_t.data_ptr(), coefs.data_ptr(), loss.data_ptr(),
+                                 ws.data_ptr(), wsb, B, Cc, HW, K, st), 'sd_ifvd_cos')
+        ctx.save_for_backward(S, cls, counts, mean_s, coefs)
         ctx.K = K
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
-        S, cls, mean_s, coef_px, coef_sorted, order, skey, offsets = ctx.saved_tensors
+        S, cls, counts, mean_s, coefs = ctx.saved_tensors
         B, Cc, H, W = S.shape
         HW, K = H * W, ctx.K
         L, dt, st = _lib.lib(), _DT[S.dtype], _stream_ptr()
         f32 = dict(dtype=torch.float32, device=S.device)
         A, Bk = torch.empty(B, Cc, K, **f32), torch.empty(B, K, **f32)
-        _lib.check(L.sd_ifvd_coef_sums(S.data_ptr(), dt, order.data_ptr(), skey.data_ptr(), offsets.data_ptr(), coef_sorted.data_ptr(), A.data_ptr(),
-                                       Bk.data_ptr(), B, Cc, HW, K, st), 'sd_ifvd_coef_sums')
+        wsb = L.sd_ifvd_workspace_bytes(B, Cc, HW, K)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=S.device)
+        _lib.check(L.sd_ifvd_coef_sums(S.data_ptr(), dt, cls.data_ptr(), counts.data_ptr(), coefs.data_ptr(), A.data_ptr(), Bk.data_ptr(), ws.data_ptr(),
+                                       wsb, B, Cc, HW, K, st), 'sd_ifvd_coef_sums')
         dS = torch.empty_like(S)
         up = grad_loss.to(torch.float32).contiguous()
-        _lib.check(L.sd_ifvd_bwd(S.data_ptr(), dt, cls.data_ptr(), mean_s.data_ptr(), coef_px.data_ptr(), A.data_ptr(), Bk.data_ptr(),
-                                 offsets.data_ptr(), up.data_ptr(), dS.data_ptr(), B, Cc, HW, K, st), 'sd_ifvd_bwd')
+        _lib.check(L.sd_ifvd_bwd(S.data_ptr(), dt, cls.data_ptr(), mean_s.data_ptr(), coefs.data_ptr(), A.data_ptr(), Bk.data_ptr(), counts.data_ptr(),
+                                 up.data_ptr(), dS.data_ptr(), B, Cc, HW, K, st), 'sd_ifvd_bwd')
         return dS, None, None, None
 
 

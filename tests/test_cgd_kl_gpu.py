@@ -392,28 +392,39 @@ def test_at_kl_fused_matches_oracle(shape, dtype):
     assert _rel_l2(sg.grad.float().cpu().numpy(), s64.grad.numpy()) < gtol
 
 
-@pytest.mark.parametrize('B,HW,K', [(3, 63, 5), (2, 16384, 150), (1, 5000, 700), (2, 1024, 1)])
-def test_ifvd_group_is_a_stable_sort_by_class(B, HW, K):
-    """sd_ifvd_group (one workgroup per image: per-wave counts, prefix, scatter) against torch's stable argsort: same order, run offsets
-    and inverse permutation -- labels outside [0, K) go last; ragged sizes, one class only, and K large enough for the > 48 KB LDS image."""
+@pytest.mark.parametrize('B,C,HW,K', [(3, 5, 63, 5), (2, 40, 4096, 150), (1, 33, 5000, 700), (2, 3, 1024, 1)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_ifvd_counts_and_class_means_against_a_mask_loop(B, C, HW, K, dtype):
+    """sd_ifvd_counts + sd_ifvd_class_means (one-hot products on the matrix pipe, features split exactly into three bf16 terms) against the
+    reference's mask loop (losses.py:226-230) in fp64: labels outside [0, K) belong to no class; ragged sizes (scalar loads), one class only,
+    more classes than one pass of 160 holds, a dominant class; fp32 tables must agree to fp32 rounding (the split loses nothing)."""
     from segdistill_amd import _lib
     dev = _dev()
-    g = torch.Generator().manual_seed(B * HW + K)
+    g = torch.Generator().manual_seed(B * HW + K + C)
     cls = torch.randint(-2, K + 3, (B, HW), generator=g, dtype=torch.int32)
-    cls[:, : HW // 3] = torch.randint(0, K, (1,), generator=g).item()          # one long run: cut by several wave ranges
-    d = cls.to(dev)
-    order, pos = torch.empty(B, HW, dtype=torch.int32, device=dev), torch.empty(B, HW, dtype=torch.int32, device=dev)
-    offsets, skey = torch.empty(B, K + 1, dtype=torch.int32, device=dev), torch.empty(B, HW, dtype=torch.int32, device=dev)
-    _lib.check(_lib.lib().sd_ifvd_group(d.data_ptr(), B, HW, K, order.data_ptr(), offsets.data_ptr(), pos.data_ptr(), skey.data_ptr(), None), 'sd_ifvd_group')
-    key = torch.where((cls >= 0) & (cls < K), cls, torch.full_like(cls, K)).long()
-    ref = key.argsort(dim=1, stable=True)
-    assert torch.equal(order.cpu().long(), ref)
-    assert torch.equal(skey.cpu().long(), torch.gather(key, 1, ref))
-    counts = torch.stack([torch.bincount(key[b], minlength=K + 1) for b in range(B)])
-    ref_off = torch.zeros(B, K + 1, dtype=torch.long)
-    ref_off[:, 1:] = counts[:, :K].cumsum(1)
-    assert torch.equal(offsets.cpu().long(), ref_off)
-    assert torch.equal(torch.gather(pos.cpu().long(), 1, ref), torch.arange(HW).expand(B, HW))
+    cls[:, : HW // 3] = torch.randint(0, K, (1,), generator=g).item()
+    xs = (torch.randn(B, C, HW, generator=g) * 3 + 0.5).to(dtype)
+    xt = (torch.randn(B, C, HW, generator=g) * 3 - 0.5).to(dtype)
+    L = _lib.lib()
+    d_cls, d_s, d_t = cls.to(dev), xs.to(dev), xt.to(dev)
+    counts = torch.empty(B, K, dtype=torch.int32, device=dev)
+    _lib.check(L.sd_ifvd_counts(d_cls.data_ptr(), B, HW, K, counts.data_ptr(), None), 'sd_ifvd_counts')
+    ref_counts = torch.stack([torch.bincount(cls[b][(cls[b] >= 0) & (cls[b] < K)].long(), minlength=K) for b in range(B)])
+    assert torch.equal(counts.cpu().long(), ref_counts)
+    wsb = L.sd_ifvd_workspace_bytes(B, C, HW, K)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    ms, mt = torch.empty(B, C, K, device=dev), torch.empty(B, C, K, device=dev)
+    code = 0 if dtype == torch.float32 else 1
+    _lib.check(L.sd_ifvd_class_means(d_s.data_ptr(), d_t.data_ptr(), code, d_cls.data_ptr(), counts.data_ptr(), ms.data_ptr(), mt.data_ptr(),
+                                     ws.data_ptr(), wsb, B, C, HW, K, None), 'sd_ifvd_class_means')
+    onehot = torch.zeros(B, K, HW, dtype=torch.float64)
+    valid = (cls >= 0) & (cls < K)
+    bi, pi = torch.nonzero(valid, as_tuple=True)
+    onehot[bi, cls[bi, pi].long(), pi] = 1.0
+    for x, m in ((xs, ms), (xt, mt)):
+        ref = torch.einsum('bkp,bcp->bck', onehot, x.double()) / (ref_counts.double()[:, None, :] + 1e-6)
+        err = (m.cpu().double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)
+        assert float(err) < 2e-6, float(err)
 
 
 @pytest.mark.parametrize('shape,dominant', [((2, 8, 200, 200), True), ((1, 5, 96, 96), True), ((2, 7, 33, 31), False)])
