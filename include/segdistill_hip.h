@@ -170,7 +170,8 @@ int sd_at_kl_bwd(const void *S, const void *T, int dtype, int B, int C, int H, i
  * cls [B][HW] int32 is the class of each pixel (-1 / >= K: no class).  Call order, forward: counts, class_means, cos; backward:
  * coef_sums, bwd.  A class sum is a product with the one-hot label matrix, run on the bf16 matrix pipe with the features split exactly
  * into three bf16 terms (fp32-grade): no sort of the pixels, no gathers, deterministic.
- *   sd_ifvd_counts       counts[b,k] = number of pixels of image b with class k
+ *   sd_ifvd_counts       counts[b,k] = number of pixels of image b with class k; stepmask (sd_ifvd_stepmask_ints ints): the class blocks
+ *                        present in every step of 16 pixels, which the products skip by
  *   sd_ifvd_class_means  mean_x[b,c,k] = sum_{p: cls = k} X[b,c,p] / (n_k + 1e-6) for both networks in one launch (T, mean_t may be NULL);
  *                        tables are [B][C][K]: the per-pixel passes read one channel's K values per wave
  *   sd_ifvd_cos          per pixel cos(X[b,:,p], mean_x[b,:,cls]) (eps 1e-8 per norm, F.cosine_similarity) for both networks,
@@ -181,12 +182,13 @@ int sd_at_kl_bwd(const void *S, const void *T, int dtype, int B, int C, int H, i
  * fp32 / int32.
  */
 size_t sd_ifvd_workspace_bytes(int B, int C, int HW, int K);
-int sd_ifvd_counts(const int *cls, int B, int HW, int K, int *counts, void *stream);
-int sd_ifvd_class_means(const void *S, const void *T /* or NULL */, int dtype, const int *cls, const int *counts, float *mean_s, float *mean_t,
-                        void *workspace, size_t workspace_bytes, int B, int C, int HW, int K, void *stream);
+size_t sd_ifvd_stepmask_ints(int B, int HW, int K);
+int sd_ifvd_counts(const int *cls, int B, int HW, int K, int *counts, int *stepmask, void *stream);
+int sd_ifvd_class_means(const void *S, const void *T /* or NULL */, int dtype, const int *cls, const int *stepmask, const int *counts,
+                        float *mean_s, float *mean_t, void *workspace, size_t workspace_bytes, int B, int C, int HW, int K, void *stream);
 int sd_ifvd_cos(const void *S, const void *T, int dtype, const int *cls, const float *mean_s, const float *mean_t, float *coefs, float *loss,
                 void *workspace, size_t workspace_bytes, int B, int C, int HW, int K, void *stream);
-int sd_ifvd_coef_sums(const void *S, int dtype, const int *cls, const int *counts, const float *coefs, float *A, float *Bk,
+int sd_ifvd_coef_sums(const void *S, int dtype, const int *cls, const int *stepmask, const int *counts, const float *coefs, float *A, float *Bk,
                       void *workspace, size_t workspace_bytes, int B, int C, int HW, int K, void *stream);
 int sd_ifvd_bwd(const void *X, int dtype, const int *cls, const float *mean, const float *coefs, const float *A, const float *Bk,
                 const int *counts, const float *upstream /* device scalar or NULL */, void *dS,

@@ -50,10 +50,11 @@ SIGNATURES = {
     'sd_pix_kl_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     'sd_pix_kl_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     'sd_ifvd_workspace_bytes': (_sz, [_i, _i, _i, _i]),
-    'sd_ifvd_counts': (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    'sd_ifvd_class_means': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
+    'sd_ifvd_stepmask_ints': (_sz, [_i, _i, _i]),
+    'sd_ifvd_counts': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    'sd_ifvd_class_means': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
     'sd_ifvd_cos': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
-    'sd_ifvd_coef_sums': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
+    'sd_ifvd_coef_sums': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _vp]),
     'sd_ifvd_bwd': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'sd_at_kl_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'sd_at_kl_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

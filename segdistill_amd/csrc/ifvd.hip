@@ -41,9 +41,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr float kCosEps = 1e-8f;   // F.cosine_similarity's eps: each norm is clamped from below
 constexpr int kNKB = 5;            // class blocks of 32 per pass of ifvd_onehot_sums (160 classes; more classes: more passes, grid.y)
 constexpr int kKGroup = 32 * kNKB;
+constexpr int kMaxSliceSteps = 256;  // steps of 16 pixels per slice of ifvd_onehot_sums (its LDS copy of the step masks)
 
-// grid (B), 1024 threads
-__global__ __launch_bounds__(1024) void ifvd_counts(const int *__restrict__ cls, int *__restrict__ counts, int HW, int K) {
+// grid (B), 1024 threads.  Also the class blocks present in every step of 16 pixels, per class group: smask[b][step][kg] bit j = some pixel of
+// the step has a class in [160 kg + 32 j, + 32) -- computed once here instead of by every (channel block, network) workgroup of the products.
+__global__ __launch_bounds__(1024) void ifvd_counts(const int *__restrict__ cls, int *__restrict__ counts, int *__restrict__ smask, int HW, int K,
+                                                     int KG) {
     extern __shared__ int cbins[];
     const int b = blockIdx.x;
     const int *row = cls + (size_t)b * HW;
@@ -60,57 +63,101 @@ __global__ __launch_bounds__(1024) void ifvd_counts(const int *__restrict__ cls,
     } else {
         for (int p = threadIdx.x; p < HW; p += 1024) count(row[p]);
     }
+    const int nsteps = (HW + 15) / 16;
+    for (int i = threadIdx.x; i < nsteps * KG; i += 1024) {
+        const int step = i / KG, kg = i - step * KG;
+        int m = 0;
+        for (int e = 0; e < 16; ++e) {
+            const int p = step * 16 + e;
+            const int c = p < HW ? row[p] : -1;
+            const int rel = c - kg * kKGroup;
+            if (c >= 0 && c < K && rel >= 0 && rel < kKGroup) m |= 1 << (rel >> 5);
+        }
+        smask[((size_t)b * nsteps + step) * KG + kg] = m;
+    }
     __syncthreads();
     for (int k = threadIdx.x; k < K; k += 1024) counts[(size_t)b * K + k] = cbins[k];
 }
 
-// grid (S slices, channel blocks * class groups, images * tensors), 256 threads.  part[z][s][Cp][Kp] (k contiguous).
+// grid (S slices, channel blocks * class groups, images * networks), 256 threads.  part[z = b * nt + t][s][Cp][Kp] (k contiguous).
 // MFMA operands (v_mfma_f32_32x32x16_bf16): lane (r = lane & 31, g = lane >> 5) holds A[row r][k = 8 g .. 8 g + 7] and B[k = 8 g ..][column r];
 // here row = class within its block, k = pixel within the 16-pixel step, column = channel within its block.
+//   !WEIGHTED (class means): network t = z % nt reads X0 or X1
+//   WEIGHTED  (backward):   alpha * X0; channel index C is the beta plane itself (-> B_k)
+// Vector-instruction bound: ~400 per step of 16 pixels x 32 channels (label tests, one-hot rows, the three-way split) against 15 MFMAs when all
+// five class blocks are present.  (Tried, same box: two feature blocks per wave sharing the one-hot rows -- 320 instructions per block-step but
+// 356 registers, one wave per SIMD: 178 vs 115 us for both networks' means.)
 template <typename T, bool WEIGHTED>
-__global__ __launch_bounds__(256) void ifvd_onehot_sums(const T *__restrict__ X0, const T *__restrict__ X1, const float *__restrict__ wgt,
-                                                         const int *__restrict__ cls, float *__restrict__ part, int C, int HW, int K, int S, int Ls,
-                                                         int KG, int nt) {
+__global__ __launch_bounds__(256) void ifvd_onehot_sums(const T *__restrict__ X0, const T *__restrict__ X1, const float *__restrict__ alpha,
+                                                         const float *__restrict__ beta, const int *__restrict__ cls, const int *__restrict__ smask,
+                                                         float *__restrict__ part, int C, int HW, int K, int S, int Ls, int KG, int Cp) {
     constexpr bool kOnePlane = sizeof(T) == 2 && !WEIGHTED;           // bf16 features: already one exact bf16 term
     __shared__ float tile[kNKB][32][33];
-    const int s = blockIdx.x, cb = blockIdx.y / KG, kg = blockIdx.y - cb * KG, z = blockIdx.z;
-    const int b = z / nt;
-    const T *X = (z - b * nt) ? X1 : X0;
+    constexpr int NQ = 1;                                             // feature blocks per wave
+    const int nt = (!WEIGHTED && X1) ? 2 : 1;
+    const int s = blockIdx.x, op = blockIdx.y / KG, kg = blockIdx.y - op * KG, b = blockIdx.z / nt, tnet = blockIdx.z - b * nt;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, g = lane >> 5;
-    const int c = cb * 32 + r, kb0 = kg * kKGroup;
-    const bool cvalid = c < C;
-    const T *xrow = X + ((size_t)b * C + (cvalid ? c : C - 1)) * HW;
+    const int kb0 = kg * kKGroup, nsteps = (HW + 15) / 16;
+    const int Call = WEIGHTED ? C + 1 : C;                            // WEIGHTED: the beta plane is channel C
+    // the B operand(s) of this wave: q -> channel block
+    int ch[NQ];
+    bool live_q[NQ], is_beta[NQ];
+    const T *xrow[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        ch[q] = (NQ * op + q) * 32 + r;
+        live_q[q] = (NQ * op + q) * 32 < Call;                        // wave-uniform: the whole block exists
+        is_beta[q] = WEIGHTED && ch[q] == C;
+        const T *X = tnet ? X1 : X0;
+        xrow[q] = X + ((size_t)b * C + min(ch[q], C - 1)) * HW;       // lanes beyond the last channel read the last one (never written out)
+    }
     const int *crow = cls + (size_t)b * HW;
-    const float *wrow = WEIGHTED ? wgt + (size_t)b * HW : nullptr;
-    const bool vec_x = HW % 8 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
-    const bool vec_c = HW % 4 == 0 && (reinterpret_cast<uintptr_t>(cls) & 15) == 0 && (!WEIGHTED || (reinterpret_cast<uintptr_t>(wgt) & 15) == 0);
-    f32x16 acc[kNKB];
+    const float *arow = WEIGHTED ? alpha + (size_t)b * HW : nullptr, *brow = WEIGHTED ? beta + (size_t)b * HW : nullptr;
+    const bool vec_x = HW % 8 == 0 && (reinterpret_cast<uintptr_t>(X0) & 15) == 0 && (reinterpret_cast<uintptr_t>(X1) & 15) == 0;
+    const bool vec_c = HW % 4 == 0 && (reinterpret_cast<uintptr_t>(cls) & 15) == 0 &&
+                       (!WEIGHTED || ((reinterpret_cast<uintptr_t>(alpha) & 15) == 0 && (reinterpret_cast<uintptr_t>(beta) & 15) == 0));
+    f32x16 acc[NQ][kNKB];
 #pragma unroll
-    for (int j = 0; j < kNKB; ++j)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        for (int j = 0; j < kNKB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[q][j][e] = 0.f;
     const int p_end = min((s + 1) * Ls, HW);
-    // U steps of 16 pixels per round: all their loads are requested before the first is consumed (a step alone would run at the memory
-    // latency -- 32 bytes per lane in flight; measured 128 us for both networks at 8 x 150 x 128 x 128, whatever the labels)
+    // the slice's step masks, once (a mask read in front of each step's loads would put a second memory latency into every round)
+    __shared__ int smask_l[kMaxSliceSteps];
+    for (int i = threadIdx.x; i < (p_end - s * Ls + 15) / 16; i += 256) smask_l[i] = smask[((size_t)b * nsteps + (s * Ls >> 4) + i) * KG + kg];
+    __syncthreads();
+    // U steps of 16 pixels per round: all their loads are requested before the first is consumed (a step alone runs at the memory latency)
     constexpr int U = 4;
     for (int q0 = s * Ls + 16 * wave; q0 < p_end; q0 += 64 * U) {
-        float x[U][8], w[U][8];
-        int ck[U][8];
+        float x[U][NQ][8], w[U][8];
+        int ck[U][8], present[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int pix = q0 + 64 * u + 8 * g;
-            const bool live = q0 + 64 * u < p_end;
+            const int p0 = q0 + 64 * u, pix = p0 + 8 * g;
+            const bool live = p0 < p_end;
+            present[u] = live ? __builtin_amdgcn_readfirstlane(smask_l[(p0 - s * Ls) >> 4]) : 0;
             const bool whole = live && pix + 8 <= HW;
-            if (whole && vec_x) {
-                if constexpr (sizeof(T) == 4) {
-                    VecIO<T>::load(xrow + pix, reinterpret_cast<float(&)[4]>(x[u][0]));
-                    VecIO<T>::load(xrow + pix + 4, reinterpret_cast<float(&)[4]>(x[u][4]));
-                } else {
-                    VecIO<T>::load(xrow + pix, x[u]);
-                }
-            } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[u][e] = (live && pix + e < HW) ? VecIO<T>::load1(xrow + pix + e) : 0.f;
+            for (int q = 0; q < NQ; ++q) {
+                if (!live_q[q] || !live) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[u][q][e] = 0.f;
+                } else if (is_beta[q]) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[u][q][e] = pix + e < HW ? brow[pix + e] : 0.f;
+                } else if (whole && vec_x) {
+                    if constexpr (sizeof(T) == 4) {
+                        VecIO<T>::load(xrow[q] + pix, reinterpret_cast<float(&)[4]>(x[u][q][0]));
+                        VecIO<T>::load(xrow[q] + pix + 4, reinterpret_cast<float(&)[4]>(x[u][q][4]));
+                    } else {
+                        VecIO<T>::load(xrow[q] + pix, x[u][q]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[u][q][e] = (live && pix + e < HW) ? VecIO<T>::load1(xrow[q] + pix + e) : 0.f;
+                }
             }
             if (whole && vec_c) {
                 const int4 c0 = *reinterpret_cast<const int4 *>(crow + pix), c1 = *reinterpret_cast<const int4 *>(crow + pix + 4);
@@ -121,89 +168,103 @@ __global__ __launch_bounds__(256) void ifvd_onehot_sums(const T *__restrict__ X0
             }
             if (WEIGHTED) {
                 if (whole && vec_c) {
-                    const float4 w0 = *reinterpret_cast<const float4 *>(wrow + pix), w1 = *reinterpret_cast<const float4 *>(wrow + pix + 4);
+                    const float4 w0 = *reinterpret_cast<const float4 *>(arow + pix), w1 = *reinterpret_cast<const float4 *>(arow + pix + 4);
                     w[u][0] = w0.x, w[u][1] = w0.y, w[u][2] = w0.z, w[u][3] = w0.w, w[u][4] = w1.x, w[u][5] = w1.y, w[u][6] = w1.z, w[u][7] = w1.w;
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) w[u][e] = (live && pix + e < HW) ? wrow[pix + e] : 0.f;
+                    for (int e = 0; e < 8; ++e) w[u][e] = (live && pix + e < HW) ? arow[pix + e] : 0.f;
                 }
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            // class blocks present among the 16 pixels of the step (the lanes of a half-wave hold the same 8 labels)
-            int present = 0;
+            if (!present[u]) continue;                                 // wave-uniform (smask: no pixel of the step has a class of this group)
+            // labels relative to the group and to this lane's row: a label matches row 32 j + r  <=>  label - r == 32 j; a label that is not a
+            // class of this group (or not a class at all) is sent out of range so that it matches no j
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int rel = ck[u][e] - kb0;
-                const bool in = ck[u][e] >= 0 && ck[u][e] < K && rel >= 0 && rel < kKGroup;
-                ck[u][e] = in ? rel : -1;                              // relative to the group; -1: matches no row
-                present |= in ? 1 << (rel >> 5) : 0;
+                const unsigned rel = (unsigned)(ck[u][e] - kb0);
+                ck[u][e] = (ck[u][e] < K && rel < (unsigned)kKGroup) ? (int)rel - r : -1;     // (negative labels: rel wraps to a huge value)
             }
-            present = __builtin_amdgcn_readlane(present, 0) | __builtin_amdgcn_readlane(present, 32);
-            if (!present) continue;
-            bf16x8 xh, xm, xl;
+            bf16x8 xh[NQ], xm[NQ], xl[NQ];
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                f32x2 v = {cvalid ? x[u][e] : 0.f, cvalid ? x[u][e + 1] : 0.f};
-                if (WEIGHTED) v[0] *= w[u][e], v[1] *= w[u][e + 1];
-                const bf16x2 hh = __builtin_convertvector(v, bf16x2);
-                xh[e] = hh[0], xh[e + 1] = hh[1];
-                if constexpr (!kOnePlane) {
-                    const f32x2 r1 = v - __builtin_convertvector(hh, f32x2);
-                    const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
-                    const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
-                    const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
-                    xm[e] = mm[0], xm[e + 1] = mm[1], xl[e] = ll[0], xl[e + 1] = ll[1];
+            for (int q = 0; q < NQ; ++q) {
+                if (!live_q[q]) continue;
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    f32x2 v = {x[u][q][e], x[u][q][e + 1]};
+                    if (WEIGHTED && !is_beta[q]) v[0] *= w[u][e], v[1] *= w[u][e + 1];
+                    const bf16x2 hh = __builtin_convertvector(v, bf16x2);
+                    xh[q][e] = hh[0], xh[q][e + 1] = hh[1];
+                    if constexpr (!kOnePlane) {
+                        const f32x2 r1 = v - __builtin_convertvector(hh, f32x2);
+                        const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
+                        const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
+                        const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
+                        xm[q][e] = mm[0], xm[q][e + 1] = mm[1], xl[q][e] = ll[0], xl[q][e + 1] = ll[1];
+                    }
                 }
             }
 #pragma unroll
             for (int j = 0; j < kNKB; ++j) {
-                if (!((present >> j) & 1)) continue;                   // wave-uniform
-                const int row = 32 * j + r;
+                if (!((present[u] >> j) & 1)) continue;                // wave-uniform
                 bf16x8 a;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = ck[u][e] == row ? (__bf16)1.0f : (__bf16)0.0f;
-                if constexpr (!kOnePlane) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xl, acc[j], 0, 0, 0);  // small terms first
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xm, acc[j], 0, 0, 0);
+                for (int e = 0; e < 8; ++e) a[e] = ck[u][e] == 32 * j ? (__bf16)1.0f : (__bf16)0.0f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (!live_q[q]) continue;
+                    if constexpr (!kOnePlane) {
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xl[q], acc[q][j], 0, 0, 0);  // small terms first
+                        acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xm[q], acc[q][j], 0, 0, 0);
+                    }
+                    acc[q][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xh[q], acc[q][j], 0, 0, 0);
                 }
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xh, acc[j], 0, 0, 0);
             }
         }
     }
-    // the four waves' accumulators, added in wave order (accumulator layout: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5))
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
+    // per operand: the four waves' accumulators, added in wave order (accumulator layout: column = lane & 31, row = (e & 3) + 8 (e >> 2) +
+    // 4 (lane >> 5)), then written out class-contiguous
+    const int Kp = KG * kKGroup;
 #pragma unroll
-            for (int j = 0; j < kNKB; ++j)
+    for (int q = 0; q < NQ; ++q) {
+        if (!live_q[q]) continue;
+        for (int w4 = 0; w4 < 4; ++w4) {
+            if (wave == w4) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = (e & 3) + 8 * (e >> 2) + 4 * g;
-                    if (w == 0) tile[j][row][r] = acc[j][e];
-                    else tile[j][row][r] += acc[j][e];
-                }
+                for (int j = 0; j < kNKB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (e & 3) + 8 * (e >> 2) + 4 * g;
+                        if (w4 == 0) tile[j][row][r] = acc[q][j][e];
+                        else tile[j][row][r] += acc[q][j][e];
+                    }
+            }
+            __syncthreads();
+        }
+        const int z = blockIdx.z, cblock = NQ * op + q;
+        float *dst = part + (((size_t)z * S + s) * Cp + cblock * 32) * Kp + kb0;
+        for (int i = threadIdx.x; i < 32 * kKGroup; i += 256) {
+            const int cl = i / kKGroup, kk = i - cl * kKGroup;
+            dst[(size_t)cl * Kp + kk] = tile[kk >> 5][kk & 31][cl];
         }
         __syncthreads();
     }
-    const int CB = gridDim.y / KG, Cp = CB * 32, Kp = KG * kKGroup;
-    float *dst = part + (((size_t)z * S + s) * Cp + cb * 32) * Kp + kb0;
-    for (int i = threadIdx.x; i < 32 * kKGroup; i += 256) {
-        const int cl = i / kKGroup, kk = i - cl * kKGroup;
-        dst[(size_t)cl * Kp + kk] = tile[kk >> 5][kk & 31][cl];
-    }
 }
 
-// grid (C, Z), 256 threads over k: out[z][c][k] = sum_s part[z][s][c][k]  (/ (n_k + 1e-6) in mean mode; n from counts[z / nt][k])
+// grid (C [+ 1 with outB], Z), 256 threads over k: out[z][c][k] = sum_s part[z][s][c][k]  (/ (n_k + 1e-6) in mean mode; n from counts[z / nt][k]);
+// channel index C (backward only): the beta plane's sums -> outB[b][k]
 __global__ __launch_bounds__(256) void ifvd_finish(const float *__restrict__ part, const int *__restrict__ counts, float *__restrict__ out0,
-                                                    float *__restrict__ out1, int C, int K, int S, int Cp, int Kp, int nt, int mean_mode) {
+                                                    float *__restrict__ out1, float *__restrict__ outB, int C, int K, int S, int Cp, int Kp, int nt,
+                                                    int mean_mode) {
     const int c = blockIdx.x, z = blockIdx.y, b = z / nt;
     float *out = (z - b * nt) ? out1 : out0;
     for (int k = threadIdx.x; k < K; k += 256) {
         float acc = 0.f;
         for (int s = 0; s < S; ++s) acc += part[(((size_t)z * S + s) * Cp + c) * Kp + k];
         if (mean_mode) acc /= (float)counts[(size_t)b * K + k] + 1e-6f;
-        out[((size_t)b * C + c) * K + k] = acc;
+        if (c == C) outB[(size_t)b * K + k] = acc;
+        else out[((size_t)b * C + c) * K + k] = acc;
     }
 }
 
@@ -327,35 +388,41 @@ int check_ifvd(const void *X, int dtype, int B, int C, int HW, int K) {
     return SD_OK;
 }
 
-struct SumPlan { int S, Ls, CB, KG; size_t floats; };
-// slices of the pixels so that the launch has ~1024 workgroups (a slice: whole 64-pixel rounds of the four waves)
-SumPlan sum_plan(int Z, int C, int HW, int K) {
+struct SumPlan { int S, Ls, OPS, KG, Cp; size_t floats; };
+// weighted: the backward's product (channels + the beta plane).  Slices of the pixels so that the launch has ~1024 workgroups (a slice: whole 64-pixel rounds of the four waves).
+SumPlan sum_plan(int B, int nt, int C, int HW, int K, bool weighted) {
     SumPlan p;
-    p.CB = (C + 31) / 32, p.KG = (K + kKGroup - 1) / kKGroup;
-    const long per_slice = (long)p.CB * p.KG * Z;
+    const int CB = ((weighted ? C + 1 : C) + 31) / 32;
+    p.OPS = CB;
+    p.Cp = CB * 32;
+    p.KG = (K + kKGroup - 1) / kKGroup;
+    const long per_slice = (long)p.OPS * p.KG * B * nt;
     int S = (int)((1024 + per_slice - 1) / per_slice);
     const int max_s = (HW + 63) / 64;
     S = S < 1 ? 1 : (S > max_s ? max_s : S);
-    if (S > 64) S = 64;
+    if (S > 32) S = 32;
+    const int min_s = (HW + 16 * kMaxSliceSteps - 1) / (16 * kMaxSliceSteps);
+    if (S < min_s) S = min_s;
     p.Ls = (((HW + S - 1) / S + 63) / 64) * 64;
     p.S = (HW + p.Ls - 1) / p.Ls;
-    p.floats = (size_t)Z * p.S * (p.CB * 32) * (p.KG * kKGroup);
+    p.floats = (size_t)B * nt * p.S * p.Cp * (p.KG * kKGroup);
     return p;
 }
 
-// sums over the classes of X0 (and X1) -> out0 (out1), tables [B][C][K]; workspace = the slices' partial tables
+// sums over the classes -> tables [B][C][K]; workspace = the slices' partial tables.  !WEIGHTED: X0 (and X1) -> out0 (out1), divided by the
+// class sizes.  WEIGHTED: alpha * X0 -> out0 and the beta plane -> outB.
 template <typename T, bool WEIGHTED>
-int class_sums(const T *X0, const T *X1, const float *wgt, const int *cls, const int *counts, float *out0, float *out1, void *workspace,
-               size_t workspace_bytes, int B, int C, int HW, int K, int mean_mode, hipStream_t st) {
-    const int nt = X1 ? 2 : 1, Z = B * nt;
-    const SumPlan p = sum_plan(Z, C, HW, K);
+int class_sums(const T *X0, const T *X1, const float *alpha, const float *beta, const int *cls, const int *smask, const int *counts, float *out0,
+               float *out1, float *outB, void *workspace, size_t workspace_bytes, int B, int C, int HW, int K, hipStream_t st) {
+    const int nt = (!WEIGHTED && X1) ? 2 : 1;
+    const SumPlan p = sum_plan(B, nt, C, HW, K, WEIGHTED);
     if (!workspace || workspace_bytes < p.floats * sizeof(float) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return SD_E_WORKSPACE;
-    if ((long)p.CB * p.KG > 65535 || Z > 65535) return SD_E_SHAPE;
+    if ((long)p.OPS * p.KG > 65535 || B * nt > 65535) return SD_E_SHAPE;
     float *part = static_cast<float *>(workspace);
-    hipLaunchKernelGGL((ifvd_onehot_sums<T, WEIGHTED>), dim3(p.S, p.CB * p.KG, Z), dim3(256), 0, st, X0, X1, wgt, cls, part, C, HW, K, p.S, p.Ls, p.KG,
-                       nt);
-    hipLaunchKernelGGL(ifvd_finish, dim3(C, Z), dim3(256), 0, st, (const float *)part, counts, out0, out1, C, K, p.S, p.CB * 32, p.KG * kKGroup, nt,
-                       mean_mode);
+    hipLaunchKernelGGL((ifvd_onehot_sums<T, WEIGHTED>), dim3(p.S, p.OPS * p.KG, B * nt), dim3(256), 0, st, X0, X1, alpha, beta, cls, smask, part, C, HW, K, p.S,
+                       p.Ls, p.KG, p.Cp);
+    hipLaunchKernelGGL(ifvd_finish, dim3(C + (WEIGHTED ? 1 : 0), B * nt), dim3(256), 0, st, (const float *)part, counts, out0, out1, outB, C, K, p.S, p.Cp,
+                       p.KG * kKGroup, nt, WEIGHTED ? 0 : 1);
     return (int)hipGetLastError();
 }
 
@@ -366,31 +433,38 @@ extern "C" {
 
 size_t sd_ifvd_workspace_bytes(int B, int C, int HW, int K) {
     if (B <= 0 || C <= 0 || HW <= 0 || K <= 0) return 0;
-    // the larger of: the slices' partial class tables of both networks (class_means), one double per 64-pixel block (cos)
-    const size_t sums = sd::sum_plan(2 * B, C, HW, K).floats * sizeof(float);
-    const size_t cosb = (size_t)((HW + 63) / 64) * B * sizeof(double);
-    return (sums > cosb ? sums : cosb) + 16;
+    // the largest of: the slices' partial class tables (class_means, coef_sums), one double per 64-pixel block (cos)
+    size_t n = sd::sum_plan(B, 2, C, HW, K, false).floats * sizeof(float);
+    const size_t n2 = sd::sum_plan(B, 1, C, HW, K, true).floats * sizeof(float), n3 = (size_t)((HW + 63) / 64) * B * sizeof(double);
+    n = n2 > n ? n2 : n;
+    return (n3 > n ? n3 : n) + 16;
 }
 
-int sd_ifvd_counts(const int *cls, int B, int HW, int K, int *counts, void *stream) {
-    if (!cls || !counts) return SD_E_NULL;
+size_t sd_ifvd_stepmask_ints(int B, int HW, int K) {
+    if (B <= 0 || HW <= 0 || K <= 0) return 0;
+    return (size_t)B * ((HW + 15) / 16) * ((K + sd::kKGroup - 1) / sd::kKGroup);
+}
+
+int sd_ifvd_counts(const int *cls, int B, int HW, int K, int *counts, int *stepmask, void *stream) {
+    if (!cls || !counts || !stepmask) return SD_E_NULL;
     if (B <= 0 || HW <= 0 || K <= 0 || K > 8192) return SD_E_SHAPE;
-    hipLaunchKernelGGL(sd::ifvd_counts, dim3(B), dim3(1024), (size_t)K * sizeof(int), static_cast<hipStream_t>(stream), cls, counts, HW, K);
+    hipLaunchKernelGGL(sd::ifvd_counts, dim3(B), dim3(1024), (size_t)K * sizeof(int), static_cast<hipStream_t>(stream), cls, counts, stepmask, HW, K,
+                       (K + sd::kKGroup - 1) / sd::kKGroup);
     return (int)hipGetLastError();
 }
 
-int sd_ifvd_class_means(const void *S, const void *T, int dtype, const int *cls, const int *counts, float *mean_s, float *mean_t, void *workspace,
-                        size_t workspace_bytes, int B, int C, int HW, int K, void *stream) {
+int sd_ifvd_class_means(const void *S, const void *T, int dtype, const int *cls, const int *stepmask, const int *counts, float *mean_s, float *mean_t,
+                        void *workspace, size_t workspace_bytes, int B, int C, int HW, int K, void *stream) {
     int rc = sd::check_ifvd(S, dtype, B, C, HW, K);
     if (rc) return rc;
-    if (!cls || !counts || !mean_s || (T && !mean_t)) return SD_E_NULL;
+    if (!cls || !stepmask || !counts || !mean_s || (T && !mean_t)) return SD_E_NULL;
     if (T && (reinterpret_cast<uintptr_t>(T) & (dtype == SD_F32 ? 3 : 1))) return SD_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == SD_F32)
-        return sd::class_sums<float, false>((const float *)S, (const float *)T, nullptr, cls, counts, mean_s, mean_t, workspace, workspace_bytes, B, C, HW,
-                                            K, 1, st);
-    return sd::class_sums<sd::bf16_t, false>((const sd::bf16_t *)S, (const sd::bf16_t *)T, nullptr, cls, counts, mean_s, mean_t, workspace,
-                                             workspace_bytes, B, C, HW, K, 1, st);
+        return sd::class_sums<float, false>((const float *)S, (const float *)T, nullptr, nullptr, cls, stepmask, counts, mean_s, mean_t, nullptr, workspace,
+                                            workspace_bytes, B, C, HW, K, st);
+    return sd::class_sums<sd::bf16_t, false>((const sd::bf16_t *)S, (const sd::bf16_t *)T, nullptr, nullptr, cls, stepmask, counts, mean_s, mean_t, nullptr,
+                                             workspace, workspace_bytes, B, C, HW, K, st);
 }
 
 int sd_ifvd_cos(const void *S, const void *T, int dtype, const int *cls, const float *mean_s, const float *mean_t, float *coefs, float *loss,
@@ -415,19 +489,18 @@ int sd_ifvd_cos(const void *S, const void *T, int dtype, const int *cls, const f
     return (int)hipGetLastError();
 }
 
-int sd_ifvd_coef_sums(const void *S, int dtype, const int *cls, const int *counts, const float *coefs, float *A, float *Bk, void *workspace,
-                      size_t workspace_bytes, int B, int C, int HW, int K, void *stream) {
+int sd_ifvd_coef_sums(const void *S, int dtype, const int *cls, const int *stepmask, const int *counts, const float *coefs, float *A, float *Bk,
+                      void *workspace, size_t workspace_bytes, int B, int C, int HW, int K, void *stream) {
     int rc = sd::check_ifvd(S, dtype, B, C, HW, K);
     if (rc) return rc;
-    if (!cls || !counts || !coefs || !A || !Bk) return SD_E_NULL;
+    if (!cls || !stepmask || !counts || !coefs || !A || !Bk) return SD_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float *alpha = coefs, *beta = coefs + (size_t)B * HW;
-    // B_k first (its partial tables are consumed by its own finish launch before the second product overwrites the workspace: stream order)
-    rc = sd::class_sums<float, false>(beta, nullptr, nullptr, cls, counts, Bk, nullptr, workspace, workspace_bytes, B, 1, HW, K, 0, st);
-    if (rc) return rc;
     if (dtype == SD_F32)
-        return sd::class_sums<float, true>((const float *)S, nullptr, alpha, cls, counts, A, nullptr, workspace, workspace_bytes, B, C, HW, K, 0, st);
-    return sd::class_sums<sd::bf16_t, true>((const sd::bf16_t *)S, nullptr, alpha, cls, counts, A, nullptr, workspace, workspace_bytes, B, C, HW, K, 0, st);
+        return sd::class_sums<float, true>((const float *)S, nullptr, alpha, beta, cls, stepmask, counts, A, nullptr, Bk, workspace, workspace_bytes, B, C, HW,
+                                           K, st);
+    return sd::class_sums<sd::bf16_t, true>((const sd::bf16_t *)S, nullptr, alpha, beta, cls, stepmask, counts, A, nullptr, Bk, workspace, workspace_bytes,
+                                            B, C, HW, K, st);
 }
 
 int sd_ifvd_bwd(const void *X, int dtype, const int *cls, const float *mean, const float *coefs, const float *A, const float *Bk,

@@ -303,23 +303,24 @@ class _IFVDFunction(torch.autograd.Function):
         L, dt, st = _lib.lib(), _DT[S.dtype], _stream_ptr()
         f32 = dict(dtype=torch.float32, device=S.device)
         counts = torch.empty(B, K, dtype=torch.int32, device=S.device)
-        _lib.check(L.sd_ifvd_counts(cls.data_ptr(), B, HW, K, counts.data_ptr(), st), 'sd_ifvd_counts')
+        smask = torch.empty(L.sd_ifvd_stepmask_ints(B, HW, K), dtype=torch.int32, device=S.device)
+        _lib.check(L.sd_ifvd_counts(cls.data_ptr(), B, HW, K, counts.data_ptr(), smask.data_ptr(), st), 'sd_ifvd_counts')
         wsb = L.sd_ifvd_workspace_bytes(B, Cc, HW, K)
         ws = torch.empty(wsb, dtype=torch.uint8, device=S.device)
         mean_s, mean_t = torch.empty(B, Cc, K, **f32), torch.empty(B, Cc, K, **f32)         # [B][C][K] (csrc/ifvd.hip)
-        _lib.check(L.sd_ifvd_class_means(S.data_ptr(), T.data_ptr(), dt, cls.data_ptr(), counts.data_ptr(), mean_s.data_ptr(), mean_t.data_ptr(),
-                                         ws.data_ptr(), wsb, B, Cc, HW, K, st), 'sd_ifvd_class_means')
+        _lib.check(L.sd_ifvd_class_means(S.data_ptr(), T.data_ptr(), dt, cls.data_ptr(), smask.data_ptr(), counts.data_ptr(), mean_s.data_ptr(),
+                                         mean_t.data_ptr(), ws.data_ptr(), wsb, B, Cc, HW, K, st), 'sd_ifvd_class_means')
         coefs = torch.empty(3, B * HW, **f32)
         loss = torch.empty((), **f32)
         _lib.check(L.sd_ifvd_cos(S.data_ptr(), T.data_ptr(), dt, cls.data_ptr(), mean_s.data_ptr(), mean_t.data_ptr(), coefs.data_ptr(), loss.data_ptr(),
                                  ws.data_ptr(), wsb, B, Cc, HW, K, st), 'sd_ifvd_cos')
-        ctx.save_for_backward(S, cls, counts, mean_s, coefs)
+        ctx.save_for_backward(S, cls, smask, counts, mean_s, coefs)
         ctx.K = K
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
-        S, cls, counts, mean_s, coefs = ctx.saved_tensors
+        S, cls, smask, counts, mean_s, coefs = ctx.saved_tensors
         B, Cc, H, W = S.shape
         HW, K = H * W, ctx.K
         L, dt, st = _lib.lib(), _DT[S.dtype], _stream_ptr()
@@ -327,8 +328,8 @@ class _IFVDFunction(torch.autograd.Function):
         A, Bk = torch.empty(B, Cc, K, **f32), torch.empty(B, K, **f32)
         wsb = L.sd_ifvd_workspace_bytes(B, Cc, HW, K)
         ws = torch.empty(wsb, dtype=torch.uint8, device=S.device)
-        _lib.check(L.sd_ifvd_coef_sums(S.data_ptr(), dt, cls.data_ptr(), counts.data_ptr(), coefs.data_ptr(), A.data_ptr(), Bk.data_ptr(), ws.data_ptr(),
-                                       wsb, B, Cc, HW, K, st), 'sd_ifvd_coef_sums')
+        _lib.check(L.sd_ifvd_coef_sums(S.data_ptr(), dt, cls.data_ptr(), smask.data_ptr(), counts.data_ptr(), coefs.data_ptr(), A.data_ptr(), Bk.data_ptr(),
+                                       ws.data_ptr(), wsb, B, Cc, HW, K, st), 'sd_ifvd_coef_sums')
         dS = torch.empty_like(S)
         up = grad_loss.to(torch.float32).contiguous()
         _lib.check(L.sd_ifvd_bwd(S.data_ptr(), dt, cls.data_ptr(), mean_s.data_ptr(), coefs.data_ptr(), A.data_ptr(), Bk.data_ptr(), counts.data_ptr(),

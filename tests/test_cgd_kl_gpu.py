@@ -408,15 +408,16 @@ def test_ifvd_counts_and_class_means_against_a_mask_loop(B, C, HW, K, dtype):
     L = _lib.lib()
     d_cls, d_s, d_t = cls.to(dev), xs.to(dev), xt.to(dev)
     counts = torch.empty(B, K, dtype=torch.int32, device=dev)
-    _lib.check(L.sd_ifvd_counts(d_cls.data_ptr(), B, HW, K, counts.data_ptr(), None), 'sd_ifvd_counts')
+    smask = torch.empty(L.sd_ifvd_stepmask_ints(B, HW, K), dtype=torch.int32, device=dev)
+    _lib.check(L.sd_ifvd_counts(d_cls.data_ptr(), B, HW, K, counts.data_ptr(), smask.data_ptr(), None), 'sd_ifvd_counts')
     ref_counts = torch.stack([torch.bincount(cls[b][(cls[b] >= 0) & (cls[b] < K)].long(), minlength=K) for b in range(B)])
     assert torch.equal(counts.cpu().long(), ref_counts)
     wsb = L.sd_ifvd_workspace_bytes(B, C, HW, K)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     ms, mt = torch.empty(B, C, K, device=dev), torch.empty(B, C, K, device=dev)
     code = 0 if dtype == torch.float32 else 1
-    _lib.check(L.sd_ifvd_class_means(d_s.data_ptr(), d_t.data_ptr(), code, d_cls.data_ptr(), counts.data_ptr(), ms.data_ptr(), mt.data_ptr(),
-                                     ws.data_ptr(), wsb, B, C, HW, K, None), 'sd_ifvd_class_means')
+    _lib.check(L.sd_ifvd_class_means(d_s.data_ptr(), d_t.data_ptr(), code, d_cls.data_ptr(), smask.data_ptr(), counts.data_ptr(), ms.data_ptr(),
+                                     mt.data_ptr(), ws.data_ptr(), wsb, B, C, HW, K, None), 'sd_ifvd_class_means')
     onehot = torch.zeros(B, K, HW, dtype=torch.float64)
     valid = (cls >= 0) & (cls < K)
     bi, pi = torch.nonzero(valid, as_tuple=True)

@@ -304,21 +304,51 @@ def bench_at(dev, reps, B=8, C=150, hw=128):
 
 
 def bench_ifvd(dev, reps, B=8, C=150, hw=128):
-    from segdistill_amd import ops
+    """The five C-ABI calls of ops._IFVDFunction on the stream handed in (the autograd binding itself cannot be timed inside a capture here: a
+    backward node runs on the stream its forward ran on).  Random labels = every class block present in every 16-pixel step: the worst case
+    of the one-hot products; `blocky` = 16 x 16 patches of one class, closer to a label map."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
     gen = torch.Generator(device=dev).manual_seed(1234)
-    S = (2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)).requires_grad_(True)
+    HW, K = hw * hw, C
+    S = 2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)
     T = 2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)
-    cls = torch.randint(0, C, (B, hw, hw), device=dev, generator=gen, dtype=torch.int32)
-    # through the autograd binding, captured and replayed like every other entry (round 3: no host-side sort any more); random labels are
-    # the worst case for the class sums (150 runs of ~109 pixels scattered over the whole plane)
-    tf = _time(lambda st: ops.ifvd_term(S.detach(), T, cls, C), reps)
-    loss = ops.ifvd_term(S, T, cls, C)
-    tb = _time(lambda st: torch.autograd.grad(loss, S, retain_graph=True), reps)
-    N = S.numel()
-    note = 'through the autograd binding; L2/Infinity-Cache resident at this size; round 2 (sort chain + one launch per network): 0.72 / 0.40 ms'
-    return [_entry('ifvd fwd (grouping + class means + cosine pass, both networks)', 'ifvd_group + ifvd_class_sums + ifvd_cos + ifvd_loss', [B, C, hw, hw],
-                   'f32', tf, 'hbm', 4 * N * 4, HBM, note),
-            _entry('ifvd bwd', 'ifvd_class_sums (weighted) + ifvd_bwd', [B, C, hw, hw], 'f32', tb, 'hbm', 3 * N * 4, HBM, note)]
+    f32 = dict(dtype=torch.float32, device=dev)
+    counts = torch.empty(B, K, dtype=torch.int32, device=dev)
+    smask = torch.empty(L.sd_ifvd_stepmask_ints(B, HW, K), dtype=torch.int32, device=dev)
+    mean_s, mean_t, A, Bk = torch.empty(B, C, K, **f32), torch.empty(B, C, K, **f32), torch.empty(B, C, K, **f32), torch.empty(B, K, **f32)
+    coefs, loss, dS = torch.empty(3, B * HW, **f32), torch.empty((), **f32), torch.empty_like(S)
+    wsb = L.sd_ifvd_workspace_bytes(B, C, HW, K)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    out = []
+    for tag in ('random labels', 'blocky labels'):
+        if tag.startswith('random'):
+            cls = torch.randint(0, C, (B, HW), device=dev, generator=gen, dtype=torch.int32)
+        else:
+            cls = torch.randint(0, C, (B, hw // 16, hw // 16), device=dev, generator=gen, dtype=torch.int32)
+            cls = cls.repeat_interleave(16, 1).repeat_interleave(16, 2).reshape(B, HW).contiguous()
+
+        def fwd(st):
+            _ok(L.sd_ifvd_counts(cls.data_ptr(), B, HW, K, counts.data_ptr(), smask.data_ptr(), st), 'ifvd counts')
+            _ok(L.sd_ifvd_class_means(S.data_ptr(), T.data_ptr(), 0, cls.data_ptr(), smask.data_ptr(), counts.data_ptr(), mean_s.data_ptr(),
+                                      mean_t.data_ptr(), ws.data_ptr(), wsb, B, C, HW, K, st), 'ifvd class_means')
+            _ok(L.sd_ifvd_cos(S.data_ptr(), T.data_ptr(), 0, cls.data_ptr(), mean_s.data_ptr(), mean_t.data_ptr(), coefs.data_ptr(), loss.data_ptr(),
+                              ws.data_ptr(), wsb, B, C, HW, K, st), 'ifvd cos')
+
+        def bwd(st):
+            _ok(L.sd_ifvd_coef_sums(S.data_ptr(), 0, cls.data_ptr(), smask.data_ptr(), counts.data_ptr(), coefs.data_ptr(), A.data_ptr(), Bk.data_ptr(),
+                                    ws.data_ptr(), wsb, B, C, HW, K, st), 'ifvd coef_sums')
+            _ok(L.sd_ifvd_bwd(S.data_ptr(), 0, cls.data_ptr(), mean_s.data_ptr(), coefs.data_ptr(), A.data_ptr(), Bk.data_ptr(), counts.data_ptr(), None,
+                              dS.data_ptr(), B, C, HW, K, st), 'ifvd bwd')
+
+        tf = _time(fwd, reps)
+        tb = _time(bwd, reps)
+        N = S.numel()
+        note = 'L2/Infinity-Cache resident at this size; round 2 (torch sort chain + one gather launch per network): 0.72 / 0.40 ms eager, 0.65 ms device'
+        out += [_entry(f'ifvd fwd, {tag} (counts + both networks\' class means + cosine pass + loss)',
+                       'ifvd_counts + ifvd_onehot_sums + ifvd_finish + ifvd_cos + ifvd_loss', [B, C, hw, hw], 'f32', tf, 'hbm', 4 * N * 4, HBM, note),
+                _entry(f'ifvd bwd, {tag}', 'ifvd_onehot_sums (weighted) + ifvd_finish + ifvd_bwd', [B, C, hw, hw], 'f32', tb, 'hbm', 3 * N * 4, HBM, note)]
+    return out
 
 
 def bench_ce(dev, reps, B=8, C=150, hw=128, F=4):
