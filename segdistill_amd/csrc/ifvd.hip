@@ -87,7 +87,7 @@ __global__ __launch_bounds__(1024) void ifvd_counts(const int *__restrict__ cls,
 // Vector-instruction bound: ~400 per step of 16 pixels x 32 channels (label tests, one-hot rows, the three-way split) against 15 MFMAs when all
 // five class blocks are present.  (Tried, same box: two feature blocks per wave sharing the one-hot rows -- 320 instructions per block-step but
 // 356 registers, one wave per SIMD: 178 vs 115 us for both networks' means.)
-template <typename T, bool WEIGHTED>
+template <typename T, bool WEIGHTED, bool FAST>
 __global__ __launch_bounds__(256) void ifvd_onehot_sums(const T *__restrict__ X0, const T *__restrict__ X1, const float *__restrict__ alpha,
                                                          const float *__restrict__ beta, const int *__restrict__ cls, const int *__restrict__ smask,
                                                          float *__restrict__ part, int C, int HW, int K, int S, int Ls, int KG, int Cp) {
@@ -136,18 +136,25 @@ __global__ __launch_bounds__(256) void ifvd_onehot_sums(const T *__restrict__ X0
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int p0 = q0 + 64 * u, pix = p0 + 8 * g;
-            const bool live = p0 < p_end;
+            // FAST (the launcher's check): 16-byte aligned rows, whole rounds in every slice -- no tail, no scalar path in the loop
+            const bool live = FAST || p0 < p_end;
             present[u] = live ? __builtin_amdgcn_readfirstlane(smask_l[(p0 - s * Ls) >> 4]) : 0;
-            const bool whole = live && pix + 8 <= HW;
+            const bool whole = FAST || (live && pix + 8 <= HW);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (!live_q[q] || !live) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) x[u][q][e] = 0.f;
                 } else if (is_beta[q]) {
+                    if (FAST) {
+                        const float4 b0 = *reinterpret_cast<const float4 *>(brow + pix), b1 = *reinterpret_cast<const float4 *>(brow + pix + 4);
+                        x[u][q][0] = b0.x, x[u][q][1] = b0.y, x[u][q][2] = b0.z, x[u][q][3] = b0.w;
+                        x[u][q][4] = b1.x, x[u][q][5] = b1.y, x[u][q][6] = b1.z, x[u][q][7] = b1.w;
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) x[u][q][e] = pix + e < HW ? brow[pix + e] : 0.f;
-                } else if (whole && vec_x) {
+                        for (int e = 0; e < 8; ++e) x[u][q][e] = pix + e < HW ? brow[pix + e] : 0.f;
+                    }
+                } else if (FAST || (whole && vec_x)) {
                     if constexpr (sizeof(T) == 4) {
                         VecIO<T>::load(xrow[q] + pix, reinterpret_cast<float(&)[4]>(x[u][q][0]));
                         VecIO<T>::load(xrow[q] + pix + 4, reinterpret_cast<float(&)[4]>(x[u][q][4]));
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void ifvd_onehot_sums(const T *__restrict__ X0
                     for (int e = 0; e < 8; ++e) x[u][q][e] = (live && pix + e < HW) ? VecIO<T>::load1(xrow[q] + pix + e) : 0.f;
                 }
             }
-            if (whole && vec_c) {
+            if (FAST || (whole && vec_c)) {
                 const int4 c0 = *reinterpret_cast<const int4 *>(crow + pix), c1 = *reinterpret_cast<const int4 *>(crow + pix + 4);
                 ck[u][0] = c0.x, ck[u][1] = c0.y, ck[u][2] = c0.z, ck[u][3] = c0.w, ck[u][4] = c1.x, ck[u][5] = c1.y, ck[u][6] = c1.z, ck[u][7] = c1.w;
             } else {
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(256) void ifvd_onehot_sums(const T *__restrict__ X0
                 for (int e = 0; e < 8; ++e) ck[u][e] = (live && pix + e < HW) ? crow[pix + e] : -1;
             }
             if (WEIGHTED) {
-                if (whole && vec_c) {
+                if (FAST || (whole && vec_c)) {
                     const float4 w0 = *reinterpret_cast<const float4 *>(arow + pix), w1 = *reinterpret_cast<const float4 *>(arow + pix + 4);
                     w[u][0] = w0.x, w[u][1] = w0.y, w[u][2] = w0.z, w[u][3] = w0.w, w[u][4] = w1.x, w[u][5] = w1.y, w[u][6] = w1.z, w[u][7] = w1.w;
                 } else {
@@ -403,7 +410,7 @@ SumPlan sum_plan(int B, int nt, int C, int HW, int K, bool weighted) {
     if (S > 32) S = 32;
     const int min_s = (HW + 16 * kMaxSliceSteps - 1) / (16 * kMaxSliceSteps);
     if (S < min_s) S = min_s;
-    p.Ls = (((HW + S - 1) / S + 63) / 64) * 64;
+    p.Ls = (((HW + S - 1) / S + 255) / 256) * 256;          // whole rounds of four waves x four 16-pixel steps
     p.S = (HW + p.Ls - 1) / p.Ls;
     p.floats = (size_t)B * nt * p.S * p.Cp * (p.KG * kKGroup);
     return p;
@@ -419,8 +426,15 @@ int class_sums(const T *X0, const T *X1, const float *alpha, const float *beta, 
     if (!workspace || workspace_bytes < p.floats * sizeof(float) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return SD_E_WORKSPACE;
     if ((long)p.OPS * p.KG > 65535 || B * nt > 65535) return SD_E_SHAPE;
     float *part = static_cast<float *>(workspace);
-    hipLaunchKernelGGL((ifvd_onehot_sums<T, WEIGHTED>), dim3(p.S, p.OPS * p.KG, B * nt), dim3(256), 0, st, X0, X1, alpha, beta, cls, smask, part, C, HW, K, p.S,
-                       p.Ls, p.KG, p.Cp);
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool fast = HW % 256 == 0 && al16(X0) && al16(X1) && al16(cls) && al16(alpha) && al16(beta);
+    const dim3 grid(p.S, p.OPS * p.KG, B * nt);
+    if (fast)
+        hipLaunchKernelGGL((ifvd_onehot_sums<T, WEIGHTED, true>), grid, dim3(256), 0, st, X0, X1, alpha, beta, cls, smask, part, C, HW, K, p.S, p.Ls, p.KG,
+                           p.Cp);
+    else
+        hipLaunchKernelGGL((ifvd_onehot_sums<T, WEIGHTED, false>), grid, dim3(256), 0, st, X0, X1, alpha, beta, cls, smask, part, C, HW, K, p.S, p.Ls, p.KG,
+                           p.Cp);
     hipLaunchKernelGGL(ifvd_finish, dim3(C + (WEIGHTED ? 1 : 0), B * nt), dim3(256), 0, st, (const float *)part, counts, out0, out1, outB, C, K, p.S, p.Cp,
                        p.KG * kKGroup, nt, WEIGHTED ? 0 : 1);
     return (int)hipGetLastError();
