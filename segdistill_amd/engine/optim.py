@@ -24,7 +24,10 @@ class HipAdamW(torch.optim.AdamW):
     step for Segformer-B0 (689 -> 707 imgs/s on the captured step).  fp32 parameters on the GPU, no amsgrad / maximize.
     Host side: the descriptor table lives in a numpy record array; a step whose gradient TENSORS are the ones of the previous step (graph
     replay, or gradients living in the data-parallel flat buffer) reuses the device copy after ~200 identity checks; new gradient tensors
-    (eager backward) cost one column update and a 10 KB upload; only a change of the set of tensors rebuilds it."""
+    (eager backward) cost one column update and a 10 KB upload; only a change of the set of tensors rebuilds it.
+    NOTE ``optimizer.state[p]['step']`` is NOT advanced by step(): the kernel keeps the per-tensor step counts on the device and the host
+    tensors are brought up to date only by ``state_dict()`` (checkpointing goes through it).  Code that reads ``state[p]['step']`` directly
+    between checkpoints sees the count of the last ``state_dict()`` / ``load_state_dict()`` call."""
     _DESC = np.dtype([('p', '<u8'), ('g', '<u8'), ('m', '<u8'), ('v', '<u8'), ('s', '<u8'), ('wd', '<f4'), ('gm', '<i4'), ('n', '<i8')])
 
     def __init__(self, params, **kw):
