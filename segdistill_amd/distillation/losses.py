@@ -26,7 +26,8 @@ from ..builder import DISTILL_LOSSES
 
 
 def _bilinear(x, size):
-    return F.interpolate(x, size=tuple(int(v) for v in size), mode='bilinear', align_corners=False)
+    from ..layers import resize            # csrc/resize.hip for contiguous NCHW maps on the GPU, ATen otherwise
+    return resize(x, size=tuple(int(v) for v in size), mode='bilinear', align_corners=False, warning=False)
 
 
 @DISTILL_LOSSES.register_module()
@@ -183,10 +184,11 @@ class KLDLoss(nn.Module):
             fusable = mode == 'bilinear' and not ac and self.fuse_resize and \
                 ops.can_fuse_resize(x_student, x_teacher, out_size, self.transform_config)
             if not fusable:
+                from ..layers import resize        # csrc/resize.hip for contiguous NCHW maps on the GPU, ATen otherwise
                 if tuple(x_student.shape[2:]) != out_size:
-                    x_student = F.interpolate(x_student, size=out_size, mode=mode, align_corners=ac)
+                    x_student = resize(x_student, size=out_size, mode=mode, align_corners=ac, warning=False)
                 if tuple(x_teacher.shape[2:]) != out_size:
-                    x_teacher = F.interpolate(x_teacher, size=out_size, mode=mode, align_corners=ac)
+                    x_teacher = resize(x_teacher, size=out_size, mode=mode, align_corners=ac, warning=False)
                 out_size = None
         kind = self.transform_config['loss_type'] if self.transform_config else None
         if kind == 'channel':

@@ -20,6 +20,7 @@ for f in $SRC/kernels_*.txt $SRC/kernels_*_stats.csv $SRC/pmc_*.json; do
   [ -e "$f" ] && put $f $DST/${P}_$(basename $f)
 done
 put $SRC/pmc_traffic_r1.json $DST/traffic_${P}.json
+put $R/gpurun_out/ab_switches.txt $DST/${P}_ab_switches.txt
 for f in $R/gpurun_out/configs/train_step_kernels_cfg*.txt; do
   [ -e "$f" ] && put $f $DST/${P}_$(basename $f)
 done
