@@ -372,6 +372,9 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
         // returns a CU's loads in order, so they queue behind the other waves' A-tile loads from HBM.  (Tried and dropped: a THIRD B register
         // set, every request a whole step ahead -- the rotation needs the k-loop unrolled by three and hipcc then allocates > 256 registers
         // (200 AGPRs as spill space at one workgroup per CU, 357-635 scratch spills when held to two), pending loads among the spilled.)
+        // (Tried and dropped: different `s_setprio` levels, by hardware wave slot, for the two waves of a SIMD in their MFMA halves, so that they
+        // alternate instead of running in lockstep -- same box, slower on 44 of 47 shapes: 114.1 vs 109.0 us at 256 -> 256 over 131072 tokens,
+        // 56.1 vs 46.9 at 320 -> 1280 over 8192; the lower-priority wave's split instructions starve and its own MFMAs start late.)
         APl PA0, PA1;
         BPl B0, B1;
         load_b(B0, 0);                                  // (the A tile of step 0 was requested above)
