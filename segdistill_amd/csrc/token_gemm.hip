@@ -948,6 +948,8 @@ __global__ __launch_bounds__(256) void presplit_planes(const PresplitTable t) {
 const float *g_gemm_stamp_buf = nullptr;     // diagnostic build: device buffer of 8 x u64 per 64 workgroups (sd_debug_gemm_stamps)
 #endif
 
+int g_planes_tile = 0;        // tunable "planes_tile"
+
 // X3 products on a pre-split B operand (planes: `nblocks` 32-column blocks x K/16 k-steps)
 int dispatch_planes(const float *A, const void *planes, int nblocks, float *C, const float *bias, const float *residual, long M, int N, int K,
                     hipStream_t st) {
@@ -955,6 +957,18 @@ int dispatch_planes(const float *A, const void *planes, int nblocks, float *C, c
     // 128 x 128 tiles, two workgroups per CU.  (Measured and dropped: 128 x 256 tiles -- each wave 64 x 128, 96 MFMAs per k-step against the
     // same A split, ~330 registers, ONE workgroup per CU -- 109.7 vs 105.1 us at 256 -> 256 over 131072 tokens, 47.3 vs 43.6 us at 64 -> 256,
     // 55.7 vs 45.4 us at 320 -> 1280 over 8192: PMC shows the same ~50 % matrix-pipe occupancy with less co-resident work to cover the waits.)
+    // 64-row tiles (each wave 32 x 64: the same MFMAs per split fragment, twice the workgroups) where 128 x 128 tiles leave the chip short
+    // of work: fewer than 160 of them (8192 tokens x 256 columns = 128 workgroups on 256 CUs, one wave per SIMD running its k-steps at the
+    // memory latency), or fewer than 384 with a short reduction.  Same box, planes forward, 128 -> 64 rows (library): 2048 x 256 -> 1024
+    // 14.3 -> 11.4 us (14.1), 8192 x 256 -> 256 14.1 -> 11.6 (13.3), 8192 x 160 -> 640 18.8 -> 17.1 (21.0) and its input gradient 27.1 ->
+    // 20.7 (17.4); but 8192 x 1280 -> 320 (192 tiles) 50.9 -> 58.3 and 32768 x 512 -> 128 28.0 -> 30.1: the weight fragments are then fetched by
+    // twice as many workgroups.  Tunable "planes_tile": 0 = this rule, 128 / 64 = force (tests, A/B: SEGDISTILL_PLANES_TILE).
+    const long tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+    const bool small = g_planes_tile == 64 || (g_planes_tile == 0 && M > 64 && (tiles128 < 160 || (tiles128 < 384 && K <= 256)));
+    if (small) {
+        if (residual) return launch_epi<64, 128, 2, 2, true, 1, true, false, true, true>(A, Bp, C, bias, residual, M, N, K, K, nblocks, N, st);
+        return launch_epi<64, 128, 2, 2, true, 0, true, false, true, true>(A, Bp, C, bias, nullptr, M, N, K, K, nblocks, N, st);
+    }
     if (residual) return launch_epi<128, 128, 2, 2, true, 1, true, false, true, true>(A, Bp, C, bias, residual, M, N, K, K, nblocks, N, st);
 #ifdef SD_GEMM_STAMPS
     return launch_epi<128, 128, 2, 2, true, 0, true, false, true, true>(A, Bp, C, bias, g_gemm_stamp_buf, M, N, K, K, nblocks, N, st);
@@ -1068,6 +1082,12 @@ int token_gemm_tunable(const char *key, int set, int v) {
         if (!set) return g_pred_tall_tile;
         if (v != 0 && v != 1) return SD_E_SHAPE;
         g_pred_tall_tile = v;
+        return SD_OK;
+    }
+    if (!strcmp(key, "planes_tile")) {
+        if (!set) return g_planes_tile;
+        if (v != 0 && v != 64 && v != 128) return SD_E_SHAPE;
+        g_planes_tile = v;
         return SD_OK;
     }
     if (strcmp(key, "align_split_bf16")) return SD_E_UNSUPPORTED;

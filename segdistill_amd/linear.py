@@ -42,7 +42,10 @@ _SPLIT_BF16 = os.environ.get('SEGDISTILL_SPLIT_BF16', '1') == '1'
 def _gemm_mode(tokens, k, n):
     if not _TOKEN_GEMM:
         return 'lib'
-    if _SPLIT_BF16 and n >= 128 and k % 32 == 0 and n % 4 == 0 and -(-tokens // 128) * -(-n // 128) >= 192 and \
+    tiles = -(-tokens // 128) * -(-n // 128)
+    # 192 tiles of 128 x 128 fill the chip; from 128 tiles on, the 64-row tile of the planes kernel (csrc: dispatch_planes) is ahead of the
+    # library for reductions up to 512 (2048 x 256 -> 1024: 11.4 vs 14.1 us, 8192 x 256 -> 256: 11.6 vs 13.3, 2048 x 512 -> 1024: 18.5 vs 21.2)
+    if _SPLIT_BF16 and n >= 128 and k % 32 == 0 and n % 4 == 0 and (tiles >= 192 or (tiles >= 128 and k <= 512)) and \
             (-(-n // 128) * 128) * 4 <= n * 5:
         return 'x3'
     if tokens >= 32768 and k <= 64:

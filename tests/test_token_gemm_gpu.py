@@ -191,11 +191,21 @@ PLANE_SHAPES = [  # tokens, in_features (K), out_features (N); K % 32 == 0 (forw
 ]
 
 
+@pytest.fixture(params=[128, 64])
+def planes_tile(request):
+    """Both row-tile heights of the planes GEMM (the launcher's own rule picks 64 rows below 384 tiles of 128 x 128, i.e. for every shape a test
+    can afford): forced through the tunable, restored afterwards."""
+    from segdistill_amd import _lib
+    _lib.set_tunable('planes_tile', request.param)
+    yield request.param
+    _lib.set_tunable('planes_tile', 0)
+
+
 @pytest.mark.parametrize('T,K,N', PLANE_SHAPES)
-def test_planes_gemm_matches_fp64_at_the_split_mode_bound(T, K, N):
+def test_planes_gemm_matches_fp64_at_the_split_mode_bound(T, K, N, planes_tile):
     """sd_presplit_multi + sd_linear_fwd_planes / sd_linear_bwd_data_planes: the same six bf16 products as mode 1 with the weight's planes
     written beforehand -- the SAME error bound as the exact-f32 path, error within 2x of it; ragged token counts, column counts that are not
-    a multiple of the 32-column block (150, 160) or of the 128-column tile, bias, residual, a single k-step (K = 32)."""
+    a multiple of the 32-column block (150, 160) or of the 128-column tile, bias, residual, a single k-step (K = 32); 128- and 64-row tiles."""
     from segdistill_amd import planes, token_gemm
     dev = torch.device('cuda:0')
     g = torch.Generator(device=dev).manual_seed(T * 5 + K * 3 + N)

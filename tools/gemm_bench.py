@@ -69,6 +69,7 @@ def main():
     ap.add_argument('--dtype', default='f32')
     ap.add_argument('--only', default=None)
     ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--planes-tile', type=int, default=0, help='force the row-tile height of the planes GEMM (128 / 64; 0 = the launcher rule)')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     dt = torch.float32 if a.dtype == 'f32' else torch.bfloat16
@@ -77,6 +78,9 @@ def main():
     except Exception as e:  # noqa: BLE001
         token_gemm = None
         print('token_gemm unavailable:', e)
+    if token_gemm and a.planes_tile:
+        from segdistill_amd import _lib
+        _lib.set_tunable('planes_tile', a.planes_tile)
     groups = {
         'student': ('Segformer-B0 student (fwd + bwd-data)', mit_shapes((32, 64, 160, 256), (2, 2, 2, 2)) + head_shapes((32, 64, 160, 256), 256), True),
         'teacher': ('Segformer-B2 teacher (fwd only)', mit_shapes((64, 128, 320, 512), (3, 4, 6, 3)), False),
