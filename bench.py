@@ -66,6 +66,53 @@ def timed_steps(trainer, data, steps, world):
     return time.perf_counter() - t0
 
 
+def traffic_from_counters(d, algorithmic_bytes=5 * 8 * 150 * 512 * 512 * 4):
+    """HBM bytes of one R1 forward + backward from a rocprofv3 PMC dump (tools/pmc_summary.py's JSON, or a published summary that keeps
+    it under `raw_counters`).  Corrections exactly as MI355X_MICROARCH.md (HBM section) prescribes: counter unit 1024 B; FETCH_SIZE tallies the
+    128-B requests of a 16-B-per-lane streaming read at 64 B, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
+    Returns the summary dict (the keys profiles/traffic_rNN.json carries); raises KeyError when the dump lacks the R1 kernels."""
+    if isinstance(d.get('cgd_kl_r1_fwd_bwd_bytes'), (int, float)):
+        return d
+    raw = d.get('raw_counters', d)
+
+    def one(prefix):
+        ks = [k for k in raw if k.startswith(prefix)]
+        if len(ks) != 1:
+            raise KeyError(prefix)
+        c = raw[ks[0]]
+        return (2 * c['FETCH_SIZE']['mean'] + c['WRITE_SIZE']['mean']) * 1024.0
+
+    fwd, bwd = one('sd::cgd_fwd_partials<'), one('sd::cgd_bwd<')
+    return {'raw_counters': raw, 'cgd_kl_r1_fwd_bytes': fwd, 'cgd_kl_r1_bwd_bytes': bwd, 'cgd_kl_r1_fwd_bwd_bytes': fwd + bwd,
+            'algorithmic_bytes': algorithmic_bytes, 'ratio_traffic_over_algorithmic': (fwd + bwd) / algorithmic_bytes}
+
+
+def source_fingerprint():
+    """sha1 over the kernel sources and the Python package: what a stored per-step kernel table (profiles/rNN_step_top5.json) was measured
+    on.  There is no .git on the GPU box, so the commit cannot be asked for there; the same bytes give the same fingerprint everywhere."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, 'segdistill_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'segdistill_amd', 'csrc', '*.h'))
+                   + glob.glob(os.path.join(ROOT, 'segdistill_amd', '**', '*.py'), recursive=True))
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def stored_step_top5():
+    """The newest profiles/r*_step_top5.json IF it was measured on this very source tree (its `fingerprint` equals source_fingerprint());
+    a table of an older tree is dropped rather than quoted next to numbers it no longer describes."""
+    top = _newest_profile('r*_step_top5.json')
+    if not top:
+        return None
+    d = json.load(open(top))
+    if not isinstance(d, dict) or d.get('fingerprint') != source_fingerprint():
+        return None
+    return {'source': 'stored: ' + os.path.relpath(top, ROOT), 'fingerprint': d['fingerprint'], 'commit': d.get('commit'), 'kernels': d['kernels'][:5]}
+
+
 def roofline_leg(device, B, C=150, HW=512, g=8, tau=4.0, reps=20):
     """R1 CGD kernels on operands of the config-2 softmax shape, HIP events on torch's current stream
     (the stream the C ABI launches on)."""
@@ -115,7 +162,7 @@ def roofline_leg(device, B, C=150, HW=512, g=8, tau=4.0, reps=20):
     import glob
     for tpath in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'traffic_r*.json')), reverse=True):
         try:
-            traffic = json.load(open(tpath)).get('cgd_kl_r1_fwd_bwd_bytes')
+            traffic = traffic_from_counters(json.load(open(tpath)))['cgd_kl_r1_fwd_bwd_bytes']
             traffic_source = 'stored: ' + os.path.relpath(tpath, ROOT)
             break
         except Exception:
@@ -358,6 +405,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-exact-f32', action='store_true', help='skip the exact-f32 A/B child run (config.value_exact_f32)')
+    ap.add_argument('--exact-f32-steps', type=int, default=0, help='timed steps of the exact-f32 A/B child (default: min(steps, 10))')
     ap.add_argument('--kernel-rooflines', action='store_true',
                     help='N=1 only: also time every hand-written kernel family against its own bound (tools/kernel_rooflines.py, child processes '
                          'started before this process touches the GPU); the table goes to a SIDE FILE named by roofline.kernels_file')
@@ -388,7 +436,9 @@ def main():
     split_on = os.environ.get('SEGDISTILL_SPLIT_BF16', '1') == '1'
     if single and split_on and not args.no_exact_f32:
         base = ['--config', args.config, '--kd-path', args.kd_path, '--graph', args.graph] + (['--batch', str(args.batch)] if args.batch else [])
-        exact_f32, err = exact_f32_child(base, args.steps, args.warmup)
+        # a SHORT child (a second full benchmark doubled the wall time under the driver's budget and heated the GPU in front of
+        # the headline run); tools/refresh_profiles.sh asks for the full-length A/B with --exact-f32-steps
+        exact_f32, err = exact_f32_child(base, args.exact_f32_steps or min(args.steps, 10), min(args.warmup, 4))
         if err:
             errors.append('exact-f32 A/B: ' + err)
 
@@ -467,9 +517,9 @@ def main():
                 torch.cuda.empty_cache()
                 roofline = roofline_leg(device, B)
                 roofline['fused_r2'] = fused_leg(device, B)
-                top = _newest_profile('r*_step_top5.json')
+                top = stored_step_top5()
                 if top:
-                    roofline['step_top5'] = {'source': 'stored: ' + os.path.relpath(top, ROOT), 'kernels': json.load(open(top))[:5]}
+                    roofline['step_top5'] = top
         except Exception as e:  # noqa: BLE001 -- an optional leg never costs the headline
             errors.append(f'roofline leg: {type(e).__name__}: {e}')
         try:

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SD_ABI_VERSION 1
+#define SD_ABI_VERSION 2
 
 enum { SD_F32 = 0, SD_BF16 = 1 };
 

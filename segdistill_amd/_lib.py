@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SEGDISTILL_LIB') or os.path.join(_HERE, 'lib', 'libsegdistill_hip.so')   # SEGDISTILL_LIB: an A/B build of the SAME library
 
 SD_F32, SD_BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 

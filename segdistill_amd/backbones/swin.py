@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from ..builder import BACKBONES
 from ..layernorm import HipLayerNorm          # nn.LayerNorm subclass: same keys, HIP kernels on CUDA tokens (ATen's ran 3.9 ms of a config-4 step)
-from ..layers import DropPath, frozen_derived, to_2tuple, trunc_normal_
+from ..layers import DropPath, to_2tuple, trunc_normal_
 
 
 _GATHER_WINDOWS = os.environ.get('SEGDISTILL_SWIN_GATHER', '1') == '1'
@@ -105,14 +105,23 @@ class WindowAttention(nn.Module):
                 nw = mask.shape[0]
                 add = (add + mask.unsqueeze(1)).repeat(bw // nw, 1, 1, 1)  # windows of one image are contiguous
             return add.to(q.dtype)
-        if torch.is_grad_enabled() and self.relative_position_bias_table.requires_grad:
+        tbl = self.relative_position_bias_table
+        if tbl.requires_grad:
             add = additive()
         else:
             # frozen network (the config-4 teacher): bias gather + mask add + the repeat over the batch -- a 111 MB copy per stage-1 block --
-            # are the same tensor every step: cached per (mask identity, windows, dtype), invalidated by a checkpoint load like every
-            # derived weight (layers.frozen_derived)
-            key = ('swin_bias', None if mask is None else (mask.data_ptr(), mask._version), bw, q.dtype)
-            add = frozen_derived(self.relative_position_bias_table, key, additive) if not self.relative_position_bias_table.requires_grad else additive()
+            # are the same tensor every step.  ONE entry per module, the most recent geometry (keyed entries were never evicted, so
+            # an eval run over variable-size images grew by one [B*nW, h, N, N] tensor per distinct size and shifted block); a checkpoint load
+            # bumps the table's version and invalidates it; nothing is stored while a hipGraph is being captured
+            sig = (tbl._version, tbl.data_ptr(), None if mask is None else (mask.data_ptr(), mask._version), bw, q.dtype)
+            hit = getattr(self, '_add_cache', None)
+            if hit is not None and hit[0] == sig:
+                add = hit[1]
+            else:
+                with torch.no_grad():
+                    add = additive()
+                if not (q.is_cuda and torch.cuda.is_current_stream_capturing()):
+                    object.__setattr__(self, '_add_cache', (sig, add))
         drop = self.attn_drop.p if self.training else 0.
         out = F.scaled_dot_product_attention(q, k, v, attn_mask=add, dropout_p=drop, scale=self.scale)
         return self.proj_drop(self.proj(out.transpose(1, 2).reshape(bw, n, c)))

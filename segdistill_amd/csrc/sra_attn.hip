@@ -322,12 +322,19 @@ __global__ __launch_bounds__(NW * 64) void sra_fwd_x3(const T *__restrict__ q, c
                                                        float *__restrict__ lse, int N, int KV, int heads, float cs /* scale*log2e */,
                                                        unsigned long long *__restrict__ stamps /* diagnostics, normally null */) {
     constexpr int KP = X3Geo<D>::KP, DB = D / 32, KS = D / 16;
+    // -DSD_SRA_STAMPS (diagnostic build only, tools/sra_stamps.py): s_memtime at the phase boundaries of workgroup 0.  The product build has
+    // neither the stores nor the branches (the undeclared export and the per-stamp `blockIdx == 0` test left the product kernel).
+#ifdef SD_SRA_STAMPS
     int stamp_i = 0;
     auto stamp = [&]() {
         if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0)
             stamps[(threadIdx.x >> 6) * 32 + stamp_i] = __builtin_amdgcn_s_memtime();
         ++stamp_i;
     };
+#else
+    (void)stamps;
+    auto stamp = []() {};
+#endif
     stamp();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_x3[];
     const int nblk = FULL ? 8 : (KV + 31) / 32, rows = nblk * 32;
@@ -1443,7 +1450,9 @@ int sra_tunable(const char *key, int set, int v) {
 
 extern "C" {
 
-void sd_debug_sra_stamps(void *buf) { sd::g_sra_stamps = static_cast<unsigned long long *>(buf); }
+#ifdef SD_SRA_STAMPS
+void sd_debug_sra_stamps(void *buf) { sd::g_sra_stamps = static_cast<unsigned long long *>(buf); }   // diagnostic build only (not in the header)
+#endif
 
 int sd_sra_supported(int head_dim) { return (head_dim == 32 || head_dim == 64) ? 1 : 0; }
 

@@ -27,7 +27,7 @@ from ..builder import DISTILL_LOSSES
 
 def _bilinear(x, size):
     from ..layers import resize            # csrc/resize.hip for contiguous NCHW maps on the GPU, ATen otherwise
-    return resize(x, size=tuple(int(v) for v in size), mode='bilinear', align_corners=False, warning=False)
+    return resize(x, size=tuple(int(v) for v in size), mode='bilinear', align_corners=False, warning=False, alias_ok=True)
 
 
 @DISTILL_LOSSES.register_module()
@@ -186,9 +186,9 @@ class KLDLoss(nn.Module):
             if not fusable:
                 from ..layers import resize        # csrc/resize.hip for contiguous NCHW maps on the GPU, ATen otherwise
                 if tuple(x_student.shape[2:]) != out_size:
-                    x_student = resize(x_student, size=out_size, mode=mode, align_corners=ac, warning=False)
+                    x_student = resize(x_student, size=out_size, mode=mode, align_corners=ac, warning=False, alias_ok=True)
                 if tuple(x_teacher.shape[2:]) != out_size:
-                    x_teacher = resize(x_teacher, size=out_size, mode=mode, align_corners=ac, warning=False)
+                    x_teacher = resize(x_teacher, size=out_size, mode=mode, align_corners=ac, warning=False, alias_ok=True)
                 out_size = None
         kind = self.transform_config['loss_type'] if self.transform_config else None
         if kind == 'channel':

@@ -10,7 +10,7 @@ import torch
 from .. import deferred
 from . import segments
 from .dp import DataParallelReducer
-from .optim import PolyLR, build_optimizer
+from .optim import HipAdamW, PolyLR, build_optimizer
 
 
 def _issues_memsets(fn):
@@ -240,6 +240,12 @@ class KDTrainer:
             torch.cuda.synchronize()
             return False
 
+    def _replays_captured_forward(self):
+        if getattr(self, '_graph', None) is not None:
+            return True
+        st = getattr(self.model, 'student', None)
+        return st is not None and getattr(st, '_graphed_backbone', None) is not None
+
     def _trainable_net(self):
         return self.model.student if hasattr(self.model, 'student') else self.model
 
@@ -354,6 +360,11 @@ class KDTrainer:
         else:
             self.reducer.all_reduce()
         self.optimizer.step()
+        if self._replays_captured_forward() and not isinstance(self.optimizer, HipAdamW):
+            # a captured forward / backward reads the pre-split planes and bf16 shadows at baked-in addresses and runs no Python forward
+            # that could notice the parameters' new versions; only HipAdamW refreshes them itself (torch SGD / Adam / AdamW --
+            # SEGDISTILL_HIP_ADAMW=0, amsgrad, non-fp32 parameters -- left them at their capture-time values)
+            self._sync_derived_weights()
         self.iter += 1
         self.last_log_vars = out['log_vars']
         return out

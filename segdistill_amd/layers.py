@@ -169,7 +169,10 @@ def to_2tuple(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
 
-def resize(input, size=None, scale_factor=None, mode='nearest', align_corners=None, warning=True):
+def resize(input, size=None, scale_factor=None, mode='nearest', align_corners=None, warning=True, alias_ok=False):
+    """The reference's `resize` wrapper (mmseg/ops/wrappers.py:8-28).  alias_ok: the caller only READS the result, so a same-size request may
+    return the input itself (the distillation criteria); everybody else gets a fresh tensor, as F.interpolate gives (UPerHead / FPN
+    style `+=` or relu_ on an aliased result would have written into the source feature, possibly a tapped one)."""
     if warning and size is not None and align_corners:
         ih, iw = (int(v) for v in input.shape[2:])
         oh, ow = (int(v) for v in size)
@@ -181,7 +184,7 @@ def resize(input, size=None, scale_factor=None, mode='nearest', align_corners=No
         from . import resize as hip_resize
         if hip_resize.supported(input, size, mode, align_corners):
             if tuple(input.shape[2:]) == tuple(int(v) for v in size):
-                return input                                   # F.interpolate would copy; every caller only reads the result
+                return input if alias_ok else input.clone()
             return hip_resize.bilinear(input, size, bool(align_corners))     # csrc/resize.hip: contiguous NCHW maps on the GPU
     return F.interpolate(input, size, scale_factor, mode, align_corners)
 

@@ -34,6 +34,15 @@ def test_header_symbols_exported(built):
     assert h.sd_error_string(-4) == b'workspace too small or misaligned'
 
 
+def test_exports_equal_declarations(built):
+    """Both directions: the product .so exports exactly the sd_* symbols the header declares -- no undeclared diagnostics."""
+    import subprocess
+    from segdistill_amd import _lib
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith('sd_') and ln.split()[-2] in 'TtWw'})
+    assert exported == _declared_symbols(), sorted(set(exported) ^ set(_declared_symbols()))
+
+
 def test_workspace_sizing_and_tunables(built):
     from segdistill_amd import _lib
     h = _lib.lib()

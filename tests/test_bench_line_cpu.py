@@ -75,3 +75,32 @@ def test_main_prints_exactly_one_stdout_line_and_children_run_before_the_gpu_is_
     for name in ('kernel_roofline_entries', 'exact_f32_child'):
         calls = [n.lineno for n in ast.walk(main) if isinstance(n, ast.Call) and getattr(n.func, 'id', None) == name]
         assert calls and max(calls) < first_gpu, name
+
+
+def test_every_published_traffic_file_yields_a_number():
+    """profiles/traffic_r03.json was the raw counter dump and the driver line said `traffic: null`.  bench.traffic_from_counters reads
+    both forms (summary keys, or the raw rocprofv3 dump alone) and applies the gfx950 corrections; the newest file must give ~6.29e9."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'traffic_r*.json')))
+    assert files
+    for f in files:
+        d = bench.traffic_from_counters(json.load(open(f)))
+        t = d['cgd_kl_r1_fwd_bwd_bytes']
+        assert isinstance(t, (int, float)) and 0.99 < t / 6291456000 < 1.02, (f, t)
+    raw = json.load(open(files[-1])).get('raw_counters')
+    if raw:                                     # the raw dump alone gives the same number as the published summary
+        assert bench.traffic_from_counters(raw)['cgd_kl_r1_fwd_bwd_bytes'] == bench.traffic_from_counters(json.load(open(files[-1])))['cgd_kl_r1_fwd_bwd_bytes']
+
+
+def test_stored_step_table_is_quoted_only_for_the_tree_it_was_measured_on(tmp_path, monkeypatch):
+    fp = bench.source_fingerprint()
+    assert len(fp) == 16 and fp == bench.source_fingerprint()
+    good = tmp_path / 'r99_step_top5.json'
+    monkeypatch.setattr(bench, '_newest_profile', lambda pattern: str(good))
+    good.write_text(json.dumps({'fingerprint': fp, 'commit': 'abc1234', 'kernels': [{'name': 'k', 'ms_per_step': 1.0, 'calls': 2.0}] * 7}))
+    got = bench.stored_step_top5()
+    assert got and len(got['kernels']) == 5 and got['fingerprint'] == fp and got['commit'] == 'abc1234'
+    good.write_text(json.dumps({'fingerprint': '0' * 16, 'commit': 'abc1234', 'kernels': []}))
+    assert bench.stored_step_top5() is None                    # another tree's table: dropped
+    good.write_text(json.dumps([{'name': 'k', 'ms_per_step': 1.0}]))
+    assert bench.stored_step_top5() is None                    # round 3's unstamped form: dropped

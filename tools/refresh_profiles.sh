@@ -23,7 +23,7 @@ want() { [[ " $STEPS " == *" $1 "* ]]; }
 echo "start $(date +%T) steps: $STEPS" | tee $OUT/progress.txt
 if want 1; then
 echo "[1] bench" | tee -a $OUT/progress.txt
-python bench.py --kernel-rooflines --kernels-out $OUT/bench_kernels.json 2>$OUT/bench.err | tail -1 > $OUT/bench.json
+python bench.py --kernel-rooflines --exact-f32-steps 20 --kernels-out $OUT/bench_kernels.json 2>$OUT/bench.err | tail -1 > $OUT/bench.json
 fi
 if want 2; then
 echo "[2] bench under rocprof" | tee -a $OUT/progress.txt

@@ -1,5 +1,7 @@
 """Diagnostic: per-phase s_memtime stamps of workgroup 0 of the split-bf16 SRA forward (csrc/sra_attn.hip, sd_debug_sra_stamps).
     python tools/sra_stamps.py [D] [N] [heads]
+Needs a DIAGNOSTIC build of the library (the product build has no stamp code and does not export sd_debug_sra_stamps):
+    make -C segdistill_amd/csrc OUTDIR=../lib_stamps EXTRA=-DSD_SRA_STAMPS && SEGDISTILL_LIB=$PWD/segdistill_amd/lib_stamps/libsegdistill_hip.so python tools/sra_stamps.py
 Prints, per wave, the cycle deltas between phase boundaries: staged | per tile: q planes, S^T issued, softmax done, PV issued, stored."""
 import ctypes as C
 import os

@@ -37,7 +37,18 @@ def main():
             e['bound'] = hits[0]['bound']
             e['frac_range'] = [round(min(h['frac'] for h in hits), 3), round(max(h['frac'] for h in hits), 3)]
         out.append(e)
-    print(json.dumps(out))
+    # stamped with what it was measured ON: bench.py quotes the table only while the source tree still has this fingerprint (a
+    # stored table silently went stale when a kernel changed without a refresh); `commit` is informative (no .git on the GPU box -> null)
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from bench import source_fingerprint
+    try:
+        commit = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:  # noqa: BLE001
+        commit = None
+    print(json.dumps({'fingerprint': source_fingerprint(), 'commit': commit, 'kernels': out}))
 
 
 if __name__ == '__main__':
