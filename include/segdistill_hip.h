@@ -138,6 +138,21 @@ int sd_cgd_kl_up_bwd(const void *s, const void *t, int dtype,
                      const float *row_lse2, const float *upstream,
                      void *ds, void *stream);
 
+/* TWO channel criteria on the SAME taps in one pass each way (BASELINE config 3: CGD g = 8, tau = 4 plus the channel-wise logit KL g = 1,
+ * tau = 1 on decode_head.linear_pred; the reference's DistillationLoss calls KLDLoss.forward once per entry -- opts.py:100-110 -> losses.py:95-113
+ * -- so both taps are resized and read twice and two tap gradients are added).  Forward: every interpolated pair is folded into both
+ * criteria's online-softmax states; outputs per criterion as sd_cgd_kl_up_fwd; workspace >= 2 x sd_cgd_kl_up_workspace_bytes.  Backward:
+ * ds = coef_a (p_s - p_t)_a + coef_b (p_s - p_t)_b through one transposed interpolation.  `perm` orders the channel slots of BOTH criteria:
+ * callers fuse only when that is what the two criteria ask for (criterion b without a shuffle of its own and g_b == 1, where the slot order is
+ * immaterial, or neither with a shuffle). */
+int sd_cgd_kl_up_fwd2(const void *s, const void *t, int dtype, int B, int C, int h, int w, int H, int W, const int32_t *perm, int g_a,
+                      float inv_tau_a, float loss_scale_a, float *row_lse2_a, float *row_kl_a, float *loss_a, int g_b, float inv_tau_b,
+                      float loss_scale_b, float *row_lse2_b, float *row_kl_b, float *loss_b, void *workspace, size_t workspace_bytes,
+                      void *stream);
+int sd_cgd_kl_up_bwd2(const void *s, const void *t, int dtype, int B, int C, int h, int w, int H, int W, const int32_t *perm, int g_a,
+                      float inv_tau_a, float coef_a, const float *row_lse2_a, const float *upstream_a, int g_b, float inv_tau_b, float coef_b,
+                      const float *row_lse2_b, const float *upstream_b, void *ds, void *stream);
+
 /* ---------------------------------------------------------------------------
  * Pixel-wise criterion (PDLoss; KL term of ATLoss / IFVDLoss): rows = (b, pixel),
  * softmax over the C channels, loss_scale = alpha/(B*H*W), coef = alpha/(B*H*W*tau).
@@ -247,6 +262,38 @@ int sd_cgd_kl_tok_fwd(const void *S, const void *T, int dtype, int B, int C, lon
                       const int32_t *perm, float *row_lse2, float *row_kl, float *loss, void *workspace, size_t workspace_bytes, void *stream);
 int sd_cgd_kl_tok_bwd(const void *S, const void *T, int dtype, int B, int C, long P, int g, float inv_tau, float coef, const int32_t *perm,
                       const float *row_lse2, const float *upstream, void *dS, void *stream);
+
+/* Several token-major criteria in ONE call (config 5 taps four decoder stages: reference call site opts.py:100-110 evaluates one entry after the
+ * other; each was four chained launches): at most sd_cgd_kl_tok_max_jobs() jobs, all of one dtype; field meanings as the arguments above.
+ * Forward = one scan launch per chunk class (long / 16-pixel chunks) + ONE finish launch (row statistics in fp64 and every job's loss, the
+ * latter by the workgroup that draws its job's last arrival ticket; the tickets live in job 0's workspace).  Backward = ONE launch. */
+typedef struct sd_cgd_tok_fwd_job {
+    const void *S, *T;          /* [B][P][C] */
+    const int32_t *perm;        /* [C] or NULL */
+    float *row_lse2;            /* [rows][2] */
+    float *row_kl;              /* [rows] */
+    float *loss;                /* [1] */
+    void *workspace;            /* >= sd_cgd_kl_tok_workspace_bytes(B, C, P), 16-byte aligned, private to the job */
+    size_t workspace_bytes;
+    long P;
+    int B, C, g;
+    float inv_tau, loss_scale;
+    int reserved;
+} sd_cgd_tok_fwd_job;
+typedef struct sd_cgd_tok_bwd_job {
+    const void *S, *T;
+    const int32_t *perm;
+    const float *row_lse2;
+    const float *upstream;      /* [1] or NULL */
+    void *dS;                   /* [B][P][C], storage dtype */
+    long P;
+    int B, C, g;
+    float inv_tau, coef;
+    int reserved;
+} sd_cgd_tok_bwd_job;
+int sd_cgd_kl_tok_max_jobs(void);
+int sd_cgd_kl_tok_fwd_multi(const sd_cgd_tok_fwd_job *jobs, int njobs, int dtype, void *stream);
+int sd_cgd_kl_tok_bwd_multi(const sd_cgd_tok_bwd_job *jobs, int njobs, int dtype, void *stream);
 
 /* ---------------------------------------------------------------------------
  * nn.Linear on token-major activations, forward and input gradient, as exact-f32 MFMA GEMMs (csrc/token_gemm.hip):

@@ -42,10 +42,15 @@ SIGNATURES = {
     'sd_cgd_kl_tok_workspace_bytes': (_sz, [_i, _i, C.c_long]),
     'sd_cgd_kl_tok_fwd': (_i, [_vp, _vp, _i, _i, _i, C.c_long, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'sd_cgd_kl_tok_bwd': (_i, [_vp, _vp, _i, _i, _i, C.c_long, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'sd_cgd_kl_tok_max_jobs': (_i, []),
+    'sd_cgd_kl_tok_fwd_multi': (_i, [_vp, _i, _i, _vp]),
+    'sd_cgd_kl_tok_bwd_multi': (_i, [_vp, _i, _i, _vp]),
     'sd_cgd_kl_up_supported': (_i, [_i, _i, _i, _i]),
     'sd_cgd_kl_up_workspace_bytes': (_sz, [_i] * 7),
     'sd_cgd_kl_up_fwd': (_i, [_vp, _vp, _i] + [_i] * 7 + [_f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'sd_cgd_kl_up_bwd': (_i, [_vp, _vp, _i] + [_i] * 7 + [_f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'sd_cgd_kl_up_fwd2': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _f, _f, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'sd_cgd_kl_up_bwd2': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _f, _f, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp]),
     'sd_pix_kl_workspace_bytes': (_sz, [_i] * 4),
     'sd_pix_kl_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     'sd_pix_kl_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),

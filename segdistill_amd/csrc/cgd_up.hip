@@ -60,9 +60,14 @@ __device__ __forceinline__ PlaneRef plane_of(int slot, int C, int hw, const int3
 // ---- forward ----------------------------------------------------------------------------------
 // grid.x = B*C*nband; workgroup (slot, k) folds the output rows of gaps [k*R, min(h,(k+1)*R)) of one
 // plane (the last band also takes the closing half gap h) and writes part[slot*nband + k].
-template <typename T, int F>
+// DUAL (round 4, SURVEY section 7 step 7 / BASELINE config 3: CGD + channel-wise logit KL on the same taps; reference call site opts.py:100-110
+// evaluates the two criteria one after the other, each re-reading and re-interpolating both taps): every interpolated pair is folded into
+// TWO online-softmax states -- temperature c2 for the first criterion's rows, c2b for the second's -- and a second partial array.  The
+// rows of both criteria are built from per-(slot, band) partials, so any two group sizes share the pass; `perm` is the first criterion's.
+template <typename T, int F, bool DUAL>
 __global__ void cgd_up_fwd_partials(const T *__restrict__ s, const T *__restrict__ t, const int32_t *__restrict__ perm,
-                                    RowPart *__restrict__ part, int C, int h, int w, int R, int nband, float c2) {
+                                    RowPart *__restrict__ part, RowPart *__restrict__ part_b, int C, int h, int w, int R, int nband, float c2,
+                                    float c2b) {
     constexpr int QB = (F >= 4) ? (16 / F) : F;  // output rows folded together (16 values, or all 4 for F=2)
     const int wg = blockIdx.x;
     const int k = wg % nband;
@@ -74,7 +79,7 @@ __global__ void cgd_up_fwd_partials(const T *__restrict__ s, const T *__restrict
     const int j0 = k * R;
     const int j1 = (k == nband - 1) ? h + 1 : min(h, j0 + R);
 
-    RowPart st = {kNegBig, 0.f, kNegBig, 0.f, 0.f};
+    RowPart st = {kNegBig, 0.f, kNegBig, 0.f, 0.f}, st_b = st;
     float sp[F], tp[F], sc[F], tc[F];
     {
         const int r = max(j0 - 1, 0);
@@ -103,12 +108,16 @@ __global__ void cgd_up_fwd_partials(const T *__restrict__ s, const T *__restrict
                         }
                     }
                     fold<QB * F>(st, vs, vt, c2);
+                    if constexpr (DUAL) fold<QB * F>(st_b, vs, vt, c2b);
                 }
             } else {
                 // half gap at the top (j == 0: q >= F/2) or bottom (j == h: q < F/2); sp == sc there
                 // (both clamp to the edge row), so every output row equals the edge row.
 #pragma unroll
-                for (int q = 0; q < F / 2; ++q) fold<F>(st, sc, tc, c2);
+                for (int q = 0; q < F / 2; ++q) {
+                    fold<F>(st, sc, tc, c2);
+                    if constexpr (DUAL) fold<F>(st_b, sc, tc, c2b);
+                }
             }
         }
 #pragma unroll
@@ -116,15 +125,23 @@ __global__ void cgd_up_fwd_partials(const T *__restrict__ s, const T *__restrict
     }
     const RowPart wsum = block_combine_dyn(st, c2);
     if (threadIdx.x == 0) part[wg] = wsum;
+    if constexpr (DUAL) {
+        __syncthreads();                                    // thread 0 has read the first combine's LDS slots
+        const RowPart wsum_b = block_combine_dyn(st_b, c2b);
+        if (threadIdx.x == 0) part_b[wg] = wsum_b;
+    }
 }
 
 // ---- backward ---------------------------------------------------------------------------------
 // Workgroup (slot, k) produces tap-gradient rows [y0, y1) = [k*R, min(h,(k+1)*R)) of one plane.
 // It walks gaps j = y0 .. y1: gap j contributes to tap rows j-1 (weight 1-lambda) and j (weight lambda).
-template <typename T, int F>
+// DUAL: dS = k_a (p_s - p_t)_a + k_b (p_s - p_t)_b formed in registers from one interpolation, ONE transposed-interpolation gather and
+// ONE tap-gradient store instead of two passes and an add.
+template <typename T, int F, bool DUAL>
 __global__ void cgd_up_bwd(const T *__restrict__ s, const T *__restrict__ t, const int32_t *__restrict__ perm,
                            const float *__restrict__ row_lse2, const float *__restrict__ upstream, T *__restrict__ ds, int C, int h,
-                           int w, int R, int nband, int g, int G, float c2, float coef) {
+                           int w, int R, int nband, int g, int G, float c2, float coef, const float *__restrict__ row_lse2_b,
+                           const float *__restrict__ upstream_b, int g_b, int G_b, float c2b, float coef_b) {
     extern __shared__ float rowbuf[];  // 2 buffers of F*blockDim.x floats
     const int wg = blockIdx.x;
     const int k = wg % nband;
@@ -134,6 +151,13 @@ __global__ void cgd_up_bwd(const T *__restrict__ s, const T *__restrict__ t, con
     const int row = pl.b * G + pl.cs / g;
     const float ls = row_lse2[2 * row], lt = row_lse2[2 * row + 1];
     const float kk = upstream ? coef * upstream[0] : coef;
+    float ls_b = 0.f, lt_b = 0.f, kk_b = 0.f;
+    if constexpr (DUAL) {
+        const int row_b = pl.b * G_b + pl.cs / g_b;
+        ls_b = row_lse2_b[2 * row_b];
+        lt_b = row_lse2_b[2 * row_b + 1];
+        kk_b = upstream_b ? coef_b * upstream_b[0] : coef_b;
+    }
     const int kx = threadIdx.x;
     const bool active = kx < w;
     const int kxc = min(kx, w - 1);
@@ -168,7 +192,8 @@ __global__ void cgd_up_bwd(const T *__restrict__ s, const T *__restrict__ t, con
             for (int rx = 0; rx < F; ++rx) {
                 const float S = fmaf(lam, dsv[rx], sp[rx]);
                 const float Tv = fmaf(lam, dtv[rx], tp[rx]);
-                const float D = kk * (ex2(fmaf(S, c2, -ls)) - ex2(fmaf(Tv, c2, -lt)));
+                float D = kk * (ex2(fmaf(S, c2, -ls)) - ex2(fmaf(Tv, c2, -lt)));
+                if constexpr (DUAL) D = fmaf(kk_b, ex2(fmaf(S, c2b, -ls_b)) - ex2(fmaf(Tv, c2b, -lt_b)), D);
                 accA[rx] = fmaf(wa, D, accA[rx]);
                 accB[rx] = fmaf(wb, D, accB[rx]);
             }
@@ -230,33 +255,50 @@ int check_up(const void *s, const void *t, int dtype, int B, int C, int h, int w
     return SD_OK;
 }
 
+struct UpSecond {                 // the second criterion of a DUAL pass (part == nullptr / row_lse2 == nullptr: single criterion)
+    RowPart *part;
+    const float *row_lse2, *upstream;
+    int g;
+    float c2, coef;
+};
+
 template <typename T, int F>
 void launch_fwd(const void *s, const void *t, const int32_t *perm, RowPart *part, int B, int C, int h, int w, const UpGeo &q, float c2,
-                hipStream_t st) {
-    hipLaunchKernelGGL((cgd_up_fwd_partials<T, F>), dim3((unsigned)((long)B * C * q.nband)), dim3(q.threads), 0, st, (const T *)s,
-                       (const T *)t, perm, part, C, h, w, q.R, q.nband, c2);
+                const UpSecond &b2, hipStream_t st) {
+    const dim3 grid((unsigned)((long)B * C * q.nband)), blk(q.threads);
+    if (b2.part)
+        hipLaunchKernelGGL((cgd_up_fwd_partials<T, F, true>), grid, blk, 0, st, (const T *)s, (const T *)t, perm, part, b2.part, C, h, w, q.R,
+                           q.nband, c2, b2.c2);
+    else
+        hipLaunchKernelGGL((cgd_up_fwd_partials<T, F, false>), grid, blk, 0, st, (const T *)s, (const T *)t, perm, part, (RowPart *)nullptr, C, h,
+                           w, q.R, q.nband, c2, 0.f);
 }
 template <typename T, int F>
 void launch_bwd(const void *s, const void *t, const int32_t *perm, const float *row_lse2, const float *upstream, void *ds, int B, int C,
-                int h, int w, int g, const UpGeo &q, float c2, float coef, hipStream_t st) {
+                int h, int w, int g, const UpGeo &q, float c2, float coef, const UpSecond &b2, hipStream_t st) {
     const size_t lds = 2ull * F * q.threads * sizeof(float);
-    hipLaunchKernelGGL((cgd_up_bwd<T, F>), dim3((unsigned)((long)B * C * q.nband)), dim3(q.threads), lds, st, (const T *)s, (const T *)t,
-                       perm, row_lse2, upstream, (T *)ds, C, h, w, q.R, q.nband, g, (C + g - 1) / g, c2, coef);
+    const dim3 grid((unsigned)((long)B * C * q.nband)), blk(q.threads);
+    if (b2.row_lse2)
+        hipLaunchKernelGGL((cgd_up_bwd<T, F, true>), grid, blk, lds, st, (const T *)s, (const T *)t, perm, row_lse2, upstream, (T *)ds, C, h, w,
+                           q.R, q.nband, g, (C + g - 1) / g, c2, coef, b2.row_lse2, b2.upstream, b2.g, (C + b2.g - 1) / b2.g, b2.c2, b2.coef);
+    else
+        hipLaunchKernelGGL((cgd_up_bwd<T, F, false>), grid, blk, lds, st, (const T *)s, (const T *)t, perm, row_lse2, upstream, (T *)ds, C, h, w,
+                           q.R, q.nband, g, (C + g - 1) / g, c2, coef, (const float *)nullptr, (const float *)nullptr, 1, 1, 0.f, 0.f);
 }
 
 template <typename T>
 void dispatch_fwd(int F, const void *s, const void *t, const int32_t *perm, RowPart *part, int B, int C, int h, int w, const UpGeo &q,
-                  float c2, hipStream_t st) {
-    if (F == 2) launch_fwd<T, 2>(s, t, perm, part, B, C, h, w, q, c2, st);
-    else if (F == 4) launch_fwd<T, 4>(s, t, perm, part, B, C, h, w, q, c2, st);
-    else launch_fwd<T, 8>(s, t, perm, part, B, C, h, w, q, c2, st);
+                  float c2, const UpSecond &b2, hipStream_t st) {
+    if (F == 2) launch_fwd<T, 2>(s, t, perm, part, B, C, h, w, q, c2, b2, st);
+    else if (F == 4) launch_fwd<T, 4>(s, t, perm, part, B, C, h, w, q, c2, b2, st);
+    else launch_fwd<T, 8>(s, t, perm, part, B, C, h, w, q, c2, b2, st);
 }
 template <typename T>
 void dispatch_bwd(int F, const void *s, const void *t, const int32_t *perm, const float *row_lse2, const float *upstream, void *ds, int B,
-                  int C, int h, int w, int g, const UpGeo &q, float c2, float coef, hipStream_t st) {
-    if (F == 2) launch_bwd<T, 2>(s, t, perm, row_lse2, upstream, ds, B, C, h, w, g, q, c2, coef, st);
-    else if (F == 4) launch_bwd<T, 4>(s, t, perm, row_lse2, upstream, ds, B, C, h, w, g, q, c2, coef, st);
-    else launch_bwd<T, 8>(s, t, perm, row_lse2, upstream, ds, B, C, h, w, g, q, c2, coef, st);
+                  int C, int h, int w, int g, const UpGeo &q, float c2, float coef, const UpSecond &b2, hipStream_t st) {
+    if (F == 2) launch_bwd<T, 2>(s, t, perm, row_lse2, upstream, ds, B, C, h, w, g, q, c2, coef, b2, st);
+    else if (F == 4) launch_bwd<T, 4>(s, t, perm, row_lse2, upstream, ds, B, C, h, w, g, q, c2, coef, b2, st);
+    else launch_bwd<T, 8>(s, t, perm, row_lse2, upstream, ds, B, C, h, w, g, q, c2, coef, b2, st);
 }
 
 }  // namespace
@@ -294,9 +336,33 @@ int sd_cgd_kl_up_fwd(const void *s, const void *t, int dtype, int B, int C, int 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float c2 = inv_tau * 1.44269504088896340736f;
     sd::RowPart *part = static_cast<sd::RowPart *>(workspace);
-    if (dtype == SD_F32) sd::dispatch_fwd<float>(q.F, s, t, perm, part, B, C, h, w, q, c2, st);
-    else sd::dispatch_fwd<sd::bf16_t>(q.F, s, t, perm, part, B, C, h, w, q, c2, st);
+    const sd::UpSecond none = {nullptr, nullptr, nullptr, 1, 0.f, 0.f};
+    if (dtype == SD_F32) sd::dispatch_fwd<float>(q.F, s, t, perm, part, B, C, h, w, q, c2, none, st);
+    else sd::dispatch_fwd<sd::bf16_t>(q.F, s, t, perm, part, B, C, h, w, q, c2, none, st);
     sd::launch_row_finalize(part, row_lse2, row_kl, loss, B, C, g, q.nband, c2, inv_tau, loss_scale, st);
+    return (int)hipGetLastError();
+}
+
+int sd_cgd_kl_up_fwd2(const void *s, const void *t, int dtype, int B, int C, int h, int w, int H, int W, const int32_t *perm, int g_a,
+                      float inv_tau_a, float loss_scale_a, float *row_lse2_a, float *row_kl_a, float *loss_a, int g_b, float inv_tau_b,
+                      float loss_scale_b, float *row_lse2_b, float *row_kl_b, float *loss_b, void *workspace, size_t workspace_bytes,
+                      void *stream) {
+    int rc = sd::check_up(s, t, dtype, B, C, h, w, H, W, g_a);
+    if (rc) return rc;
+    if (g_b <= 0) return SD_E_SHAPE;
+    if (!row_lse2_a || !row_kl_a || !loss_a || !row_lse2_b || !row_kl_b || !loss_b || !workspace) return SD_E_NULL;
+    const sd::UpGeo q = sd::up_geometry(h, w, H, W);
+    const long nwg = (long)B * C * q.nband;
+    if (nwg > 0x7fffffffL) return SD_E_SHAPE;
+    if (workspace_bytes < 2 * (size_t)nwg * sizeof(sd::RowPart) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return SD_E_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float k = 1.44269504088896340736f;
+    sd::RowPart *part = static_cast<sd::RowPart *>(workspace);
+    const sd::UpSecond b2 = {part + nwg, nullptr, nullptr, g_b, inv_tau_b * k, 0.f};
+    if (dtype == SD_F32) sd::dispatch_fwd<float>(q.F, s, t, perm, part, B, C, h, w, q, inv_tau_a * k, b2, st);
+    else sd::dispatch_fwd<sd::bf16_t>(q.F, s, t, perm, part, B, C, h, w, q, inv_tau_a * k, b2, st);
+    sd::launch_row_finalize(part, row_lse2_a, row_kl_a, loss_a, B, C, g_a, q.nband, inv_tau_a * k, inv_tau_a, loss_scale_a, st);
+    sd::launch_row_finalize(part + nwg, row_lse2_b, row_kl_b, loss_b, B, C, g_b, q.nband, inv_tau_b * k, inv_tau_b, loss_scale_b, st);
     return (int)hipGetLastError();
 }
 
@@ -309,8 +375,26 @@ int sd_cgd_kl_up_bwd(const void *s, const void *t, int dtype, int B, int C, int 
     if ((long)B * C * q.nband > 0x7fffffffL) return SD_E_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float c2 = inv_tau * 1.44269504088896340736f;
-    if (dtype == SD_F32) sd::dispatch_bwd<float>(q.F, s, t, perm, row_lse2, upstream, ds, B, C, h, w, g, q, c2, coef, st);
-    else sd::dispatch_bwd<sd::bf16_t>(q.F, s, t, perm, row_lse2, upstream, ds, B, C, h, w, g, q, c2, coef, st);
+    const sd::UpSecond none = {nullptr, nullptr, nullptr, 1, 0.f, 0.f};
+    if (dtype == SD_F32) sd::dispatch_bwd<float>(q.F, s, t, perm, row_lse2, upstream, ds, B, C, h, w, g, q, c2, coef, none, st);
+    else sd::dispatch_bwd<sd::bf16_t>(q.F, s, t, perm, row_lse2, upstream, ds, B, C, h, w, g, q, c2, coef, none, st);
+    return (int)hipGetLastError();
+}
+
+int sd_cgd_kl_up_bwd2(const void *s, const void *t, int dtype, int B, int C, int h, int w, int H, int W, const int32_t *perm, int g_a,
+                      float inv_tau_a, float coef_a, const float *row_lse2_a, const float *upstream_a, int g_b, float inv_tau_b, float coef_b,
+                      const float *row_lse2_b, const float *upstream_b, void *ds, void *stream) {
+    int rc = sd::check_up(s, t, dtype, B, C, h, w, H, W, g_a);
+    if (rc) return rc;
+    if (g_b <= 0) return SD_E_SHAPE;
+    if (!row_lse2_a || !row_lse2_b || !ds) return SD_E_NULL;
+    const sd::UpGeo q = sd::up_geometry(h, w, H, W);
+    if ((long)B * C * q.nband > 0x7fffffffL) return SD_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const float k = 1.44269504088896340736f;
+    const sd::UpSecond b2 = {nullptr, row_lse2_b, upstream_b, g_b, inv_tau_b * k, coef_b};
+    if (dtype == SD_F32) sd::dispatch_bwd<float>(q.F, s, t, perm, row_lse2_a, upstream_a, ds, B, C, h, w, g_a, q, inv_tau_a * k, coef_a, b2, st);
+    else sd::dispatch_bwd<sd::bf16_t>(q.F, s, t, perm, row_lse2_a, upstream_a, ds, B, C, h, w, g_a, q, inv_tau_a * k, coef_a, b2, st);
     return (int)hipGetLastError();
 }
 

@@ -153,8 +153,8 @@ class KLDLoss(nn.Module):
         """forward() for token-major operands [B, N, C] (same schedule / shuffle state machine, csrc/cgd_tok.hip kernels)."""
         return self.forward(x_student, x_teacher, gt, n_iter, _tokens=True)
 
-    def forward(self, x_student, x_teacher, gt, n_iter, _tokens=False):
-        channels = x_student.shape[2] if _tokens else x_student.shape[1]
+    def _prepare(self, x_student, channels, n_iter):
+        """Host-side decisions of this call (schedule, shuffle draw) -> (alpha for the kernel, device alpha factor or None, perm or None)."""
         self._seen = (channels, x_student.device)
         capturing = x_student.is_cuda and torch.cuda.is_current_stream_capturing()
         if not capturing:
@@ -162,16 +162,35 @@ class KLDLoss(nn.Module):
             if self.graph_safe:
                 self.sync_device_state(channels, x_student.device)
         if self.graph_safe:
-            alpha, alpha_t = 1.0, self._alpha_t
-            perm = self._perm_t if self.shuffle_config else None
-        else:
-            alpha, alpha_t = self.alpha, None
-            perm = None if self._perm_host is None else self._perm_host.to(device=x_student.device, dtype=torch.int32)
+            return 1.0, self._alpha_t, (self._perm_t if self.shuffle_config else None)
+        perm = None if self._perm_host is None else self._perm_host.to(device=x_student.device, dtype=torch.int32)
+        return self.alpha, None, perm
+
+    def token_job(self, x_student, n_iter):
+        """The token-major form of this call as a job of ops.cgd_kl_tokens_multi: ((group_size, tau, alpha, perm), alpha_t) -- the caller
+        batches the jobs of several entries into one launch each way and multiplies loss_i by alpha_t_i when it is not None."""
+        alpha, alpha_t, perm = self._prepare(x_student, x_student.shape[2], n_iter)
+        return (self.transform_config['group_size'], self.tau, alpha, perm), alpha_t
+
+    def forward(self, x_student, x_teacher, gt, n_iter, _tokens=False):
         if _tokens:
-            loss = ops.cgd_kl_tokens(x_student, x_teacher, group_size=self.transform_config['group_size'], tau=self.tau, alpha=alpha, perm=perm)
-        else:
-            loss = self._device_part(x_student, x_teacher, gt, alpha, perm)
+            meta, alpha_t = self.token_job(x_student, n_iter)
+            loss = ops.cgd_kl_tokens_multi([(x_student, x_teacher)], [meta])[0]
+            return loss if alpha_t is None else loss * alpha_t
+        alpha, alpha_t, perm = self._prepare(x_student, x_student.shape[1], n_iter)
+        loss = self._device_part(x_student, x_teacher, gt, alpha, perm)
         return loss if alpha_t is None else loss * alpha_t
+
+    def fused_up_size(self, x_student, x_teacher, gt):
+        """The label size this call would up-sample both taps to INSIDE the fused R2 kernels (ops.cgd_kl_up), or None when it takes another
+        route -- what DistillationLoss needs to know to run two such criteria on the same taps as one pass each way (ops.cgd_kl_up2)."""
+        if not self.resize_config or not self.transform_config or self.transform_config.get('loss_type') != 'channel' or not self.fuse_resize:
+            return None
+        if x_student.dim() != 4 or self.resize_config['mode'] != 'bilinear' or self.resize_config['align_corners']:
+            return None
+        ref = x_teacher if self.resize_config.get('target', 'gt') == 'teacher' else gt
+        out_size = tuple(int(v) for v in ref.shape[2:])
+        return out_size if ops.can_fuse_resize(x_student, x_teacher, out_size, self.transform_config) else None
 
     def _device_part(self, x_student, x_teacher, gt, alpha, perm):
         out_size = None

@@ -130,31 +130,106 @@ class DistillationLoss(nn.Module):
             if hasattr(c, 'prepare_replay'):
                 c.prepare_replay(step)
 
+    def _token_form(self, i, x_student, x_teacher):
+        """Entry i stays token-major ([B,N,C] taps as decode_head.linear_c1..4 emit them) when its criterion has a token form for them
+        (KLDLoss 'channel' rows without a resize: csrc/cgd_tok.hip) -- no [B,C,h,w] view, hence no transpose copy of either tap or of the
+        gradient."""
+        crit = self.criteria[i]
+        if not (x_student.dim() == 3 and x_teacher.dim() == 3 and hasattr(crit, 'tokens_ok')):
+            return False
+        align = self.aligns[str(i)] if str(i) in self.aligns else None
+        cs_out = align.weight.shape[0] if align is not None else x_student.shape[2]
+        return cs_out == x_teacher.shape[2] and x_student.shape[:2] == x_teacher.shape[:2] and crit.tokens_ok(x_teacher)
+
     def entry_loss(self, i, x_student, x_teacher, gt_semantic_seg, step):
-        """Entry i of the config on RAW taps ([B,C,h,w], or token-major [B,N,C] as decode_head.linear_c1..4 emit them): align projection of
-        the student feature (when the entry has channel_nums) + criterion.  Token-major taps stay token-major when the criterion has a
-        token form for them (KLDLoss 'channel' rows without a resize: csrc/cgd_tok.hip) -- no [B,C,h,w] view, hence no transpose copy of
-        either tap or of the gradient; otherwise they are viewed as [B,C,h,w] (reference opts.py:25-27)."""
+        """Entry i of the config on RAW taps ([B,C,h,w], or token-major [B,N,C]): align projection of the student feature (when the entry has
+        channel_nums) + criterion.  Token-major taps without a token form are viewed as [B,C,h,w] (reference opts.py:25-27)."""
         crit = self.criteria[i]
         align = self.aligns[str(i)] if str(i) in self.aligns else None
-        if x_student.dim() == 3 and x_teacher.dim() == 3 and hasattr(crit, 'tokens_ok'):
-            ct = x_teacher.shape[2]
-            cs_out = align.weight.shape[0] if align is not None else x_student.shape[2]
-            if cs_out == ct and x_student.shape[:2] == x_teacher.shape[:2] and crit.tokens_ok(x_teacher):
-                y = align.forward_tokens(x_student) if align is not None else x_student
-                return crit.forward_tokens(y, x_teacher, gt_semantic_seg, step)
+        if self._token_form(i, x_student, x_teacher):
+            y = align.forward_tokens(x_student) if align is not None else x_student
+            return crit.forward_tokens(y, x_teacher, gt_semantic_seg, step)
         x_s, x_t = _to_nchw(x_student), _to_nchw(x_teacher)
         if align is not None:
             x_s = align(x_s)
         return crit(x_s, x_t, gt_semantic_seg, step)
 
+    def _fuse_pairs(self, losses, student_features, teacher_features, gt_semantic_seg, step):
+        """Two channel criteria on the SAME pair of taps (BASELINE config 3: CGD g = 8 + channel-wise KL g = 1 on decode_head.linear_pred;
+        SURVEY section 7 step 7) run as ONE fused-upsample pass each way (ops.cgd_kl_up2) instead of two passes and a gradient add.  Fused only
+        when one permutation table can order the channel slots of both: the second criterion has no shuffle of its own and either a group
+        size of 1 (slot order immaterial) or a partner without a shuffle as well."""
+        from .losses import KLDLoss
+        by_taps = {}
+        for i, entry in enumerate(self.distillation):
+            if losses[i] is not None or str(i) in self.aligns or not isinstance(self.criteria[i], KLDLoss) or isinstance(entry['student_layer'], list):
+                continue
+            by_taps.setdefault((entry['student_layer'], entry['teacher_layer']), []).append(i)
+        for (s_name, t_name), idx in by_taps.items():
+            xs, xt = student_features[s_name], teacher_features[t_name]
+            while len(idx) >= 2:
+                ia = idx.pop(0)
+                ca = self.criteria[ia]
+                size = ca.fused_up_size(xs, xt, gt_semantic_seg) if xs.dim() == 4 and xt.dim() == 4 else None
+                partner = None
+                for ib in idx:
+                    cb = self.criteria[ib]
+                    if size is None or cb.fused_up_size(xs, xt, gt_semantic_seg) != size:
+                        continue
+                    # the criterion WITH a shuffle (if any) leads; the other one must not care about the slot order
+                    lead, other = (ca, cb) if (ca.shuffle_config or not cb.shuffle_config) else (cb, ca)
+                    if other.shuffle_config or (lead.shuffle_config and other.transform_config['group_size'] != 1):
+                        continue
+                    partner = ib
+                    break
+                if partner is None:
+                    continue
+                idx.remove(partner)
+                cb = self.criteria[partner]
+                first, second = (ia, partner) if (ca.shuffle_config or not cb.shuffle_config) else (partner, ia)
+                cf, cs_ = self.criteria[first], self.criteria[second]
+                alpha_f, at_f, perm = cf._prepare(xs, xs.shape[1], step)
+                alpha_s, at_s, _ = cs_._prepare(xs, xs.shape[1], step)
+                lf, ls = ops.cgd_kl_up2(xs, xt, size, (cf.transform_config['group_size'], cf.tau, alpha_f),
+                                        (cs_.transform_config['group_size'], cs_.tau, alpha_s), perm)
+                losses[first] = lf if at_f is None else lf * at_f
+                losses[second] = ls if at_s is None else ls * at_s
+
     def forward(self, student_features, teacher_features, gt_semantic_seg, step, student=None, teacher=None):
-        out = {}
+        losses = [None] * len(self.distillation)
+        # token-major entries first: their align projections run one by one, their criteria in ONE call each way (config 5 taps four decoder
+        # stages; evaluated one after the other -- reference opts.py:100-110 -- each criterion was four chained launches forward)
+        batch = []
         for i, entry in enumerate(self.distillation):
             s_name, t_name = entry['student_layer'], entry['teacher_layer']
             if isinstance(s_name, list):
                 raise NotImplementedError('list-typed layers (attention-pair criteria) are not used by any shipped config')
-            loss = self.entry_loss(i, student_features[s_name], teacher_features[t_name], gt_semantic_seg, step)
+            xs, xt = student_features[s_name], teacher_features[t_name]
+            align = self.aligns[str(i)] if str(i) in self.aligns else None
+            crit = self.criteria[i]
+            if hasattr(crit, 'host_prepare') and not (xs.is_cuda and torch.cuda.is_current_stream_capturing()):
+                # schedules and shuffle draws in ENTRY order whatever the launch order below (the draws come from one CPU generator)
+                crit.host_prepare(step, align.weight.shape[0] if align is not None else xs.shape[2 if xs.dim() == 3 else 1])
+            if self._token_form(i, xs, xt):
+                batch.append((i, align.forward_tokens(xs) if align is not None else xs, xt))
+        by_dtype = {}
+        for item in batch:
+            by_dtype.setdefault(item[1].dtype, []).append(item)
+        cap = ops.cgd_kl_tokens_max_jobs() if batch else 1
+        for items in by_dtype.values():
+            for lo in range(0, len(items), cap):
+                part = items[lo:lo + cap]
+                jobs = [self.criteria[i].token_job(y, step) for i, y, _ in part]
+                out = ops.cgd_kl_tokens_multi([(y, xt) for _, y, xt in part], [m for m, _ in jobs])
+                for (i, _, _), (_, alpha_t), loss in zip(part, jobs, out):
+                    losses[i] = loss if alpha_t is None else loss * alpha_t
+        self._fuse_pairs(losses, student_features, teacher_features, gt_semantic_seg, step)
+        out = {}
+        for i, entry in enumerate(self.distillation):
+            s_name, t_name = entry['student_layer'], entry['teacher_layer']
+            loss = losses[i]
+            if loss is None:
+                loss = self.entry_loss(i, student_features[s_name], teacher_features[t_name], gt_semantic_seg, step)
             try:
                 info = entry['loss_config']['transform_config']
             except (KeyError, TypeError):

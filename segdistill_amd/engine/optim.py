@@ -160,6 +160,26 @@ class HipAdamW(torch.optim.AdamW):
         return loss
 
 
+def sync_derived_weights(params):
+    """Copies of the weights that kernels read instead of the fp32 parameter -- pre-split bf16 planes (planes.py), bf16 shadows
+    (linear.lowp_copy) -- rewritten IN PLACE from the parameters' current values, one launch for all planes."""
+    from .. import planes
+    params = [p for p in params if p.is_cuda]
+    if not params:
+        return
+    planes.sync(params)
+    with torch.no_grad():
+        for p in params:
+            sh = getattr(p, '_sd_shadow', None)
+            if sh is not None:
+                sh[1].copy_(p)
+                p._sd_shadow = (p._version, sh[1])
+
+
+def _refresh_after_step(optimizer, *_args, **_kw):
+    sync_derived_weights([p for g in optimizer.param_groups for p in g['params']])
+
+
 def build_optimizer(model, cfg):
     cfg = dict(cfg)
     kind = cfg.pop('type')
@@ -190,7 +210,13 @@ def build_optimizer(model, cfg):
         extra['fused'] = True  # one multi-tensor kernel per group instead of ~10 tiny kernels per parameter
     cfg.pop('lr', None)
     cfg.pop('weight_decay', None)
-    return cls(groups, lr=base_lr, weight_decay=base_wd, **cfg, **extra)
+    opt = cls(groups, lr=base_lr, weight_decay=base_wd, **cfg, **extra)
+    # Only HipAdamW rewrites the planes / shadows itself.  Any torch optimizer gets a step post-hook that does: torch's FUSED optimizers
+    # (what `extra` asks for) do NOT bump the parameters' in-place version counters, so the "fresh iff versions agree" rule of planes.py
+    # never fires for them -- eager steps kept multiplying by the first step's planes (found in round 4 with tests/test_graph_gpu.py; ADVICE
+    # r3 had flagged the graph-replay half of it, where no Python forward runs at all).  One launch per step.
+    opt.register_step_post_hook(_refresh_after_step)
+    return opt
 
 
 class PolyLR:

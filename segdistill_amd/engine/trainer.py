@@ -10,7 +10,7 @@ import torch
 from .. import deferred
 from . import segments
 from .dp import DataParallelReducer
-from .optim import HipAdamW, PolyLR, build_optimizer
+from .optim import PolyLR, build_optimizer, sync_derived_weights
 
 
 def _issues_memsets(fn):
@@ -240,12 +240,6 @@ class KDTrainer:
             torch.cuda.synchronize()
             return False
 
-    def _replays_captured_forward(self):
-        if getattr(self, '_graph', None) is not None:
-            return True
-        st = getattr(self.model, 'student', None)
-        return st is not None and getattr(st, '_graphed_backbone', None) is not None
-
     def _trainable_net(self):
         return self.model.student if hasattr(self.model, 'student') else self.model
 
@@ -359,12 +353,7 @@ class KDTrainer:
             self.reducer.exchange()         # packed by the replayed graph
         else:
             self.reducer.all_reduce()
-        self.optimizer.step()
-        if self._replays_captured_forward() and not isinstance(self.optimizer, HipAdamW):
-            # a captured forward / backward reads the pre-split planes and bf16 shadows at baked-in addresses and runs no Python forward
-            # that could notice the parameters' new versions; only HipAdamW refreshes them itself (torch SGD / Adam / AdamW --
-            # SEGDISTILL_HIP_ADAMW=0, amsgrad, non-fp32 parameters -- left them at their capture-time values)
-            self._sync_derived_weights()
+        self.optimizer.step()             # a torch optimizer rewrites planes / shadows through its step post-hook (engine/optim.py)
         self.iter += 1
         self.last_log_vars = out['log_vars']
         return out
@@ -401,19 +390,9 @@ class KDTrainer:
             m.cnt = int(meta['cnt'])
 
     def _sync_derived_weights(self):
-        """Copies of the weights that kernels read instead of the fp32 parameter -- pre-split bf16 planes (planes.py), bf16 shadows
-        (linear.lowp_copy) -- are rewritten IN PLACE now: a captured graph has their addresses baked in and a replay runs no Python forward
-        that would notice the parameters' new versions."""
-        from .. import planes
-        params = self.reducer.params
-        if params and params[0].is_cuda:
-            planes.sync(params)
-            with torch.no_grad():
-                for p in params:
-                    sh = getattr(p, '_sd_shadow', None)
-                    if sh is not None:
-                        sh[1].copy_(p)
-                        p._sd_shadow = (p._version, sh[1])
+        """Copies of the weights that kernels read instead of the fp32 parameter are rewritten IN PLACE now (engine/optim.py::
+        sync_derived_weights): a captured graph has their addresses baked in and a replay runs no Python forward."""
+        sync_derived_weights(self.reducer.params)
 
     def save(self, path):
         import os

@@ -1,6 +1,8 @@
 """torch.autograd bindings over the C ABI (device pointers + the current HIP stream)."""
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 
 from . import _lib
@@ -77,49 +79,89 @@ def cgd_kl(S, T, *, group_size, tau, alpha, perm=None, return_rows=False):
     return (loss, rows) if return_rows else loss
 
 
-class _CGDKLTokFunction(torch.autograd.Function):
-    """The same criterion on token-major operands [B, P, C] (csrc/cgd_tok.hip): no NCHW view / transpose copy of the taps."""
+class _TokFwdJob(C.Structure):     # include/segdistill_hip.h: sd_cgd_tok_fwd_job
+    _fields_ = [('S', C.c_void_p), ('T', C.c_void_p), ('perm', C.c_void_p), ('row_lse2', C.c_void_p), ('row_kl', C.c_void_p), ('loss', C.c_void_p),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('P', C.c_long), ('B', C.c_int), ('C', C.c_int), ('g', C.c_int),
+                ('inv_tau', C.c_float), ('loss_scale', C.c_float), ('reserved', C.c_int)]
+
+
+class _TokBwdJob(C.Structure):     # sd_cgd_tok_bwd_job
+    _fields_ = [('S', C.c_void_p), ('T', C.c_void_p), ('perm', C.c_void_p), ('row_lse2', C.c_void_p), ('upstream', C.c_void_p), ('dS', C.c_void_p),
+                ('P', C.c_long), ('B', C.c_int), ('C', C.c_int), ('g', C.c_int), ('inv_tau', C.c_float), ('coef', C.c_float), ('reserved', C.c_int)]
+
+
+class _CGDKLTokMultiFunction(torch.autograd.Function):
+    """n criteria on token-major operands [B, P, C] (csrc/cgd_tok.hip) in ONE call each way: forward = scan launch(es) + one finish launch
+    for all of them, backward = one launch.  apply(meta, S_1, T_1, ..., S_n, T_n) -> (loss_1, rows_1, ..., loss_n, rows_n);
+    meta = [(group_size, tau, alpha, perm or None)] * n."""
 
     @staticmethod
-    def forward(ctx, S, T, group_size, tau, alpha, perm):
-        _require_gpu(S, T)
-        if S.shape != T.shape or S.dim() != 3:
-            raise ValueError(f'expected equal token-major [B, P, C] shapes, got {tuple(S.shape)} and {tuple(T.shape)}')
-        if S.dtype != T.dtype or S.dtype not in _DT:
-            raise TypeError(f'unsupported dtypes {S.dtype}/{T.dtype}')
-        S, T = S.contiguous(), T.contiguous()
-        B, P, Cc = S.shape
-        g = int(group_size)
-        rows = B * (-(-Cc // g))
+    def forward(ctx, meta, *ops_):
+        n = len(meta)
+        if len(ops_) != 2 * n or n == 0:
+            raise ValueError('expected one (S, T) pair per criterion')
         L = _lib.lib()
-        if perm is not None:
-            perm = perm.to(device=S.device, dtype=torch.int32).contiguous()
-            if perm.numel() != Cc:
-                raise ValueError('perm must have C entries')
-        ws_bytes = L.sd_cgd_kl_tok_workspace_bytes(B, Cc, P)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=S.device)
-        row_lse2 = torch.empty(rows, 2, dtype=torch.float32, device=S.device)
-        row_kl = torch.empty(rows, dtype=torch.float32, device=S.device)
-        loss = torch.empty((), dtype=torch.float32, device=S.device)
-        rc = L.sd_cgd_kl_tok_fwd(S.data_ptr(), T.data_ptr(), _DT[S.dtype], B, Cc, P, g, 1.0 / float(tau), float(alpha) / rows, _ptr(perm),
-                                 row_lse2.data_ptr(), row_kl.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr())
-        _lib.check(rc, 'sd_cgd_kl_tok_fwd')
-        ctx.save_for_backward(S, T, row_lse2, perm if perm is not None else torch.empty(0, device=S.device))
-        ctx.meta = (g, float(tau), float(alpha), rows, perm is not None)
-        ctx.mark_non_differentiable(row_kl)
-        return loss, row_kl
+        if n > L.sd_cgd_kl_tok_max_jobs():
+            raise ValueError(f'at most {L.sd_cgd_kl_tok_max_jobs()} criteria per call')
+        jobs = (_TokFwdJob * n)()
+        keep, outs, saved, info = [], [], [], []
+        dt0 = ops_[0].dtype
+        for i, (g, tau, alpha, perm) in enumerate(meta):
+            S, T = ops_[2 * i], ops_[2 * i + 1]
+            _require_gpu(S, T)
+            if S.shape != T.shape or S.dim() != 3:
+                raise ValueError(f'expected equal token-major [B, P, C] shapes, got {tuple(S.shape)} and {tuple(T.shape)}')
+            if S.dtype != T.dtype or S.dtype not in _DT or S.dtype != dt0:
+                raise TypeError(f'unsupported dtypes {S.dtype}/{T.dtype} (all criteria of one call share a dtype)')
+            S, T = S.contiguous(), T.contiguous()
+            B, P, Cc = S.shape
+            g = int(g)
+            rows = B * (-(-Cc // g))
+            if perm is not None:
+                perm = perm.to(device=S.device, dtype=torch.int32).contiguous()
+                if perm.numel() != Cc:
+                    raise ValueError('perm must have C entries')
+            ws_bytes = L.sd_cgd_kl_tok_workspace_bytes(B, Cc, P)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=S.device)
+            row_lse2 = torch.empty(rows, 2, dtype=torch.float32, device=S.device)
+            row_kl = torch.empty(rows, dtype=torch.float32, device=S.device)
+            loss = torch.empty((), dtype=torch.float32, device=S.device)
+            j = jobs[i]
+            j.S, j.T, j.perm, j.row_lse2, j.row_kl, j.loss = S.data_ptr(), T.data_ptr(), _ptr(perm), row_lse2.data_ptr(), row_kl.data_ptr(), loss.data_ptr()
+            j.workspace, j.workspace_bytes, j.P, j.B, j.C, j.g = ws.data_ptr(), ws_bytes, P, B, Cc, g
+            j.inv_tau, j.loss_scale = 1.0 / float(tau), float(alpha) / rows
+            keep.append(ws)
+            outs += [loss, row_kl]
+            saved += [S, T, row_lse2, perm if perm is not None else torch.empty(0, device=S.device)]
+            info.append((g, float(tau), float(alpha), rows, perm is not None))
+        _lib.check(L.sd_cgd_kl_tok_fwd_multi(C.cast(jobs, C.c_void_p), n, _DT[dt0], _stream_ptr()), 'sd_cgd_kl_tok_fwd_multi')
+        ctx.save_for_backward(*saved)
+        ctx.info = info
+        ctx.mark_non_differentiable(*outs[1::2])
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, grad_loss, _grad_rows):
-        S, T, row_lse2, perm = ctx.saved_tensors
-        g, tau, alpha, rows, has_perm = ctx.meta
-        B, P, Cc = S.shape
-        dS = torch.empty_like(S)
-        up = grad_loss.to(torch.float32).contiguous()
-        rc = _lib.lib().sd_cgd_kl_tok_bwd(S.data_ptr(), T.data_ptr(), _DT[S.dtype], B, Cc, P, g, 1.0 / tau, alpha / (rows * tau),
-                                          perm.data_ptr() if has_perm else None, row_lse2.data_ptr(), up.data_ptr(), dS.data_ptr(), _stream_ptr())
-        _lib.check(rc, 'sd_cgd_kl_tok_bwd')
-        return dS, None, None, None, None, None
+    def backward(ctx, *grads):
+        info, saved = ctx.info, ctx.saved_tensors
+        n = len(info)
+        jobs = (_TokBwdJob * n)()
+        dSs, keep = [], []
+        for i, (g, tau, alpha, rows, has_perm) in enumerate(info):
+            S, T, row_lse2, perm = saved[4 * i:4 * i + 4]
+            B, P, Cc = S.shape
+            dS = torch.empty_like(S)
+            gl = grads[2 * i]
+            up = (gl if gl is not None else torch.zeros((), device=S.device)).to(torch.float32).contiguous()
+            j = jobs[i]
+            j.S, j.T, j.perm, j.row_lse2, j.upstream, j.dS = S.data_ptr(), T.data_ptr(), perm.data_ptr() if has_perm else None, row_lse2.data_ptr(), up.data_ptr(), dS.data_ptr()
+            j.P, j.B, j.C, j.g, j.inv_tau, j.coef = P, B, Cc, g, 1.0 / tau, alpha / (rows * tau)
+            dSs.append(dS)
+            keep.append(up)
+        _lib.check(_lib.lib().sd_cgd_kl_tok_bwd_multi(C.cast(jobs, C.c_void_p), n, _DT[saved[0].dtype], _stream_ptr()), 'sd_cgd_kl_tok_bwd_multi')
+        out = [None]
+        for dS in dSs:
+            out += [dS, None]
+        return tuple(out)
 
 
 def cgd_kl_tokens_supported(S, T, perm_len=None):
@@ -132,8 +174,20 @@ def cgd_kl_tokens_supported(S, T, perm_len=None):
 
 def cgd_kl_tokens(S, T, *, group_size, tau, alpha, perm=None, return_rows=False):
     """Channel-group KL on token-major operands [B, P, C] at equal resolution.  HIP only."""
-    loss, rows = _CGDKLTokFunction.apply(S, T, group_size, tau, alpha, perm)
+    loss, rows = _CGDKLTokMultiFunction.apply([(group_size, tau, alpha, perm)], S, T)
     return (loss, rows) if return_rows else loss
+
+
+def cgd_kl_tokens_max_jobs():
+    return int(_lib.lib().sd_cgd_kl_tok_max_jobs())
+
+
+def cgd_kl_tokens_multi(pairs, meta, return_rows=False):
+    """Several token-major criteria in one call each way (config 5's four decoder stages): pairs = [(S_i, T_i)], meta = [(group_size, tau,
+    alpha, perm or None)].  -> [loss_i] (or [(loss_i, rows_i)])."""
+    flat = [x for st in pairs for x in st]
+    out = _CGDKLTokMultiFunction.apply(list(meta), *flat)
+    return [(out[2 * i], out[2 * i + 1]) if return_rows else out[2 * i] for i in range(len(pairs))]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -198,6 +252,72 @@ class _CGDKLUpFunction(torch.autograd.Function):
                                          up.data_ptr(), ds.data_ptr(), _stream_ptr())
         _lib.check(rc, 'sd_cgd_kl_up_bwd')
         return ds, None, None, None, None, None, None
+
+
+class _CGDKLUp2Function(torch.autograd.Function):
+    """Two channel criteria (a, b) on the SAME taps with the bilinear resize fused in, one pass each way (csrc/cgd_up.hip DUAL kernels):
+    apply(s, t, out_size, (g_a, tau_a, alpha_a), (g_b, tau_b, alpha_b), perm) -> (loss_a, rows_a, loss_b, rows_b); `perm` orders the channel
+    slots of both (callers fuse only when that is right: see include/segdistill_hip.h, sd_cgd_kl_up_fwd2)."""
+
+    @staticmethod
+    def forward(ctx, s, t, out_size, crit_a, crit_b, perm):
+        _require_gpu(s, t)
+        if s.shape != t.shape or s.dim() != 4:
+            raise ValueError(f'expected equal 4-D shapes, got {tuple(s.shape)} and {tuple(t.shape)}')
+        if s.dtype != t.dtype or s.dtype not in _DT:
+            raise TypeError(f'unsupported dtypes {s.dtype}/{t.dtype}')
+        s, t = s.contiguous(), t.contiguous()
+        B, Cc, h, w = s.shape
+        H, W = int(out_size[0]), int(out_size[1])
+        (ga, taua, alphaa), (gb, taub, alphab) = crit_a, crit_b
+        ga, gb = int(ga), int(gb)
+        rows_a, rows_b = B * (-(-Cc // ga)), B * (-(-Cc // gb))
+        L = _lib.lib()
+        if perm is not None:
+            perm = perm.to(device=s.device, dtype=torch.int32).contiguous()
+            if perm.numel() != Cc:
+                raise ValueError('perm must have C entries')
+        ws_bytes = 2 * L.sd_cgd_kl_up_workspace_bytes(B, Cc, h, w, H, W, ga)
+        if ws_bytes == 0:
+            raise RuntimeError(f'no fused-upsample kernel for {h}x{w} -> {H}x{W}')
+        f32 = dict(dtype=torch.float32, device=s.device)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=s.device)
+        lse_a, kl_a, loss_a = torch.empty(rows_a, 2, **f32), torch.empty(rows_a, **f32), torch.empty((), **f32)
+        lse_b, kl_b, loss_b = torch.empty(rows_b, 2, **f32), torch.empty(rows_b, **f32), torch.empty((), **f32)
+        rc = L.sd_cgd_kl_up_fwd2(s.data_ptr(), t.data_ptr(), _DT[s.dtype], B, Cc, h, w, H, W, _ptr(perm),
+                                 ga, 1.0 / float(taua), float(alphaa) / rows_a, lse_a.data_ptr(), kl_a.data_ptr(), loss_a.data_ptr(),
+                                 gb, 1.0 / float(taub), float(alphab) / rows_b, lse_b.data_ptr(), kl_b.data_ptr(), loss_b.data_ptr(),
+                                 ws.data_ptr(), ws_bytes, _stream_ptr())
+        _lib.check(rc, 'sd_cgd_kl_up_fwd2')
+        ctx.save_for_backward(s, t, lse_a, lse_b, perm if perm is not None else torch.empty(0, device=s.device))
+        ctx.meta = (H, W, (ga, float(taua), float(alphaa), rows_a), (gb, float(taub), float(alphab), rows_b), perm is not None)
+        ctx.mark_non_differentiable(kl_a, kl_b)
+        return loss_a, kl_a, loss_b, kl_b
+
+    @staticmethod
+    def backward(ctx, grad_a, _ra, grad_b, _rb):
+        s, t, lse_a, lse_b, perm = ctx.saved_tensors
+        H, W, (ga, taua, alphaa, rows_a), (gb, taub, alphab, rows_b), has_perm = ctx.meta
+        B, Cc, h, w = s.shape
+        ds = torch.empty_like(s)
+        zero = None
+        ups = []
+        for gr in (grad_a, grad_b):
+            if gr is None:
+                zero = torch.zeros((), dtype=torch.float32, device=s.device) if zero is None else zero
+                gr = zero
+            ups.append(gr.to(torch.float32).contiguous())
+        rc = _lib.lib().sd_cgd_kl_up_bwd2(s.data_ptr(), t.data_ptr(), _DT[s.dtype], B, Cc, h, w, H, W, perm.data_ptr() if has_perm else None,
+                                          ga, 1.0 / taua, alphaa / (rows_a * taua), lse_a.data_ptr(), ups[0].data_ptr(),
+                                          gb, 1.0 / taub, alphab / (rows_b * taub), lse_b.data_ptr(), ups[1].data_ptr(), ds.data_ptr(), _stream_ptr())
+        _lib.check(rc, 'sd_cgd_kl_up_bwd2')
+        return ds, None, None, None, None, None
+
+
+def cgd_kl_up2(s, t, out_size, crit_a, crit_b, perm=None, return_rows=False):
+    """crit_x = (group_size, tau, alpha).  -> (loss_a, loss_b) or ((loss_a, rows_a), (loss_b, rows_b))."""
+    la, ra, lb, rb = _CGDKLUp2Function.apply(s, t, tuple(out_size), tuple(crit_a), tuple(crit_b), perm)
+    return ((la, ra), (lb, rb)) if return_rows else (la, lb)
 
 
 def cgd_kl_up(s, t, out_size, *, group_size, tau, alpha, perm=None, return_rows=False):

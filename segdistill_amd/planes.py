@@ -10,7 +10,9 @@ matrix cores consume -- are written once per change instead of being re-derived 
 Freshness has ONE rule, shared by the forward and the optimizer (two predicates drifted apart for the bf16 shadows): an entry is
 fresh iff `entry.version == weight._version` and its base parameter is alive.  Anything that writes the parameter through torch (checkpoint
 load, another optimizer, `copy_`) bumps the version and the next forward recomputes in place -- also inside a capture, where the recompute
-simply becomes a node of the graph.  `param.data` writes do not bump versions: call `invalidate(param)` after such an edit.
+simply becomes a node of the graph.  NOT every torch write bumps the version: `param.data` writes and torch's FUSED optimizers
+(`fused=True`: `_fused_adamw_` / `_fused_sgd_`) leave it unchanged -- call `invalidate(param)` / `sync(params)` after such a write;
+engine/optim.py::build_optimizer registers a step post-hook that does so for every torch optimizer it builds.
 """
 from __future__ import annotations
 

@@ -518,3 +518,95 @@ def test_ifvd_kernels_match_oracle(shape, dtype):
     ltol, gtol = (LOSS_RTOL, GRAD_RL2) if dtype == torch.float32 else (3e-3, 2e-2)
     assert float(loss) == pytest.approx(float(ref), rel=ltol)
     assert _rel_l2(sg.grad.float().cpu().numpy(), s64.grad.numpy()) < gtol
+
+
+# ---- two criteria on the same taps in one pass each way (csrc/cgd_up.hip DUAL; BASELINE config 3) -------------------------------------
+UP2_CASES = [
+    # (B, C, h, w, F, (g_a, tau_a, alpha_a), (g_b, tau_b, alpha_b), perm?)
+    (2, 22, 16, 16, 4, (8, 4.0, 3.0), (1, 1.0, 1.0), True),       # config 3's pair, pad (22 % 8), a shuffle iteration
+    (2, 150, 32, 32, 4, (8, 4.0, 3.0), (1, 1.0, 1.0), False),
+    (1, 7, 8, 8, 8, (3, 2.0, 2.0), (7, 3.0, 1.0), False),         # two group sizes > 1 (neither shuffled), x8
+    (1, 5, 20, 12, 2, (2, 3.0, 1.0), (1, 2.0, 0.5), True),        # several bands, w not a multiple of 64, x2
+]
+
+
+@pytest.mark.parametrize('case', UP2_CASES)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_r2_two_criteria_in_one_pass(case, dtype):
+    """ops.cgd_kl_up2 against (i) the fp64 oracle: loss_a + loss_b and the gradient of their weighted sum = kd_ref.full_kld summed over the two
+    criteria (reference: two KLDLoss.forward calls, opts.py:100-110 -> losses.py:95-113); (ii) the two single-criterion launches: every
+    interpolated value is folded in the same order, so losses and row values are bit-equal and the gradient agrees to rounding."""
+    from segdistill_amd import ops
+    B, C, h, w, F, ca, cb, with_perm = case
+    s_np, t_np = wavy_pair((B, C, h, w))
+    dev = _dev()
+    t = torch.tensor(t_np, dtype=dtype, device=dev)
+    perm_np = np.random.RandomState(C).permutation(C) if with_perm else None
+    perm = None if perm_np is None else torch.tensor(perm_np, dtype=torch.int32, device=dev)
+    H, W = h * F, w * F
+    ua, ub = 0.7, 1.3                                                # different upstream factors per criterion
+    s2 = torch.tensor(s_np, dtype=dtype, device=dev, requires_grad=True)
+    (la, ra), (lb, rb) = ops.cgd_kl_up2(s2, t, (H, W), ca, cb, perm, return_rows=True)
+    (ua * la + ub * lb).backward()
+    s1 = torch.tensor(s_np, dtype=dtype, device=dev, requires_grad=True)
+    la1, ra1 = ops.cgd_kl_up(s1, t, (H, W), group_size=ca[0], tau=ca[1], alpha=ca[2], perm=perm, return_rows=True)
+    lb1, rb1 = ops.cgd_kl_up(s1, t, (H, W), group_size=cb[0], tau=cb[1], alpha=cb[2], perm=perm, return_rows=True)
+    (ua * la1 + ub * lb1).backward()
+    assert torch.equal(la, la1) and torch.equal(lb, lb1) and torch.equal(ra, ra1) and torch.equal(rb, rb1)
+    g2, g1 = s2.grad.float().cpu().numpy(), s1.grad.float().cpu().numpy()
+    assert _rel_l2(g2, g1) < (2e-6 if dtype == torch.float32 else 6e-3)
+    # oracle on the operands as stored
+    s64, t64 = s2.detach().double().cpu().numpy(), t.double().cpu().numpy()
+    ref_a = kd_ref.full_kld(s64, t64, out_size=(H, W), alpha=ca[2], tau=ca[1], group_size=ca[0], perm=perm_np)
+    ref_b = kd_ref.full_kld(s64, t64, out_size=(H, W), alpha=cb[2], tau=cb[1], group_size=cb[0], perm=perm_np)
+    assert float(la) == pytest.approx(ref_a['loss'], rel=LOSS_RTOL) and float(lb) == pytest.approx(ref_b['loss'], rel=LOSS_RTOL)
+    assert float(la + lb) == pytest.approx(ref_a['loss'] + ref_b['loss'], rel=LOSS_RTOL)
+    assert _rel_l2(g2, ua * ref_a['grad_s'] + ub * ref_b['grad_s']) < (GRAD_RL2 if dtype == torch.float32 else 6e-3)
+
+
+def test_distillation_loss_fuses_config3_pair_and_only_such_pairs():
+    """DistillationLoss._fuse_pairs: config 3's two KLDLoss entries on decode_head.linear_pred run as ONE fused call each way (same keys and
+    values as the entry-by-entry flow; one tap gradient); a pair whose second criterion has its own shuffle is left alone."""
+    from segdistill_amd import ops
+    from segdistill_amd.distillation.opts import DistillationLoss
+    dev = _dev()
+    bil = dict(mode='bilinear', align_corners=False)
+
+    def entries(second_shuffles):
+        e2 = dict(alpha=1, tau=1, resize_config=bil, transform_config={'loss_type': 'channel', 'group_size': 1})
+        if second_shuffles:
+            e2['shuffle_config'] = {'interval': 1000}
+        return [dict(student_layer='a', teacher_layer='b', loss_name='KLDLoss',
+                     loss_config=dict(alpha=3, tau=4, resize_config=bil, shuffle_config={'interval': 1000},
+                                      transform_config={'loss_type': 'channel', 'group_size': 8})),
+                dict(student_layer='a', teacher_layer='b', loss_name='KLDLoss', loss_config=e2)]
+    s_np, t_np = wavy_pair((2, 22, 16, 16))
+    t = torch.tensor(t_np, dtype=torch.float32, device=dev)
+    gt = torch.zeros(2, 1, 64, 64, device=dev)
+    calls = {'fused': 0}
+    real = ops.cgd_kl_up2
+
+    def counting(*a, **k):
+        calls['fused'] += 1
+        return real(*a, **k)
+    ops.cgd_kl_up2 = counting
+    try:
+        for second_shuffles, want_fused in ((False, 1), (True, 0)):
+            calls['fused'] = 0
+            dl = DistillationLoss(entries(second_shuffles)).to(dev)
+            s = torch.tensor(s_np, dtype=torch.float32, device=dev, requires_grad=True)
+            torch.manual_seed(3)
+            out = dl({'a': s}, {'b': t}, gt, 1000)              # a shuffle iteration for the CGD entry
+            assert calls['fused'] == want_fused
+            assert len(out) == 2
+            sum(out.values()).backward()
+            s1 = torch.tensor(s_np, dtype=torch.float32, device=dev, requires_grad=True)
+            torch.manual_seed(3)
+            dl1 = DistillationLoss(entries(second_shuffles)).to(dev)
+            vals = [dl1.entry_loss(i, s1, t, gt, 1000) for i in range(2)]
+            sum(vals).backward()
+            for v, (k, o) in zip(vals, out.items()):
+                assert float(o) == pytest.approx(float(v), rel=1e-6), k
+            assert _rel_l2(s.grad.cpu().numpy(), s1.grad.cpu().numpy()) < 2e-6
+    finally:
+        ops.cgd_kl_up2 = real

@@ -81,3 +81,73 @@ def test_token_major_equals_nchw_kernels_at_config5_stage_shape():
     assert float(l1) == pytest.approx(float(l2), rel=1e-5)
     g2 = s2.grad.reshape(2, 768, 4096).transpose(1, 2)
     assert float((s1.grad.float() - g2.float()).norm() / g2.float().norm()) < 2e-3      # two bf16 roundings of the same fp32 values: identical up to ties
+
+
+def _stage_operands(dev, dtype, shapes, seed=3):
+    out = []
+    for i, (B, P, C) in enumerate(shapes):
+        s, t = _operands(B, P, C, seed + i, dtype)
+        out.append((s.to(dev), t.to(dev)))
+    return out
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_multi_job_call_equals_the_single_job_calls(dtype):
+    """Several criteria in one call each way (ops.cgd_kl_tokens_multi: one scan launch per chunk class + ONE finish launch + ONE backward launch)
+    give, bit for bit, what one call per criterion gives -- long chunks (64 pixels, 256 of them) and 16-pixel chunks in the same call,
+    different widths, group sizes, temperatures, a permutation on two of them, a ragged tail."""
+    from segdistill_amd import ops
+    dev = torch.device('cuda:0')
+    shapes = [(2, 16384, 64), (2, 1024, 768), (1, 333, 96), (2, 256, 768), (1, 4096, 128)]
+    meta = [(8, 4.0, 3.0, None), (8, 4.0, 3.0, torch.randperm(768, generator=torch.Generator().manual_seed(1)).to(dev)), (7, 2.0, 1.0, None),
+            (1, 1.0, 1.0, torch.randperm(768, generator=torch.Generator().manual_seed(2)).to(dev)), (128, 3.0, 2.0, None)]
+    pairs = _stage_operands(dev, dtype, shapes)
+    single = []
+    for (s, t), (g, tau, alpha, perm) in zip(pairs, meta):
+        s1 = s.clone().requires_grad_(True)
+        loss, rows = ops.cgd_kl_tokens(s1, t, group_size=g, tau=tau, alpha=alpha, perm=perm, return_rows=True)
+        (loss * 0.5).backward()
+        single.append((loss.detach().clone(), rows.clone(), s1.grad.clone()))
+    ss = [s.clone().requires_grad_(True) for s, _ in pairs]
+    out = ops.cgd_kl_tokens_multi([(a, t) for a, (_, t) in zip(ss, pairs)], meta, return_rows=True)
+    sum(l for l, _ in out).mul(0.5).backward()
+    for (loss, rows), s_req, (l1, r1, g1) in zip(out, ss, single):
+        assert torch.equal(loss, l1) and torch.equal(rows, r1) and torch.equal(s_req.grad, g1)
+    # and against the oracle for the widest one
+    B, P, C = shapes[1]
+    ref = kd_ref.rowwise_kld(_as_nchw64(pairs[1][0].float().cpu()), _as_nchw64(pairs[1][1].float().cpu()), alpha=3.0, tau=4.0, perm=meta[1][3].cpu().numpy(),
+                             group_size=8)
+    assert float(out[1][0]) == pytest.approx(ref['loss'], rel=2e-5)
+
+
+def test_finish_launch_is_run_to_run_identical_under_uneven_load():
+    """The loss of a stage is written by whichever workgroup draws that stage's last arrival ticket (hand-off by agent-scope release /
+    acquire): 30 launches of a four-stage call, with an unrelated streaming kernel racing on a second stream, must give the same bits, and
+    the tickets must work again on every launch (they are re-zeroed by the scan launch)."""
+    from segdistill_amd import ops
+    dev = torch.device('cuda:0')
+    shapes = [(8, 4096, 768), (8, 1024, 768), (8, 256, 768), (4, 16384, 256)]
+    pairs = _stage_operands(dev, torch.bfloat16, shapes, seed=9)
+    meta = [(8, 4.0, 3.0, None)] * 4
+    first = None
+    noise = torch.randn(64 << 20, device=dev)
+    side = torch.cuda.Stream()
+    for it in range(30):
+        if it % 2:
+            with torch.cuda.stream(side):
+                noise.mul_(1.0001)
+        out = ops.cgd_kl_tokens_multi(pairs, meta, return_rows=True)
+        vals = torch.stack([l for l, _ in out]).clone()
+        rows = torch.cat([r for _, r in out]).clone()
+        if first is None:
+            first = (vals, rows)
+            for (s, t), l in zip(pairs, out):
+                lone = ops.cgd_kl_tokens(s, t, group_size=8, tau=4.0, alpha=3.0)
+                assert torch.equal(lone, l[0])
+        else:
+            assert torch.equal(vals, first[0]) and torch.equal(rows, first[1]), it
+    torch.cuda.synchronize()
+    # each loss IS the fixed-order sum of its rows
+    for (l, r), (s, _) in zip(out, pairs):
+        rows_n = s.shape[0] * (768 // 8 if s.shape[2] == 768 else 256 // 8)
+        assert float(l) == pytest.approx(float(r.double().sum()) * 3.0 / rows_n, rel=1e-6)

@@ -111,47 +111,48 @@ def test_bf16_graph_modes_match_eager(mode):
             assert vg[k] == pytest.approx(ve[k], abs=tol), (it, k, ve[k], vg[k])
 
 
-@pytest.mark.parametrize('mode', ['full', 'hybrid'])
-def test_graph_replay_with_a_torch_optimizer_keeps_derived_weights_fresh(mode, monkeypatch):
-    """only HipAdamW rewrites the pre-split weight planes after its step; with any torch optimizer
-    (SEGDISTILL_HIP_ADAMW=0, amsgrad, SGD) a replayed capture kept multiplying by the capture-time planes.  KDTrainer.step now
-    rewrites them in place after such an optimizer; checked directly (planes == a fresh split of the live weight) and through the losses."""
+@pytest.mark.parametrize('mode', ['full', 'hybrid', 'eager'])
+def test_a_torch_optimizer_keeps_derived_weights_fresh(mode, monkeypatch):
+    """Only HipAdamW rewrites the pre-split weight planes itself.  ADVICE r3 (high): under graph replay with a torch optimizer
+    (SEGDISTILL_HIP_ADAMW=0, amsgrad, SGD) the captured GEMMs kept multiplying by the capture-time planes.  Round 4 found the eager half: torch's
+    FUSED optimizers do not bump the parameters' version counters, so planes.get() never noticed the update either.  build_optimizer now gives
+    every torch optimizer a step post-hook that rewrites planes (and bf16 shadows) in place.  Checked directly -- planes == a fresh split of the
+    live weight, bit for bit -- and through the losses against a HipAdamW eager run (the two optimizers agree to ~1e-6 per step)."""
     from segdistill_amd import planes
     from segdistill_amd.engine import KDTrainer, SyntheticADE
     from segdistill_amd.engine.optim import HipAdamW
-    monkeypatch.setenv('SEGDISTILL_HIP_ADAMW', '0')
-    opt = dict(type='AdamW', lr=2e-3, betas=(0.9, 0.999), weight_decay=0.01)     # a large rate: stale weights show at once
+    opt = dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
     ref = _model()
     gra = copy.deepcopy(ref)
     t_e = KDTrainer(ref, opt, None)
+    monkeypatch.setenv('SEGDISTILL_HIP_ADAMW', '0')
     t_g = KDTrainer(gra, opt, None)
-    assert not isinstance(t_g.optimizer, HipAdamW)
-    data_e = SyntheticADE(2, size=(128, 128), device='cuda:0', pool=3, seed=1)
-    data_g = SyntheticADE(2, size=(128, 128), device='cuda:0', pool=3, seed=1)
+    assert isinstance(t_e.optimizer, HipAdamW) and not isinstance(t_g.optimizer, HipAdamW)
+    size = (256, 256)                           # 8192 stage-1 tokens: enough tiles for the planes GEMMs to be dispatched
+    data_e = SyntheticADE(2, size=size, device='cuda:0', pool=3, seed=1)
+    data_g = SyntheticADE(2, size=size, device='cuda:0', pool=3, seed=1)
     example = dict(img=data_g._pool[0][0], img_metas=None, gt_semantic_seg=data_g._pool[0][1])
-    assert (t_g.enable_graph(example) if mode == 'full' else t_g.enable_hybrid_graph(example))
-    for it in range(4):
+    if mode != 'eager':
+        assert (t_g.enable_graph(example) if mode == 'full' else t_g.enable_hybrid_graph(example))
+    for it in range(5):
         torch.manual_seed(100 + it)
         t_e.step(data_e.next())
         torch.manual_seed(100 + it)
         t_g.step(data_g.next())
+        torch.cuda.synchronize()
+        mine = {id(p) for p in gra.parameters()}
+        ents = [e for e in planes._ENTRIES.values() if e.base() is not None and id(e.base()) in mine]
+        assert len(ents) >= 2, 'the student registered too few pre-split planes: the test does not test anything'
+        for e in ents:
+            for d in ('fwd', 'bwd', 'rows'):
+                buf = getattr(e, d)
+                if buf is None:
+                    continue
+                have = buf.clone()
+                planes._launch([e])             # a fresh split of the LIVE weight into the same buffers
+                torch.cuda.synchronize()
+                assert torch.equal(have, getattr(e, d)), (it, d, e.out, e.inp)
         ve, vg = t_e.log_values(), t_g.log_values()
         for k in ve:
             if 'acc' not in k:
-                assert vg[k] == pytest.approx(ve[k], rel=2e-2, abs=2e-3), (it, k, ve[k], vg[k])
-    torch.cuda.synchronize()
-    mine = {id(p) for p in gra.student.parameters()}
-    ents = [e for e in planes._ENTRIES.values() if e.base() is not None and id(e.base()) in mine]
-    assert ents, 'the student registered no pre-split planes: the test does not test anything'
-    checked = 0
-    for e in ents:
-        for d in ('fwd', 'bwd', 'rows'):
-            buf = getattr(e, d)
-            if buf is None:
-                continue
-            have = buf.clone()
-            planes._launch([e])                 # a fresh split of the LIVE weight into the same buffers
-            torch.cuda.synchronize()
-            assert torch.equal(have, getattr(e, d)), (d, e.out, e.inp)
-            checked += 1
-    assert checked >= 4
+                assert vg[k] == pytest.approx(ve[k], abs=3e-4 * max(1.0, abs(ve[k]))), (it, k, ve[k], vg[k])

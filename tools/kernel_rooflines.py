@@ -114,11 +114,16 @@ def bench_r1(dev, reps, B=8, C=150, HW=512, g=8, tau=4.0, dtype=torch.float32):
 
 
 def bench_tok(dev, reps, B=8, C=768, g=8, tau=4.0, dtype=torch.bfloat16):
-    """Token-major criterion at the four config-5 stage shapes [8, h*h, 768] (bf16 taps), h = 128, 64, 32, 16."""
+    """Token-major criterion at the four config-5 stage shapes [8, h*h, 768] (bf16 taps), h = 128, 64, 32, 16: each stage as its own call
+    (2 launches forward: scan + finish; 1 backward) and -- what the train step issues since round 4 -- stages 2-4 and all four stages as ONE
+    call (sd_cgd_kl_tok_fwd_multi / _bwd_multi)."""
+    import ctypes as C_
     from segdistill_amd import _lib
+    from segdistill_amd.ops import _TokBwdJob, _TokFwdJob
     L = _lib.lib()
     DT = 0 if dtype == torch.float32 else 1
-    out = []
+    tag = 'bf16' if dtype == torch.bfloat16 else 'f32'
+    out, st_ = [], []
     for h in (128, 64, 32, 16):
         P = h * h
         gen = torch.Generator(device=dev).manual_seed(1234)
@@ -128,16 +133,31 @@ def bench_tok(dev, reps, B=8, C=768, g=8, tau=4.0, dtype=torch.bfloat16):
         lse, kl, loss, dS = torch.empty(rows, 2, device=dev), torch.empty(rows, device=dev), torch.empty((), device=dev), torch.empty_like(S)
         wsb = L.sd_cgd_kl_tok_workspace_bytes(B, C, P)
         ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        st_.append((S, T, lse, kl, loss, dS, ws, wsb, P, rows))
         tf = _time(lambda st: _ok(L.sd_cgd_kl_tok_fwd(S.data_ptr(), T.data_ptr(), DT, B, C, P, g, 1 / tau, 3.0 / rows, None, lse.data_ptr(), kl.data_ptr(),
                                                       loss.data_ptr(), ws.data_ptr(), wsb, st), 'tok fwd'), reps)
         tb = _time(lambda st: _ok(L.sd_cgd_kl_tok_bwd(S.data_ptr(), T.data_ptr(), DT, B, C, P, g, 1 / tau, 3.0 / (rows * tau), None, lse.data_ptr(), None,
                                                       dS.data_ptr(), st), 'tok bwd'), reps)
         N, e = S.numel(), S.element_size()
-        tag = 'bf16' if dtype == torch.bfloat16 else 'f32'
         note = None if h >= 64 else 'operands fit the 256 MiB Infinity Cache / launch-bound at this size'
-        out += [_entry(f'cgd_kl token-major fwd, cfg5 stage {(128, 64, 32, 16).index(h) + 1} ({tag})', 'cgd_tok_fwd_partials + cgd_fwd_rows + cgd_fwd_loss',
+        out += [_entry(f'cgd_kl token-major fwd, cfg5 stage {(128, 64, 32, 16).index(h) + 1} ({tag})', 'cgd_tok_fwd_partials + cgd_tok_finish',
                        [B, P, C], tag, tf, 'hbm', 2 * N * e, HBM, note),
                 _entry(f'cgd_kl token-major bwd, cfg5 stage {(128, 64, 32, 16).index(h) + 1} ({tag})', 'cgd_tok_bwd', [B, P, C], tag, tb, 'hbm', 3 * N * e, HBM, note)]
+    for name, sel in (('stages 2-4 in one call', st_[1:]), ('all four stages in one call', st_)):
+        fj, bj = (_TokFwdJob * len(sel))(), (_TokBwdJob * len(sel))()
+        nbytes = 0
+        for i, (S, T, lse, kl, loss, dS, ws, wsb, P, rows) in enumerate(sel):
+            f, b = fj[i], bj[i]
+            f.S, f.T, f.perm, f.row_lse2, f.row_kl, f.loss, f.workspace, f.workspace_bytes = S.data_ptr(), T.data_ptr(), None, lse.data_ptr(), kl.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb
+            f.P, f.B, f.C, f.g, f.inv_tau, f.loss_scale = P, B, C, g, 1 / tau, 3.0 / rows
+            b.S, b.T, b.perm, b.row_lse2, b.upstream, b.dS = S.data_ptr(), T.data_ptr(), None, lse.data_ptr(), None, dS.data_ptr()
+            b.P, b.B, b.C, b.g, b.inv_tau, b.coef = P, B, C, g, 1 / tau, 3.0 / (rows * tau)
+            nbytes += S.numel() * S.element_size()
+        tf = _time(lambda st: _ok(L.sd_cgd_kl_tok_fwd_multi(C_.cast(fj, C_.c_void_p), len(sel), DT, st), 'tok fwd multi'), reps)
+        tb = _time(lambda st: _ok(L.sd_cgd_kl_tok_bwd_multi(C_.cast(bj, C_.c_void_p), len(sel), DT, st), 'tok bwd multi'), reps)
+        shape = [[B, q[8], C] for q in sel]
+        out += [_entry(f'cgd_kl token-major fwd, cfg5 {name} ({tag})', 'cgd_tok_fwd_partials (x1-2) + cgd_tok_finish', shape, tag, tf, 'hbm', 2 * nbytes, HBM),
+                _entry(f'cgd_kl token-major bwd, cfg5 {name} ({tag})', 'cgd_tok_bwd', shape, tag, tb, 'hbm', 3 * nbytes, HBM)]
     return out
 
 
@@ -162,8 +182,23 @@ def bench_r2(dev, reps, B=8, C=150, hw=128, F=4, g=8, tau=4.0):
     fwd_ops = N * (2 * 1.75 + 9 + 2.125 * 4)
     bwd_ops = N * (2 * 1.75 + 6 + 2 * 4 + 2.0)      # recompute lerps, two exponentials, dS, transposed-interpolation FMAs
     note = 'exp/VALU-bound by design (reads only the taps: 5*B*C*h*w*e bytes); lane-instruction count is a MODEL, the measured SQ_INSTS_VALU is in profiles/'
-    return [_entry('cgd_kl R2 fwd (fused x4 upsample)', 'cgd_up_fwd_partials (+ rows, loss)', [B, C, hw, hw, '->', H, H], 'f32', tf, 'valu', fwd_ops, VALU, note),
-            _entry('cgd_kl R2 bwd (fused x4 upsample)', 'cgd_up_bwd', [B, C, hw, hw, '->', H, H], 'f32', tb, 'valu', bwd_ops, VALU, note)]
+    out = [_entry('cgd_kl R2 fwd (fused x4 upsample)', 'cgd_up_fwd_partials (+ rows, loss)', [B, C, hw, hw, '->', H, H], 'f32', tf, 'valu', fwd_ops, VALU, note),
+           _entry('cgd_kl R2 bwd (fused x4 upsample)', 'cgd_up_bwd', [B, C, hw, hw, '->', H, H], 'f32', tb, 'valu', bwd_ops, VALU, note)]
+    # config 3: the CGD criterion (g = 8, tau = 4) and the channel-wise KL (g = 1, tau = 1) on the same taps in ONE pass each way
+    rows_b = B * C
+    lse_b, kl_b, loss_b = torch.empty(rows_b, 2, device=dev), torch.empty(rows_b, device=dev), torch.empty((), device=dev)
+    ws2 = torch.empty(2 * wsb, dtype=torch.uint8, device=dev)
+    tf2 = _time(lambda st: _ok(L.sd_cgd_kl_up_fwd2(s.data_ptr(), t.data_ptr(), 0, B, C, hw, hw, H, H, None, g, 1 / tau, 3.0 / rows, lse.data_ptr(), kl.data_ptr(),
+                                                 loss.data_ptr(), 1, 1.0, 1.0 / rows_b, lse_b.data_ptr(), kl_b.data_ptr(), loss_b.data_ptr(), ws2.data_ptr(), 2 * wsb, st),
+                               'fwd2'), reps)
+    tb2 = _time(lambda st: _ok(L.sd_cgd_kl_up_bwd2(s.data_ptr(), t.data_ptr(), 0, B, C, hw, hw, H, H, None, g, 1 / tau, 3.0 / (rows * tau), lse.data_ptr(), None,
+                                                 1, 1.0, 1.0 / rows_b, lse_b.data_ptr(), None, ds.data_ptr(), st), 'bwd2'), reps)
+    note2 = note + '; TWO criteria per pass: the fold / the exponentials are per criterion, loads and interpolation are shared'
+    out += [_entry('cgd_kl R2 fwd, two criteria in one pass (config 3: g=8 tau=4 + g=1 tau=1)', 'cgd_up_fwd_partials<DUAL> (+ 2 x rows, loss)',
+                   [B, C, hw, hw, '->', H, H], 'f32', tf2, 'valu', N * (2 * 1.75 + 2 * (9 + 2.125 * 4)), VALU, note2),
+            _entry('cgd_kl R2 bwd, two criteria in one pass (config 3)', 'cgd_up_bwd<DUAL>', [B, C, hw, hw, '->', H, H], 'f32', tb2, 'valu',
+                   N * (2 * 1.75 + 6 + 4 * 4 + 2.0 + 2.0), VALU, note2)]
+    return out
 
 
 def bench_align(dev, reps, B, Cs, Ct, h, dtype, tag):
