@@ -163,8 +163,6 @@ def lib():
     if os.environ.get('SEGDISTILL_SPLIT_BF16', '1') == '0':   # A/B switch shared with linear.py: exact-f32 MFMA everywhere
         h.sd_set_tunable(b'sra_split_bf16', 0)
         h.sd_set_tunable(b'align_split_bf16', 0)
-    if os.environ.get('SEGDISTILL_PRED_TALL_TILE', '1') == '0':   # A/B switch: 128-row tiles for the class-plane linear_pred
-        h.sd_set_tunable(b'pred_tall_tile', 0)
     if os.environ.get('SEGDISTILL_PLANES_TILE') in ('64', '128'):   # A/B switch: force the row-tile height of the planes GEMMs
         h.sd_set_tunable(b'planes_tile', int(os.environ['SEGDISTILL_PLANES_TILE']))
     return h

@@ -167,7 +167,7 @@ class SRAttention(nn.Module):
         kv = kv_lin.reshape(b, -1, 2, h, d).permute(2, 0, 3, 1, 4)
         k, v = self.K(kv[0]), self.V(kv[1])
         explicit = bool(self.ATTN._forward_hooks) or dropping
-        # measured on MI355X (tools/attn_probe.py, fp32): the fused SDPA kernels win everywhere in the forward, but their
+        # measured on MI355X (round-1 attention probe, fp32): the fused SDPA kernels win everywhere in the forward, but their
         # backward parallelises over the 256 keys only; with >= 8192 queries the explicit form's fwd+bwd is 1.7-2.2x faster
         explicit = explicit or (n >= 8192 and torch.is_grad_enabled() and x.requires_grad)
         if explicit:

@@ -40,7 +40,7 @@ def build_loss(cfg):
 
 def build_segmentor(cfg, train_cfg=None, test_cfg=None):
     if train_cfg is not None or test_cfg is not None:
-        warnings.warn('train_cfg and test_cfg is deprecated, please specify them in model', UserWarning)
-    assert cfg.get('train_cfg') is None or train_cfg is None, 'train_cfg specified in both outer field and model field '
-    assert cfg.get('test_cfg') is None or test_cfg is None, 'test_cfg specified in both outer field and model field '
+        warnings.warn('passing train_cfg / test_cfg beside the model config is the old calling convention: put them inside the model dict', UserWarning)
+    assert cfg.get('train_cfg') is None or train_cfg is None, 'train_cfg was given twice: as an argument and inside the model config'
+    assert cfg.get('test_cfg') is None or test_cfg is None, 'test_cfg was given twice: as an argument and inside the model config'
     return build(cfg, SEGMENTORS, dict(train_cfg=train_cfg, test_cfg=test_cfg))

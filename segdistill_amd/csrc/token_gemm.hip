@@ -1075,15 +1075,7 @@ int pred_splits(int B, long P) {
     return per_img;
 }
 
-int g_pred_tall_tile = 1;    // tunable "pred_tall_tile": 160-row tile for 129 ... 160 output planes (sd_linear_nchw_fwd, split-bf16 mode)
-
 int token_gemm_tunable(const char *key, int set, int v) {
-    if (!strcmp(key, "pred_tall_tile")) {
-        if (!set) return g_pred_tall_tile;
-        if (v != 0 && v != 1) return SD_E_SHAPE;
-        g_pred_tall_tile = v;
-        return SD_OK;
-    }
     if (!strcmp(key, "planes_tile")) {
         if (!set) return g_planes_tile;
         if (v != 0 && v != 64 && v != 128) return SD_E_SHAPE;
@@ -1114,7 +1106,7 @@ int linear_nchw_f32_fwd(const float *X, const float *W, const float *bias, float
     if (g_pred_split_bf16 && in_features % 32 == 0) {
         // 129 ... 160 output rows (the 150 classes): ONE 160-row tile (five 32-row MFMA blocks per wave, four waves along the pixels) instead of
         // two 128-row tiles of which the second is 83 % padding
-        if (out_features > 128 && out_features <= 160 && g_pred_tall_tile)
+        if (out_features > 128 && out_features <= 160)
             return launch_epi<160, 128, 1, 4, true, 0, true, true, true>(W, X, Y, bias, nullptr, out_features, (int)P, in_features, in_features,
                                                                              in_features, P, st, B, 0L, sB, sC);
         return launch_epi<128, 128, 2, 2, true, 0, true, true, true>(W, X, Y, bias, nullptr, out_features, (int)P, in_features, in_features, in_features, P,
@@ -1161,7 +1153,7 @@ int linear_nchw_f32_bwd_weight(const float *dY, const float *X, float *dW, float
     float *slabs = static_cast<float *>(workspace);
     float *bias_part = slabs + (size_t)B * pred_splits(B, P) * slab;
     int rc;
-    if (g_pred_split_bf16 && klen % 32 == 0 && P % 32 == 0 && out_features > 128 && out_features <= 160 && g_pred_tall_tile)   // one 160-row tile, see the forward
+    if (g_pred_split_bf16 && klen % 32 == 0 && P % 32 == 0 && out_features > 128 && out_features <= 160)   // one 160-row tile, see the forward
         rc = launch_epi<160, 128, 1, 4, false, 0, true, false, true>(dY, X, slabs, nullptr, nullptr, out_features, in_features, (int)P, P, in_features,
                                                                          in_features, st, B, P * out_features, P * in_features, slab, nsplit, klen);
     else if (g_pred_split_bf16 && klen % 32 == 0 && P % 32 == 0)

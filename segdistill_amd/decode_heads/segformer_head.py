@@ -192,7 +192,7 @@ class SegFormerHead(BaseDecodeHead):
         # Linear form + one transpose copy (39-79 MB) rather than W x tokens^T: (a) its weight gradient -- a 150 x E product over
         # 131072 tokens -- then runs on the split-K kernel instead of a 20-workgroup library GEMM (0.39 ms at config 2);
         # (b) ROCm 7.0 hipBLASLt's bf16 kernel for the batched W x tokens^T form (E=768, HW=16384) reads out of bounds
-        # (tools/gemm_fault_probe.py reproduces the GPU memory fault).
+        # (reproduced in isolation in round 1).
         frozen_f32 = not torch.is_grad_enabled() and tokens.dtype == torch.float32 and not torch.is_autocast_enabled()
         if linear_to_planes_supported(tokens, w2d, pred.bias) and (not frozen_f32 or (e % 32 == 0 and _lib.get_tunable('align_split_bf16') == 1)):
             # the swapped-role product writes the class planes directly and its backward reads the gradient planes (csrc: sd_linear_nchw_*):

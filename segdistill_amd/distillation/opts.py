@@ -159,7 +159,10 @@ class DistillationLoss(nn.Module):
         SURVEY section 7 step 7) run as ONE fused-upsample pass each way (ops.cgd_kl_up2) instead of two passes and a gradient add.  Fused only
         when one permutation table can order the channel slots of both: the second criterion has no shuffle of its own and either a group
         size of 1 (slot order immaterial) or a partner without a shuffle as well."""
+        import os
         from .losses import KLDLoss
+        if os.environ.get('SEGDISTILL_FUSE_PAIRS', '1') != '1':        # A/B: every criterion as its own pass
+            return
         by_taps = {}
         for i, entry in enumerate(self.distillation):
             if losses[i] is not None or str(i) in self.aligns or not isinstance(self.criteria[i], KLDLoss) or isinstance(entry['student_layer'], list):

@@ -16,7 +16,7 @@ from .optim import PolyLR, build_optimizer, sync_derived_weights
 def _issues_memsets(fn):
     """True if running `fn` enqueues any hipMemset command (seen through the torch profiler).
 
-    Why it matters (tools/memset_graph_probe.py, ROCm 7.x runtime bundled with PyTorch 2.10): a memset NODE inside a
+    Why it matters (ROCm 7.x runtime bundled with PyTorch 2.10): a memset NODE inside a
     replayed hipGraph takes its fill pattern from a staging area shared with every other memset on the device; a
     hipMemsetAsync issued on ANOTHER stream while the node is pending makes the node write garbage (kernel-argument
     words of the other memset) instead of its value.  Two pieces of work may therefore only overlap on different
@@ -78,7 +78,7 @@ class KDTrainer:
             model.activation_dtype = torch.bfloat16     # the teacher forward opens its own autocast region (sd_module.py)
 
     # ---- hipGraph mode ------------------------------------------------------------------------------------------------
-    # The KD step is ~1300 kernel launches; eager host enqueue costs ~24 ms/step on the GPU box (tools/host_probe.py),
+    # The KD step is ~1300 kernel launches; eager host enqueue costs ~24 ms/step on the GPU box (round-1 host probe),
     # about as much as the GPU work itself.  Forward + backward are therefore captured ONCE into a hipGraph (static
     # input buffers; the teacher's side stream forks/joins inside the capture) and replayed; everything that changes
     # per iteration reaches the kernels as data (alpha scalar, permutation table -- distillation/losses.py), the

@@ -85,8 +85,6 @@ def _bwd_data(dy2, weight):
     return None
 
 
-_SHADOWS = os.environ.get('SEGDISTILL_BF16_SHADOWS', '1') == '1'
-_PRED_PLANES_A = os.environ.get('SEGDISTILL_PRED_PLANES_A', '1') == '1'    # A/B: 0 = linear_pred's forward splits W in registers (round 2)
 _BF16_WGRAD_LIB = os.environ.get('SEGDISTILL_BF16_WGRAD_LIB', '0') == '1'
 _SPLITK_WGRAD = os.environ.get('SEGDISTILL_SPLITK_WGRAD', '1') == '1'      # A/B: 0 = the library's dY^T @ X for the non-tall-skinny weight gradients
 
@@ -96,9 +94,9 @@ def lowp_copy(t, dt):
     shadow (`_sd_shadow` = (parameter version, tensor)): engine/optim.py::HipAdamW rewrites it together with the parameter, so the next
     forward -- eager or a graph replay -- finds the cast already done instead of running one tiny kernel per weight and bias.  Any torch
     op that writes the parameter (checkpoint load, another optimizer) bumps its version and the shadow is remade.  (A write through
-    `param.data` does NOT bump it: code that edits weights that way mid-training must delete `param._sd_shadow` or run with
-    SEGDISTILL_BF16_SHADOWS=0.)"""
-    if not (_SHADOWS and dt == torch.bfloat16 and isinstance(t, torch.nn.Parameter) and t.requires_grad and t.dtype == torch.float32 and t.is_cuda):
+    `param.data` -- or by a torch FUSED optimizer -- does NOT bump it: engine/optim.py's step post-hook rewrites the shadows then; other code
+    that edits weights that way mid-training must delete `param._sd_shadow`.)"""
+    if not (dt == torch.bfloat16 and isinstance(t, torch.nn.Parameter) and t.requires_grad and t.dtype == torch.float32 and t.is_cuda):
         return t.to(dt)
     sh = getattr(t, '_sd_shadow', None)
     if sh is not None and sh[0] == t._version and sh[1].dtype == dt:
@@ -288,7 +286,7 @@ class _LinearToPlanes(torch.autograd.Function):
         L = _lib.lib()
         y = torch.empty(B, N, P, dtype=x.dtype, device=x.device)
         b = None if bias is None else bias.detach().float().contiguous()
-        if (x.dtype == torch.float32 and _SPLIT_BF16 and _PRED_PLANES_A and N <= 160 and K % 32 == 0 and planes.supported(weight) and weight.is_contiguous()
+        if (x.dtype == torch.float32 and _SPLIT_BF16 and N <= 160 and K % 32 == 0 and planes.supported(weight) and weight.is_contiguous()
                 and L.sd_get_tunable(b'align_split_bf16') == 1):
             # the weight's row-major bf16 planes, split once per optimizer step (never, for the frozen teacher): every wave of the 160-row tile
             # needs all class rows, so splitting W in registers was 5/6 of the kernel's vector work (290 -> see profiles/r03_kernels.txt)

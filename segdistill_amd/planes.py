@@ -17,15 +17,12 @@ engine/optim.py::build_optimizer registers a step post-hook that does so for eve
 from __future__ import annotations
 
 import ctypes as C
-import os
 import weakref
 
 import torch
 
 from . import _lib
 from .ops import _stream_ptr
-
-ENABLED = os.environ.get('SEGDISTILL_PRESPLIT', '1') == '1'
 
 
 class _Job(C.Structure):
@@ -49,7 +46,7 @@ _GEN = 0           # bumped whenever the set of entries or of their buffers chan
 
 
 def supported(weight):
-    return (ENABLED and weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2 and weight.stride(1) == 1
+    return (weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2 and weight.stride(1) == 1
             and weight.stride(0) >= weight.shape[1])
 
 

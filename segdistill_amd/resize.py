@@ -16,13 +16,17 @@ ENABLED = os.environ.get('SEGDISTILL_HIP_RESIZE', '1') == '1'
 
 
 def supported(x, size, mode, align_corners):
-    return (ENABLED and mode == 'bilinear' and size is not None and x.is_cuda and x.dim() == 4 and x.dtype in _DT and x.is_contiguous()
-            and x.numel() > 0 and len(size) == 2)
+    # contiguous NCHW maps; a strided view that is NOT channels-last (a slice, an expand) is made contiguous first -- ATen would do the same
+    # copy and then run its 3 %-of-HBM NCHW kernel (profiles/r03_train_step_kernels_cfg4.txt: one such call, 2.47 ms); channels-last maps keep
+    # ATen's NHWC kernel
+    return (ENABLED and mode == 'bilinear' and size is not None and x.is_cuda and x.dim() == 4 and x.dtype in _DT and x.numel() > 0 and len(size) == 2
+            and (x.is_contiguous() or not x.is_contiguous(memory_format=torch.channels_last)))
 
 
 class _Bilinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, H, W, align):
+        x = x.contiguous()
         B, C, h, w = x.shape
         y = torch.empty(B, C, H, W, dtype=x.dtype, device=x.device)
         _lib.check(_lib.lib().sd_resize_bilinear_fwd(x.data_ptr(), y.data_ptr(), _DT[x.dtype], B * C, h, w, H, W, int(align), _stream_ptr()),

@@ -29,19 +29,13 @@ def main():
         b = torch.randn(a.classes, device=dev)
         with torch.no_grad():
             lib = timeit(lambda: torch.baddbmm(b.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), x.transpose(1, 2)))
-            _linear._PRED_PLANES_A = False
-            _lib.set_tunable('pred_tall_tile', 0)
-            hip128 = timeit(lambda: linear_to_planes(x, w, b))
-            _lib.set_tunable('pred_tall_tile', 1)
-            hip = timeit(lambda: linear_to_planes(x, w, b))
-            _linear._PRED_PLANES_A = True            # round 3: W as pre-split row planes (sd_linear_nchw_fwd_planes)
-            hip_pl = timeit(lambda: linear_to_planes(x, w, b))
+            hip_pl = timeit(lambda: linear_to_planes(x, w, b))     # 160-row tile on pre-split row planes (round-3 A/B arms: profiles/r03_pred_bench.txt)
             ref = torch.baddbmm(b.view(1, -1, 1).double(), w.double().unsqueeze(0).expand(B, -1, -1), x.double().transpose(1, 2))
             e_lib = (torch.baddbmm(b.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), x.transpose(1, 2)).double() - ref).abs().max().item()
             e_hip = (linear_to_planes(x, w, b).double() - ref).abs().max().item()
         gf = 2.0 * B * P * E * a.classes / 1e9
-        print(f'B={B} P={P} E={E} -> {a.classes}: library {lib:7.1f} us ({gf / lib * 1e3:5.1f} TF, max err {e_lib:.2e}) | class-plane kernel, 128-row tiles '
-              f'{hip128:7.1f} us | 160-row tile {hip:7.1f} us ({gf / hip * 1e3:5.1f} TF) | 160-row tile on pre-split W planes {hip_pl:7.1f} us ({gf / hip_pl * 1e3:5.1f} TF, max err {e_hip:.2e})')
+        print(f'B={B} P={P} E={E} -> {a.classes}: library {lib:7.1f} us ({gf / lib * 1e3:5.1f} TF, max err {e_lib:.2e}) | class-plane kernel, 160-row tile on '
+              f'pre-split W planes {hip_pl:7.1f} us ({gf / hip_pl * 1e3:5.1f} TF, max err {e_hip:.2e})')
 
 
 if __name__ == '__main__':

@@ -17,6 +17,7 @@ for c in $CFGS; do
   echo "[$tag] $(date +%T)" | tee -a $OUT/progress.txt
   ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_$tag -o step -- python3 $R/bench.py --config $R/configs/kd/$c.py --steps 12 --warmup 6 --no-cpu-baseline --no-roofline --no-exact-f32 > $OUT/bench_$tag.json 2> $OUT/bench_$tag.err )
   python tools/prof_summary.py /tmp/prof_$tag --marker adamw_multi --skip 7 --top 60 --out $OUT/train_step_kernels_$tag.txt > /dev/null 2>> $OUT/progress.txt
+  python tools/step_kernel_shapes.py /tmp/prof_$tag "" --marker=adamw_multi --steps=4 > $OUT/step_shapes_$tag.txt 2>> $OUT/progress.txt
   head -2 $OUT/train_step_kernels_$tag.txt | tee -a $OUT/progress.txt
   grep -c naive_conv $OUT/train_step_kernels_$tag.txt | sed "s/^/[$tag] naive_conv rows in the steady-state table: /" | tee -a $OUT/progress.txt
 done

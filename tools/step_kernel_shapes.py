@@ -9,7 +9,7 @@ import re
 import sys
 
 d, pats = sys.argv[1], [a for a in sys.argv[2:] if not a.startswith('--')]
-steps = 18
+steps = int(next((a.split('=', 1)[1] for a in sys.argv[2:] if a.startswith('--steps=')), 18))
 rows = []
 for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
     rows += list(csv.DictReader(open(f)))
@@ -27,9 +27,9 @@ for r in rows:
     n = r['Kernel_Name']
     if any(p in n for p in pats):
         m = re.search(r'(\w+)<([^>]*)>', n)
-        key = ((m.group(1) + '<' + m.group(2) + '>') if m else n[:60], r['Grid_Size_X'], r['Grid_Size_Y'], r['Workgroup_Size_X'])
+        key = ((m.group(1) + '<' + m.group(2) + '>') if m else n[:60], r['Grid_Size_X'], r['Grid_Size_Y'] + 'x' + r.get('Grid_Size_Z', '1'), r['Workgroup_Size_X'])
         g[key].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
 tot = sum(sum(v) for v in g.values())
 for k, v in sorted(g.items(), key=lambda kv: -sum(kv[1])):
     v.sort()
-    print(f'{k[0][:70]:70s} grid {k[1]:>8s}x{k[2]:<4s} wg {k[3]:>4s}  n/step {len(v) / steps:5.1f}  median {v[len(v) // 2] / 1e3:8.1f} us  ms/step {sum(v) / steps / 1e6:6.3f}  share {100 * sum(v) / tot:5.1f} %')
+    print(f'{k[0][:70]:70s} grid {k[1]:>8s}x{k[2]:<8s} wg {k[3]:>4s}  n/step {len(v) / steps:5.1f}  median {v[len(v) // 2] / 1e3:8.1f} us  ms/step {sum(v) / steps / 1e6:6.3f}  share {100 * sum(v) / tot:5.1f} %')
