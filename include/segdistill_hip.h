@@ -250,6 +250,18 @@ int sd_linear_wgrad(const void *dY, const void *X, float *dW, float *dbias /* [o
                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * The adaptive average pools of a Pyramid Pooling Module, every pool scale in ONE pass over the map (csrc/ppm_pool.hip).
+ * Replaces: nn.AdaptiveAvgPool2d(s) per scale in PPM.forward (reference mmseg/models/decode_heads/psp_head.py:10-58, used by PSPHead :61-101 and
+ * UPerHead, uper_head.py:76-126) and their autograd -- ATen's float-atomic `atomic_adaptive_average_gradinput` plus the adds of the branch gradients.
+ *   x [planes = B*C][h][w] contiguous; pooled[k] / d_pooled[k]: [planes][s_k][s_k]; bins as ATen's (start = floor(i h / s), end = ceil((i+1) h / s)).
+ *   forward reads x once; backward writes dx once as a gather (deterministic, no atomics).
+ * _supported(): at most 4 scales of at most 8 bins, one plane + its row sums within 48 KB of LDS (else SD_E_UNSUPPORTED: use the framework's op).
+ */
+int sd_ppm_pool_supported(int h, int w, const int *scales, int nscales);
+int sd_ppm_pool_fwd(const void *x, int dtype, long planes, int h, int w, const int *scales, int nscales, void *const *pooled, void *stream);
+int sd_ppm_pool_bwd(void *const *d_pooled, int dtype, long planes, int h, int w, const int *scales, int nscales, void *dx, void *stream);
+
+/* ---------------------------------------------------------------------------
  * CGD / CD criterion on TOKEN-MAJOR operands S, T [B][P][C] (C contiguous; P = h*w pixels): the decoder features of a SegFormer head
  * (decode_head.linear_c1..4 emit [B, h*w, E]; SURVEY a-16, reference opts.py:25-27 / the reshape helper commented out at
  * losses.py:300-318).  Same rows, closed form, row_lse2 / row_kl / loss outputs and `perm` semantics as sd_cgd_kl_fwd / _bwd

@@ -59,7 +59,12 @@ def test_layers_resize_routes_contiguous_cuda_maps_and_keeps_aten_elsewhere():
     assert type(y.grad_fn).__name__ == '_BilinearBackward'
     ref = F.interpolate(x, size=(64, 64), mode='bilinear', align_corners=False)
     assert float((y - ref).abs().max()) < 2e-6          # against ATen's own fp32 kernel: the same index arithmetic
-    assert layers.resize(x, size=torch.Size((16, 16)), mode='bilinear') is x                       # same size: no copy
+    same = layers.resize(x, size=torch.Size((16, 16)), mode='bilinear')                          # same size: a fresh tensor, as F.interpolate
+    assert same is not x and same.data_ptr() != x.data_ptr() and torch.equal(same, x)
+    assert layers.resize(x, size=(16, 16), mode='bilinear', alias_ok=True) is x                    # read-only callers (the criteria) may alias
+    view = torch.randn(2, 16, 16, 16, device=dev)[:, ::2]                                          # strided, not channels-last: copied, then the HIP kernel
+    yv = layers.resize(view, size=(48, 40), mode='bilinear', align_corners=False)
+    assert float((yv - F.interpolate(view, size=(48, 40), mode='bilinear', align_corners=False)).abs().max()) < 2e-6
     cl = x.detach().contiguous(memory_format=torch.channels_last)
     assert float((layers.resize(cl, size=(32, 32), mode='bilinear', align_corners=False) - F.interpolate(cl, size=(32, 32), mode='bilinear',
                                                                                                           align_corners=False)).abs().max()) == 0.0
