@@ -564,9 +564,10 @@ __global__ __launch_bounds__(256) void linear_wgrad_direct(const T *__restrict__
 // dW[M x N] = dY^T . X for token-major dY [T][M], X [T][N] (the weight gradient of nn.Linear):
 // both operands K-major, K = T split over workgroups, partial slabs combined deterministically.
 struct WgradPlan {
-    bool direct;
+    bool direct, tn;
     int nsplit, klen, regions_m, regions_n, regions_per_wg, nslabs;
 };
+
 WgradPlan linear_wgrad_plan(long T, int M, int N, bool bf16 = false) {
     WgradPlan p{};
     p.regions_m = (M + 63) / 64;
@@ -588,6 +589,14 @@ WgradPlan linear_wgrad_plan(long T, int M, int N, bool bf16 = false) {
         p.nslabs = p.nsplit * (4 / p.regions_per_wg);
         return p;
     }
+    if (bf16 && M % 8 == 0 && N % 8 == 0) {
+        // round 4: both operands are token-major (the reduction index is the slow one) -- csrc/wgrad_tn.hip copies the tiles as they are and
+        // transposes in the LDS read (ds_read_b64_tr_b16); its own split plan (fewer, longer splits: fewer slabs to combine)
+        p.tn = true;
+        wgrad_tn_plan(T, M, N, &p.nsplit, &p.klen);
+        p.nslabs = p.nsplit;
+        return p;
+    }
     const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     long nsplit = 1024 / tiles;
     if (nsplit > T / 256) nsplit = T / 256;
@@ -604,7 +613,9 @@ int linear_wgrad(const void *dY, const void *X, float *dW, float *dbias, void *w
     const WgradPlan p = linear_wgrad_plan(Tn, M, N, sizeof(T) == 2);
     if (dbias && !p.direct) return SD_E_UNSUPPORTED;   // ask sd_linear_wgrad_fuses_bias_dtype() first
     const long slab = (long)M * N + (dbias ? M : 0);
+    const bool tn = p.tn && wgrad_tn_supported(Tn, M, N, dY, X);
     if (!p.direct && p.nsplit == 1) {
+        if (tn) return wgrad_tn_launch(dY, X, dW, Tn, M, N, 1, p.klen, st);
         dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, 1);
         launch_gemm<T, T, float, true, true>(grid, st, (const T *)dY, (const T *)X, dW, nullptr, M, N,
                            (int)Tn, (long)M, (long)N, (long)N, 0L, 0L, 0L, 1, (int)Tn);
@@ -617,6 +628,9 @@ int linear_wgrad(const void *dY, const void *X, float *dW, float *dbias, void *w
         dim3 grid(p.nsplit, (regions + p.regions_per_wg - 1) / p.regions_per_wg);
         hipLaunchKernelGGL((linear_wgrad_direct<T>), grid, dim3(256), 0, st, (const T *)dY, (const T *)X, slabs, M, N, Tn, p.klen, p.regions_m,
                            p.regions_n, p.regions_per_wg, dbias ? 1 : 0);
+    } else if (tn) {
+        int rc = wgrad_tn_launch(dY, X, slabs, Tn, M, N, p.nsplit, p.klen, st);
+        if (rc) return rc;
     } else {
         dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, p.nsplit);
         launch_gemm<T, T, float, true, true>(grid, st, (const T *)dY, (const T *)X, slabs, nullptr, M, N,
@@ -834,6 +848,8 @@ int sd_linear_wgrad_generic_partials(const void *dY, const void *X, int dtype, l
     if (dtype == SD_F32)
         sd::launch_gemm<float, float, float, true, true>(grid, st, (const float *)dY, (const float *)X, slabs, nullptr, M, N, (int)tokens, (long)M, (long)N,
                                                          (long)N, 0L, 0L, slab, p.nsplit, p.klen);
+    else if (p.tn && sd::wgrad_tn_supported(tokens, M, N, dY, X))
+        return sd::wgrad_tn_launch(dY, X, slabs, tokens, M, N, p.nsplit, p.klen, st);
     else
         sd::launch_gemm<sd::bf16_t, sd::bf16_t, float, true, true>(grid, st, (const sd::bf16_t *)dY, (const sd::bf16_t *)X, slabs, nullptr, M, N,
                                                                    (int)tokens, (long)M, (long)N, (long)N, 0L, 0L, slab, p.nsplit, p.klen);

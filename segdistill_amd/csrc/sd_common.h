@@ -25,6 +25,7 @@ int sra_tunable(const char *key, int set, int v);
 int token_gemm_tunable(const char *key, int set, int v);
 int ce_tunable(const char *key, int set, int v);
 int headfuse_tunable(const char *key, int set, int v);
+int wgrad_tn_tunable(const char *key, int set, int v);
 // token-major -> class-planes Linear, fp32 (token_gemm.hip); the dtype-dispatching C entry points live in align1x1.hip
 size_t linear_nchw_workspace_bytes(int B, long P, int in_features, int out_features);
 int pred_splits(int B, long P);
@@ -32,5 +33,10 @@ int linear_nchw_f32_fwd(const float *X, const float *W, const float *bias, float
 int linear_nchw_f32_bwd_data(const float *dY, const float *W, float *dX, int B, long P, int in_features, int out_features, void *stream);
 int linear_nchw_f32_bwd_weight(const float *dY, const float *X, float *dW, float *dbias, int B, long P, int in_features, int out_features, void *workspace,
                                size_t workspace_bytes, void *stream);
+
+// bf16 token-major weight gradient on transposed LDS reads (wgrad_tn.hip); used by the generic weight-gradient entry points of align1x1.hip
+bool wgrad_tn_supported(long T, int M, int N, const void *dY, const void *X);
+void wgrad_tn_plan(long T, int M, int N, int *nsplit, int *klen);
+int wgrad_tn_launch(const void *dY, const void *X, float *slabs, long T, int M, int N, int nsplit, int klen, hipStream_t st);
 
 }  // namespace sd

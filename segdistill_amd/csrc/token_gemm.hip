@@ -304,6 +304,17 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
         // ~13 cycles above the two scalar ones it replaces, MI355X_MICROARCH.md -- 106.8 vs 105.1 / 107.1 us at 256 -> 256 over 131072
         // tokens, no shape moved by more than the run-to-run noise: the asm operands cost s_nop pads and scheduling freedom.)
         auto split8 = [&](const float (&x)[8], bf16x8 &h, bf16x8 &m, bf16x8 &l) {
+#ifdef SD_DIAG_NOSPLIT
+            // diagnostic A/B build only (tools/gemm_nosplit_probe.py; WRONG numerics): one conversion per pair and NO residual arithmetic -- the time
+            // this build saves is an upper bound on what moving the split of the activation operand out of the k-loop (into its producer) can buy
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 v = {x[e], x[e + 1]};
+                const bf16x2 hh = __builtin_convertvector(v, bf16x2);
+                h[e] = hh[0], h[e + 1] = hh[1], m[e] = hh[0], m[e + 1] = hh[1], l[e] = hh[0], l[e + 1] = hh[1];
+            }
+            return;
+#endif
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
                 const f32x2 v = {x[e], x[e + 1]};

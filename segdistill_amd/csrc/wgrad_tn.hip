@@ -1,0 +1,286 @@
+// wgrad_tn.hip -- the weight gradient of a token-major Linear under bf16 storage, dW [M x N] = dY [T x M]^T . X [T x N], as split-K fp32 slabs
+// on the bf16 matrix pipe with HARDWARE-TRANSPOSED operand reads, gfx950.
+//
+// reference: autograd's `grad_output.t().mm(input)` of every nn.Linear of the MiT encoders / SegFormer heads (mix_transformer.py:24-27,48-55,
+// 75-84,107-133; segformer_head.py:22-33) and of the token-major feature-align projection of BASELINE config 5 (opts.py:25-27).
+// Both operands are stored token-major, i.e. the REDUCTION index (the token) is the slow one: an MFMA fragment wants 8 consecutive k of one
+// row m / column n, which in memory are 8 elements M (N) apart.  Round 1's gemm_mfma_bf16<.., K-major, K-major> transposed them with 2-byte
+// LDS stores and ran config 5's align gradient (768 x 256 over 131072 tokens) in 239 us against 42 us of HBM time (profiles of round 4:
+// gpurun_out/configs/step_shapes_cfg5.txt) -- the top row of that step's GEMM time.  Here:
+//   * tiles [32 tokens][128 m] and [32 tokens][128 n] are copied into LDS as they are (16-byte global loads, 16-byte LDS stores, 256-byte rows
+//     with the XOR swizzle of cdna_hip_programming.md T10 (b)), double-buffered, the next tile's loads in flight during the current MFMAs;
+//   * every operand fragment is two `ds_read_b64_tr_b16` (a 4-row x 16-column block delivered column-major: the transpose is free);
+//   * 128 x 128 output tile, four waves 2 x 2, `v_mfma_f32_32x32x16_bf16`, fp32 accumulation, one fp32 slab per k-split (deterministic
+//     combine by sd_multi_slab_reduce); workgroups of one k-split are placed on ONE XCD (consecutive logical ids share an XCD), so the tiles
+//     that share a token range share its rows through that XCD's L2 instead of re-reading them from HBM.
+// HBM-bound: dY and X once (2 T (M + N) bytes) + nsplit slabs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "sd_common.h"
+
+namespace sd {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TBM = 128, TBN = 128, TBK = 32;
+constexpr int kStageBytes = TBK * 256;                 // one operand tile: 32 rows of 128 bf16
+
+// byte offset of 16-byte chunk `ch` (0..15) of row `row` in a tile of 256-byte rows (T10 image (b): conflict-free row stores AND transposed reads)
+__device__ __forceinline__ int swz(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+// the 8 k-values (rows r0 .. r0+7) of column block c0 (16 columns = chunks c0, c0 + 1) as one MFMA fragment: two transposed reads
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char *tile, int r0, int c0, int li) {
+    const int q = li >> 2, p = li & 3;
+    typedef s16x4 __attribute__((address_space(3))) * lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tile + swz(r0 + q, c0 + (p >> 1)) + 8 * (p & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(tile + swz(r0 + 4 + q, c0 + (p >> 1)) + 8 * (p & 1)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// C_z[M x N] = sum over tokens k of split z of A[k][m] B[k][n].  grid.x = tiles_m * tiles_n * nsplit (XCD-remapped); klen % TBK == 0;
+// M % 8 == 0 and N % 8 == 0 (rows are whole 16-byte chunks), A and B 16-byte aligned.
+__global__ __launch_bounds__(256) void wgrad_tn_bf16(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, float *__restrict__ C, int M, int N,
+                                                      long T, int klen, int tiles_m, int tiles_n, int nsplit) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * kStageBytes];     // [stage][A | B]
+    // consecutive LOGICAL ids on one XCD (bijective remap, cdna_hip_programming.md section 5): the tiles of a k-split then share an L2
+    const long nblk = gridDim.x, id = blockIdx.x;
+    const long qd = nblk / 8, rem = nblk % 8, xcd = id % 8;
+    const long L = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + id / 8;
+    const int tiles = tiles_m * tiles_n;
+    const int split = (int)(L / tiles), tile = (int)(L - (long)split * tiles);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * TBM, n0 = tn * TBN;
+    const long k_begin = (long)split * klen, k_end = min(T, k_begin + klen);
+    const int nk = (int)((k_end - k_begin + TBK - 1) / TBK);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int h = lane >> 5, g = (lane >> 4) & 1, li = lane & 15;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // staging: thread -> (row = t / 16 (+16), chunk = t % 16) of each operand tile
+    const int srow = t >> 4, sch = t & 15;
+    const bool a_in = m0 + 8 * sch < M, b_in = n0 + 8 * sch < N;          // whole chunks: M, N % 8 == 0
+    const bf16_t *pa = A + (size_t)(m0 + (a_in ? 8 * sch : 0));
+    const bf16_t *pb = B + (size_t)(n0 + (b_in ? 8 * sch : 0));
+    u32x4 ra[2], rb[2];
+    auto load_regs = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long k = k_begin + (long)kt * TBK + srow + 16 * u;
+            const bool kin = k < k_end;
+            const long kc = kin ? k : k_end - 1;                             // clamped address, zeroed value
+            const u32x4 va = *reinterpret_cast<const u32x4 *>(pa + (size_t)kc * M);
+            const u32x4 vb = *reinterpret_cast<const u32x4 *>(pb + (size_t)kc * N);
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            ra[u] = (kin && a_in) ? va : z;
+            rb[u] = (kin && b_in) ? vb : z;
+        }
+    };
+    auto store_regs = [&](int stage) {
+        unsigned char *sa = lds + (size_t)stage * 2 * kStageBytes, *sb = sa + kStageBytes;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            *reinterpret_cast<u32x4 *>(sa + swz(srow + 16 * u, sch)) = ra[u];
+            *reinterpret_cast<u32x4 *>(sb + swz(srow + 16 * u, sch)) = rb[u];
+        }
+    };
+    if (nk > 0) {
+        load_regs(0);
+        store_regs(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_regs(kt + 1);                                  // in flight during the MFMAs below
+        const unsigned char *sa = lds + (size_t)(kt & 1) * 2 * kStageBytes, *sb = sa + kStageBytes;
+#pragma unroll
+        for (int s = 0; s < TBK / 16; ++s) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = tr_frag(sa, 16 * s + 8 * h, (wm + 32 * i) / 8 + 2 * g, li);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = tr_frag(sb, 16 * s + 8 * h, (wn + 32 * j) / 8 + 2 * g, li);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_regs((kt + 1) & 1);                           // the other stage: last read before the previous barrier
+        __syncthreads();
+    }
+    // slab z = split: C layout of the 32x32 MFMA -- col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float *Cz = C + (size_t)split * M * N;
+    const int col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 32 * j + col;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < M && n < N) Cz[(size_t)m * N + n] = acc[i][j][e];
+            }
+        }
+}
+
+// ---- the same product with the tiles brought in by LDS-DMA into a ring of four stages ----------------------------------------------------
+// The register-staged kernel above keeps ONE tile (16 KB) in flight per workgroup and runs every k-step at the memory latency: PMC says its
+// HBM traffic is ideal (FETCH_SIZE x 2 = dY + X once: the tiles of a k-split do share their rows through the XCD's L2), yet 768 x 256 over
+// 131072 tokens took 132 us = 24 GB/s per CU.  Here `global_load_lds_dwordx4` copies global -> LDS without staging registers (the XOR swizzle
+// is applied to the per-lane SOURCE address: the LDS image of one wave-instruction is lane-linear), THREE tiles are in flight behind the one
+// being multiplied, one raw barrier per k-step.  The DMA is issued from inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS
+// read that follows a `__builtin_amdgcn_global_load_lds` it can see, which would drain the ring; the counts are kept by hand -- every
+// iteration issues exactly kDmaPerTile instructions per wave (past the last tile: a harmless re-load of it into a free stage), so the wait
+// that retires tile kt is always vmcnt(2 * kDmaPerTile).  Whole tiles only: T % 32 == 0 (the launcher checks).
+constexpr int kRing = 4, kDmaPerTile = 4;              // per wave and tile: rows 8w .. 8w+7 of A and of B, 4 rows (1 KB) per instruction
+
+__device__ __forceinline__ void dma16(const void *gptr, unsigned lds_byte) {
+    // M0 = wave-uniform LDS byte address of lane 0's 16 bytes; lane l lands at M0 + 16 l
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte) : "memory");   // M0 is reserved in LLVM (a clobber entry is rejected with a warning); nothing else in this kernel uses it (checked in the ISA)
+}
+
+__global__ __launch_bounds__(256) void wgrad_tn_bf16_ring(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, float *__restrict__ C, int M,
+                                                           int N, long T, int klen, int tiles_m, int tiles_n, int nsplit) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[kRing * 2 * kStageBytes];      // [stage][A | B]: 64 KB
+    const long nblk = gridDim.x, id = blockIdx.x;
+    const long qd = nblk / 8, rem = nblk % 8, xcd = id % 8;
+    const long L = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + id / 8;
+    const int tiles = tiles_m * tiles_n;
+    const int split = (int)(L / tiles), tile = (int)(L - (long)split * tiles);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * TBM, n0 = tn * TBN;
+    const long k_begin = (long)split * klen, k_end = min(T, k_begin + klen);
+    const int nk = (int)((k_end - k_begin) / TBK);
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int h = lane >> 5, g = (lane >> 4) & 1, li = lane & 15;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // DMA geometry: instruction u (0, 1) of wave w moves tile rows 8w + 4u .. + 3; lane -> (row r = 8w + 4u + lane / 16, LDS chunk c' = lane % 16)
+    // which must hold source chunk c' ^ f(r) (swz is an involution in the chunk index).  Chunks beyond M / N: clamped to a valid chunk -- they
+    // only feed output columns that are never stored.
+    const unsigned lds0 = (unsigned)(uintptr_t)lds;
+    const bf16_t *ga[2], *gb[2];
+    unsigned la[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = 8 * wave + 4 * u + (lane >> 4);
+        const int ch = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
+        const int ca = m0 + 8 * ch < M ? m0 + 8 * ch : 0, cb = n0 + 8 * ch < N ? n0 + 8 * ch : 0;
+        ga[u] = A + (size_t)(k_begin + r) * M + ca;
+        gb[u] = B + (size_t)(k_begin + r) * N + cb;
+        la[u] = 256u * (unsigned)(8 * wave + 4 * u);
+    }
+    auto issue = [&](int kt) {                          // tile kt (clamped) -> stage kt % kRing; kDmaPerTile instructions
+        const int kc = kt < nk ? kt : nk - 1;
+        const unsigned st = lds0 + (unsigned)(kt % kRing) * 2u * kStageBytes;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            dma16(ga[u] + (size_t)kc * TBK * M, __builtin_amdgcn_readfirstlane(st + la[u]));
+            dma16(gb[u] + (size_t)kc * TBK * N, __builtin_amdgcn_readfirstlane(st + kStageBytes + la[u]));
+        }
+    };
+    if (nk > 0) {
+        issue(0);
+        issue(1);
+        issue(2);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kDmaPerTile) : "memory");     // all but the two youngest tiles: tile kt has landed (this wave's part)
+        __builtin_amdgcn_s_barrier();                                                // ... everyone's part; and stage (kt + 3) % 4 is no longer read
+        __builtin_amdgcn_sched_barrier(0);
+        issue(kt + 3);
+        const unsigned char *sa = lds + (size_t)(kt % kRing) * 2 * kStageBytes, *sb = sa + kStageBytes;
+#pragma unroll
+        for (int s = 0; s < TBK / 16; ++s) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = tr_frag(sa, 16 * s + 8 * h, (wm + 32 * i) / 8 + 2 * g, li);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = tr_frag(sb, 16 * s + 8 * h, (wn + 32 * j) / 8 + 2 * g, li);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tail's placeholder DMAs must not land after the workgroup's LDS is gone
+    float *Cz = C + (size_t)split * M * N;
+    const int col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn + 32 * j + col;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < M && n < N) Cz[(size_t)m * N + n] = acc[i][j][e];
+            }
+        }
+}
+
+}  // namespace
+
+// ---- plan + launcher shared with align1x1.hip (the generic weight-gradient entry points) -------------------------------------------------
+int g_wgrad_ring = 1;      // tunable "wgrad_tn_ring": 0 = the register-staged kernel everywhere (A/B, tests)
+bool wgrad_tn_supported(long T, int M, int N, const void *dY, const void *X) {
+    return T > 0 && M > 0 && N > 0 && M % 8 == 0 && N % 8 == 0 && ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) == 0;
+}
+
+// number of k-splits (= slabs): ~3 workgroups per CU, every split at least two k-steps, at most 256 slabs
+void wgrad_tn_plan(long T, int M, int N, int *nsplit, int *klen) {
+    const long tiles = (long)((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN);
+    long ns = 768 / tiles;
+    if (ns > T / (2 * TBK)) ns = T / (2 * TBK);
+    if (ns > 256) ns = 256;
+    if (ns < 1) ns = 1;
+    const long kl = ((T + ns - 1) / ns + TBK - 1) / TBK * TBK;
+    *klen = (int)kl;
+    *nsplit = (int)((T + kl - 1) / kl);
+}
+
+int wgrad_tn_tunable(const char *key, int set, int v) {
+    if (strcmp(key, "wgrad_tn_ring")) return SD_E_UNSUPPORTED;
+    if (!set) return g_wgrad_ring;
+    if (v != 0 && v != 1) return SD_E_SHAPE;
+    g_wgrad_ring = v;
+    return SD_OK;
+}
+
+int wgrad_tn_launch(const void *dY, const void *X, float *slabs, long T, int M, int N, int nsplit, int klen, hipStream_t st) {
+    const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (N + TBN - 1) / TBN;
+    const long nblk = (long)tiles_m * tiles_n * nsplit;
+    if (nblk > 0x7fffffffL) return SD_E_SHAPE;
+    if (T % TBK == 0 && klen >= 3 * TBK && g_wgrad_ring)
+        hipLaunchKernelGGL(wgrad_tn_bf16_ring, dim3((unsigned)nblk), dim3(256), 0, st, (const bf16_t *)dY, (const bf16_t *)X, slabs, M, N, T, klen,
+                           tiles_m, tiles_n, nsplit);
+    else
+        hipLaunchKernelGGL(wgrad_tn_bf16, dim3((unsigned)nblk), dim3(256), 0, st, (const bf16_t *)dY, (const bf16_t *)X, slabs, M, N, T, klen, tiles_m,
+                           tiles_n, nsplit);
+    return (int)hipGetLastError();
+}
+
+}  // namespace sd

@@ -96,7 +96,9 @@ def test_feature_align_module_in_distillation_loss():
 
 
 @pytest.mark.parametrize('shape', [(131072, 32, 32), (32768, 128, 32), (5000, 37, 21), (8192, 256, 64), (4096, 512, 2048), (300, 16, 8),
-                                   (20001, 100, 70), (16384, 256, 256), (9000, 33, 129), (8193, 64, 64)])
+                                   (20001, 100, 70), (16384, 256, 256), (9000, 33, 129), (8193, 64, 64),
+                                   # bf16: csrc/wgrad_tn.hip (transposed LDS reads) -- ragged tiles, ragged k-splits, the config-5 align shape
+                                   (5000, 40, 24), (777, 136, 72), (2048, 1024, 256), (65536, 768, 256), (8192, 1280, 320), (33, 8, 8)])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_linear_wgrad_kernel(shape, dtype):
     """dW = dY^T . X (split-K MFMA) vs fp64 matmul of the same (rounded) operands."""

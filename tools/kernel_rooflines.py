@@ -535,7 +535,31 @@ def bench_pred(dev, reps):
     return out
 
 
+def bench_wgrad_bf16(dev, reps):
+    """dW = dY^T . X of token-major Linears under bf16 storage (config 5: the 256 -> 768 align projections of the four decoder stages and the
+    B1 student's Mix-FFN weights): sd_linear_wgrad_generic_partials = csrc/wgrad_tn.hip since round 4 (slabs only; the combine is deferred)."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    out = []
+    for tag, T, M, N in (('align s1 768x256 over 131072', 131072, 768, 256), ('align s2 768x256 over 32768', 32768, 768, 256),
+                         ('align s3 768x256 over 8192', 8192, 768, 256), ('B1 s3 fc1 1280x320 over 8192', 8192, 1280, 320),
+                         ('B1 s4 fc1 2048x512 over 2048', 2048, 2048, 512), ('B1 s2 fc2 128x512 over 32768', 32768, 128, 512)):
+        gen = torch.Generator(device=dev).manual_seed(3)
+        dy = torch.randn(T, M, device=dev, generator=gen).to(torch.bfloat16)
+        x = torch.randn(T, N, device=dev, generator=gen).to(torch.bfloat16)
+        ns = L.sd_linear_wgrad_generic_slabs(1, T, M, N)
+        if ns == 0:
+            continue
+        ws = torch.empty(ns * M * N, dtype=torch.float32, device=dev)
+        t = _time(lambda st: _ok(L.sd_linear_wgrad_generic_partials(dy.data_ptr(), x.data_ptr(), 1, T, M, N, ws.data_ptr(), ws.numel() * 4, st), 'wgrad'), reps)
+        nbytes = 2.0 * T * (M + N) + 4.0 * ns * M * N
+        out.append(_entry(f'bf16 Linear weight gradient, {tag} ({ns} slabs)', 'wgrad_tn_bf16', [T, M, N], 'bf16', t, 'hbm', nbytes, HBM,
+                          'bytes = dY + X once + the fp32 slabs written'))
+    return out
+
+
 GROUPS = {
+    'wgrad_bf16': lambda dev, reps: bench_wgrad_bf16(dev, reps),
     'r1': lambda dev, reps: bench_r1(dev, reps),
     'r1_bf16': lambda dev, reps: bench_r1(dev, reps, C=768, HW=128, dtype=torch.bfloat16),      # config 5 stage 1
     'r2': lambda dev, reps: bench_r2(dev, reps),
