@@ -242,6 +242,160 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_ring(const bf16_t *__restri
         }
 }
 
+// ---- fp32 storage: the same product in split-bf16 arithmetic ("bf16x3", fp32-grade: token_gemm.hip section 3.9 of DESIGN.md) ---------------
+// dY and X arrive as fp32.  A staging thread owns 8 consecutive floats of a tile row (two 16-byte loads), splits them EXACTLY into three bf16
+// planes (hi = rn(x), mid = rn(x - hi), lo = rn(x - hi - mid): the bits token_gemm.hip derives) and stores one 16-byte chunk per plane into
+// three LDS images of the bf16 layout above; fragments are transposed reads of those planes and every (i, j, k16) keeps the six products of
+// weight >= 2^-16, small terms first, fp32 accumulation.  Round 3's tall-skinny kernel (linear_wgrad_direct, exact f32 MFMA: 64 matrix-pipe
+// cycles per k where this needs 12 per plane pair x 6 = 24) ran the SegFormer head's 256 x 256 / 160 / 64 / 32 weight gradients over 131072
+// tokens at 225 / ~150 / ~60 / 42 us -- 0.48 of its 0.675 ms per config-2 step.  One LDS stage (48 KB: three workgroups per CU), the next tile's
+// loads in flight in registers during the MFMAs.  BN_ = 128 / 64 / 32 columns of X per tile (the head's in_features are 256, 160, 64, 32).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split8_planes(const f32x4 &v0, const f32x4 &v1, u32x4 &h, u32x4 &m, u32x4 &l) {
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const f32x2 v = {x[e], x[e + 1]};
+        const bf16x2 hh = __builtin_convertvector(v, bf16x2);
+        const f32x2 r1 = v - __builtin_convertvector(hh, f32x2);
+        const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
+        const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
+        const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
+        h[e >> 1] = __builtin_bit_cast(unsigned, hh);
+        m[e >> 1] = __builtin_bit_cast(unsigned, mm);
+        l[e >> 1] = __builtin_bit_cast(unsigned, ll);
+    }
+}
+
+template <int BN_, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_tn_x3(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, long T,
+                                                    int klen, int tiles_m, int tiles_n, int nsplit) {
+    constexpr int TM = TBM / (32 * WM), TN = BN_ / (32 * WN);
+    constexpr int BCH = BN_ / 8;                                     // 8-float chunks per B row
+    constexpr int NB = (32 * BCH + 255) / 256;                       // B chunks per thread (1 for BN_ <= 64, 2 for 128)
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "four waves");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[6 * kStageBytes];        // A planes h, m, l | B planes h, m, l
+    const long nblk = gridDim.x, id = blockIdx.x;
+    const long qd = nblk / 8, rem = nblk % 8, xcd = id % 8;
+    const long L = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + id / 8;
+    const int tiles = tiles_m * tiles_n;
+    const int split = (int)(L / tiles), tile = (int)(L - (long)split * tiles);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * TBM, n0 = tn * BN_;
+    const long k_begin = (long)split * klen, k_end = min(T, k_begin + klen);
+    const int nk = (int)((k_end - k_begin + TBK - 1) / TBK);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = (wave / WN) * (32 * TM), wn = (wave % WN) * (32 * TN);
+    const int h = lane >> 5, g = (lane >> 4) & 1, li = lane & 15;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // staging: A chunk e = t + 256 u (u = 0, 1) -> (row = e / 16, ch = e % 16); B chunk e = t + 256 u (u < NB) -> (row = e / BCH, ch = e % BCH)
+    f32x4 ra[2][2], rb[NB][2];
+    auto load_regs = [&](int kt) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = t + 256 * u, row = e >> 4, ch = e & 15;
+            const long k = k_begin + (long)kt * TBK + row;
+            const bool in = k < k_end && m0 + 8 * ch < M;
+            const float *p = A + (size_t)(in ? k : k_begin) * M + (in ? m0 + 8 * ch : 0);
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(p), v1 = *reinterpret_cast<const f32x4 *>(p + 4);
+            ra[u][0] = in ? v0 : z;
+            ra[u][1] = in ? v1 : z;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int e = t + 256 * u, row = e / BCH, ch = e % BCH;
+            const long k = k_begin + (long)kt * TBK + row;
+            const bool in = row < TBK && k < k_end && n0 + 8 * ch < N;
+            const float *p = B + (size_t)(in ? k : k_begin) * N + (in ? n0 + 8 * ch : 0);
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(p), v1 = *reinterpret_cast<const f32x4 *>(p + 4);
+            rb[u][0] = in ? v0 : z;
+            rb[u][1] = in ? v1 : z;
+        }
+    };
+    auto store_regs = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = t + 256 * u, row = e >> 4, ch = e & 15;
+            u32x4 ph, pm, pl;
+            split8_planes(ra[u][0], ra[u][1], ph, pm, pl);
+            unsigned char *d = lds + swz(row, ch);
+            *reinterpret_cast<u32x4 *>(d) = ph;
+            *reinterpret_cast<u32x4 *>(d + kStageBytes) = pm;
+            *reinterpret_cast<u32x4 *>(d + 2 * kStageBytes) = pl;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int e = t + 256 * u, row = e / BCH, ch = e % BCH;
+            if (row < TBK) {
+                u32x4 ph, pm, pl;
+                split8_planes(rb[u][0], rb[u][1], ph, pm, pl);
+                unsigned char *d = lds + 3 * kStageBytes + swz(row, ch);
+                *reinterpret_cast<u32x4 *>(d) = ph;
+                *reinterpret_cast<u32x4 *>(d + kStageBytes) = pm;
+                *reinterpret_cast<u32x4 *>(d + 2 * kStageBytes) = pl;
+            }
+        }
+    };
+    if (nk > 0) load_regs(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        store_regs();                                                        // tile kt: split + 16-byte LDS stores
+        __syncthreads();
+        if (kt + 1 < nk) load_regs(kt + 1);                                  // in flight during the MFMAs below
+        const unsigned char *sa = lds, *sb = lds + 3 * kStageBytes;
+#pragma unroll
+        for (int s = 0; s < TBK / 16; ++s) {
+            bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) fa[i][pl] = tr_frag(sa + pl * kStageBytes, 16 * s + 8 * h, (wm + 32 * i) / 8 + 2 * g, li);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) fb[j][pl] = tr_frag(sb + pl * kStageBytes, 16 * s + 8 * h, (wn + 32 * j) / 8 + 2 * g, li);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);      // small terms first (token_gemm.hip's order)
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+        __syncthreads();                                                     // every wave is done reading before the next tile is stored
+    }
+    float *Cz = C + (size_t)split * M * N;
+    const int col = lane & 31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn + 32 * j + col;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m < M && n < N) Cz[(size_t)m * N + n] = acc[i][j][e];
+            }
+        }
+}
+
 }  // namespace
 
 // ---- plan + launcher shared with align1x1.hip (the generic weight-gradient entry points) -------------------------------------------------
@@ -283,4 +437,49 @@ int wgrad_tn_launch(const void *dY, const void *X, float *slabs, long T, int M, 
     return (int)hipGetLastError();
 }
 
+// fp32 storage: which products take wgrad_tn_x3, and with how many k-splits (0: not this kernel's)
+int wgrad_tn_x3_plan(long T, int M, int N, int *klen, int *bn) {
+    if (T < 8192 || T > 0x7fffffffL || M < 128 || N < 32 || M % 8 || N % 8) return 0;          // tall-skinny, at least one full tile row of dY
+    const int BNt = N > 64 ? 128 : (N > 32 ? 64 : 32);
+    const long tiles = (long)((M + TBM - 1) / TBM) * ((N + BNt - 1) / BNt);
+    if (tiles > 32) return 0;                                                                    // large weights: the split-K plan of token_gemm.hip
+    long ns = 768 / tiles;
+    if (ns > T / (4 * TBK)) ns = T / (4 * TBK);
+    if (ns > 256) ns = 256;
+    if (ns < 1) ns = 1;
+    const long kl = ((T + ns - 1) / ns + TBK - 1) / TBK * TBK;
+    *klen = (int)kl;
+    *bn = BNt;
+    return (int)((T + kl - 1) / kl);
+}
+
 }  // namespace sd
+
+extern "C" {
+
+/* fp32 token-major Linear weight gradient dW = dY^T . X as split-K slabs in split-bf16 arithmetic on transposed LDS reads (see above): number of
+ * [out x in] fp32 slabs sd_linear_wgrad_tn writes for this shape, 0 when the shape is not this kernel's (few tokens, out_features < 128,
+ * features not multiples of 8, more than 32 tiles).  The caller combines the slabs (sd_multi_slab_reduce) and forms the bias gradient separately. */
+int sd_linear_wgrad_tn_slabs(long tokens, int out_features, int in_features) {
+    int klen, bn;
+    return sd::wgrad_tn_x3_plan(tokens, out_features, in_features, &klen, &bn);
+}
+
+int sd_linear_wgrad_tn(const float *dY, const float *X, float *slabs, size_t slabs_bytes, long tokens, int out_features, int in_features, void *stream) {
+    if (!dY || !X || !slabs) return SD_E_NULL;
+    int klen = 0, bn = 0;
+    const int M = out_features, N = in_features;
+    const int nsplit = sd::wgrad_tn_x3_plan(tokens, M, N, &klen, &bn);
+    if (!nsplit) return SD_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) return SD_E_ALIGN;
+    if (slabs_bytes < (size_t)nsplit * M * N * sizeof(float)) return SD_E_WORKSPACE;
+    const int tiles_m = (M + sd::TBM - 1) / sd::TBM, tiles_n = (N + bn - 1) / bn;
+    const dim3 grid((unsigned)((long)tiles_m * tiles_n * nsplit));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bn == 128) hipLaunchKernelGGL((sd::wgrad_tn_x3<128, 2, 2>), grid, dim3(256), 0, st, dY, X, slabs, M, N, tokens, klen, tiles_m, tiles_n, nsplit);
+    else if (bn == 64) hipLaunchKernelGGL((sd::wgrad_tn_x3<64, 2, 2>), grid, dim3(256), 0, st, dY, X, slabs, M, N, tokens, klen, tiles_m, tiles_n, nsplit);
+    else hipLaunchKernelGGL((sd::wgrad_tn_x3<32, 4, 1>), grid, dim3(256), 0, st, dY, X, slabs, M, N, tokens, klen, tiles_m, tiles_n, nsplit);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

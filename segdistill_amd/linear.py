@@ -86,6 +86,7 @@ def _bwd_data(dy2, weight):
 
 
 _BF16_WGRAD_LIB = os.environ.get('SEGDISTILL_BF16_WGRAD_LIB', '0') == '1'
+_TN_WGRAD = os.environ.get('SEGDISTILL_TN_WGRAD', '1') == '1'              # A/B: 0 = round 3's tall-skinny exact-f32 kernel for the head's weight gradients
 _SPLITK_WGRAD = os.environ.get('SEGDISTILL_SPLITK_WGRAD', '1') == '1'      # A/B: 0 = the library's dY^T @ X for the non-tall-skinny weight gradients
 
 
@@ -149,6 +150,22 @@ class _TokenLinear(torch.autograd.Function):
             dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
             T, M, N = x2.shape[0], weight.shape[0], weight.shape[1]
             L = _lib.lib()
+            ns_tn = 0
+            if (_TN_WGRAD and _SPLIT_BF16 and x.dtype == torch.float32 and ctx.w_dtype == torch.float32 and dyc.data_ptr() % 16 == 0
+                    and x2.data_ptr() % 16 == 0):
+                ns_tn = L.sd_linear_wgrad_tn_slabs(T, M, N)
+            if ns_tn:
+                # round 4: the tall-skinny products with out_features >= 128 (the SegFormer head over 131072 tokens) on transposed LDS reads in
+                # split-bf16 arithmetic (csrc/wgrad_tn.hip) instead of the exact-f32 tall-skinny kernel; slabs combined by the deferred pass
+                ws = torch.empty(ns_tn, M * N, dtype=torch.float32, device=x.device)
+                _lib.check(L.sd_linear_wgrad_tn(dyc.data_ptr(), x2.data_ptr(), ws.data_ptr(), ws.numel() * 4, T, M, N, _stream_ptr()), 'sd_linear_wgrad_tn')
+                buf = torch.empty(M * N, dtype=torch.float32, device=x.device)
+                if ctx.defer_ok and deferred.enabled():
+                    deferred.add(ws, buf, M * N, ns_tn)
+                else:
+                    deferred.reduce_now(ws, buf, M * N, ns_tn)
+                db = deferred.column_sum(dyc, ctx.defer_bias_ok) if want_db else None
+                return dx, buf.view(M, N), db, None, None
             direct = bool(L.sd_linear_wgrad_fuses_bias_dtype(_DT[x.dtype], T, M, N))
             if not direct and x.dtype == torch.float32:
                 # fewer than 8192 tokens or a weight of more than 16 64x64 regions: no longer tall-skinny.  Round 3: split-K over the tokens
