@@ -206,7 +206,7 @@ class DistillationLoss(nn.Module):
         for i, entry in enumerate(self.distillation):
             s_name, t_name = entry['student_layer'], entry['teacher_layer']
             if isinstance(s_name, list):
-                raise NotImplementedError('list-typed layers (attention-pair criteria) are not used by any shipped config')
+                continue                    # attention-pair entry (reference opts.py:91-98): dispatched in the naming loop below
             xs, xt = student_features[s_name], teacher_features[t_name]
             align = self.aligns[str(i)] if str(i) in self.aligns else None
             crit = self.criteria[i]
@@ -230,6 +230,14 @@ class DistillationLoss(nn.Module):
         out = {}
         for i, entry in enumerate(self.distillation):
             s_name, t_name = entry['student_layer'], entry['teacher_layer']
+            if isinstance(s_name, list):
+                # reference opts.py:91-98: two taps per network (attention map + value) and the networks themselves go to a criterion with the
+                # 8-argument signature; none of the reference's LIVE loss classes has it (they sit in the commented-out generation of
+                # losses.py), so this only serves criteria a user registers in DISTILL_LOSSES.  Key as the reference names it.
+                loss = self.criteria[i](student_features[s_name[0]], student_features[s_name[1]], teacher_features[t_name[0]],
+                                        teacher_features[t_name[1]], student, teacher, gt_semantic_seg, step)
+                out[f"loss_{s_name[0]}<->{t_name}_{entry['loss_name']}"] = loss
+                continue
             loss = losses[i]
             if loss is None:
                 loss = self.entry_loss(i, student_features[s_name], teacher_features[t_name], gt_semantic_seg, step)

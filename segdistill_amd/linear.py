@@ -86,7 +86,6 @@ def _bwd_data(dy2, weight):
 
 
 _BF16_WGRAD_LIB = os.environ.get('SEGDISTILL_BF16_WGRAD_LIB', '0') == '1'
-_TN_WGRAD = os.environ.get('SEGDISTILL_TN_WGRAD', '1') == '1'              # A/B: 0 = round 3's tall-skinny exact-f32 kernel for the head's weight gradients
 _SPLITK_WGRAD = os.environ.get('SEGDISTILL_SPLITK_WGRAD', '1') == '1'      # A/B: 0 = the library's dY^T @ X for the non-tall-skinny weight gradients
 
 
@@ -151,7 +150,7 @@ class _TokenLinear(torch.autograd.Function):
             T, M, N = x2.shape[0], weight.shape[0], weight.shape[1]
             L = _lib.lib()
             ns_tn = 0
-            if (_TN_WGRAD and _SPLIT_BF16 and x.dtype == torch.float32 and ctx.w_dtype == torch.float32 and dyc.data_ptr() % 16 == 0
+            if (_SPLIT_BF16 and x.dtype == torch.float32 and ctx.w_dtype == torch.float32 and dyc.data_ptr() % 16 == 0
                     and x2.data_ptr() % 16 == 0):
                 ns_tn = L.sd_linear_wgrad_tn_slabs(T, M, N)
             if ns_tn:

@@ -498,3 +498,48 @@ def test_bench_launcher_builds_one_rank_per_gpu(monkeypatch):
     assert cmd[-5].endswith('bench.py') and seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
     import torch
     assert not torch.cuda.is_initialized()
+
+
+def test_list_typed_distillation_entries_dispatch_like_the_reference():
+    """reference opts.py:91-98: an entry whose layers are LISTS hands (attn_s, v_s, attn_t, v_t, student, teacher, gt, step) to its criterion and
+    names the loss `loss_{student_layer[0]}<->{teacher_layer}_{loss_name}`.  No live reference loss has that signature (they are in the commented
+    generation of losses.py); a user-registered one must work and must coexist with ordinary entries."""
+    import torch.nn as nn
+    import segdistill_amd
+    from segdistill_amd.builder import DISTILL_LOSSES
+    from segdistill_amd.distillation.opts import DistillationLoss, Extractor
+    segdistill_amd.register_all()
+    seen = {}
+
+    if 'PairProbeLoss' not in DISTILL_LOSSES.module_dict:
+        @DISTILL_LOSSES.register_module()
+        class PairProbeLoss(nn.Module):
+            def __init__(self, weight=1.0):
+                super().__init__()
+                self.weight = weight
+
+            def forward(self, attn_s, v_s, attn_t, v_t, student, teacher, gt, step):
+                seen['args'] = (attn_s, v_s, attn_t, v_t, student, teacher, gt, step)
+                return self.weight * ((attn_s - attn_t).pow(2).mean() + (v_s - v_t).pow(2).mean())
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.v = nn.Linear(4, 4), nn.Linear(4, 4)
+
+        def forward(self, x):
+            return self.a(x) + self.v(x)
+    torch.manual_seed(0)
+    student, teacher = Net(), Net()
+    entries = [dict(student_layer=['a', 'v'], teacher_layer=['a', 'v'], loss_name='PairProbeLoss', loss_config=dict(weight=2.0))]
+    ext = Extractor(student, teacher, entries)
+    ext.train()
+    dl = DistillationLoss(entries)
+    x = torch.randn(3, 4)
+    student(x)
+    teacher(x)
+    out = dl(ext.student_features, ext.teacher_features, torch.zeros(3, 1, 2, 2), 7, student, teacher)
+    assert list(out) == ["loss_a<->['a', 'v']_PairProbeLoss"]
+    want = 2.0 * ((student.a(x) - teacher.a(x)).pow(2).mean() + (student.v(x) - teacher.v(x)).pow(2).mean())
+    assert float(out["loss_a<->['a', 'v']_PairProbeLoss"]) == pytest.approx(float(want), rel=1e-6)
+    assert seen['args'][4] is student and seen['args'][5] is teacher and seen['args'][7] == 7
