@@ -558,7 +558,30 @@ def bench_wgrad_bf16(dev, reps):
     return out
 
 
+def bench_ppm(dev, reps):
+    """All adaptive average pools of a PPM in one pass each way (csrc/ppm_pool.hip): the PSPNet-R18 student's [8, 512, 64, 64] map and the
+    ResNet-101 teacher's [2, 2048, 64, 64] (config 1).  HBM-bound: forward reads the map once, backward writes it once."""
+    import ctypes as C_
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    out = []
+    scales = (1, 2, 3, 6)
+    sc = (C_.c_int * 4)(*scales)
+    for tag, B, C, h in (('PSPNet-R18 student [8,512,64,64]', 8, 512, 64), ('PSPNet-R101 [2,2048,64,64]', 2, 2048, 64)):
+        x = torch.randn(B, C, h, h, device=dev)
+        pooled = [torch.empty(B, C, s, s, device=dev) for s in scales]
+        dx = torch.empty_like(x)
+        ptrs = (C_.c_void_p * 4)(*[p.data_ptr() for p in pooled])
+        tf = _time(lambda st: _ok(L.sd_ppm_pool_fwd(x.data_ptr(), 0, B * C, h, h, sc, 4, ptrs, st), 'ppm fwd'), reps)
+        tb = _time(lambda st: _ok(L.sd_ppm_pool_bwd(ptrs, 0, B * C, h, h, sc, 4, dx.data_ptr(), st), 'ppm bwd'), reps)
+        nbytes = x.numel() * 4
+        out += [_entry(f'PPM pools (1, 2, 3, 6) fwd, {tag}', 'ppm_pool_fwd', [B, C, h, h], 'f32', tf, 'hbm', nbytes, HBM),
+                _entry(f'PPM pools (1, 2, 3, 6) bwd, {tag}', 'ppm_pool_bwd', [B, C, h, h], 'f32', tb, 'hbm', nbytes, HBM)]
+    return out
+
+
 GROUPS = {
+    'ppm': lambda dev, reps: bench_ppm(dev, reps),
     'wgrad_bf16': lambda dev, reps: bench_wgrad_bf16(dev, reps),
     'r1': lambda dev, reps: bench_r1(dev, reps),
     'r1_bf16': lambda dev, reps: bench_r1(dev, reps, C=768, HW=128, dtype=torch.bfloat16),      # config 5 stage 1

@@ -11,7 +11,7 @@ DST=$R/profiles
 n=0
 put() { [ -s "$1" ] && cp "$1" "$2" && n=$((n + 1)); }
 for f in bench.json bench_kernels.json bench_kernel_stats.csv bench_under_rocprof.json train_step_kernels.txt step_shapes.txt step_top5.json \
-         gemm_bench.txt wgrad_splitk_bench.txt pred_bench.txt; do
+         gemm_bench.txt wgrad_splitk_bench.txt pred_bench.txt wgrad_bench.txt gemm_nosplit_probe_product.txt gemm_nosplit_probe_diag.txt step_gap_probe.txt; do
   put $SRC/$f $DST/${P}_$f
 done
 put $SRC/other_configs.txt $DST/${P}_other_configs_throughput.txt
@@ -34,7 +34,9 @@ PY
   ) && n=$((n + 1))
 fi
 put $R/gpurun_out/ab_switches.txt $DST/${P}_ab_switches.txt
-for f in $R/gpurun_out/configs/train_step_kernels_cfg*.txt; do
+put $R/gpurun_out/ab_round4.txt $DST/${P}_ab_round4.txt
+put $R/gpurun_out/ab_round4b.txt $DST/${P}_ab_round4_ppm.txt
+for f in $R/gpurun_out/configs/train_step_kernels_cfg*.txt $R/gpurun_out/configs/step_shapes_cfg*.txt; do
   [ -e "$f" ] && put $f $DST/${P}_$(basename $f)
 done
 echo "published $n files under $DST/${P}_*"

@@ -38,6 +38,13 @@ python tools/prof_summary.py /tmp/prof_step --skip 8 --top 90 --gaps 12 --out $O
 python tools/step_kernel_shapes.py /tmp/prof_step "" > $OUT/step_shapes.txt 2>/dev/null
 python tools/step_top5.py $OUT/train_step_kernels.txt $OUT/bench_kernels.json > $OUT/step_top5.json 2>/dev/null
 fi
+if want 7; then
+echo "[7] step gap probes" | tee -a $OUT/progress.txt
+{ python tools/step_gap_probe.py 2>/dev/null | tail -1 | sed 's/^/cfg2 one rank:                      /'
+  SEGDISTILL_FORCE_COLLECTIVES=1 SEGDISTILL_FORCE_SYNCBN=1 python tools/step_gap_probe.py 2>/dev/null | tail -1 | sed 's/^/cfg2 one rank, SyncBN + RCCL forced (3 segments): /'
+  python tools/step_gap_probe.py --config configs/kd/cfg5_segformer_b4_b1_multistage_bf16.py 2>/dev/null | tail -1 | sed 's/^/cfg5 (bf16) one rank:               /'
+} > $OUT/step_gap_probe.txt
+fi
 if want 4; then
 echo "[4] other configs" | tee -a $OUT/progress.txt
 : > $OUT/other_configs.txt
@@ -52,7 +59,7 @@ done
 fi
 if want 5; then
 echo "[5] kernel rooflines: trace + PMC passes" | tee -a $OUT/progress.txt
-for g in r1 tok r2 ce align sra optim dw ln upsum resize gemm pred ifvd pix at; do
+for g in r1 tok r2 ce align sra optim dw ln upsum resize gemm pred ifvd pix at wgrad_bf16 ppm; do
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kr_$g -o k -- python3 $R/tools/kernel_rooflines.py --only $g > $OUT/kernels_$g.txt 2>/dev/null )
   cp $(find /tmp/kr_$g -name '*kernel_stats.csv' | head -1) $OUT/kernels_${g}_stats.csv 2>/dev/null
 done
@@ -71,6 +78,9 @@ if want 6; then
 echo "[6] gemm bench" | tee -a $OUT/progress.txt
 python tools/gemm_bench.py 2>/dev/null | grep -v amdgpu.ids > $OUT/gemm_bench.txt
 python tools/wgrad_splitk_bench.py 2>/dev/null | grep -v amdgpu.ids > $OUT/wgrad_splitk_bench.txt
+python tools/wgrad_bench.py 2>/dev/null | grep -v amdgpu.ids > $OUT/wgrad_bench.txt
+python tools/gemm_nosplit_probe.py 2>/dev/null | grep -v amdgpu.ids > $OUT/gemm_nosplit_probe_product.txt
+[ -f segdistill_amd/lib_ab/libsegdistill_hip.so ] && SEGDISTILL_LIB=$R/segdistill_amd/lib_ab/libsegdistill_hip.so python tools/gemm_nosplit_probe.py 2>/dev/null | grep -v amdgpu.ids > $OUT/gemm_nosplit_probe_diag.txt
 python tools/pred_bench.py 2>/dev/null | grep -v amdgpu.ids > $OUT/pred_bench.txt
 tools/gemm_pmc.sh $OUT --mode pl > $OUT/gemm_pmc_planes.txt 2>&1
 fi
