@@ -40,9 +40,10 @@ class _PPMPool(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         B, Cc, h, w, scales, dt = ctx.geom
+        dev = next(g.device for g in grads if g is not None)       # autograd calls backward only when at least one output has a gradient
         gs = []
         for g, s in zip(grads, scales):
-            g = torch.zeros(B, Cc, s, s, dtype=dt, device=grads[0].device if grads[0] is not None else None) if g is None else g
+            g = torch.zeros(B, Cc, s, s, dtype=dt, device=dev) if g is None else g
             gs.append(g.to(dt).contiguous())
         dx = torch.empty(B, Cc, h, w, dtype=dt, device=gs[0].device)
         ptrs = (C.c_void_p * len(scales))(*[g.data_ptr() for g in gs])
