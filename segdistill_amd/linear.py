@@ -68,7 +68,14 @@ def linear_forward(x, weight, bias):
         dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else x.dtype
         if dt in (torch.bfloat16, torch.float16):
             from .layers import frozen_derived
-            w16 = frozen_derived(weight, ('cast', dt), lambda: weight.to(dt))
+            # cached on the BASE parameter, the view's geometry in the key: the SR conv's patch-ordered matrix and the head's linear_fuse
+            # blocks are VIEWS made anew on every call, and a cache keyed on the view object never hit -- 42 cast kernels per config-5 step
+            # for the B4 teacher's 38 SR convs and 4 fuse blocks (tools/cast_probe.py, round 4)
+            root = weight._base if weight._base is not None else weight
+            if root.requires_grad:
+                w16 = weight.to(dt)
+            else:
+                w16 = frozen_derived(root, ('cast', dt, weight.data_ptr(), tuple(weight.shape), tuple(weight.stride())), lambda: weight.to(dt))
             b16 = None if bias is None else frozen_derived(bias, ('cast', dt), lambda: bias.to(dt))
             return F.linear(x if x.dtype == dt else x.to(dt), w16, b16)
     return F.linear(x, weight, bias)
@@ -96,6 +103,14 @@ def lowp_copy(t, dt):
     op that writes the parameter (checkpoint load, another optimizer) bumps its version and the shadow is remade.  (A write through
     `param.data` -- or by a torch FUSED optimizer -- does NOT bump it: engine/optim.py's step post-hook rewrites the shadows then; other code
     that edits weights that way mid-training must delete `param._sd_shadow`.)"""
+    base = t._base
+    if (dt == torch.bfloat16 and base is not None and isinstance(base, torch.nn.Parameter) and base.requires_grad and base.dtype == torch.float32
+            and base.is_cuda and t.dtype == torch.float32):
+        # a VIEW of a trainable parameter (the SR conv's patch-ordered matrix, a block of linear_fuse): the same view of the parameter's shadow --
+        # the shadow keeps the parameter's layout, so shape / strides / offset carry over -- instead of one cast kernel per view and step
+        sh = lowp_copy(base, dt)
+        if sh.stride() == base.stride():
+            return sh.as_strided(t.shape, t.stride(), t.storage_offset() - base.storage_offset() + sh.storage_offset())
     if not (dt == torch.bfloat16 and isinstance(t, torch.nn.Parameter) and t.requires_grad and t.dtype == torch.float32 and t.is_cuda):
         return t.to(dt)
     sh = getattr(t, '_sd_shadow', None)

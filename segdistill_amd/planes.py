@@ -73,6 +73,8 @@ def _alloc(n_cols, k_depth, device):
 
 def _drop(key, base_id):
     global _GEN
+    if _ENTRIES is None:            # interpreter shutdown
+        return
     e = _ENTRIES.pop(key, None)
     if e is not None:
         lst = _BY_BASE.get(base_id)
@@ -110,7 +112,7 @@ def get(weight, direction):
         e = None
     if e is None:
         e = Entry()
-        e.base = weakref.ref(base, lambda _, k=key, b=id(base): _drop(k, b))
+        e.base = weakref.ref(base, lambda _, k=key, b=id(base), drop=_drop: drop(k, b))     # `drop` bound now: module globals are gone at interpreter exit
         e.key, e.w_ptr, e.ldw, e.out, e.inp, e.fwd, e.bwd, e.rows, e.version = key, weight.data_ptr(), weight.stride(0), out, inp, None, None, None, None
         _ENTRIES[key] = e
         _BY_BASE.setdefault(id(base), []).append(e)
