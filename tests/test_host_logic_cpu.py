@@ -543,3 +543,69 @@ def test_list_typed_distillation_entries_dispatch_like_the_reference():
     want = 2.0 * ((student.a(x) - teacher.a(x)).pow(2).mean() + (student.v(x) - teacher.v(x)).pow(2).mean())
     assert float(out["loss_a<->['a', 'v']_PairProbeLoss"]) == pytest.approx(float(want), rel=1e-6)
     assert seen['args'][4] is student and seen['args'][5] is teacher and seen['args'][7] == 7
+
+
+def test_fuse_pairs_rule_which_criteria_may_share_a_pass(monkeypatch):
+    """DistillationLoss._fuse_pairs (host logic only: the fused kernel call is replaced by a recorder): two KLDLoss 'channel' entries on the SAME
+    taps fuse iff one permutation table can order the slots of both -- the partner has no shuffle of its own and a group size of 1, or neither
+    shuffles; entries with an align projection, on other taps, or without a fusable resize never do; keys keep the reference's naming + #k."""
+    import segdistill_amd
+    from segdistill_amd import ops
+    from segdistill_amd.distillation import losses as L
+    from segdistill_amd.distillation.opts import DistillationLoss
+    segdistill_amd.register_all()
+    bil = dict(mode='bilinear', align_corners=False)
+
+    def kld(g, shuffle, resize=True, **kw):
+        cfg = dict(alpha=1, tau=1, transform_config={'loss_type': 'channel', 'group_size': g}, **kw)
+        if resize:
+            cfg['resize_config'] = bil
+        if shuffle:
+            cfg['shuffle_config'] = {'interval': 1000}
+        return cfg
+
+    def entry(s, t, cfg, **kw):
+        return dict(student_layer=s, teacher_layer=t, loss_name='KLDLoss', loss_config=cfg, **kw)
+    calls = []
+
+    def fake_up2(xs, xt, size, ca, cb, perm):
+        calls.append((ca[0], cb[0], perm is not None))
+        return torch.tensor(1.0), torch.tensor(2.0)
+    monkeypatch.setattr(ops, 'cgd_kl_up2', fake_up2)
+    monkeypatch.setattr(L.KLDLoss, 'fused_up_size', lambda self, xs, xt, gt: (64, 64) if self.resize_config else None)
+    monkeypatch.setattr(L.KLDLoss, '_prepare', lambda self, x, c, n: (float(self.alpha), None, torch.arange(c) if self.shuffle_config else None))
+    monkeypatch.setattr(DistillationLoss, 'entry_loss', lambda self, i, xs, xt, gt, step: torch.tensor(10.0 + i))
+    feats = {'a': torch.zeros(2, 6, 16, 16), 'b': torch.zeros(2, 6, 16, 16), 'c': torch.zeros(2, 6, 16, 16)}
+    gt = torch.zeros(2, 1, 64, 64)
+
+    def run(entries):
+        calls.clear()
+        out = DistillationLoss(entries)(feats, feats, gt, 5)
+        return [float(v) for v in out.values()], list(out)
+    # config 3's pair: CGD with a shuffle + channel-wise KL (g = 1, no shuffle) -> fused, the shuffled criterion leads
+    vals, keys = run([entry('a', 'b', kld(8, True)), entry('a', 'b', kld(1, False))])
+    assert calls == [(8, 1, True)] and vals == [1.0, 2.0] and len(set(keys)) == 2
+    # the same pair listed the other way round: still fused, still led by the shuffled one; values go back to their own entries
+    vals, _ = run([entry('a', 'b', kld(1, False)), entry('a', 'b', kld(8, True))])
+    assert calls == [(8, 1, True)] and vals == [2.0, 1.0]
+    # neither shuffles: any two group sizes
+    run([entry('a', 'b', kld(3, False)), entry('a', 'b', kld(7, False))])
+    assert calls == [(3, 7, False)]
+    # the partner shuffles too, or has g > 1 beside a shuffled lead: two different slot orders -> not fused
+    vals, _ = run([entry('a', 'b', kld(8, True)), entry('a', 'b', kld(1, True))])
+    assert calls == [] and vals == [10.0, 11.0]
+    run([entry('a', 'b', kld(8, True)), entry('a', 'b', kld(4, False))])
+    assert calls == []
+    # other taps, no resize, or an align projection: entry by entry
+    run([entry('a', 'b', kld(8, False)), entry('a', 'c', kld(1, False))])
+    assert calls == []
+    run([entry('a', 'b', kld(8, False, resize=False)), entry('a', 'b', kld(1, False, resize=False))])
+    assert calls == []
+    run([entry('a', 'b', kld(8, False), channel_nums=(6, 6)), entry('a', 'b', kld(1, False))])
+    assert calls == []
+    # three entries on the same taps: one pair fuses, the third runs alone; A/B switch off: nothing fuses
+    vals, _ = run([entry('a', 'b', kld(8, True)), entry('a', 'b', kld(1, False)), entry('a', 'b', kld(2, False))])
+    assert calls == [(8, 1, True)] and vals == [1.0, 2.0, 12.0]
+    monkeypatch.setenv('SEGDISTILL_FUSE_PAIRS', '0')
+    vals, _ = run([entry('a', 'b', kld(8, True)), entry('a', 'b', kld(1, False))])
+    assert calls == [] and vals == [10.0, 11.0]

@@ -17,6 +17,8 @@ from segdistill_amd.engine import KDTrainer, SyntheticADE  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--config', default='configs/kd/cfg5_segformer_b4_b1_multistage_bf16.py')
 ap.add_argument('--ops', default='aten::_to_copy', help='comma-separated ATen op names to list (e.g. aten::copy_,aten::add,aten::clone,aten::sum)')
+ap.add_argument('--by-bytes', action='store_true', help='sort by count x elements instead of count')
+ap.add_argument('--all', action='store_true', help='every aten:: op (ignores --ops)')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
 cfg = Config.fromfile(os.path.join(bench.ROOT, a.config))
@@ -32,10 +34,18 @@ with profile(activities=[ProfilerActivity.CPU], record_shapes=True, with_stack=T
     torch.cuda.synchronize()
 groups = collections.Counter()
 for ev in prof.events():
-    if ev.name in a.ops.split(','):
+    if (a.all and ev.name.startswith('aten::') and ev.input_shapes and ev.input_shapes[0]) or ev.name in a.ops.split(','):
         shp = tuple(ev.input_shapes[0]) if ev.input_shapes else ()
         site = next((s for s in (ev.stack or []) if 'segdistill_amd' in s), (ev.stack or ['?'])[0] if ev.stack else '?')
         groups[(ev.name, shp, site.split('/')[-1][:90])] += 1
-for (name, shp, site), n in sorted(groups.items(), key=lambda kv: -kv[1])[:60]:
+def _numel(shp):
+    n = 1
+    for v in shp:
+        n *= v
+    return n
+
+
+order = (lambda kv: -kv[1] * _numel(kv[0][1])) if '--by-bytes' in sys.argv else (lambda kv: -kv[1])
+for (name, shp, site), n in sorted(groups.items(), key=order)[:60]:
     print(f'{n:4d} x {name:16s} {str(shp):28s} {site}')
 print('total:', sum(groups.values()))
