@@ -147,60 +147,74 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16(const bf16_t *__restrict__ 
 // read that follows a `__builtin_amdgcn_global_load_lds` it can see, which would drain the ring; the counts are kept by hand -- every
 // iteration issues exactly kDmaPerTile instructions per wave (past the last tile: a harmless re-load of it into a free stage), so the wait
 // that retires tile kt is always vmcnt(2 * kDmaPerTile).  Whole tiles only: T % 32 == 0 (the launcher checks).
-constexpr int kRing = 4, kDmaPerTile = 4;              // per wave and tile: rows 8w .. 8w+7 of A and of B, 4 rows (1 KB) per instruction
+constexpr int kRing = 4;                               // stages; per wave and tile: rows 8w .. 8w+7 of every 128-column image, 4 rows (1 KB) per DMA instruction
 
 __device__ __forceinline__ void dma16(const void *gptr, unsigned lds_byte) {
     // M0 = wave-uniform LDS byte address of lane 0's 16 bytes; lane l lands at M0 + 16 l
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte) : "memory");   // M0 is reserved in LLVM (a clobber entry is rejected with a warning); nothing else in this kernel uses it (checked in the ISA)
 }
 
+// IM = images of 128 columns per operand tile: 1 -> 128 x 128 output tiles (64 x 64 per wave), 2 -> 256 x 256 (128 x 128 per wave, 256 accumulator
+// registers, one workgroup per CU).  PMC of the IM = 1 form at 768 x 256 over 131072 tokens (profiles/r04_pmc_wgrad_tn.json): no LDS bank conflict,
+// LDS array ~12 % busy, matrix pipe 25 % busy, FETCH_SIZE = dY + X once -- the kernel runs at what ~96 KB in flight per CU buy from L2 at this
+// latency (804 MB of L2 -> CU traffic in 93 us): the big tile halves that traffic per MFMA (402 MB) instead of deepening the ring.
+template <int IM>
 __global__ __launch_bounds__(256) void wgrad_tn_bf16_ring(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, float *__restrict__ C, int M,
                                                            int N, long T, int klen, int tiles_m, int tiles_n, int nsplit) {
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[kRing * 2 * kStageBytes];      // [stage][A | B]: 64 KB
+    constexpr int BT = 128 * IM;                       // tile extent along m and along n
+    constexpr int TW = 2 * IM;                         // 32-row (-column) MFMA blocks per wave and axis
+    constexpr int kStage = 2 * IM * kStageBytes;       // A images, then B images
+    constexpr int kDma = 4 * IM;                       // DMA instructions per wave and tile
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[kRing * kStage];      // 64 KB (IM = 1) / 128 KB (IM = 2)
     const long nblk = gridDim.x, id = blockIdx.x;
     const long qd = nblk / 8, rem = nblk % 8, xcd = id % 8;
     const long L = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + id / 8;
     const int tiles = tiles_m * tiles_n;
     const int split = (int)(L / tiles), tile = (int)(L - (long)split * tiles);
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * TBM, n0 = tn * TBN;
+    const int m0 = tm * BT, n0 = tn * BT;
     const long k_begin = (long)split * klen, k_end = min(T, k_begin + klen);
     const int nk = (int)((k_end - k_begin) / TBK);
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * (BT / 2), wn = (wave & 1) * (BT / 2);
     const int h = lane >> 5, g = (lane >> 4) & 1, li = lane & 15;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TW][TW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // DMA geometry: instruction u (0, 1) of wave w moves tile rows 8w + 4u .. + 3; lane -> (row r = 8w + 4u + lane / 16, LDS chunk c' = lane % 16)
-    // which must hold source chunk c' ^ f(r) (swz is an involution in the chunk index).  Chunks beyond M / N: clamped to a valid chunk -- they
-    // only feed output columns that are never stored.
+    // DMA geometry: per 128-column image, instruction u (0, 1) of wave w moves tile rows 8w + 4u .. + 3; lane -> (row r = 8w + 4u + lane / 16, LDS
+    // chunk c' = lane % 16), which must hold source chunk c' ^ f(r) (swz is an involution in the chunk index).  Chunks beyond M / N: clamped to a
+    // valid chunk -- they only feed output columns that are never stored.
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
-    const bf16_t *ga[2], *gb[2];
+    const bf16_t *ga[IM][2], *gb[IM][2];
     unsigned la[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int r = 8 * wave + 4 * u + (lane >> 4);
         const int ch = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
-        const int ca = m0 + 8 * ch < M ? m0 + 8 * ch : 0, cb = n0 + 8 * ch < N ? n0 + 8 * ch : 0;
-        ga[u] = A + (size_t)(k_begin + r) * M + ca;
-        gb[u] = B + (size_t)(k_begin + r) * N + cb;
+#pragma unroll
+        for (int im = 0; im < IM; ++im) {
+            const int ma = m0 + 128 * im + 8 * ch, nb = n0 + 128 * im + 8 * ch;
+            ga[im][u] = A + (size_t)(k_begin + r) * M + (ma < M ? ma : 0);
+            gb[im][u] = B + (size_t)(k_begin + r) * N + (nb < N ? nb : 0);
+        }
         la[u] = 256u * (unsigned)(8 * wave + 4 * u);
     }
-    auto issue = [&](int kt) {                          // tile kt (clamped) -> stage kt % kRing; kDmaPerTile instructions
+    auto issue = [&](int kt) {                          // tile kt (clamped) -> stage kt % kRing; kDma instructions
         const int kc = kt < nk ? kt : nk - 1;
-        const unsigned st = lds0 + (unsigned)(kt % kRing) * 2u * kStageBytes;
+        const unsigned st = lds0 + (unsigned)(kt % kRing) * (unsigned)kStage;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            dma16(ga[u] + (size_t)kc * TBK * M, __builtin_amdgcn_readfirstlane(st + la[u]));
-            dma16(gb[u] + (size_t)kc * TBK * N, __builtin_amdgcn_readfirstlane(st + kStageBytes + la[u]));
-        }
+        for (int im = 0; im < IM; ++im)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                dma16(ga[im][u] + (size_t)kc * TBK * M, __builtin_amdgcn_readfirstlane(st + (unsigned)im * kStageBytes + la[u]));
+                dma16(gb[im][u] + (size_t)kc * TBK * N, __builtin_amdgcn_readfirstlane(st + (unsigned)(IM + im) * kStageBytes + la[u]));
+            }
     };
     if (nk > 0) {
         issue(0);
@@ -208,31 +222,37 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_ring(const bf16_t *__restri
         issue(2);
     }
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kDmaPerTile) : "memory");     // all but the two youngest tiles: tile kt has landed (this wave's part)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kDma) : "memory");            // all but the two youngest tiles: tile kt has landed (this wave's part)
         __builtin_amdgcn_s_barrier();                                                // ... everyone's part; and stage (kt + 3) % 4 is no longer read
         __builtin_amdgcn_sched_barrier(0);
         issue(kt + 3);
-        const unsigned char *sa = lds + (size_t)(kt % kRing) * 2 * kStageBytes, *sb = sa + kStageBytes;
+        const unsigned char *sa = lds + (size_t)(kt % kRing) * kStage, *sb = sa + IM * kStageBytes;
 #pragma unroll
         for (int s = 0; s < TBK / 16; ++s) {
-            bf16x8 fa[2], fb[2];
+            bf16x8 fa[TW], fb[TW];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = tr_frag(sa, 16 * s + 8 * h, (wm + 32 * i) / 8 + 2 * g, li);
+            for (int i = 0; i < TW; ++i) {
+                const int cm = wm + 32 * i;                                          // column of the A tile = row block of the output
+                fa[i] = tr_frag(sa + (cm >> 7) * kStageBytes, 16 * s + 8 * h, (cm & 127) / 8 + 2 * g, li);
+            }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = tr_frag(sb, 16 * s + 8 * h, (wn + 32 * j) / 8 + 2 * g, li);
+            for (int j = 0; j < TW; ++j) {
+                const int cn = wn + 32 * j;
+                fb[j] = tr_frag(sb + (cn >> 7) * kStageBytes, 16 * s + 8 * h, (cn & 127) / 8 + 2 * g, li);
+            }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TW; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tail's placeholder DMAs must not land after the workgroup's LDS is gone
     float *Cz = C + (size_t)split * M * N;
     const int col = lane & 31;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TW; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TW; ++j) {
             const int n = n0 + wn + 32 * j + col;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -399,16 +419,29 @@ __global__ __launch_bounds__(256) void wgrad_tn_x3(const float *__restrict__ A, 
 }  // namespace
 
 // ---- plan + launcher shared with align1x1.hip (the generic weight-gradient entry points) -------------------------------------------------
-int g_wgrad_ring = 1;      // tunable "wgrad_tn_ring": 0 = the register-staged kernel everywhere (A/B, tests)
+int g_wgrad_ring = 1;      // tunable "wgrad_tn_ring": 0 = the register-staged kernel everywhere, 1 = the rules below, 2 = 256 x 256 tiles wherever legal (A/B, tests)
 bool wgrad_tn_supported(long T, int M, int N, const void *dY, const void *X) {
     return T > 0 && M > 0 && N > 0 && M % 8 == 0 && N % 8 == 0 && ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) == 0;
 }
 
-// number of k-splits (= slabs): ~3 workgroups per CU, every split at least two k-steps, at most 256 slabs
+// big (256 x 256) tiles of the ring kernel: both extents at least 256, whole 32-token tiles,
+// and at least 32 k-steps per workgroup at one workgroup per CU -- measured (profiles/r04_kernels_wgrad_bf16.txt): 96 -> 86 us at 768 x 256 over
+// 131072 tokens (49 k-steps), but 28 -> 29 us over 32768 tokens (13 k-steps): below that the unoverlapped prologue and 256 KB slab store of a
+// lone workgroup per CU cost more than the halved L2 -> CU traffic saves.
+static bool wgrad_tn_big(long T, int M, int N) {
+    if (!g_wgrad_ring || M < 256 || N < 256 || T % TBK != 0) return false;
+    const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+    const long ns = 256 / tiles < 1 ? 1 : 256 / tiles;
+    return g_wgrad_ring == 2 ? T >= 8 * TBK : T / ns >= 32 * TBK;
+}
+
+// number of k-splits (= slabs): ~3 workgroups per CU (one per CU for the big tiles), every split at least two k-steps, at most 256 slabs
 void wgrad_tn_plan(long T, int M, int N, int *nsplit, int *klen) {
-    const long tiles = (long)((M + TBM - 1) / TBM) * ((N + TBN - 1) / TBN);
-    long ns = 768 / tiles;
-    if (ns > T / (2 * TBK)) ns = T / (2 * TBK);
+    const bool big = wgrad_tn_big(T, M, N);
+    const int bt = big ? 256 : TBM;
+    const long tiles = (long)((M + bt - 1) / bt) * ((N + bt - 1) / bt);
+    long ns = (big ? 256 : 768) / tiles;
+    if (ns > T / ((big ? 4 : 2) * TBK)) ns = T / ((big ? 4 : 2) * TBK);
     if (ns > 256) ns = 256;
     if (ns < 1) ns = 1;
     const long kl = ((T + ns - 1) / ns + TBK - 1) / TBK * TBK;
@@ -419,21 +452,25 @@ void wgrad_tn_plan(long T, int M, int N, int *nsplit, int *klen) {
 int wgrad_tn_tunable(const char *key, int set, int v) {
     if (strcmp(key, "wgrad_tn_ring")) return SD_E_UNSUPPORTED;
     if (!set) return g_wgrad_ring;
-    if (v != 0 && v != 1) return SD_E_SHAPE;
+    if (v < 0 || v > 2) return SD_E_SHAPE;
     g_wgrad_ring = v;
     return SD_OK;
 }
 
 int wgrad_tn_launch(const void *dY, const void *X, float *slabs, long T, int M, int N, int nsplit, int klen, hipStream_t st) {
-    const int tiles_m = (M + TBM - 1) / TBM, tiles_n = (N + TBN - 1) / TBN;
+    const bool big = wgrad_tn_big(T, M, N) && klen >= 3 * TBK;
+    const int bt = big ? 256 : TBM;
+    const int tiles_m = (M + bt - 1) / bt, tiles_n = (N + bt - 1) / bt;
     const long nblk = (long)tiles_m * tiles_n * nsplit;
     if (nblk > 0x7fffffffL) return SD_E_SHAPE;
-    if (T % TBK == 0 && klen >= 3 * TBK && g_wgrad_ring)
-        hipLaunchKernelGGL(wgrad_tn_bf16_ring, dim3((unsigned)nblk), dim3(256), 0, st, (const bf16_t *)dY, (const bf16_t *)X, slabs, M, N, T, klen,
-                           tiles_m, tiles_n, nsplit);
-    else
-        hipLaunchKernelGGL(wgrad_tn_bf16, dim3((unsigned)nblk), dim3(256), 0, st, (const bf16_t *)dY, (const bf16_t *)X, slabs, M, N, T, klen, tiles_m,
-                           tiles_n, nsplit);
+    const bf16_t *a = (const bf16_t *)dY, *b = (const bf16_t *)X;
+    if (big) {
+        hipLaunchKernelGGL(wgrad_tn_bf16_ring<2>, dim3((unsigned)nblk), dim3(256), 0, st, a, b, slabs, M, N, T, klen, tiles_m, tiles_n, nsplit);
+    } else if (T % TBK == 0 && klen >= 3 * TBK && g_wgrad_ring) {
+        hipLaunchKernelGGL(wgrad_tn_bf16_ring<1>, dim3((unsigned)nblk), dim3(256), 0, st, a, b, slabs, M, N, T, klen, tiles_m, tiles_n, nsplit);
+    } else {
+        hipLaunchKernelGGL(wgrad_tn_bf16, dim3((unsigned)nblk), dim3(256), 0, st, a, b, slabs, M, N, T, klen, tiles_m, tiles_n, nsplit);
+    }
     return (int)hipGetLastError();
 }
 

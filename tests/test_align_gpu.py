@@ -98,7 +98,9 @@ def test_feature_align_module_in_distillation_loss():
 @pytest.mark.parametrize('shape', [(131072, 32, 32), (32768, 128, 32), (5000, 37, 21), (8192, 256, 64), (4096, 512, 2048), (300, 16, 8),
                                    (20001, 100, 70), (16384, 256, 256), (9000, 33, 129), (8193, 64, 64),
                                    # bf16: csrc/wgrad_tn.hip (transposed LDS reads) -- ragged tiles, ragged k-splits, the config-5 align shape
-                                   (5000, 40, 24), (777, 136, 72), (2048, 1024, 256), (65536, 768, 256), (8192, 1280, 320), (33, 8, 8)])
+                                   (5000, 40, 24), (777, 136, 72), (2048, 1024, 256), (65536, 768, 256), (8192, 1280, 320), (33, 8, 8),
+                                   # ... and the 256 x 256 tiles of the ring kernel with both extents ragged
+                                   (4096, 296, 264), (1024, 520, 256)])
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_linear_wgrad_kernel(shape, dtype):
     """dW = dY^T . X (split-K MFMA) vs fp64 matmul of the same (rounded) operands."""
@@ -125,6 +127,37 @@ def test_linear_wgrad_kernel(shape, dtype):
         assert _err(db, dy.double().sum(0)) < 2e-5
     else:  # the tiled kernel does not produce the bias gradient and says so
         assert L.sd_linear_wgrad(dyg.data_ptr(), xg.data_ptr(), dw.data_ptr(), dw.data_ptr(), _DT[dtype], T, M, N, ws.data_ptr(), wsb, None) == -6
+
+
+@pytest.mark.parametrize('shape', [(16384, 256, 256), (4096, 296, 264), (1024, 520, 256), (2048, 1024, 256), (8192, 1280, 320), (65536, 768, 256),
+                                   (131072, 768, 256)])
+def test_linear_wgrad_tn_big_tiles(shape):
+    """csrc/wgrad_tn.hip, 256 x 256 tiles of the LDS-DMA ring (product rule: only long k ranges; tunable 2 = wherever legal) vs fp64 and vs the
+    128 x 128 tiles: ragged tile rows / columns, ragged last k-split, both ring depths of the prologue."""
+    from segdistill_amd import _lib
+    T, M, N = shape
+    g = torch.Generator().manual_seed(T + M)
+    dy = torch.randn(T, M, generator=g).to(torch.bfloat16)
+    x = torch.randn(T, N, generator=g).to(torch.bfloat16)
+    dev = torch.device('cuda:0')
+    dyg, xg = dy.to(dev), x.to(dev)
+    ref = dyg.double().t() @ xg.double()
+    L = _lib.lib()
+    old = _lib.get_tunable('wgrad_tn_ring')
+    out = {}
+    try:
+        for mode in (1, 2):
+            _lib.set_tunable('wgrad_tn_ring', mode)
+            dw = torch.full((M, N), float('nan'), device=dev)
+            wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            assert L.sd_linear_wgrad(dyg.data_ptr(), xg.data_ptr(), dw.data_ptr(), None, 1, T, M, N, ws.data_ptr(), wsb,
+                                     torch.cuda.current_stream().cuda_stream) == 0
+            out[mode] = dw
+            assert _err(dw, ref) < 2e-5
+    finally:
+        _lib.set_tunable('wgrad_tn_ring', old)
+    assert _err(out[2], out[1]) < 1e-6
 
 
 def test_token_linear_autograd_matches_f_linear():
