@@ -224,7 +224,7 @@ def fused_leg(device, B, C=150, hw=128, F=4, g=8, tau=4.0, reps=20):
 
 
 def kernel_roofline_entries(groups=('r2', 'r1_bf16', 'tok', 'align', 'ce', 'pix', 'at', 'ifvd', 'sra', 'optim', 'dw', 'ln', 'upsum', 'resize', 'gemm', 'pred',
-                                    'wgrad_bf16', 'ppm'), reps=10):
+                                    'wgrad_bf16', 'ppm', 'wattn'), reps=10):
     """tools/kernel_rooflines.py, one CHILD process per kernel family.  Called only from a parent that has not touched the GPU yet
     (main() runs it before init_distributed / any torch.cuda call) and only at N = 1.  A family that times out, dies or writes bad
     JSON becomes one error entry; nothing here can take the bench line down."""

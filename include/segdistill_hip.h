@@ -262,6 +262,19 @@ int sd_ppm_pool_fwd(const void *x, int dtype, long planes, int h, int w, const i
 int sd_ppm_pool_bwd(void *const *d_pooled, int dtype, long planes, int h, int w, const int *scales, int nscales, void *dx, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Window multi-head self-attention of a Swin block, forward only (the frozen teacher of BASELINE config 4): reference
+ * mmseg/models/backbones/swin_transformer.py:119-153 -- per window and head  softmax((q*scale) k^T + bias[head] + mask[window % nW]) v.
+ *   qkv    [windows, N, 3, heads, D]  the qkv Linear's output as it stands (swin_transformer.py:128-129 before the permute)
+ *   bias_t [heads, N, N]  relative position bias TRANSPOSED: bias_t[h][j][i] = table[index[i][j]][h]   (:133-136)
+ *   mask_t [mask_windows, N, N] or NULL, TRANSPOSED: mask_t[w][j][i] = mask[w][i][j]; window b uses mask b % mask_windows  (:138-142)
+ *   out    [windows, N, heads*D]  = (attn @ v).transpose(1, 2).reshape(B_, N, C)   (:148)
+ * fp32 storage only (SD_E_DTYPE otherwise); _supported(): N == 49 (7 x 7 windows) and D == 32, else SD_E_UNSUPPORTED -- use the framework's op.
+ */
+int sd_window_attn_supported(int tokens_per_window, int head_dim);
+int sd_window_attn_fwd(const void *qkv, const float *bias_t, const float *mask_t, void *out, int dtype, long windows, int mask_windows, int heads,
+                       int tokens_per_window, int head_dim, float scale, void *stream);
+
+/* ---------------------------------------------------------------------------
  * CGD / CD criterion on TOKEN-MAJOR operands S, T [B][P][C] (C contiguous; P = h*w pixels): the decoder features of a SegFormer head
  * (decode_head.linear_c1..4 emit [B, h*w, E]; SURVEY a-16, reference opts.py:25-27 / the reshape helper commented out at
  * losses.py:300-318).  Same rows, closed form, row_lse2 / row_kl / loss outputs and `perm` semantics as sd_cgd_kl_fwd / _bwd

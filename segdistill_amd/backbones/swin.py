@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 from ..builder import BACKBONES
 from ..layernorm import HipLayerNorm          # nn.LayerNorm subclass: same keys, HIP kernels on CUDA tokens (ATen's ran 3.9 ms of a config-4 step)
+from .. import window_attn
 from ..layers import DropPath, to_2tuple, trunc_normal_
 
 
@@ -93,11 +94,45 @@ class WindowAttention(nn.Module):
         trunc_normal_(self.relative_position_bias_table, std=.02)
         self.softmax = nn.Softmax(dim=-1)
 
+    def _bias_t(self, n, h):
+        """relative position bias [h, N(key), N(query)] -- transposed for the kernel's column reads; cached per table version."""
+        tbl = self.relative_position_bias_table
+        sig = (tbl._version, tbl.data_ptr(), n)
+        hit = None if tbl.requires_grad else getattr(self, '_bias_t_cache', None)     # a trainable table is gathered every call: fused
+        if hit is not None and hit[0] == sig:                                          # optimizers do not bump _version
+            return hit[1]
+        with torch.no_grad():
+            bt = tbl[self.relative_position_index.view(-1)].view(n, n, h).permute(2, 1, 0).float().contiguous()
+        if not tbl.requires_grad and not (tbl.is_cuda and torch.cuda.is_current_stream_capturing()):
+            object.__setattr__(self, '_bias_t_cache', (sig, bt))
+        return bt
+
+    def _mask_t(self, mask):
+        if mask is None:
+            return None
+        sig = (mask.data_ptr(), mask._version, tuple(mask.shape))
+        hit = getattr(self, '_mask_t_cache', None)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        with torch.no_grad():
+            mt = mask.transpose(1, 2).float().contiguous()
+        if not (mask.is_cuda and torch.cuda.is_current_stream_capturing()):
+            object.__setattr__(self, '_mask_t_cache', (sig, mt))
+        return mt
+
     def forward(self, x, mask=None):
         """x: [nW*B, N, C]; mask: [nW, N, N] additive (0 / -100) or None."""
         bw, n, c = x.shape
         h = self.num_heads
-        q, k, v = self.qkv(x).reshape(bw, n, 3, h, c // h).permute(2, 0, 3, 1, 4)
+        tbl = self.relative_position_bias_table
+        qkv = self.qkv(x)
+        if (not (torch.is_grad_enabled() and qkv.requires_grad) and not (self.training and self.attn_drop.p > 0)
+                and window_attn.supported(qkv, n, h, c // h) and (mask is None or bw % mask.shape[0] == 0)):
+            # no graph to build (the frozen teacher): one kernel over the qkv Linear's output, bias and mask read from their tables
+            # (csrc/window_attn.hip) -- no [windows, heads, N, N] additive tensor, no permuted copies of q / k / v or of the output
+            out = window_attn.forward(qkv.contiguous(), self._bias_t(n, h), self._mask_t(mask), h, self.scale)
+            return self.proj_drop(self.proj(out))
+        q, k, v = qkv.reshape(bw, n, 3, h, c // h).permute(2, 0, 3, 1, 4)
         def additive():
             bias = self.relative_position_bias_table[self.relative_position_index.view(-1)].view(n, n, h).permute(2, 0, 1)  # [h,N,N]
             add = bias.unsqueeze(0)
@@ -105,7 +140,6 @@ class WindowAttention(nn.Module):
                 nw = mask.shape[0]
                 add = (add + mask.unsqueeze(1)).repeat(bw // nw, 1, 1, 1)  # windows of one image are contiguous
             return add.to(q.dtype)
-        tbl = self.relative_position_bias_table
         if tbl.requires_grad:
             add = additive()
         else:

@@ -580,7 +580,32 @@ def bench_ppm(dev, reps):
     return out
 
 
+def bench_wattn(dev, reps):
+    """Window attention of the frozen Swin-B teacher (config 4: 512 x 512 crops, batch 8, 7 x 7 windows) -- csrc/window_attn.hip, one launch per
+    block over the qkv Linear's output.  Bytes = qkv read once + the token-major output written; the shifted blocks also read the mask table
+    (nW x 49 x 49 floats, L2-resident).  The arithmetic (2 x 49 x 49 x 32 packed FMAs per window and head) is ~30 % of the VALU time at stage 1."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    out = []
+    for tag, windows, nw, heads in (('stage 1: 2888 windows x 4 heads', 2888, 361, 4), ('stage 2: 800 windows x 8 heads', 800, 100, 8),
+                                    ('stage 3: 200 windows x 16 heads', 200, 25, 16), ('stage 4: 72 windows x 32 heads', 72, 9, 32)):
+        C = heads * 32
+        gen = torch.Generator(device=dev).manual_seed(5)
+        qkv = torch.randn(windows, 49, 3 * C, device=dev, generator=gen)
+        bias = torch.randn(heads, 49, 49, device=dev, generator=gen)
+        mask = torch.where(torch.rand(nw, 49, 49, device=dev, generator=gen) < 0.3, -100.0, 0.0)
+        o = torch.empty(windows, 49, C, device=dev)
+        nbytes = 4.0 * windows * 49 * C * 4
+        for shifted in (False, True):
+            t = _time(lambda st: _ok(L.sd_window_attn_fwd(qkv.data_ptr(), bias.data_ptr(), mask.data_ptr() if shifted else None, o.data_ptr(), 0,
+                                                          windows, nw if shifted else 0, heads, 49, 32, 32 ** -0.5, st), 'wattn'), reps)
+            out.append(_entry(f'Swin-B window attention fwd, {tag}{" (shifted: mask)" if shifted else ""}', 'window_attn_fwd', [windows, 49, 3 * C],
+                              'f32', t, 'hbm', nbytes, HBM, 'bytes = qkv + out once'))
+    return out
+
+
 GROUPS = {
+    'wattn': lambda dev, reps: bench_wattn(dev, reps),
     'ppm': lambda dev, reps: bench_ppm(dev, reps),
     'wgrad_bf16': lambda dev, reps: bench_wgrad_bf16(dev, reps),
     'r1': lambda dev, reps: bench_r1(dev, reps),
