@@ -11,6 +11,9 @@
 //   backward: GATHER form, deterministic, no atomics, SEPARABLE (rows, then columns, through an fp32 workspace of planes x h x W): every
 //             sum runs over the conservative candidate range of outputs and re-evaluates the forward's own index arithmetic, so forward and
 //             backward agree on every tap by construction.
+// Integer factors 2 / 4 / 8 with align_corners = False (every use inside the BASELINE networks but the PPM's 3- and 6-bin branches) take the
+// gap-wise kernels further down: forward 64-69 % of HBM with streaming stores, ONE backward kernel without the workspace at 46-79 %
+// (profiles/r04_kernels_resize.txt; the generic pair: 23-36 % and 18-28 %).
 // Index arithmetic as ATen's area_pixel_compute_source_index: align_corners ? scale * dst : max(0, scale * (dst + 0.5) - 0.5) with
 // scale = align_corners ? (in - 1) / (out - 1) : in / out in fp32.
 #include <hip/hip_runtime.h>
@@ -161,6 +164,187 @@ __global__ __launch_bounds__(256) void resize_bwd_cols(const float *__restrict__
     VecIO<T>::store1(din + item, acc);
 }
 
+// ---- integer up-sampling factors F in {2, 4, 8}, align_corners = False (round 4) -------------------------------------------
+// Every use of this file inside the BASELINE networks is one of these (UPerHead's top-down path and level fusion: x2, x4, x8; the PPM
+// branches with 1 / 2 bins): the output rows F j - F/2 .. F j + F/2 - 1 lie between tap rows j-1 and j ("gap j", j = 0..h, the first and
+// last being half gaps whose taps clamp), with the tap weight (q + 1/2) / F -- exact in fp32 for a power of two, so these kernels and the
+// generic ones above (ATen's index arithmetic) agree on every weight.  The generic forward spends 16 scalar gathers and four float -> int
+// source-index evaluations per 16-byte store; the generic backward goes through an fp32 workspace of planes x h x W.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+// streaming (non-temporal) stores: the up-sampled map is 4 - 64x the input and is not read again by this kernel
+template <typename T, int F>
+__device__ __forceinline__ void store_row(T *dst, const float (&o)[F]) {
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (F == 2) {
+            __builtin_nontemporal_store(f32x2_t{o[0], o[1]}, reinterpret_cast<f32x2_t *>(dst));
+        } else {
+#pragma unroll
+            for (int e = 0; e < F; e += 4) __builtin_nontemporal_store(f32x4_t{o[e], o[e + 1], o[e + 2], o[e + 3]}, reinterpret_cast<f32x4_t *>(dst + e));
+        }
+    } else {
+        unsigned v[F / 2];
+#pragma unroll
+        for (int e = 0; e < F / 2; ++e) v[e] = (unsigned)f32_to_bf16(o[2 * e]) | ((unsigned)f32_to_bf16(o[2 * e + 1]) << 16);
+        if constexpr (F == 2) __builtin_nontemporal_store(v[0], reinterpret_cast<unsigned *>(dst));
+        else if constexpr (F == 4) __builtin_nontemporal_store(u32x2_t{v[0], v[1]}, reinterpret_cast<u32x2_t *>(dst));
+        else __builtin_nontemporal_store(u32x4_t{v[0], v[1], v[2], v[3]}, reinterpret_cast<u32x4_t *>(dst));
+    }
+}
+
+template <typename T> __device__ __forceinline__ float2 ld2(const T *p);
+// (plain loads: neighbouring windows overlap and the second reader should hit L1 -- non-temporal loads measured 10-90 % slower here)
+template <> __device__ __forceinline__ float2 ld2<float>(const float *p) { return *reinterpret_cast<const float2 *>(p); }
+template <> __device__ __forceinline__ float2 ld2<bf16_t>(const bf16_t *p) {
+    const unsigned v = *reinterpret_cast<const unsigned *>(p);
+    return make_float2(__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ float4 ld4(const T *p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t *p) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(p);
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+}
+
+// forward: one thread per (plane, gap j, FOUR consecutive output columns): lane l of a row writes bytes 16 l .. 16 l + 15 of each of the gap's F
+// output rows, so every store instruction covers whole contiguous lines -- which is what lets the stores be non-temporal (with 32 bytes per
+// lane in two instructions the same kernel ran 2x SLOWER with streaming stores, and 1.5x slower than this form without them).  The four
+// columns lie in one or two x-gaps: taps gx0 - 1 .. gx0 - 1 + NT - 1 of the two tap rows (NT = 4 / 3 / 2 for F = 2 / 4 / 8).
+template <typename T, int F>
+__global__ __launch_bounds__(256) void resize_up_fwd(const T *__restrict__ in, T *__restrict__ out, int h, int w) {
+    constexpr int LF = F == 2 ? 1 : F == 4 ? 2 : 3, NT = F == 2 ? 4 : F == 4 ? 3 : 2;
+    const int wq = F * w / 4;
+    const int item = (int)blockIdx.y * 256 + (int)threadIdx.x;      // within the plane: 32-bit index arithmetic
+    if (item >= (h + 1) * wq) return;
+    const int j = item / wq, c = item - j * wq;
+    const long p = blockIdx.x;
+    const T *src = in + p * (long)h * w;
+    const T *r0 = src + (long)max(j - 1, 0) * w, *r1 = src + (long)min(j, h - 1) * w;
+    const int gx0 = (4 * c + F / 2) >> LF;                           // x-gap of the first column; taps gx0 - 1, gx0, ...
+    float t0[NT], t1[NT];
+#pragma unroll
+    for (int e = 0; e < NT; ++e) {
+        const int x = min(max(gx0 - 1 + e, 0), w - 1);
+        t0[e] = VecIO<T>::load1(r0 + x);
+        t1[e] = VecIO<T>::load1(r1 + x);
+    }
+    float top[4], bot[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        constexpr int kRel[3][4] = {{0, 1, 1, 2}, {0, 0, 1, 1}, {0, 0, 0, 0}};      // x-gap of column e relative to gx0, per F
+        const int rel = kRel[LF - 1][e];
+        const int q = (4 * c + e + F / 2) & (F - 1);
+        const float l1 = (gx0 + rel) > 0 ? (q + 0.5f) * (1.f / F) : 0.f, l0 = 1.f - l1;      // gap 0: the source index clamps to 0 (weights 1, 0)
+        top[e] = l0 * t0[rel] + l1 * t0[rel + 1];
+        bot[e] = l0 * t1[rel] + l1 * t1[rel + 1];
+    }
+    const int H = F * h, W = F * w;
+    T *dst = out + p * (long)H * W + 4 * c;
+#pragma unroll
+    for (int q = 0; q < F; ++q) {
+        const int Y = F * j - F / 2 + q;
+        if (Y < 0 || Y >= H) continue;
+        const float l1 = j > 0 ? (q + 0.5f) / F : 0.f, l0 = 1.f - l1;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = l0 * top[e] + l1 * bot[e];
+        store_row<T, 4>(dst + (long)Y * W, o);
+    }
+}
+
+// weight of output index F k - F/2 + t (t = 0 .. 2F-1: gap k, then gap k + 1) on tap k of n taps; the edge taps also collect the clamped halves
+template <int F>
+__device__ __forceinline__ float up_weight(int t, int k, int n) {
+    if (t < F) {
+        const float l = (t + 0.5f) / F;
+        return k == 0 ? 1.f : l;                         // gap 0: both taps are tap 0
+    }
+    const float l = (t - F + 0.5f) / F;
+    return k == n - 1 ? 1.f : 1.f - l;                   // gap n: both taps are tap n - 1
+}
+
+// sum over x of one output-gradient row onto KT taps starting at k0: the window F k0 - F/2 .. F (k0 + KT) + F/2 - 1 comes straight from global
+// memory in the widest loads its alignment allows (neighbouring threads overlap by F values: L1 hits); out-of-row halves read as 0
+template <typename T, int F, int KT>
+__device__ __forceinline__ void fold_x(const T *__restrict__ row, int k0, int w, float (&acc)[KT]) {
+    constexpr int LW = F * KT + F;
+    const int W = F * w, X0 = F * k0 - F / 2;
+    float v[LW];
+    if constexpr (F == 2) {                              // KT == 2: X0 = 4 m - 1
+        v[0] = X0 >= 0 ? VecIO<T>::load1(row + X0) : 0.f;
+        const float4 c = ld4<T>(row + X0 + 1);
+        v[1] = c.x, v[2] = c.y, v[3] = c.z, v[4] = c.w;
+        v[5] = X0 + 5 < W ? VecIO<T>::load1(row + X0 + 5) : 0.f;
+    } else if constexpr (F == 4) {                       // X0 = 4 k - 2
+        const float2 a = X0 >= 0 ? ld2<T>(row + X0) : make_float2(0.f, 0.f);
+        const float4 b = ld4<T>(row + X0 + 2);
+        const float2 c = X0 + 6 < W ? ld2<T>(row + X0 + 6) : make_float2(0.f, 0.f);
+        v[0] = a.x, v[1] = a.y, v[2] = b.x, v[3] = b.y, v[4] = b.z, v[5] = b.w, v[6] = c.x, v[7] = c.y;
+    } else {                                             // F == 8: X0 = 8 k - 4
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 a = X0 >= 0 ? ld4<T>(row + X0) : z, b = ld4<T>(row + X0 + 4), c = ld4<T>(row + X0 + 8), d = X0 + 12 < W ? ld4<T>(row + X0 + 12) : z;
+        v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+        v[8] = c.x, v[9] = c.y, v[10] = c.z, v[11] = c.w, v[12] = d.x, v[13] = d.y, v[14] = d.z, v[15] = d.w;
+    }
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2 * F; ++t) s = fmaf(up_weight<F>(t, k0 + c, w), v[F * c + t], s);
+        acc[c] = s;
+    }
+}
+
+// backward, ONE kernel, no workspace: a workgroup owns R input rows of one plane (the whole plane when its x-folded rows fit 48 KB of LDS).  Pass 1
+// folds every output-gradient row that touches them along x into tmp[row][w] in LDS (fold_x: global -> registers, consecutive lanes write
+// consecutive words); pass 2 folds 2F of those rows along y into each input row, written contiguously.  Adjacent bands re-read F rows.
+template <typename T, int F, int KT>
+__global__ __launch_bounds__(256) void resize_up_bwd(const T *__restrict__ dout, T *__restrict__ din, int h, int w, int R, int bands) {
+    extern __shared__ __attribute__((aligned(16))) float up_lds[];
+    const int W = F * w, H = F * h, wk = w / KT;
+    const long p = blockIdx.x / bands;
+    const int j0 = (int)(blockIdx.x % bands) * R, j1 = min(j0 + R, h);
+    const int Ylo = max(0, F * j0 - F / 2), Yhi = min(H, F * (j1 - 1) + 3 * F / 2 + (j1 == h ? F : 0));
+    const int nrows = Yhi - Ylo;
+    const T *g = dout + (p * H + Ylo) * (long)W;
+    for (int it = threadIdx.x; it < nrows * wk; it += 256) {
+        const int r = it / wk, m = it - r * wk;
+        float acc[KT];
+        fold_x<T, F, KT>(g + (long)r * W, KT * m, w, acc);
+#pragma unroll
+        for (int c = 0; c < KT; ++c) up_lds[(size_t)r * w + KT * m + c] = acc[c];
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < (j1 - j0) * w; it += 256) {
+        const int jj = it / w, k = it - jj * w, j = j0 + jj;
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2 * F; ++t) {
+            const int Y = F * j - F / 2 + t;
+            if (Y >= 0 && Y < H) acc = fmaf(up_weight<F>(t, j, h), up_lds[(size_t)(Y - Ylo) * w + k], acc);
+        }
+        VecIO<T>::store1(din + (p * h + j) * (long)w + k, acc);
+    }
+}
+
+// integer factor of the fast path (0: not covered), and rows per workgroup of its backward for ~40 KB of LDS
+int up_factor(int h, int w, int H, int W, int align, int dtype, const void *a, const void *b) {
+    if (align || h <= 0 || w <= 0 || H % h || W % w || H / h != W / w) return 0;
+    const int F = H / h;
+    if (F != 2 && F != 4 && F != 8) return 0;
+    const size_t es = dtype == SD_F32 ? 4 : 2;
+    if ((W * es) % 16 || ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15)) return 0;
+    return F;
+}
+int up_band_rows(int h, int w, int F) {
+    const long budget = 48 * 1024 / ((long)w * 4);       // x-folded rows that fit
+    if ((long)F * h <= budget) return h;                   // the whole plane: nothing is read twice
+    const long R = (budget - F - F / 2) / F;
+    return R < 1 ? 0 : (int)(R > h ? h : R);
+}
+
 float scale_of(int n_in, int n_out, int align) {
     if (align) return n_out > 1 ? (float)(n_in - 1) / (float)(n_out - 1) : 0.f;
     return (float)n_in / (float)n_out;
@@ -180,6 +364,16 @@ int sd_resize_bilinear_fwd(const void *in, void *out, int dtype, long planes, in
     if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & (dtype == SD_F32 ? 15 : 7))) return SD_E_ALIGN;
     const float sy = sd::scale_of(h, H, align_corners), sx = sd::scale_of(w, W, align_corners);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (const int F = sd::up_factor(h, w, H, W, align_corners, dtype, in, out)) {
+        if (planes <= 0x7fffffffL && ((long)(h + 1) * (W / 4) + 255) / 256 <= 65535) {
+            const dim3 b(256);
+#define SD_UPF(T, FF) hipLaunchKernelGGL((sd::resize_up_fwd<T, FF>), dim3((unsigned)planes, (unsigned)(((h + 1) * (W / 4) + 255) / 256)), b, 0, st, (const T *)in, (T *)out, h, w)
+            if (dtype == SD_F32) { if (F == 2) SD_UPF(float, 2); else if (F == 4) SD_UPF(float, 4); else SD_UPF(float, 8); }
+            else { if (F == 2) SD_UPF(sd::bf16_t, 2); else if (F == 4) SD_UPF(sd::bf16_t, 4); else SD_UPF(sd::bf16_t, 8); }
+#undef SD_UPF
+            return (int)hipGetLastError();
+        }
+    }
     const unsigned grid = (unsigned)((items + 255) / 256);
     if (dtype == SD_F32)
         hipLaunchKernelGGL(sd::resize_bilinear_fwd<float>, dim3(grid), dim3(256), 0, st, (const float *)in, (float *)out, planes, h, w, H, W, sy, sx,
@@ -206,6 +400,19 @@ int sd_resize_bilinear_bwd(const void *dout, void *din, int dtype, long planes, 
     if ((items1 + 255) / 256 > 0x7fffffffL) return SD_E_SHAPE;
     const float sy = sd::scale_of(h, H, align_corners), sx = sd::scale_of(w, W, align_corners);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (const int F = sd::up_factor(h, w, H, W, align_corners, dtype, dout, din)) {
+        const int R = sd::up_band_rows(h, w, F);
+        const long bands = R ? (h + R - 1) / R : 0;
+        if (R && planes * bands <= 0x7fffffffL) {
+            const size_t lds = (size_t)((R + 1) * F < H ? (R + 1) * F : H) * (size_t)w * sizeof(float);      // <= 48 KB (up_band_rows)
+            const dim3 g((unsigned)(planes * bands)), b(256);
+#define SD_UPB(T, FF, KK) hipLaunchKernelGGL((sd::resize_up_bwd<T, FF, KK>), g, b, lds, st, (const T *)dout, (T *)din, h, w, R, (int)bands)
+            if (dtype == SD_F32) { if (F == 2) SD_UPB(float, 2, 2); else if (F == 4) SD_UPB(float, 4, 1); else SD_UPB(float, 8, 1); }
+            else { if (F == 2) SD_UPB(sd::bf16_t, 2, 2); else if (F == 4) SD_UPB(sd::bf16_t, 4, 1); else SD_UPB(sd::bf16_t, 8, 1); }
+#undef SD_UPB
+            return (int)hipGetLastError();
+        }
+    }
     float *tmp = static_cast<float *>(workspace);
     const unsigned g1 = (unsigned)((items1 + 255) / 256), g2 = (unsigned)((items2 + 255) / 256);
     const int al = align_corners ? 1 : 0;

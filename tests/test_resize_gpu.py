@@ -10,6 +10,10 @@ pytestmark = pytest.mark.gpu
 CASES = [  # B, C, h, w, H, W
     (2, 5, 16, 16, 64, 64), (1, 3, 6, 6, 16, 16), (2, 4, 1, 1, 8, 8), (1, 7, 2, 3, 64, 64), (2, 3, 33, 20, 128, 100), (1, 2, 40, 56, 128, 128),
     (1, 4, 64, 64, 16, 16), (2, 2, 30, 50, 17, 23), (1, 3, 16, 16, 128, 128), (1, 2, 17, 9, 17, 31), (1, 6, 3, 3, 512, 512),
+    # integer factors 2 / 4 / 8 (round 4: the gap-wise forward and the one-kernel LDS backward): several bands per plane with a ragged last
+    # one, one-row and one-column maps, widths whose rows are / are not 16-byte multiples (the latter stay on the generic kernels)
+    (2, 3, 64, 64, 128, 128), (1, 2, 7, 10, 14, 20), (1, 3, 5, 6, 40, 48), (3, 2, 33, 12, 132, 48), (1, 2, 64, 64, 256, 256), (1, 2, 1, 16, 2, 32),
+    (1, 2, 16, 1, 128, 8), (1, 1, 100, 8, 200, 16), (1, 2, 3, 3, 6, 6),
 ]
 
 

@@ -481,7 +481,8 @@ def bench_resize(dev, reps):
     from segdistill_amd import _lib
     L = _lib.lib()
     out = []
-    for (B, C, h, H, tag) in ((8, 512, 64, 128, 'UPerHead level fusion'), (8, 512, 16, 128, 'UPerHead coarsest level x8'), (8, 128, 6, 64, 'PPM branch 6x6 -> 64x64')):
+    for (B, C, h, H, tag) in ((8, 512, 64, 128, 'UPerHead level fusion x2'), (8, 512, 32, 128, 'UPerHead level x4'), (8, 512, 16, 128, 'UPerHead coarsest level x8'),
+                              (8, 128, 6, 64, 'PPM branch 6x6 -> 64x64')):
         x = torch.randn(B, C, h, h, device=dev)
         y = torch.empty(B, C, H, H, device=dev)
         dx = torch.empty_like(x)
@@ -492,7 +493,7 @@ def bench_resize(dev, reps):
         nb_in, nb_out = x.numel() * 4, y.numel() * 4
         out += [_entry(f'bilinear resize fwd ({tag})', 'resize_bilinear_fwd', [B, C, h, h, H, H], 'f32', tf, 'hbm', nb_in + nb_out, HBM),
                 _entry(f'bilinear resize bwd ({tag})', 'resize_bilinear_bwd', [B, C, h, h, H, H], 'f32', tb, 'hbm', nb_in + nb_out, HBM,
-                       'separable gather: rows then columns through an fp32 workspace of B*C*h*W elements (extra traffic)')]
+                       'integer factors: one kernel, x-fold from global, y-fold through LDS; other sizes: separable gather through an fp32 workspace')]
     return out
 
 
