@@ -430,6 +430,17 @@ int sd_layernorm_bwd(const void *x, const void *dy, const float *gamma, const fl
                      void *dx, float *dgamma, float *dbeta, int dtype, long rows, int C,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* Inference form with row maps -- the Swin blocks of a frozen network (reference mmseg/models/backbones/swin_transformer.py:195-262).  Per image
+ * (`images` of them) output row r in [0, rows_out) normalises
+ *     v = x[xi] (+ res[ri]),   xi = x_map ? x_map[r] : r,   ri = res_map ? res_map[r] : xi        (x: rows_in rows, res: rows_res rows per image)
+ * writes y[r] = LayerNorm(v) and, when res != NULL, xsum[xi] = v.  xi == rows_in marks a padding row: y[r] = 0, nothing else is touched.
+ *   x_map = window-partition table: pad (:206-210) + cyclic shift (:213-215) + window_partition (:222) of norm1(x [+ pending residual]);
+ *   res_map = its inverse: x + un-pad / un-shift / window_reverse (:233-247) of the attention output, then norm2 (:250).
+ * Maps are int32, values in [0, rows_in] / [0, rows_res); x_map must hit every row of x at most once when res is given.  No saved statistics. */
+int sd_layernorm_map_fwd(const void *x, const void *res /* or NULL */, void *xsum /* or NULL */, const float *gamma, const float *beta, void *y,
+                         const int32_t *x_map /* [rows_out] or NULL */, const int32_t *res_map /* [rows_out] or NULL */, int dtype, long images,
+                         int rows_out, int rows_in, int rows_res, int C, float eps, void *stream);
+
 /* Residual form: the encoder block's "x = x + drop_path(f(x))" (mix_transformer.py:150-151; timm DropPath: per-sample
  * factor mask/keep_prob) fused with the LayerNorm that consumes the sum (the block's norm2, the next block's norm1 or the
  * stage norm :336-365):

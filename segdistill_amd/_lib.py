@@ -44,6 +44,7 @@ SIGNATURES = {
     'sd_ppm_pool_supported': (_i, [_i, _i, _vp, _i]),
     'sd_ppm_pool_fwd': (_i, [_vp, _i, C.c_long, _i, _i, _vp, _i, _vp, _vp]),
     'sd_ppm_pool_bwd': (_i, [_vp, _i, C.c_long, _i, _i, _vp, _i, _vp, _vp]),
+    'sd_layernorm_map_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_long, _i, _i, _i, _i, _f, _vp]),
     'sd_window_attn_supported': (_i, [_i, _i]),
     'sd_window_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _i, C.c_long, _i, _i, _i, _i, _f, _vp]),
     'sd_cgd_kl_tok_workspace_bytes': (_sz, [_i, _i, C.c_long]),

@@ -249,7 +249,17 @@ class OverlapPatchEmbed(nn.Module):
             self.proj.weight.data = self.proj.weight.data.contiguous(memory_format=torch.channels_last)
 
     def forward(self, x):
-        x = self.proj(x)
+        p = self.proj
+        if (x.is_cuda and torch.is_autocast_enabled() and p.weight.dtype == torch.float32 and not p.weight.requires_grad
+                and (p.bias is None or not p.bias.requires_grad) and not (p._forward_hooks or p._forward_pre_hooks)):
+            # frozen network under low-precision storage (the config-5 teacher): autocast would cast filter and bias again on every call --
+            # 8 cast kernels per step for the four stages; the copies are cached per parameter (frozen_derived; strides preserved)
+            dt = torch.get_autocast_dtype('cuda')
+            w = frozen_derived(p.weight, ('cast', dt), lambda: p.weight.to(dt))
+            b = None if p.bias is None else frozen_derived(p.bias, ('cast', dt), lambda: p.bias.to(dt))
+            x = F.conv2d(x if x.dtype == dt else x.to(dt), w, b, p.stride, p.padding, p.dilation, p.groups)
+        else:
+            x = p(x)
         hw = tuple(x.shape[2:])
         return self.norm(tokens_of(x)), hw
 

@@ -21,12 +21,13 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..builder import BACKBONES
-from ..layernorm import HipLayerNorm          # nn.LayerNorm subclass: same keys, HIP kernels on CUDA tokens (ATen's ran 3.9 ms of a config-4 step)
+from ..layernorm import HipLayerNorm, layernorm_map, map_supported          # nn.LayerNorm subclass: same keys, HIP kernels on CUDA tokens (ATen's ran 3.9 ms of a config-4 step)
 from .. import window_attn
 from ..layers import DropPath, to_2tuple, trunc_normal_
 
 
 _GATHER_WINDOWS = os.environ.get('SEGDISTILL_SWIN_GATHER', '1') == '1'
+_FUSE_NORMS = os.environ.get('SEGDISTILL_SWIN_FUSE_NORMS', '1') == '1'      # A/B: 0 = LayerNorm, zero-row cat, index_select and add as separate kernels
 _TABLES = {}
 
 
@@ -45,7 +46,8 @@ def _window_tables(h, w, ws, shift, device):
         fwd = window_partition(idx, ws).reshape(-1)
         inv = torch.empty(h * w + 1, dtype=torch.long)
         inv[fwd] = torch.arange(fwd.numel())
-        hit = (fwd.to(device), inv[:h * w].contiguous().to(device))
+        fwd, inv = fwd.to(device), inv[:h * w].contiguous().to(device)
+        hit = (fwd, inv, fwd.int(), inv.int())          # int32 copies: the row maps of layernorm_map
         _TABLES[key] = hit
     return hit
 
@@ -174,6 +176,27 @@ class SwinTransformerBlock(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio), drop)
         self.H = self.W = None
 
+    def fusable(self, x):
+        """no graph to build, nothing stochastic, both norms on the HIP kernels: forward_fused applies"""
+        return (_GATHER_WINDOWS and _FUSE_NORMS and (not self.training or isinstance(self.drop_path, nn.Identity))
+                and map_supported(x, self.norm1) and map_supported(x, self.norm2))
+
+    def forward_fused(self, x, mask_matrix, pending=None):
+        """The block of a frozen network as  norm1 + pad + shift + window partition  (one kernel, folding in the previous block's pending MLP
+        residual), qkv / attention / proj,  window reverse + un-shift + un-pad + residual add + norm2  (one kernel), MLP.  Returns
+        (x after the attention residual, MLP output): the caller adds the second to the first -- the next block does it inside its first
+        kernel.  Replaces per block: LayerNorm, zero-row cat, two index_selects and two adds."""
+        b, n, c = x.shape
+        h, w, ws = self.H, self.W, self.window_size
+        assert n == h * w, 'input feature has wrong size'
+        _, _, fwd32, inv32 = _window_tables(h, w, ws, self.shift_size, x.device)
+        xs, win = layernorm_map(x, self.norm1, res=pending, x_map=fwd32)
+        if xs is None:
+            xs = x
+        att = self.attn(win.view(-1, ws * ws, c), mask=mask_matrix if self.shift_size > 0 else None)
+        x1, y2 = layernorm_map(xs, self.norm2, res=att.view(b, -1, c), res_map=inv32)
+        return x1, self.mlp(y2)
+
     def forward(self, x, mask_matrix):
         b, n, c = x.shape
         h, w = self.H, self.W
@@ -184,7 +207,7 @@ class SwinTransformerBlock(nn.Module):
             # no autograd graph to build (the frozen teacher): pad + cyclic shift + window partition are ONE row gather (they were three
             # copies), window reverse + un-shift + un-pad another (index tables cached per geometry; padded positions read an appended
             # zero row, exactly what F.pad produced)
-            fwd_idx, inv_idx = _window_tables(h, w, ws, self.shift_size, x.device)
+            fwd_idx, inv_idx = _window_tables(h, w, ws, self.shift_size, x.device)[:2]
             y = self.norm1(x)
             y = torch.cat([y, y.new_zeros(b, 1, c)], 1) if (pad_r or pad_b) else y
             win = y.index_select(1, fwd_idx).view(-1, ws * ws, c)
@@ -262,9 +285,17 @@ class BasicLayer(nn.Module):
         ws = self.window_size
         hp, wp = -(-h // ws) * ws, -(-w // ws) * ws
         mask = self._shift_mask(hp, wp, x.device)
+        pend = None                                    # MLP output of the previous fused block, not yet added to x
         for blk in self.blocks:
             blk.H, blk.W = h, w
+            if blk.fusable(x):
+                x, pend = blk.forward_fused(x, mask, pend)
+                continue
+            if pend is not None:
+                x, pend = x + pend, None
             x = blk(x, mask)
+        if pend is not None:
+            x = x + pend
         if self.downsample is not None:
             return x, h, w, self.downsample(x, h, w), (h + 1) // 2, (w + 1) // 2
         return x, h, w, x, h, w

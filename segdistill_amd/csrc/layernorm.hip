@@ -129,6 +129,75 @@ __global__ __launch_bounds__(kLnThreads) void ln_fwd(const T *__restrict__ x, co
     if (gl == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 
+// Inference form with ROW MAPS (round 4: the Swin blocks of a frozen network, reference swin_transformer.py:195-262).  Output row r of image b
+// (L_out rows per image) normalises
+//     v = x[b][xi] (+ res[b][ri]),   xi = x_map ? x_map[r] : r,   ri = res_map ? res_map[r] : xi
+// and, with res, also writes v to xsum[b][xi].  xi == L_in (one past the image's rows) means "padding": the output row is zeros and nothing
+// else is read or written.  With x_map = the window-partition table this is  pad + cyclic shift + window_partition(norm1(x [+ pending]))  in
+// one pass (:206-221); with res_map = its inverse it is  x + window_reverse / un-shift / un-pad (attention output)  followed by norm2
+// (:232-250).  No mean / rstd outputs: there is no backward.
+template <typename T, int G, int V>
+__global__ __launch_bounds__(kLnThreads) void ln_map_fwd(const T *__restrict__ x, const T *__restrict__ res, T *__restrict__ xsum,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta, T *__restrict__ y,
+                                                          const int *__restrict__ x_map, const int *__restrict__ res_map, long rows_out, int L_out,
+                                                          int L_in, int L_res, int C, float eps) {
+    const int gl = threadIdx.x % G;
+    const long row = (long)blockIdx.x * (kLnThreads / G) + threadIdx.x / G;
+    if (row >= rows_out) return;                       // whole row groups leave together (the sums below are group-wide shuffles)
+    const int cv = C / 4;
+    const long b = row / L_out;
+    const int r = (int)(row - b * L_out);
+    const int xi = x_map ? x_map[r] : r;
+    if (xi >= L_in) {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int j = gl + i * G;
+            if (j < cv) LV<T>::store(y + row * C + 4 * j, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        return;
+    }
+    const long xrow = b * L_in + xi;
+    const long rrow = res ? b * L_res + (res_map ? res_map[r] : xi) : 0;
+    float4 v[V];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int j = gl + i * G;
+        v[i] = j < cv ? LV<T>::load(x + xrow * C + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res && j < cv) {
+            const float4 rv = LV<T>::load(res + rrow * C + 4 * j);
+            v[i].x += rv.x; v[i].y += rv.y; v[i].z += rv.z; v[i].w += rv.w;
+            LV<T>::store(xsum + xrow * C + 4 * j, v[i]);
+            v[i] = LV<T>::round(v[i]);
+        }
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = group_sum<G>(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int j = gl + i * G;
+        if (j < cv) {
+            const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + bb * bb + c * c + d * d;
+        }
+    }
+    const float rstd = rsqrtf(group_sum<G>(q) / C + eps);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int j = gl + i * G;
+        if (j < cv) {
+            const float4 g = *reinterpret_cast<const float4 *>(gamma + 4 * j), bt = *reinterpret_cast<const float4 *>(beta + 4 * j);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * g.x + bt.x;
+            o.y = (v[i].y - mean) * rstd * g.y + bt.y;
+            o.z = (v[i].z - mean) * rstd * g.z + bt.z;
+            o.w = (v[i].w - mean) * rstd * g.w + bt.w;
+            LV<T>::store(y + row * C + 4 * j, o);
+        }
+    }
+}
+
 // grid: nblk workgroups, each walking rows blockIdx.x*RPB + k*gridDim.x*RPB ...; partial dgamma/dbeta per workgroup in
 // part[blk][2][C] (gamma first).
 // Residual form: dres (nullable) is the gradient that reaches the normalised row from its OTHER consumer (the residual path) and is
@@ -303,6 +372,18 @@ int ln_fwd_launch(const void *x, const void *res, const float *row_scale, long r
 }
 
 template <typename T>
+int ln_map_launch(const void *x, const void *res, void *xsum, const float *gamma, const float *beta, void *y, const int *x_map, const int *res_map,
+                  long rows_out, int L_out, int L_in, int L_res, int C, float eps, hipStream_t st) {
+    const LnPlan p = ln_plan(C);
+#define SD_CALL(GG, VV)                                                                                                                  \
+    hipLaunchKernelGGL((ln_map_fwd<T, GG, VV>), dim3((unsigned)((rows_out + kLnThreads / GG - 1) / (kLnThreads / GG))), dim3(kLnThreads), 0, st, \
+                       (const T *)x, (const T *)res, (T *)xsum, gamma, beta, (T *)y, x_map, res_map, rows_out, L_out, L_in, L_res, C, eps)
+    SD_LN_DISPATCH(SD_CALL);
+#undef SD_CALL
+    return (int)hipGetLastError();
+}
+
+template <typename T>
 int ln_bwd_launch(const void *x, const void *dy, const float *gamma, const float *mean, const float *rstd, const void *dres,
                   const float *row_scale, long rows_per_sample, void *dx, void *dr, float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
                   long rows, int C, hipStream_t st, const void *dy2 = nullptr, PatchGeom pg = PatchGeom{0, 0, -1}) {
@@ -424,6 +505,24 @@ int sd_add_layernorm_fwd(const void *x, const void *res, const float *row_scale,
     if (dtype == SD_F32)
         return sd::ln_fwd_launch<float>(x, res, row_scale, rows_per_sample, xsum, gamma, beta, y, mean, rstd, rows, C, eps, st);
     return sd::ln_fwd_launch<sd::bf16_t>(x, res, row_scale, rows_per_sample, xsum, gamma, beta, y, mean, rstd, rows, C, eps, st);
+}
+
+int sd_layernorm_map_fwd(const void *x, const void *res, void *xsum, const float *gamma, const float *beta, void *y, const int32_t *x_map,
+                         const int32_t *res_map, int dtype, long images, int rows_out, int rows_in, int rows_res, int C, float eps, void *stream) {
+    if (images <= 0 || rows_out <= 0 || rows_in <= 0) return SD_E_SHAPE;
+    int rc = sd::check_ln(x, y, dtype, images * rows_out, C);
+    if (rc) return rc;
+    if (!gamma || !beta) return SD_E_NULL;
+    if (res) {
+        if (!xsum) return SD_E_NULL;
+        if (rows_res <= 0) return SD_E_SHAPE;
+        if ((reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(xsum)) & 15) return SD_E_ALIGN;
+    }
+    if (!x_map && rows_out != rows_in) return SD_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SD_F32)
+        return sd::ln_map_launch<float>(x, res, xsum, gamma, beta, y, x_map, res_map, images * rows_out, rows_out, rows_in, rows_res, C, eps, st);
+    return sd::ln_map_launch<sd::bf16_t>(x, res, xsum, gamma, beta, y, x_map, res_map, images * rows_out, rows_out, rows_in, rows_res, C, eps, st);
 }
 
 int sd_layernorm_bwd(const void *x, const void *dy, const float *gamma, const float *mean, const float *rstd, void *dx, float *dgamma,

@@ -130,6 +130,38 @@ def add_layernorm(x, res, norm, scale=None):
     return _AddLayerNormFn.apply(x, res, scale, norm.weight, norm.bias, norm.eps)
 
 
+# ---- inference LayerNorm with row maps: the Swin blocks of a frozen network (round 4) ---------------------------------------------------------------
+def map_supported(x, norm):
+    return (isinstance(norm, HipLayerNorm) and x.is_cuda and x.dtype in _DT and x.dim() == 3 and norm.elementwise_affine and norm.bias is not None
+            and len(norm.normalized_shape) == 1 and norm.normalized_shape[0] == x.shape[-1] and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024
+            and x.numel() > 0 and not (torch.is_grad_enabled() and (x.requires_grad or norm.weight.requires_grad))
+            and not (norm._forward_hooks or norm._forward_pre_hooks))
+
+
+def layernorm_map(x, norm, res=None, x_map=None, res_map=None, rows_out=None):
+    """No-graph LayerNorm over gathered rows (csrc/layernorm.hip::ln_map_fwd).  x [B, L, C]; per image, output row r normalises
+    x[x_map[r]] (+ res[res_map[r]], default the same row as x) -- x_map value L = a zero output row (window padding).  Returns
+    (xsum [B, L, C] = x + gathered res, or None without res;  y [B, rows_out, C])."""
+    B, L, C = x.shape
+    xc = x.contiguous()
+    n_out = int(rows_out if rows_out is not None else (x_map.numel() if x_map is not None else L))
+    y = torch.empty(B, n_out, C, dtype=x.dtype, device=x.device)
+    rc_, xsum, L_res = None, None, 0
+    if res is not None:
+        rc_ = (res if res.dtype == x.dtype else res.to(x.dtype)).contiguous()
+        L_res = rc_.shape[1]
+        xsum = torch.empty_like(xc)
+    from .layers import frozen_derived
+    w = norm.weight if norm.weight.dtype == torch.float32 else frozen_derived(norm.weight, 'f32', lambda: norm.weight.detach().float())
+    b = norm.bias if norm.bias.dtype == torch.float32 else frozen_derived(norm.bias, 'f32', lambda: norm.bias.detach().float())
+    rc = _lib.lib().sd_layernorm_map_fwd(xc.data_ptr(), None if rc_ is None else rc_.data_ptr(), None if xsum is None else xsum.data_ptr(),
+                                         w.data_ptr(), b.data_ptr(), y.data_ptr(), None if x_map is None else x_map.data_ptr(),
+                                         None if res_map is None else res_map.data_ptr(), _DT[xc.dtype], B, n_out, L, L_res, C, float(norm.eps),
+                                         _stream_ptr())
+    _lib.check(rc, 'sd_layernorm_map_fwd')
+    return xsum, y
+
+
 # ---- LayerNorm whose consumer is a spatial-reduction attention: the output is also produced in the SR conv's patch order (round 3) -------------
 def patch_supported(x, hw, r):
     return (x.is_cuda and x.dtype in _DT and x.dim() == 3 and r > 1 and x.shape[1] == hw[0] * hw[1]

@@ -220,3 +220,47 @@ def test_mit_stage_with_patch_fused_norms_matches_the_gather_copy_path():
     for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         assert pa.grad is not None and pb.grad is not None, n
         assert float((pa.grad - pb.grad).norm()) <= 2e-5 * float(pb.grad.norm()) + 1e-8, n
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('C', [96, 128, 512, 1024])
+def test_layernorm_map_is_gather_add_layer_norm(dtype, C):
+    """csrc/layernorm.hip::ln_map_fwd (the Swin blocks of a frozen network): output rows gathered through x_map (value L = a zero row), a
+    residual gathered through res_map, the sum written back in x's order -- against index_select / add / F.layer_norm in fp64."""
+    from segdistill_amd.layernorm import HipLayerNorm, layernorm_map, map_supported
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device=dev).manual_seed(C)
+    B, L, n_out = 3, 37, 49
+    norm = HipLayerNorm(C).to(dev)
+    with torch.no_grad():
+        norm.weight.copy_(torch.randn(C, device=dev, generator=g))
+        norm.bias.copy_(torch.randn(C, device=dev, generator=g))
+    x = torch.randn(B, L, C, device=dev, generator=g).to(dtype)
+    pend = torch.randn(B, L, C, device=dev, generator=g).to(dtype)
+    perm = torch.randperm(n_out, device=dev, generator=g)
+    x_map = torch.full((n_out,), L, dtype=torch.int32, device=dev)
+    x_map[perm[:L]] = torch.arange(L, dtype=torch.int32, device=dev)          # every row of x exactly once, 12 padding rows
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    with torch.no_grad():
+        assert map_supported(x, norm)
+        # (a) norm(x + pending) gathered into n_out rows with zero padding rows; the sum comes back in token order
+        xs, y = layernorm_map(x, norm, res=pend, x_map=x_map)
+        s64 = x.double() + pend.double()
+        assert float((xs.double() - s64).abs().max()) <= tol * float(s64.abs().max())
+        ref = torch.nn.functional.layer_norm(xs.double(), (C,), norm.weight.double(), norm.bias.double(), norm.eps)
+        ref = torch.cat([ref, ref.new_zeros(B, 1, C)], 1).index_select(1, x_map.long())
+        assert float((y.double() - ref).abs().max()) <= tol * float(ref.abs().max())
+        assert float(y[:, x_map == L].abs().max()) == 0.0
+        # without a residual nothing is written back
+        xs0, y0 = layernorm_map(x, norm, x_map=x_map)
+        assert xs0 is None and y0.shape == (B, n_out, C)
+        # (b) x + res gathered through the inverse map, then the norm, in token order
+        win = torch.randn(B, n_out, C, device=dev, generator=g).to(dtype)
+        inv = torch.empty(L, dtype=torch.int32, device=dev)
+        inv[x_map[x_map < L].long()] = torch.nonzero(x_map < L).flatten().int()
+        xs2, y2 = layernorm_map(x, norm, res=win, res_map=inv)
+        s64 = x.double() + win.double().index_select(1, inv.long())
+        assert float((xs2.double() - s64).abs().max()) <= tol * float(s64.abs().max())
+        ref2 = torch.nn.functional.layer_norm(xs2.double(), (C,), norm.weight.double(), norm.bias.double(), norm.eps)
+        assert float((y2.double() - ref2).abs().max()) <= tol * float(ref2.abs().max())
+    assert not map_supported(x.requires_grad_(True), norm)                     # a graph to build: the autograd modules

@@ -30,6 +30,20 @@ def test_frozen_swin_gather_path_equals_the_module_chain(size):
             swin._GATHER_WINDOWS = True
     for a, b in zip(outs[True], outs[False]):
         assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+    # round 4: the fused block form (norm1 + window partition in one kernel, window reverse + residual + norm2 in another, the MLP residual
+    # folded into the next block's first kernel) against the separate kernels: the same arithmetic on the same values
+    fused = outs[True]
+    swin._FUSE_NORMS = False
+    try:
+        with torch.no_grad():
+            plain = net(img)
+    finally:
+        swin._FUSE_NORMS = True
+    for a, b in zip(fused, plain):
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+    blk = net.layers[0].blocks[0]
+    blk.H = blk.W = 8
+    assert blk.fusable(torch.zeros(1, 64, 32, device='cuda:0'))
     # a trainable Swin keeps the autograd-friendly chain (index_select's backward would be an atomic scatter)
     for p in net.parameters():
         p.requires_grad = True

@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--config', default='configs/kd/cfg5_segformer_b4_b1_multistage_bf16.py')
 ap.add_argument('--ops', default='copy_,_to_copy')
 ap.add_argument('--min-numel', type=int, default=1024)
+ap.add_argument('--graph', action='store_true', help='log what gets CAPTURED into the step hipGraph (trainer.enable_graph) instead of an eager step')
 a = ap.parse_args()
 want = set(a.ops.split(','))
 groups = collections.Counter()
@@ -32,7 +33,7 @@ class Log(TorchDispatchMode):
         if name in want:
             ts = [t for t in args if isinstance(t, torch.Tensor)]
             o = out if isinstance(out, torch.Tensor) else (ts[0] if ts else None)
-            if o is not None and o.is_cuda and o.numel() >= a.min_numel:
+            if o is not None and o.is_cuda and o.numel() >= a.min_numel and (not a.graph or torch.cuda.is_current_stream_capturing()):
                 if name in ('copy_', '_to_copy') and len(ts) >= 1:
                     src = ts[-1]
                     if name == 'copy_' and len(ts) >= 2 and ts[0].dtype == ts[1].dtype and ts[1].is_contiguous() and ts[0].is_contiguous():
@@ -59,8 +60,14 @@ data = SyntheticADE(int(cfg.data.samples_per_gpu), device=dev)
 for _ in range(2):
     tr.step(data.next())
 torch.cuda.synchronize()
-with Log():
-    tr.step(data.next())
+if a.graph:
+    only_captured = True
+    with Log():
+        ok = tr.enable_graph(data.next())
+    print('enable_graph:', ok)
+else:
+    with Log():
+        tr.step(data.next())
 torch.cuda.synchronize()
 tot = 0
 for (name, tag, shp, site), n in sorted(groups.items(), key=lambda kv: -kv[1] * max(1, int(torch.tensor(kv[0][2]).prod()) if kv[0][2] else 1))[:70]:
