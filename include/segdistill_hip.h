@@ -263,16 +263,23 @@ int sd_ppm_pool_bwd(void *const *d_pooled, int dtype, long planes, int h, int w,
 
 /* ---------------------------------------------------------------------------
  * Window multi-head self-attention of a Swin block, forward only (the frozen teacher of BASELINE config 4): reference
- * mmseg/models/backbones/swin_transformer.py:119-153 -- per window and head  softmax((q*scale) k^T + bias[head] + mask[window % nW]) v.
+ * mmseg/models/backbones/swin_transformer.py:119-153 -- per window and head  softmax((q*scale) k^T + bias[head] + mask[window % nW]) v
+ * on the matrix pipe (v_mfma_f32_32x32x2_f32, exact fp32).
  *   qkv    [windows, N, 3, heads, D]  the qkv Linear's output as it stands (swin_transformer.py:128-129 before the permute)
- *   bias_t [heads, N, N]  relative position bias TRANSPOSED: bias_t[h][j][i] = table[index[i][j]][h]   (:133-136)
- *   mask_t [mask_windows, N, N] or NULL, TRANSPOSED: mask_t[w][j][i] = mask[w][i][j]; window b uses mask b % mask_windows  (:138-142)
  *   out    [windows, N, heads*D]  = (attn @ v).transpose(1, 2).reshape(B_, N, C)   (:148)
+ * Bias and mask come PACKED in the accumulator layout of the kernel, sd_window_attn_packed_floats() (= 64 * 64) floats per table:
+ * sd_window_attn_pack converts `count` tables [49][49] in the reference's orientation ([query][key]: relative_position_bias[head] of :133-135,
+ * mask[window] of :138; window b uses mask b % mask_windows, :140) and fills padded keys with pad_key_value (-INFINITY for the bias, 0 for the
+ * mask); flags[count] (optional) receives 1 for a table with a nonzero entry -- the kernel skips the mask read of windows whose mask is all
+ * zero (all but 37 of a 19 x 19 shifted partition).  mask_packed NULL: no mask (mask_flags ignored).
  * fp32 storage only (SD_E_DTYPE otherwise); _supported(): N == 49 (7 x 7 windows) and D == 32, else SD_E_UNSUPPORTED -- use the framework's op.
  */
 int sd_window_attn_supported(int tokens_per_window, int head_dim);
-int sd_window_attn_fwd(const void *qkv, const float *bias_t, const float *mask_t, void *out, int dtype, long windows, int mask_windows, int heads,
-                       int tokens_per_window, int head_dim, float scale, void *stream);
+size_t sd_window_attn_packed_floats(void);
+int sd_window_attn_pack(const float *tables, float *packed, int32_t *flags /* or NULL */, int count, int tokens_per_window, float pad_key_value,
+                        void *stream);
+int sd_window_attn_fwd_packed(const void *qkv, const float *bias_packed, const float *mask_packed, const int32_t *mask_flags, void *out, int dtype,
+                              long windows, int mask_windows, int heads, int tokens_per_window, int head_dim, float scale, void *stream);
 
 /* ---------------------------------------------------------------------------
  * CGD / CD criterion on TOKEN-MAJOR operands S, T [B][P][C] (C contiguous; P = h*w pixels): the decoder features of a SegFormer head

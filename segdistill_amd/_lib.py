@@ -46,7 +46,9 @@ SIGNATURES = {
     'sd_ppm_pool_bwd': (_i, [_vp, _i, C.c_long, _i, _i, _vp, _i, _vp, _vp]),
     'sd_layernorm_map_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_long, _i, _i, _i, _i, _f, _vp]),
     'sd_window_attn_supported': (_i, [_i, _i]),
-    'sd_window_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _i, C.c_long, _i, _i, _i, _i, _f, _vp]),
+    'sd_window_attn_packed_floats': (_sz, []),
+    'sd_window_attn_pack': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    'sd_window_attn_fwd_packed': (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_long, _i, _i, _i, _i, _f, _vp]),
     'sd_cgd_kl_tok_workspace_bytes': (_sz, [_i, _i, C.c_long]),
     'sd_cgd_kl_tok_fwd': (_i, [_vp, _vp, _i, _i, _i, C.c_long, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'sd_cgd_kl_tok_bwd': (_i, [_vp, _vp, _i, _i, _i, C.c_long, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -96,31 +96,31 @@ class WindowAttention(nn.Module):
         trunc_normal_(self.relative_position_bias_table, std=.02)
         self.softmax = nn.Softmax(dim=-1)
 
-    def _bias_t(self, n, h):
-        """relative position bias [h, N(key), N(query)] -- transposed for the kernel's column reads; cached per table version."""
+    def _bias_packed(self, n, h):
+        """relative position bias [h, N, N] in the attention kernel's accumulator layout (padded keys = -inf); cached for a frozen table."""
         tbl = self.relative_position_bias_table
         sig = (tbl._version, tbl.data_ptr(), n)
-        hit = None if tbl.requires_grad else getattr(self, '_bias_t_cache', None)     # a trainable table is gathered every call: fused
+        hit = None if tbl.requires_grad else getattr(self, '_bias_p_cache', None)     # a trainable table is gathered every call: fused
         if hit is not None and hit[0] == sig:                                          # optimizers do not bump _version
             return hit[1]
         with torch.no_grad():
-            bt = tbl[self.relative_position_index.view(-1)].view(n, n, h).permute(2, 1, 0).float().contiguous()
+            bp = window_attn.pack_tables(tbl[self.relative_position_index.view(-1)].view(n, n, h).permute(2, 0, 1), float('-inf'))[0]
         if not tbl.requires_grad and not (tbl.is_cuda and torch.cuda.is_current_stream_capturing()):
-            object.__setattr__(self, '_bias_t_cache', (sig, bt))
-        return bt
+            object.__setattr__(self, '_bias_p_cache', (sig, bp))
+        return bp
 
-    def _mask_t(self, mask):
+    def _mask_packed(self, mask):
         if mask is None:
-            return None
+            return None, None
         sig = (mask.data_ptr(), mask._version, tuple(mask.shape))
-        hit = getattr(self, '_mask_t_cache', None)
+        hit = getattr(self, '_mask_p_cache', None)
         if hit is not None and hit[0] == sig:
             return hit[1]
         with torch.no_grad():
-            mt = mask.transpose(1, 2).float().contiguous()
+            mp = window_attn.pack_tables(mask, 0.0, True)
         if not (mask.is_cuda and torch.cuda.is_current_stream_capturing()):
-            object.__setattr__(self, '_mask_t_cache', (sig, mt))
-        return mt
+            object.__setattr__(self, '_mask_p_cache', (sig, mp))
+        return mp
 
     def forward(self, x, mask=None):
         """x: [nW*B, N, C]; mask: [nW, N, N] additive (0 / -100) or None."""
@@ -132,7 +132,7 @@ class WindowAttention(nn.Module):
                 and window_attn.supported(qkv, n, h, c // h) and (mask is None or bw % mask.shape[0] == 0)):
             # no graph to build (the frozen teacher): one kernel over the qkv Linear's output, bias and mask read from their tables
             # (csrc/window_attn.hip) -- no [windows, heads, N, N] additive tensor, no permuted copies of q / k / v or of the output
-            out = window_attn.forward(qkv.contiguous(), self._bias_t(n, h), self._mask_t(mask), h, self.scale)
+            out = window_attn.forward_packed(qkv.contiguous(), self._bias_packed(n, h), *self._mask_packed(mask), h, self.scale)
             return self.proj_drop(self.proj(out))
         q, k, v = qkv.reshape(bw, n, 3, h, c // h).permute(2, 0, 3, 1, 4)
         def additive():

@@ -33,9 +33,15 @@ def test_window_attn_kernel_matches_fp64(bw, nw, heads):
         mask = torch.where(torch.rand(nw, n, n, device=dev, generator=g) < 0.3, -100.0, 0.0)   # not symmetric either
         mask[:, torch.arange(n), torch.arange(n)] = 0.0
     scale = d ** -0.5
-    out = window_attn.forward(qkv, bias.transpose(1, 2).contiguous(), None if mask is None else mask.transpose(1, 2).contiguous(), heads, scale)
+    if mask is not None and nw > 1:
+        mask[0] = 0.0                        # an all-zero mask table must read as "no mask" through its flag
     ref = _ref(qkv, bias, mask, heads, scale)
-    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    bias_p, _ = window_attn.pack_tables(bias, float('-inf'))
+    mask_p, flags = window_attn.pack_tables(mask, 0.0, True) if mask is not None else (None, None)
+    if flags is not None and nw > 1:
+        assert int(flags[0]) == 0 and int(flags[1:].min()) == 1
+    out_p = window_attn.forward_packed(qkv, bias_p, mask_p, flags, heads, scale)
+    err = float((out_p.double() - ref).abs().max() / ref.abs().max())
     assert err < 2e-6, err
     # the framework's fp32 attention on the same operands is no closer to fp64
     q, k, v = qkv.reshape(bw, n, 3, heads, d).permute(2, 0, 3, 1, 4)
@@ -49,15 +55,20 @@ def test_window_attn_rejects_what_it_does_not_cover():
     from segdistill_amd import _lib
     L = _lib.lib()
     assert L.sd_window_attn_supported(49, 32) == 1 and L.sd_window_attn_supported(144, 32) == 0 and L.sd_window_attn_supported(49, 64) == 0
+    assert L.sd_window_attn_packed_floats() == 4096
     dev = torch.device('cuda:0')
     x = torch.zeros(2, 49, 3 * 32, device=dev)
-    b = torch.zeros(1, 49, 49, device=dev)
+    b = torch.zeros(1, 4096, device=dev)
+    f = torch.zeros(2, dtype=torch.int32, device=dev)
     o = torch.empty(2, 49, 32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    assert L.sd_window_attn_fwd(x.data_ptr(), b.data_ptr(), None, o.data_ptr(), 1, 2, 0, 1, 49, 32, 1.0, st) == -3       # bf16: SD_E_DTYPE
-    assert L.sd_window_attn_fwd(x.data_ptr(), b.data_ptr(), None, o.data_ptr(), 0, 2, 0, 1, 64, 32, 1.0, st) == -6       # N: SD_E_UNSUPPORTED
-    assert L.sd_window_attn_fwd(x.data_ptr(), b.data_ptr(), b.data_ptr(), o.data_ptr(), 0, 3, 2, 1, 49, 32, 1.0, st) == -2  # 3 windows, 2 masks
-    assert L.sd_window_attn_fwd(None, b.data_ptr(), None, o.data_ptr(), 0, 2, 0, 1, 49, 32, 1.0, st) == -1
+    args = (x.data_ptr(), b.data_ptr(), None, None, o.data_ptr())
+    assert L.sd_window_attn_fwd_packed(*args, 1, 2, 0, 1, 49, 32, 1.0, st) == -3       # bf16: SD_E_DTYPE
+    assert L.sd_window_attn_fwd_packed(*args, 0, 2, 0, 1, 64, 32, 1.0, st) == -6       # N: SD_E_UNSUPPORTED
+    assert L.sd_window_attn_fwd_packed(x.data_ptr(), b.data_ptr(), b.data_ptr(), f.data_ptr(), o.data_ptr(), 0, 3, 2, 1, 49, 32, 1.0, st) == -2  # 3 windows, 2 masks
+    assert L.sd_window_attn_fwd_packed(x.data_ptr(), b.data_ptr(), b.data_ptr(), None, o.data_ptr(), 0, 2, 2, 1, 49, 32, 1.0, st) == -2        # mask without flags
+    assert L.sd_window_attn_fwd_packed(None, b.data_ptr(), None, None, o.data_ptr(), 0, 2, 0, 1, 49, 32, 1.0, st) == -1
+    assert L.sd_window_attn_pack(x.data_ptr(), b.data_ptr(), None, 1, 144, 0.0, st) == -6
 
 
 @pytest.mark.parametrize('hw', [(28, 28), (30, 26)])      # whole windows; padded bottom / right
@@ -75,8 +86,8 @@ def test_swin_stage_with_the_kernel_matches_the_framework_attention(hw, monkeypa
     h, w = hw
     x = torch.randn(2, h * w, 96, device=dev)
     calls = []
-    real = window_attn.forward
-    monkeypatch.setattr(window_attn, 'forward', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    real = window_attn.forward_packed
+    monkeypatch.setattr(window_attn, 'forward_packed', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     with torch.no_grad():
         y_k = layer(x, h, w)[0]
     assert len(calls) == 2

@@ -583,8 +583,8 @@ def bench_ppm(dev, reps):
 
 def bench_wattn(dev, reps):
     """Window attention of the frozen Swin-B teacher (config 4: 512 x 512 crops, batch 8, 7 x 7 windows) -- csrc/window_attn.hip, one launch per
-    block over the qkv Linear's output.  Bytes = qkv read once + the token-major output written; the shifted blocks also read the mask table
-    (nW x 49 x 49 floats, L2-resident).  The arithmetic (2 x 49 x 49 x 32 packed FMAs per window and head) is ~30 % of the VALU time at stage 1."""
+    block over the qkv Linear's output, f32 MFMA.  Bytes = qkv read once + the token-major output written (bias / mask tables are L2-resident).
+    The matrix work (128 MFMAs of 64 cycles per window and head) is ~46 us at stage 1 -- the same order as the 53 us the bytes take at 5.5 TB/s."""
     from segdistill_amd import _lib
     L = _lib.lib()
     out = []
@@ -597,11 +597,16 @@ def bench_wattn(dev, reps):
         mask = torch.where(torch.rand(nw, 49, 49, device=dev, generator=gen) < 0.3, -100.0, 0.0)
         o = torch.empty(windows, 49, C, device=dev)
         nbytes = 4.0 * windows * 49 * C * 4
+        from segdistill_amd import window_attn
+        bias_p = window_attn.pack_tables(bias, float('-inf'))[0]
+        mask[::3] = 0.0                                                      # some windows without a mask, as in a shifted partition
+        mask_p, flags = window_attn.pack_tables(mask, 0.0, True)
         for shifted in (False, True):
-            t = _time(lambda st: _ok(L.sd_window_attn_fwd(qkv.data_ptr(), bias.data_ptr(), mask.data_ptr() if shifted else None, o.data_ptr(), 0,
-                                                          windows, nw if shifted else 0, heads, 49, 32, 32 ** -0.5, st), 'wattn'), reps)
-            out.append(_entry(f'Swin-B window attention fwd, {tag}{" (shifted: mask)" if shifted else ""}', 'window_attn_fwd', [windows, 49, 3 * C],
-                              'f32', t, 'hbm', nbytes, HBM, 'bytes = qkv + out once'))
+            t = _time(lambda st: _ok(L.sd_window_attn_fwd_packed(qkv.data_ptr(), bias_p.data_ptr(), mask_p.data_ptr() if shifted else None,
+                                                                 flags.data_ptr() if shifted else None, o.data_ptr(), 0, windows,
+                                                                 nw if shifted else 0, heads, 49, 32, 32 ** -0.5, st), 'wattn mfma'), reps)
+            out.append(_entry(f'Swin-B window attention fwd {tag}{" (shifted: mask)" if shifted else ""}', 'window_attn_mfma',
+                              [windows, 49, 3 * C], 'f32', t, 'hbm', nbytes, HBM, 'bytes = qkv + out once'))
     return out
 
 
