@@ -41,7 +41,7 @@ __device__ __forceinline__ void dma16(const void *gptr, unsigned lds_byte) {
 constexpr int kPackFloats = 2 * 2 * 4 * 64 * 4;     // 64 x 64 per table
 
 template <bool MASK>
-__global__ __launch_bounds__(256) void window_attn_mfma(const float *__restrict__ qkv, const float *__restrict__ bias_p, const float *__restrict__ mask_p,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void window_attn_mfma(const float *__restrict__ qkv, const float *__restrict__ bias_p, const float *__restrict__ mask_p,
                                                          const int *__restrict__ mask_any, float *__restrict__ out, int njobs, int nW, int heads,
                                                          float scale) {
     constexpr int N = 49, D = 32;
