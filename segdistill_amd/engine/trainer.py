@@ -157,6 +157,7 @@ class KDTrainer:
             return True
         except Exception as e:  # noqa: BLE001 -- any capture problem must degrade to eager, not kill the run
             warnings.warn(f'hipGraph capture failed ({type(e).__name__}: {e}); continuing in eager mode')
+            self.graph_error = f'{type(e).__name__}: {e}'     # for callers that must say why (bench.py's line, the tests)
             self._graph = None
             self._seg = None
             segments.attach(m, None)
@@ -234,6 +235,7 @@ class KDTrainer:
             return True
         except Exception as e:  # noqa: BLE001
             warnings.warn(f'hybrid hipGraph capture failed ({type(e).__name__}: {e}); continuing in eager mode')
+            self.graph_error = f'{type(e).__name__}: {e}'
             m._graphed_teacher = None
             if hasattr(m, 'student') and getattr(m.student, '_graphed_backbone', None) is not None:
                 object.__setattr__(m.student, '_graphed_backbone', None)

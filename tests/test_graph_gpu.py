@@ -52,7 +52,7 @@ def test_graph_replay_matches_eager(mode):
     data_g = SyntheticADE(2, size=(128, 128), device='cuda:0', pool=3, seed=1)
     example = dict(img=data_g._pool[0][0], img_metas=None, gt_semantic_seg=data_g._pool[0][1])
     if mode != 'eager_prefetch':
-        assert (t_g.enable_graph(example) if mode == 'full' else t_g.enable_hybrid_graph(example))
+        assert (t_g.enable_graph(example) if mode == 'full' else t_g.enable_hybrid_graph(example)), getattr(t_g, 'graph_error', None)
     assert gra.cnt == 0
     perms = []
     cur_g = data_g.next()
@@ -60,6 +60,9 @@ def test_graph_replay_matches_eager(mode):
         torch.manual_seed(100 + it)            # the shuffle draws torch.randperm from the CPU RNG
         oe = t_e.step(data_e.next())
         pe = ref.distillation_loss.criteria[0].last_perm
+        # two trainers in one process is a test-only situation: the eager one's side-stream work (memsets among it) must have drained before
+        # the other's graph -- which holds memset NODES -- replays (the runtime hazard of engine/trainer.py::_issues_memsets)
+        torch.cuda.synchronize()
         torch.manual_seed(100 + it)
         nxt_g = data_g.next()
         og = t_g.step(cur_g, nxt_g if it != 4 else None)   # teacher one batch ahead (and one iteration without a hint)
@@ -100,6 +103,7 @@ def test_bf16_graph_modes_match_eager(mode):
     for it in range(3):
         torch.manual_seed(100 + it)
         t_e.step(data_e.next())
+        torch.cuda.synchronize()               # as above: drain the eager trainer before the other's graph replays
         torch.manual_seed(100 + it)
         nxt_g = data_g.next()
         t_g.step(cur_g, nxt_g)
