@@ -51,7 +51,7 @@ echo "[4] other configs" | tee -a $OUT/progress.txt
 CONFIGS=${CONFIGS:-"cfg3_segformer_b2_b0_cgd_cd cfg5_segformer_b4_b1_multistage_bf16 cfg1_pspnet_r101_r18_cd cfg4_pspnet_r18_swin_b_cgd_align"}
 for c in $CONFIGS; do
   for g in on hybrid; do
-    timeout 900 python bench.py --config configs/kd/$c.py --steps 10 --warmup 4 --graph $g --no-cpu-baseline --no-roofline --no-exact-f32 2>/dev/null | tail -1 | \
+    timeout 900 python bench.py --config configs/kd/$c.py --steps 30 --warmup 5 --graph $g --no-cpu-baseline --no-roofline --no-exact-f32 2>/dev/null | tail -1 | \
       python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$c', 'graph=$g', d['config']['hip_graph'], d['value'], 'imgs/s', d['ms_per_step'], 'ms/step', d['dtype'], 'B=%d' % d['config']['per_gpu_batch'])" >> $OUT/other_configs.txt 2>&1
     echo "   $c $g done" | tee -a $OUT/progress.txt
   done
