@@ -582,6 +582,10 @@ WgradPlan linear_wgrad_plan(long T, int M, int N, bool bf16 = false) {
         const int wg_y = (regions + p.regions_per_wg - 1) / p.regions_per_wg;
         long nsplit = 256 / wg_y;  // x (4 / regions_per_wg) k-sub-ranges: ~1024 waves, and few enough slabs that the combine stays cheap
         if (nsplit > T / 128) nsplit = T / 128;
+        {
+            const long cap = wgrad_slab_cap(T, M, N, bf16 ? 2 : 4) / (4 / p.regions_per_wg);     // slabs = nsplit x k-sub-ranges
+            if (nsplit > cap) nsplit = cap;
+        }
         if (nsplit < 1) nsplit = 1;
         long klen = ((T + nsplit - 1) / nsplit + 63) / 64 * 64;  // multiple of 64: every k-sub-range stays even-aligned
         p.nsplit = (int)((T + klen - 1) / klen);
@@ -600,6 +604,7 @@ WgradPlan linear_wgrad_plan(long T, int M, int N, bool bf16 = false) {
     const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     long nsplit = 1024 / tiles;
     if (nsplit > T / 256) nsplit = T / 256;
+    if (nsplit > wgrad_slab_cap(T, M, N, bf16 ? 2 : 4)) nsplit = wgrad_slab_cap(T, M, N, bf16 ? 2 : 4);
     if (nsplit < 1) nsplit = 1;
     long klen = ((T + nsplit - 1) / nsplit + BK - 1) / BK * BK;
     p.nsplit = (int)((T + klen - 1) / klen);

@@ -38,5 +38,6 @@ int linear_nchw_f32_bwd_weight(const float *dY, const float *X, float *dW, float
 bool wgrad_tn_supported(long T, int M, int N, const void *dY, const void *X);
 void wgrad_tn_plan(long T, int M, int N, int *nsplit, int *klen);
 int wgrad_tn_launch(const void *dY, const void *X, float *slabs, long T, int M, int N, int nsplit, int klen, hipStream_t st);
+long wgrad_slab_cap(long T, int M, int N, int es);      // most k-splits whose slabs stay within the set percentage of the operand bytes
 
 }  // namespace sd

@@ -419,6 +419,17 @@ __global__ __launch_bounds__(256) void wgrad_tn_x3(const float *__restrict__ A, 
 }  // namespace
 
 // ---- plan + launcher shared with align1x1.hip (the generic weight-gradient entry points) -------------------------------------------------
+// Split-K weight gradients write one M x N fp32 slab per split and the combine reads it back; the most splits a bf16-storage product may take so
+// that the slab bytes stay within `wgrad_slab_ratio` % (tunable, 0 = no cap) of its operand bytes 2 T (M + N).  Config 5, same box
+// (profiles/r04_ab_cfg5_slab_ratio.txt): no cap 693.8 imgs/s, 200 % 705.3, 100 % 712.5 / 705, 50 % 719.2 / 712.4, 35 % 718.2, 25 % 714.1, 12 % 692.0.
+// fp32 storage (es == 4) is NOT capped: config 2, same box, no cap 781.6 / 784.5 imgs/s, 100 % 783.1, 60 % 780.7, 40 % 771.9, 20 % 744.6 -- its
+// split-bf16 / f32-MFMA weight-gradient kernels need the parallelism more than they pay for the slabs.
+int g_slab_ratio = 40;
+long wgrad_slab_cap(long T, int M, int N, int es) {
+    if (es != 2 || g_slab_ratio <= 0) return 1L << 40;
+    const long cap = (long)((double)g_slab_ratio * 0.01 * (double)T * (M + N) * 2.0 / ((double)M * N * 4.0));
+    return cap < 1 ? 1 : cap;
+}
 int g_wgrad_ring = 1;      // tunable "wgrad_tn_ring": 0 = the register-staged kernel everywhere, 1 = the rules below, 2 = 256 x 256 tiles wherever legal (A/B, tests)
 bool wgrad_tn_supported(long T, int M, int N, const void *dY, const void *X) {
     return T > 0 && M > 0 && N > 0 && M % 8 == 0 && N % 8 == 0 && ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) == 0;
@@ -443,6 +454,11 @@ void wgrad_tn_plan(long T, int M, int N, int *nsplit, int *klen) {
     long ns = (big ? 256 : 768) / tiles;
     if (ns > T / ((big ? 4 : 2) * TBK)) ns = T / ((big ? 4 : 2) * TBK);
     if (ns > 256) ns = 256;
+    // Every split writes an M x N fp32 slab and the combine reads it back: for the few-token / large-weight Linears (2048 tokens x 1024 x 512:
+    // 22 splits of 3 k-steps each) that was 46 MB of slabs each way next to 6 MB of operands -- 2.9 GB of slab traffic per config-5 step against
+    // 1.4 GB of operands.  wgrad_slab_cap: no more slab bytes than a set percentage of the operand bytes.
+    const long cap = wgrad_slab_cap(T, M, N, 2);
+    if (ns > cap) ns = cap;
     if (ns < 1) ns = 1;
     const long kl = ((T + ns - 1) / ns + TBK - 1) / TBK * TBK;
     *klen = (int)kl;
@@ -450,6 +466,12 @@ void wgrad_tn_plan(long T, int M, int N, int *nsplit, int *klen) {
 }
 
 int wgrad_tn_tunable(const char *key, int set, int v) {
+    if (!strcmp(key, "wgrad_slab_ratio")) {
+        if (!set) return g_slab_ratio;
+        if (v < 0 || v > 100000) return SD_E_SHAPE;
+        g_slab_ratio = v;
+        return SD_OK;
+    }
     if (strcmp(key, "wgrad_tn_ring")) return SD_E_UNSUPPORTED;
     if (!set) return g_wgrad_ring;
     if (v < 0 || v > 2) return SD_E_SHAPE;
