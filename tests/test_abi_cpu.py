@@ -82,3 +82,28 @@ def test_ctypes_signatures_match_header_arity(built):
         params = m.group(1).strip()
         n = 0 if params in ('', 'void') else params.count(',') + 1
         assert n == len(args), f'{name}: header has {n} parameters, ctypes binding {len(args)}'
+
+
+def test_bf16_split_k_weight_gradient_plans_bound_their_slab_traffic():
+    """csrc/wgrad_tn.hip::wgrad_slab_cap (host-side planning only: no GPU): under bf16 storage a split-K weight gradient takes no more k-splits
+    than keep its fp32 slabs within `wgrad_slab_ratio` % of its operand bytes (the few-token / large-weight Linears of BASELINE config 5 wrote
+    7x their operand bytes before); 0 lifts the cap; fp32 storage is not capped."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    shapes = [(2048, 1024, 512), (2048, 512, 512), (8192, 1280, 320), (8192, 768, 256), (32768, 768, 256), (131072, 768, 256), (32768, 512, 128)]
+    old = _lib.get_tunable('wgrad_slab_ratio')
+    assert old == 40
+    try:
+        capped = [L.sd_linear_wgrad_generic_slabs(1, *s) for s in shapes]
+        for (T, M, N), ns in zip(shapes, capped):
+            assert ns == 0 or ns * M * N * 4 <= 0.4 * T * (M + N) * 2 + M * N * 4, (T, M, N, ns)      # 0: a single split writes dW directly
+        _lib.set_tunable('wgrad_slab_ratio', 0)
+        free = [L.sd_linear_wgrad_generic_slabs(1, *s) for s in shapes]
+        assert all(f >= c for f, c in zip(free, capped)) and free[0] > 8 and free[1] > 8
+        f32 = [L.sd_linear_wgrad_tn_slabs(8192, 640, 160), L.sd_linear_wgrad_splitk_slabs(2048, 256, 256)]
+        _lib.set_tunable('wgrad_slab_ratio', 40)
+        assert f32 == [L.sd_linear_wgrad_tn_slabs(8192, 640, 160), L.sd_linear_wgrad_splitk_slabs(2048, 256, 256)]
+        with pytest.raises(RuntimeError):
+            _lib.set_tunable('wgrad_slab_ratio', -1)
+    finally:
+        _lib.set_tunable('wgrad_slab_ratio', old)
