@@ -593,9 +593,11 @@ int sd_linear_wgrad_partials(const void *dY, const void *X, int dtype, long toke
  * [out x in] fp32 slabs (0: un-split or direct plan -- use the calls above), _partials() writes them, the caller sums them. */
 /* fp32 token-major Linear weight gradient as split-K slabs in split-bf16 arithmetic on hardware-transposed LDS reads (csrc/wgrad_tn.hip;
  * the tall-skinny products of the SegFormer head: 256 x {256, 160, 64, 32} over 131072 tokens).  _slabs(): number of [out x in] fp32 slabs for
- * this shape, 0 when the shape is not this kernel's (use sd_linear_wgrad / _splitk).  No bias gradient: sd_colsum_partials. */
+ * this shape, 0 when the shape is not this kernel's (use sd_linear_wgrad / _splitk).  with_bias != 0: every slab is [out x in] followed by `out`
+ * column sums of dY over the split's tokens (the bias gradient, fp32 sums of the staged values: no second pass over dY), out * in + out floats. */
 int sd_linear_wgrad_tn_slabs(long tokens, int out_features, int in_features);
-int sd_linear_wgrad_tn(const float *dY, const float *X, float *slabs, size_t slabs_bytes, long tokens, int out_features, int in_features, void *stream);
+int sd_linear_wgrad_tn(const float *dY, const float *X, float *slabs, size_t slabs_bytes, long tokens, int out_features, int in_features, int with_bias,
+                       void *stream);
 int sd_linear_wgrad_generic_slabs(int dtype, long tokens, int out_features, int in_features);
 int sd_linear_wgrad_generic_partials(const void *dY, const void *X, int dtype, long tokens, int out_features, int in_features, void *workspace,
                                      size_t workspace_bytes, void *stream);

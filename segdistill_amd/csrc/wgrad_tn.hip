@@ -290,7 +290,10 @@ __device__ __forceinline__ void split8_planes(const f32x4 &v0, const f32x4 &v1, 
     }
 }
 
-template <int BN_, int WM, int WN>
+// BIAS: the slab of split z is [M x N] followed by M column sums of dY over the split's tokens (the Linear's bias gradient: every dY value passes
+// through the staging registers of exactly one thread of the tn == 0 workgroup of its row tile, in fp32 -- the separate pass that re-read every dY for
+// the bias gradients was 98 us per config-2 step at full HBM speed).
+template <int BN_, int WM, int WN, bool BIAS>
 __global__ __launch_bounds__(256) void wgrad_tn_x3(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, long T,
                                                     int klen, int tiles_m, int tiles_n, int nsplit) {
     constexpr int TM = TBM / (32 * WM), TN = BN_ / (32 * WN);
@@ -321,6 +324,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_x3(const float *__restrict__ A, 
 
     // staging: A chunk e = t + 256 u (u = 0, 1) -> (row = e / 16, ch = e % 16); B chunk e = t + 256 u (u < NB) -> (row = e / BCH, ch = e % BCH)
     f32x4 ra[2][2], rb[NB][2];
+    f32x4 bsum[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};     // BIAS: this thread's share of 8 column sums
     auto load_regs = [&](int kt) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -348,6 +352,10 @@ __global__ __launch_bounds__(256) void wgrad_tn_x3(const float *__restrict__ A, 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = t + 256 * u, row = e >> 4, ch = e & 15;
+            if (BIAS) {
+                bsum[u][0] += ra[u][0];
+                bsum[u][1] += ra[u][1];
+            }
             u32x4 ph, pm, pl;
             split8_planes(ra[u][0], ra[u][1], ph, pm, pl);
             unsigned char *d = lds + swz(row, ch);
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_x3(const float *__restrict__ A, 
         }
         __syncthreads();                                                     // every wave is done reading before the next tile is stored
     }
-    float *Cz = C + (size_t)split * M * N;
+    float *Cz = C + (size_t)split * ((size_t)M * N + (BIAS ? M : 0));
     const int col = lane & 31;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -414,6 +422,22 @@ __global__ __launch_bounds__(256) void wgrad_tn_x3(const float *__restrict__ A, 
                 if (m < M && n < N) Cz[(size_t)m * N + n] = acc[i][j][e];
             }
         }
+    if (BIAS && tn == 0) {
+        // thread t staged chunk t % 16 (8 columns) of rows t / 16 and t / 16 + 16 of every tile: 16 threads share a chunk; fixed-order fold through LDS
+        // (the staging buffers are free: the main loop ended on a barrier)
+        float *red = reinterpret_cast<float *>(lds);                 // [16 row groups][128 columns]
+        const f32x4 s0 = bsum[0][0] + bsum[1][0], s1 = bsum[0][1] + bsum[1][1];
+        float *r = red + (t >> 4) * TBM + 8 * (t & 15);
+        *reinterpret_cast<f32x4 *>(r) = s0;
+        *reinterpret_cast<f32x4 *>(r + 4) = s1;
+        __syncthreads();
+        if (t < TBM) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v += red[q * TBM + t];
+            if (m0 + t < M) Cz[(size_t)M * N + m0 + t] = v;
+        }
+    }
 }
 
 }  // namespace
@@ -518,26 +542,34 @@ extern "C" {
 
 /* fp32 token-major Linear weight gradient dW = dY^T . X as split-K slabs in split-bf16 arithmetic on transposed LDS reads (see above): number of
  * [out x in] fp32 slabs sd_linear_wgrad_tn writes for this shape, 0 when the shape is not this kernel's (few tokens, out_features < 128,
- * features not multiples of 8, more than 32 tiles).  The caller combines the slabs (sd_multi_slab_reduce) and forms the bias gradient separately. */
+ * features not multiples of 8, more than 32 tiles).  The caller combines the slabs (sd_multi_slab_reduce); with_bias: each slab is [out x in] followed by
+ * `out` column sums of dY over the split's tokens (the bias gradient), i.e. out * in + out floats. */
 int sd_linear_wgrad_tn_slabs(long tokens, int out_features, int in_features) {
     int klen, bn;
     return sd::wgrad_tn_x3_plan(tokens, out_features, in_features, &klen, &bn);
 }
 
-int sd_linear_wgrad_tn(const float *dY, const float *X, float *slabs, size_t slabs_bytes, long tokens, int out_features, int in_features, void *stream) {
+int sd_linear_wgrad_tn(const float *dY, const float *X, float *slabs, size_t slabs_bytes, long tokens, int out_features, int in_features, int with_bias,
+                       void *stream) {
     if (!dY || !X || !slabs) return SD_E_NULL;
     int klen = 0, bn = 0;
     const int M = out_features, N = in_features;
     const int nsplit = sd::wgrad_tn_x3_plan(tokens, M, N, &klen, &bn);
     if (!nsplit) return SD_E_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) return SD_E_ALIGN;
-    if (slabs_bytes < (size_t)nsplit * M * N * sizeof(float)) return SD_E_WORKSPACE;
+    if (slabs_bytes < (size_t)nsplit * ((size_t)M * N + (with_bias ? M : 0)) * sizeof(float)) return SD_E_WORKSPACE;
     const int tiles_m = (M + sd::TBM - 1) / sd::TBM, tiles_n = (N + bn - 1) / bn;
     const dim3 grid((unsigned)((long)tiles_m * tiles_n * nsplit));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (bn == 128) hipLaunchKernelGGL((sd::wgrad_tn_x3<128, 2, 2>), grid, dim3(256), 0, st, dY, X, slabs, M, N, tokens, klen, tiles_m, tiles_n, nsplit);
-    else if (bn == 64) hipLaunchKernelGGL((sd::wgrad_tn_x3<64, 2, 2>), grid, dim3(256), 0, st, dY, X, slabs, M, N, tokens, klen, tiles_m, tiles_n, nsplit);
-    else hipLaunchKernelGGL((sd::wgrad_tn_x3<32, 4, 1>), grid, dim3(256), 0, st, dY, X, slabs, M, N, tokens, klen, tiles_m, tiles_n, nsplit);
+#define SD_X3(BNN, WMM, WNN)                                                                                                                       \
+    do {                                                                                                                                           \
+        if (with_bias) hipLaunchKernelGGL((sd::wgrad_tn_x3<BNN, WMM, WNN, true>), grid, dim3(256), 0, st, dY, X, slabs, M, N, tokens, klen, tiles_m, tiles_n, nsplit); \
+        else hipLaunchKernelGGL((sd::wgrad_tn_x3<BNN, WMM, WNN, false>), grid, dim3(256), 0, st, dY, X, slabs, M, N, tokens, klen, tiles_m, tiles_n, nsplit);         \
+    } while (0)
+    if (bn == 128) SD_X3(128, 2, 2);
+    else if (bn == 64) SD_X3(64, 2, 2);
+    else SD_X3(32, 4, 1);
+#undef SD_X3
     return (int)hipGetLastError();
 }
 

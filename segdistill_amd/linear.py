@@ -93,6 +93,9 @@ def _bwd_data(dy2, weight):
 
 
 _BF16_WGRAD_LIB = os.environ.get('SEGDISTILL_BF16_WGRAD_LIB', '0') == '1'
+# A/B: 0 = the bias gradient of the transposed-read fp32 weight gradients from the batched column-sum pass (a second read of dY) instead of riding along
+# in their slabs.  Config 2, same box: 793.2 - 795.5 imgs/s with it, 787.0 / 787.1 without (profiles/r04_ab_cfg2_tn_fused_bias.txt)
+_TN_FUSED_BIAS = os.environ.get('SEGDISTILL_TN_FUSED_BIAS', '1') == '1'
 _SPLITK_WGRAD = os.environ.get('SEGDISTILL_SPLITK_WGRAD', '1') == '1'      # A/B: 0 = the library's dY^T @ X for the non-tall-skinny weight gradients
 
 
@@ -171,15 +174,19 @@ class _TokenLinear(torch.autograd.Function):
             if ns_tn:
                 # round 4: the tall-skinny products with out_features >= 128 (the SegFormer head over 131072 tokens) on transposed LDS reads in
                 # split-bf16 arithmetic (csrc/wgrad_tn.hip) instead of the exact-f32 tall-skinny kernel; slabs combined by the deferred pass
-                ws = torch.empty(ns_tn, M * N, dtype=torch.float32, device=x.device)
-                _lib.check(L.sd_linear_wgrad_tn(dyc.data_ptr(), x2.data_ptr(), ws.data_ptr(), ws.numel() * 4, T, M, N, _stream_ptr()), 'sd_linear_wgrad_tn')
-                buf = torch.empty(M * N, dtype=torch.float32, device=x.device)
-                if ctx.defer_ok and deferred.enabled():
-                    deferred.add(ws, buf, M * N, ns_tn)
+                # the bias gradient rides along as M extra floats per slab (column sums of the staged dY values): no second pass over dY
+                fuse_db = want_db and _TN_FUSED_BIAS
+                slab = M * N + (M if fuse_db else 0)
+                ws = torch.empty(ns_tn, slab, dtype=torch.float32, device=x.device)
+                _lib.check(L.sd_linear_wgrad_tn(dyc.data_ptr(), x2.data_ptr(), ws.data_ptr(), ws.numel() * 4, T, M, N, int(fuse_db), _stream_ptr()),
+                           'sd_linear_wgrad_tn')
+                buf = torch.empty(slab, dtype=torch.float32, device=x.device)
+                if ctx.defer_ok and deferred.enabled() and (ctx.defer_bias_ok or not fuse_db):
+                    deferred.add(ws, buf, slab, ns_tn)
                 else:
-                    deferred.reduce_now(ws, buf, M * N, ns_tn)
-                db = deferred.column_sum(dyc, ctx.defer_bias_ok) if want_db else None
-                return dx, buf.view(M, N), db, None, None
+                    deferred.reduce_now(ws, buf, slab, ns_tn)
+                db = buf[M * N:] if fuse_db else (deferred.column_sum(dyc, ctx.defer_bias_ok) if want_db else None)
+                return dx, buf[:M * N].view(M, N), db, None, None
             direct = bool(L.sd_linear_wgrad_fuses_bias_dtype(_DT[x.dtype], T, M, N))
             if not direct and x.dtype == torch.float32:
                 # fewer than 8192 tokens or a weight of more than 16 64x64 regions: no longer tall-skinny.  Round 3: split-K over the tokens

@@ -255,9 +255,17 @@ def test_linear_wgrad_tn_split_bf16(shape):
     slabs = torch.empty(ns, M * N, device=dev)
     out = torch.empty(M * N, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    assert L.sd_linear_wgrad_tn(dyg.data_ptr(), xg.data_ptr(), slabs.data_ptr(), slabs.numel() * 4, T, M, N, st) == 0
+    assert L.sd_linear_wgrad_tn(dyg.data_ptr(), xg.data_ptr(), slabs.data_ptr(), slabs.numel() * 4, T, M, N, 0, st) == 0
     deferred.reduce_now(slabs, out, M * N, ns)
     e_tn = _err(out.view(M, N), ref)
+    # with the bias gradient riding along: M more floats per slab = fp32 column sums of dY; the weight part is the same bits
+    slabs_b = torch.full((ns, M * N + M), float('nan'), device=dev)
+    out_b = torch.empty(M * N + M, device=dev)
+    assert L.sd_linear_wgrad_tn(dyg.data_ptr(), xg.data_ptr(), slabs_b.data_ptr(), slabs_b.numel() * 4, T, M, N, 1, st) == 0
+    deferred.reduce_now(slabs_b, out_b, M * N + M, ns)
+    assert torch.equal(out_b[:M * N], out)
+    assert _err(out_b[M * N:], dy.double().sum(0)) < 2e-5
+    assert L.sd_linear_wgrad_tn(dyg.data_ptr(), xg.data_ptr(), slabs.data_ptr(), slabs.numel() * 4, T, M, N, 1, st) == -4      # workspace without room for it
     dw = torch.empty(M, N, device=dev)
     wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)

@@ -55,7 +55,7 @@ for (T, M, N) in SHAPES:
         slabs, out = torch.empty(ns, M * N, device=dev), torch.empty(M * N, device=dev)
 
         def run_tn():
-            rc = L.sd_linear_wgrad_tn(dy.data_ptr(), x.data_ptr(), slabs.data_ptr(), slabs.numel() * 4, T, M, N, st)
+            rc = L.sd_linear_wgrad_tn(dy.data_ptr(), x.data_ptr(), slabs.data_ptr(), slabs.numel() * 4, T, M, N, 0, st)
             assert rc == 0, rc
             reduce_now(slabs, out, M * N, ns)
         for _ in range(5):
