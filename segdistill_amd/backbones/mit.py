@@ -237,6 +237,38 @@ def _run_stage(x, hw, blocks, stage_norm):
     return n
 
 
+class _ConvDeferredBias(torch.autograd.Function):
+    """F.conv2d whose bias gradient joins the batched column-sum pass of the backward (segdistill_amd/deferred.py) instead of being one ATen
+    reduction per layer inside convolution_backward (4 x 14 us per config-2 step, at ~1.2 TB/s): the incoming gradient of a channels-last
+    convolution output IS a token-major [B*H*W, C] matrix.  Input and weight gradients stay the library's.  fp32 storage only: the same under
+    bf16 autocast (operand casts from the parameters' shadows, 16 -> 8 cast kernels per step) measured neutral on config 5 and was not kept.
+    Config 2, same box: 780.6 - 784.3 imgs/s with it, 774.9 / 778.6 without (profiles/r04_ab_cfg2_conv_deferred_bias.txt)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding, dilation, groups):
+        ctx.save_for_backward(x, weight)
+        ctx.conf = (stride, padding, dilation, groups, bias.dtype)
+        return F.conv2d(x, weight, bias, stride, padding, dilation, groups)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import deferred
+        x, weight = ctx.saved_tensors
+        stride, padding, dilation, groups, bdtype = ctx.conf
+        dx, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, stride, padding, dilation, False, [0, 0], groups,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        db = None
+        if ctx.needs_input_grad[2]:
+            if dy.dim() == 4 and dy.is_contiguous(memory_format=torch.channels_last):
+                db = deferred.column_sum(dy.permute(0, 2, 3, 1).reshape(-1, dy.shape[1]), True).to(bdtype)
+            else:
+                db = dy.sum((0, 2, 3)).to(bdtype)
+        return dx, dw, db, None, None, None, None
+
+
+_CONV_DEFERRED_BIAS = os.environ.get('SEGDISTILL_CONV_DEFERRED_BIAS', '1') == '1'
+
+
 class OverlapPatchEmbed(nn.Module):
     def __init__(self, patch_size, stride, in_chans, embed_dim):
         super().__init__()
@@ -258,6 +290,9 @@ class OverlapPatchEmbed(nn.Module):
             w = frozen_derived(p.weight, ('cast', dt), lambda: p.weight.to(dt))
             b = None if p.bias is None else frozen_derived(p.bias, ('cast', dt), lambda: p.bias.to(dt))
             x = F.conv2d(x if x.dtype == dt else x.to(dt), w, b, p.stride, p.padding, p.dilation, p.groups)
+        elif (_CONV_DEFERRED_BIAS and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and torch.is_grad_enabled()
+              and p.bias is not None and p.bias.requires_grad and p.weight.requires_grad and not (p._forward_hooks or p._forward_pre_hooks)):
+            x = _ConvDeferredBias.apply(x, p.weight, p.bias, p.stride, p.padding, p.dilation, p.groups)
         else:
             x = p(x)
         hw = tuple(x.shape[2:])

@@ -176,3 +176,41 @@ def test_bf16_generic_weight_gradient_defers_its_combine(T, M, N):
     assert float((grads[1][0].double() - ref).abs().max() / ref.abs().max()) < 2e-3
     assert float((grads[0][0] - grads[1][0]).abs().max()) <= 1e-5 * float(grads[0][0].abs().max())
     assert float((grads[0][1] - grads[1][1]).abs().max()) <= 1e-4 * float(grads[0][1].abs().max())
+
+
+@pytest.mark.parametrize('scoped', [True, False])
+def test_patch_embed_conv_bias_gradient_through_the_column_sum_pass(scoped):
+    """backbones/mit.py::_ConvDeferredBias: the patch-embed convolution whose bias gradient is a column sum of the channels-last incoming gradient
+    (batched with the Linears' inside a deferred scope) -- against nn.Conv2d's own backward: same input gradient, filter and bias gradients to rounding."""
+    from segdistill_amd import deferred
+    from segdistill_amd.backbones import mit
+    dev = torch.device('cuda:0')
+    torch.manual_seed(2)
+    emb = mit.OverlapPatchEmbed(3, 2, 32, 64).to(dev)
+    x = torch.randn(2, 32, 24, 40, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    up = torch.randn(2, 12 * 20, 64, device=dev)
+    grads = {}
+    for flag in (True, False):
+        mit._CONV_DEFERRED_BIAS = flag
+        calls = []
+        real = mit._ConvDeferredBias.apply
+        mit._ConvDeferredBias.apply = lambda *a: (calls.append(1), real(*a))[1]
+        try:
+            for p in emb.parameters():
+                p.grad = None
+            x.grad = None
+            if scoped:
+                with deferred.scope():
+                    emb(x)[0].backward(up)
+            else:
+                emb(x)[0].backward(up)
+            torch.cuda.synchronize()
+        finally:
+            mit._ConvDeferredBias.apply = real
+            mit._CONV_DEFERRED_BIAS = True
+        assert len(calls) == (1 if flag else 0)
+        grads[flag] = (x.grad.clone(), emb.proj.weight.grad.clone(), emb.proj.bias.grad.clone())
+    assert torch.equal(grads[True][0], grads[False][0])
+    for k in (1, 2):       # the library's filter gradient is a split reduction (not bit-reproducible between calls); the bias gradient a different sum order
+        ref = grads[False][k]
+        assert float((grads[True][k] - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
