@@ -179,7 +179,9 @@ class SwinTransformerBlock(nn.Module):
     def fusable(self, x):
         """no graph to build, nothing stochastic, both norms on the HIP kernels: forward_fused applies"""
         return (_GATHER_WINDOWS and _FUSE_NORMS and (not self.training or isinstance(self.drop_path, nn.Identity))
-                and map_supported(x, self.norm1) and map_supported(x, self.norm2))
+                and map_supported(x, self.norm1) and map_supported(x, self.norm2)
+                # a tapped block (Extractor hooks) must be CALLED and must return its complete output: forward_fused does neither
+                and not (self._forward_hooks or self._forward_pre_hooks or self.drop_path._forward_hooks or self.drop_path._forward_pre_hooks))
 
     def forward_fused(self, x, mask_matrix, pending=None):
         """The block of a frozen network as  norm1 + pad + shift + window partition  (one kernel, folding in the previous block's pending MLP

@@ -44,6 +44,27 @@ def test_frozen_swin_gather_path_equals_the_module_chain(size):
     blk = net.layers[0].blocks[0]
     blk.H = blk.W = 8
     assert blk.fusable(torch.zeros(1, 64, 32, device='cuda:0'))
+    # a tapped block is called as a module and hands its hook the complete block output (the KD Extractor's contract)
+    seen = []
+    h = net.layers[1].blocks[1].register_forward_hook(lambda m, i, o: seen.append(o.detach().clone()))
+    try:
+        with torch.no_grad():
+            hooked = net(img)
+    finally:
+        h.remove()
+    assert len(seen) == 1 and not net.layers[1].blocks[1]._forward_hooks
+    for a, b in zip(fused, hooked):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+    with torch.no_grad():                              # the hooked block's output is what the next stage consumed
+        swin._FUSE_NORMS = False
+        try:
+            seen2 = []
+            h = net.layers[1].blocks[1].register_forward_hook(lambda m, i, o: seen2.append(o.detach().clone()))
+            net(img)
+            h.remove()
+        finally:
+            swin._FUSE_NORMS = True
+    assert float((seen[0] - seen2[0]).abs().max()) <= 2e-6 * float(seen2[0].abs().max())
     # a trainable Swin keeps the autograd-friendly chain (index_select's backward would be an atomic scatter)
     for p in net.parameters():
         p.requires_grad = True
