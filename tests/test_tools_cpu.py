@@ -48,3 +48,18 @@ def test_no_compiler_instruction_touches_a_register_with_a_pinned_load_pending()
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'asm_pending_audit.py')], capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert 'ce_up.hip: 0 compiler' in res.stdout and 'token_gemm.hip: 0 compiler' in res.stdout, res.stdout
+
+
+def test_slab_budget_of_config_5_stays_under_its_operand_bytes():
+    """tools/slab_budget.py (host-side plans only): with the default cap the bf16 B1 student's split-K weight gradients move fewer slab bytes than
+    operand bytes per step; without it more than twice as many (the 2.9 GB / 1.4 GB finding of round 4)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import slab_budget
+    lines = []
+    slab, op = slab_budget.budget(**slab_budget.PRESETS['cfg5'], out=lines.append)
+    assert len(lines) > 25 and slab < op
+    slab0, op0 = slab_budget.budget(**slab_budget.PRESETS['cfg5'], ratio=0, out=lambda s: None)
+    assert op0 == op and slab0 > 2 * op
+    slab2, op2 = slab_budget.budget(**slab_budget.PRESETS['cfg2'], out=lambda s: None)
+    assert slab2 > 0 and op2 > 0
