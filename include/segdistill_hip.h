@@ -328,6 +328,45 @@ int sd_cgd_kl_tok_fwd_multi(const sd_cgd_tok_fwd_job *jobs, int njobs, int dtype
 int sd_cgd_kl_tok_bwd_multi(const sd_cgd_tok_bwd_job *jobs, int njobs, int dtype, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * The feature-align projection of a token-major tap FUSED with the channel-group criterion it feeds (csrc/align_tok.hip; bf16 storage).
+ * Replaces, for one distillation entry with `channel_nums=(Cs, Ct)` on token-major taps [B, P, Cs] / [B, P, Ct] (BASELINE config 5):
+ * the 1x1 projection of the student feature (opts.py:25-27; commented `self.ff = nn.Conv2d(**ff_config, kernel_size=1)` of
+ * losses.py:258,332-333,373-374) AND KLDLoss.forward on its output (losses.py:95-113) -- the projected feature Y = X.W^T + bias is consumed
+ * in the MFMA accumulators (fp32) and never written.
+ *   forward   X [B*P][K] bf16, W [C][K] bf16 (the rounded copy of the fp32 master weight), bias [C] fp32 or NULL, T [B*P][C] bf16
+ *             -> row_lse2 / row_kl / loss exactly as sd_cgd_kl_tok_fwd (row geometry of the header's top comment; perm orders the C
+ *             projected channels).  Launches: one scan + the finish launch of sd_cgd_kl_tok_fwd_multi for all jobs.
+ *   backward  recomputes Y, writes dY [B*P][C] bf16 = upstream * coef * (softmax_row(Y/tau) - softmax_row(T/tau)) -- the operand of the
+ *             input- and weight-gradient GEMMs (sd_linear_tok_bf16_bwd_data, sd_linear_wgrad_generic_partials) -- and, when db_part is
+ *             not NULL, [sd_align_cgd_tok_tiles(B, P)][C] fp32 partial column sums of dY whose sum over the first axis is the bias gradient.
+ * All jobs of a call share K; K in {64, 128, 256}, C % 32 == 0 (sd_align_cgd_tok_supported); operands 16-byte aligned.
+ * sd_linear_tok_bf16_fwd is the same tile loop with Y stored (bf16): the stand-alone projection.
+ */
+typedef struct sd_align_tok_job {
+    const void *X, *W;
+    const float *bias;          /* [C] or NULL */
+    const void *T;
+    const int32_t *perm;        /* [C] device, or NULL */
+    float *row_lse2;            /* [rows][2]: forward out, backward in */
+    float *row_kl, *loss;       /* forward */
+    const float *upstream;      /* backward: [1] or NULL */
+    void *out;                  /* backward: dY [B*P][C] bf16 */
+    float *db_part;             /* backward: [tiles][C] or NULL */
+    void *workspace;            /* forward: >= sd_align_cgd_tok_workspace_bytes(B, C, P), 16-byte aligned, private to the job */
+    size_t workspace_bytes;
+    long P;
+    int B, K, C, g;
+    float inv_tau, loss_scale, coef;
+    int reserved;
+} sd_align_tok_job;
+int sd_align_cgd_tok_supported(int in_channels, int out_channels);
+int sd_align_cgd_tok_tiles(int B, long P);
+size_t sd_align_cgd_tok_workspace_bytes(int B, int C, long P);
+int sd_align_cgd_tok_fwd_multi(const sd_align_tok_job *jobs, int njobs, void *stream);
+int sd_align_cgd_tok_bwd_multi(const sd_align_tok_job *jobs, int njobs, void *stream);
+int sd_linear_tok_bf16_fwd(const void *X, const void *W, const float *bias, void *Y, long tokens, int in_features, int out_features, void *stream);
+
+/* ---------------------------------------------------------------------------
  * nn.Linear on token-major activations, forward and input gradient, as exact-f32 MFMA GEMMs (csrc/token_gemm.hip):
  *   forward   Y [tokens][out] = act( X [tokens][in] . W[out][in]^T + bias[out] ) (+ residual [tokens][out])
  *   bwd-data  dX [tokens][in] = dY [tokens][out] . W[out][in]

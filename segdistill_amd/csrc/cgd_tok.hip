@@ -20,7 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "cgd_device.h"
+#include "cgd_tok_device.h"
 
 namespace sd {
 namespace {
@@ -96,8 +96,6 @@ __device__ __forceinline__ void fold_channel(RowPart &st, const float (&s)[U], c
 // pure latency each, and config 5 has four stages: 16 launches.  Now any number of stages (<= kTokMaxJobs) is ONE scan launch for the
 // long-chunk stages, ONE for the 16-pixel-chunk stages, and ONE finish launch that folds every row's chunks in fp64 straight from the
 // chunk-major partials and ends with the loss, computed by the workgroup whose arrival ticket is the last of its stage.
-constexpr int kTokMaxJobs = 8;
-
 struct TokScanTable {
     const void *S[kTokMaxJobs];
     const void *T[kTokMaxJobs];
@@ -108,13 +106,6 @@ struct TokScanTable {
     int blk_begin[kTokMaxJobs + 1];
     int njobs;
 };
-
-template <typename Table>
-__device__ __forceinline__ int tok_find_job(const Table &t, int blk) {       // wave-uniform; at most kTokMaxJobs entries
-    int j = 0;
-    while (j + 1 < t.njobs && blk >= t.blk_begin[j + 1]) ++j;
-    return j;
-}
 
 // One workgroup: ceil(nchunk / r) * nvb of them per image; VS vector positions x r chunk lanes, each lane one chunk of pix_chunk pixels of
 // its 16-byte channel vector.  The lane states go through LDS and thread m folds the r states of the workgroup's channel m in chunk order
@@ -235,18 +226,6 @@ __global__ __launch_bounds__(256) void cgd_tok_fwd_partials(const TokScanTable t
 // payload): row_kl is stored `sc1` (a relaxed agent-scope atomic store: no dirty L2 line, so no release fence -- 1.7 us per workgroup
 // saved), every storing wave drains, barrier, ONE lane draws the relaxed agent ticket; the last arriver acquires (agent), waits, barrier,
 // then loads row_kl.  The tickets are zeroed by the first scan launch of the call (a kernel boundary earlier).
-struct TokFinTable {
-    const RowPart *part[kTokMaxJobs];
-    const int32_t *perm[kTokMaxJobs];
-    float *row_lse2[kTokMaxJobs];
-    float *row_kl[kTokMaxJobs];
-    float *loss[kTokMaxJobs];
-    int B[kTokMaxJobs], C[kTokMaxJobs], g[kTokMaxJobs], G[kTokMaxJobs], nkb[kTokMaxJobs];
-    float c2[kTokMaxJobs], inv_tau[kTokMaxJobs], loss_scale[kTokMaxJobs];
-    int blk_begin[kTokMaxJobs + 1];
-    int njobs;
-};
-
 __global__ __launch_bounds__(256) void cgd_tok_finish(const TokFinTable tab, unsigned *counters) {
     __shared__ int is_last;
     __shared__ double acc[4];
@@ -412,10 +391,6 @@ int check_tok(const void *S, const void *Tt, int dtype, int B, int C, long P, in
     return SD_OK;
 }
 
-// the arrival tickets of the finish launch live behind job 0's partials (16-byte aligned; sd_cgd_kl_tok_workspace_bytes reserves the room)
-inline size_t tok_part_bytes(int B, int C, int nkb) { return ((size_t)B * C * nkb * sizeof(RowPart) + 15) & ~(size_t)15; }
-constexpr size_t kTokTicketBytes = 64;
-
 template <typename T>
 int tok_fwd_multi(const sd_cgd_tok_fwd_job *jobs, int njobs, hipStream_t st) {
     TokScanTable scan[2] = {};         // [0]: stepped form (long chunks), [1]: PRE form (16-pixel chunks)
@@ -458,8 +433,7 @@ int tok_fwd_multi(const sd_cgd_tok_fwd_job *jobs, int njobs, hipStream_t st) {
     if (nb[1])
         hipLaunchKernelGGL((cgd_tok_fwd_partials<T, true>), dim3((unsigned)nb[1]), dim3(256), 0, st, scan[1], zeroed ? (unsigned *)nullptr : tickets,
                            kTokMaxJobs);
-    hipLaunchKernelGGL(cgd_tok_finish, dim3((unsigned)fb), dim3(256), 0, st, fin, tickets);
-    return (int)hipGetLastError();
+    return tok_finish_launch(fin, tickets, st);
 }
 
 template <typename T>
@@ -511,6 +485,12 @@ int check_bwd_jobs(const sd_cgd_tok_bwd_job *jobs, int njobs, int dtype) {
 }
 
 }  // namespace
+
+int tok_finish_launch(const TokFinTable &fin, unsigned *tickets, hipStream_t st) {
+    hipLaunchKernelGGL(cgd_tok_finish, dim3((unsigned)fin.blk_begin[fin.njobs]), dim3(256), 0, st, fin, tickets);
+    return (int)hipGetLastError();
+}
+
 }  // namespace sd
 
 extern "C" {

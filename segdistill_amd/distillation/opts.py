@@ -147,6 +147,13 @@ class DistillationLoss(nn.Module):
         crit = self.criteria[i]
         align = self.aligns[str(i)] if str(i) in self.aligns else None
         if self._token_form(i, x_student, x_teacher):
+            if align is not None and ops.align_cgd_tokens_supported(x_student, align.weight, x_teacher):
+                # projection and criterion in one pass each way (csrc/align_tok.hip): the projected feature is never written
+                if hasattr(crit, 'host_prepare') and not (x_student.is_cuda and torch.cuda.is_current_stream_capturing()):
+                    crit.host_prepare(step, align.weight.shape[0])
+                meta, alpha_t = crit.token_job(x_teacher, step)
+                loss = ops.align_cgd_tokens_multi([(x_student, align.weight, align.bias, x_teacher)], [meta])[0]
+                return loss if alpha_t is None else loss * alpha_t
             y = align.forward_tokens(x_student) if align is not None else x_student
             return crit.forward_tokens(y, x_teacher, gt_semantic_seg, step)
         x_s, x_t = _to_nchw(x_student), _to_nchw(x_teacher)
@@ -202,7 +209,7 @@ class DistillationLoss(nn.Module):
         losses = [None] * len(self.distillation)
         # token-major entries first: their align projections run one by one, their criteria in ONE call each way (config 5 taps four decoder
         # stages; evaluated one after the other -- reference opts.py:100-110 -- each criterion was four chained launches forward)
-        batch = []
+        batch, fused = [], []
         for i, entry in enumerate(self.distillation):
             s_name, t_name = entry['student_layer'], entry['teacher_layer']
             if isinstance(s_name, list):
@@ -214,7 +221,23 @@ class DistillationLoss(nn.Module):
                 # schedules and shuffle draws in ENTRY order whatever the launch order below (the draws come from one CPU generator)
                 crit.host_prepare(step, align.weight.shape[0] if align is not None else xs.shape[2 if xs.dim() == 3 else 1])
             if self._token_form(i, xs, xt):
-                batch.append((i, align.forward_tokens(xs) if align is not None else xs, xt))
+                if align is not None and ops.align_cgd_tokens_supported(xs, align.weight, xt):
+                    fused.append((i, xs, align, xt))
+                else:
+                    batch.append((i, align.forward_tokens(xs) if align is not None else xs, xt))
+        # entries whose projection feeds nothing but the criterion: projection + criterion fused (csrc/align_tok.hip), all stages of one student
+        # width in ONE scan launch + ONE finish launch forward and one launch backward
+        by_k = {}
+        for item in fused:
+            by_k.setdefault(item[1].shape[2], []).append(item)
+        cap = ops.cgd_kl_tokens_max_jobs() if fused else 1
+        for items in by_k.values():
+            for lo in range(0, len(items), cap):
+                part = items[lo:lo + cap]
+                jobs = [self.criteria[i].token_job(xt, step) for i, _, _, xt in part]
+                out = ops.align_cgd_tokens_multi([(xs, al.weight, al.bias, xt) for _, xs, al, xt in part], [m for m, _ in jobs])
+                for (i, _, _, _), (_, alpha_t), loss in zip(part, jobs, out):
+                    losses[i] = loss if alpha_t is None else loss * alpha_t
         by_dtype = {}
         for item in batch:
             by_dtype.setdefault(item[1].dtype, []).append(item)

@@ -92,6 +92,11 @@ def _bwd_data(dy2, weight):
     return None
 
 
+def linear_bwd_data_bf16(dy2, wc):
+    """dX [T, in] = dY [T, out] . W [out, in] for bf16 operands (the align projection's input gradient)."""
+    return dy2 @ wc
+
+
 _BF16_WGRAD_LIB = os.environ.get('SEGDISTILL_BF16_WGRAD_LIB', '0') == '1'
 # A/B: 0 = the bias gradient of the transposed-read fp32 weight gradients from the batched column-sum pass (a second read of dY) instead of riding along
 # in their slabs.  Config 2, same box: 793.2 - 795.5 imgs/s with it, 787.0 / 787.1 without (profiles/r04_ab_cfg2_tn_fused_bias.txt)
@@ -125,6 +130,103 @@ def lowp_copy(t, dt):
         val = t.detach().to(dt)         # preserves the parameter's dense layout
     t._sd_shadow = (t._version, val)
     return val
+
+
+def linear_weight_grads(x, dy2, w_shape, w_dtype, want_db, defer_ok, defer_bias_ok):
+    """dW [out, in] (fp32 slabs combined at once or by the deferred pass) and, when it rides along or is cheap to take here, the bias gradient of a
+    token-major Linear: x [..., in] as saved by the forward, dy2 [tokens, out] in x's dtype.  -> (dw, db or None)."""
+    dw = db = None
+    x2 = x.reshape(-1, x.shape[-1])
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
+    T, M, N = x2.shape[0], w_shape[0], w_shape[1]
+    L = _lib.lib()
+    ns_tn = 0
+    if (_SPLIT_BF16 and x.dtype == torch.float32 and w_dtype == torch.float32 and dyc.data_ptr() % 16 == 0
+            and x2.data_ptr() % 16 == 0):
+        ns_tn = L.sd_linear_wgrad_tn_slabs(T, M, N)
+    if ns_tn:
+        # round 4: the tall-skinny products with out_features >= 128 (the SegFormer head over 131072 tokens) on transposed LDS reads in
+        # split-bf16 arithmetic (csrc/wgrad_tn.hip) instead of the exact-f32 tall-skinny kernel; slabs combined by the deferred pass
+        # the bias gradient rides along as M extra floats per slab (column sums of the staged dY values): no second pass over dY
+        fuse_db = want_db and _TN_FUSED_BIAS
+        slab = M * N + (M if fuse_db else 0)
+        ws = torch.empty(ns_tn, slab, dtype=torch.float32, device=x.device)
+        _lib.check(L.sd_linear_wgrad_tn(dyc.data_ptr(), x2.data_ptr(), ws.data_ptr(), ws.numel() * 4, T, M, N, int(fuse_db), _stream_ptr()),
+                   'sd_linear_wgrad_tn')
+        buf = torch.empty(slab, dtype=torch.float32, device=x.device)
+        if defer_ok and deferred.enabled() and (defer_bias_ok or not fuse_db):
+            deferred.add(ws, buf, slab, ns_tn)
+        else:
+            deferred.reduce_now(ws, buf, slab, ns_tn)
+        db = buf[M * N:] if fuse_db else (deferred.column_sum(dyc, defer_bias_ok) if want_db else None)
+        return buf[:M * N].view(M, N), db
+    direct = bool(L.sd_linear_wgrad_fuses_bias_dtype(_DT[x.dtype], T, M, N))
+    if not direct and x.dtype == torch.float32:
+        # fewer than 8192 tokens or a weight of more than 16 64x64 regions: no longer tall-skinny.  Round 3: split-K over the tokens
+        # on the pipelined MFMA kernel (sd_linear_wgrad_splitk), slabs combined by the deferred batched pass -- the library ran
+        # these on ~100 workgroups of 32 x 32 tiles (63 us for 1024 x 256 over 2048 tokens; profiles/r03_step_shapes.txt)
+        ns = L.sd_linear_wgrad_splitk_slabs(T, M, N) if _SPLITK_WGRAD and w_dtype == torch.float32 else 0
+        if ns:
+            ws = torch.empty(ns, M * N, dtype=torch.float32, device=x.device)
+            _lib.check(L.sd_linear_wgrad_splitk(dyc.data_ptr(), x2.data_ptr(), ws.data_ptr(), ws.numel() * 4, T, M, N, _stream_ptr()),
+                       'sd_linear_wgrad_splitk')
+            buf = torch.empty(M * N, dtype=torch.float32, device=x.device)
+            if defer_ok and deferred.enabled():
+                deferred.add(ws, buf, M * N, ns)
+            else:
+                deferred.reduce_now(ws, buf, M * N, ns)
+            dw = buf.view(M, N)
+        else:
+            dw = (dyc.t() @ x2).to(w_dtype)
+        db = deferred.column_sum(dyc, defer_bias_ok and w_dtype == torch.float32).to(w_dtype) if want_db else None
+        return dw, db
+    fuse_b = want_db and direct
+    if direct and defer_ok and deferred.enabled() and w_dtype == torch.float32:
+        # tall-skinny plan inside a deferred scope, gradients going straight to fp32 leaf parameters: leave the split-K slabs
+        # in the workspace, the scope's exit combines them together with everybody else's (segdistill_amd/deferred.py)
+        slab = M * N + (M if fuse_b else 0)
+        buf = torch.empty(slab, dtype=torch.float32, device=x.device)
+        wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+        deferred.side_launch(lambda: _lib.check(L.sd_linear_wgrad_partials(dyc.data_ptr(), x2.data_ptr(), _DT[x.dtype], T, M, N, int(fuse_b),
+                                                                            ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_wgrad_partials'),
+                             dyc, x2, ws)
+        deferred.add(ws, buf, slab, L.sd_linear_wgrad_slabs(_DT[x.dtype], T, M, N))
+        dw = buf[:M * N].view(M, N)
+        if fuse_b:
+            db = buf[M * N:]
+        elif want_db:
+            db = deferred.column_sum(dyc, defer_bias_ok)
+        return dw, db
+    if not direct and _BF16_WGRAD_LIB and x.dtype == torch.bfloat16:
+        # A/B switch: the library's bf16 GEMM for the generic (not tall-skinny) weight gradients under bf16 storage.  Measured on MI355X,
+        # config 5, same box: 515 imgs/s with it against 638 / 636 with the split-K kernel + deferred combine -- off by default
+        dw = (dyc.t() @ x2).to(w_dtype)
+        db = deferred.column_sum(dyc, defer_bias_ok and w_dtype == torch.float32).to(w_dtype) if want_db else None
+        return dw, db
+    gs = 0 if direct else L.sd_linear_wgrad_generic_slabs(_DT[x.dtype], T, M, N)
+    if gs and defer_ok and deferred.enabled() and w_dtype == torch.float32:
+        # the generic split-K plan (bf16 storage: most Linears of config 5) inside a deferred scope: its slab combine joins the batched
+        # pass at the end of the backward instead of running as one more launch per layer (54 of them per config-5 step)
+        ws = torch.empty(gs, M * N, dtype=torch.float32, device=x.device)
+        _lib.check(L.sd_linear_wgrad_generic_partials(dyc.data_ptr(), x2.data_ptr(), _DT[x.dtype], T, M, N, ws.data_ptr(), ws.numel() * 4,
+                                                      _stream_ptr()), 'sd_linear_wgrad_generic_partials')
+        buf = torch.empty(M * N, dtype=torch.float32, device=x.device)
+        deferred.add(ws, buf, M * N, gs)
+        db = deferred.column_sum(dyc, defer_bias_ok) if want_db else None
+        return buf.view(M, N), db
+    dw32 = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    db32 = torch.empty(M, dtype=torch.float32, device=x.device) if fuse_b else None
+    wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    _lib.check(L.sd_linear_wgrad(dyc.data_ptr(), x2.data_ptr(), dw32.data_ptr(), None if db32 is None else db32.data_ptr(),
+                                 _DT[x.dtype], T, M, N, ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_wgrad')
+    dw = dw32.to(w_dtype)
+    if fuse_b:
+        db = db32.to(w_dtype)
+    return dw, db
 
 
 class _TokenLinear(torch.autograd.Function):
@@ -161,96 +263,7 @@ class _TokenLinear(torch.autograd.Function):
             dx = dx.reshape(x.shape) if dx is not None else (dy2 @ weight).reshape(x.shape).to(ctx.in_dtype)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            x2 = x.reshape(-1, x.shape[-1])
-            if not x2.is_contiguous():
-                x2 = x2.contiguous()
-            dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
-            T, M, N = x2.shape[0], weight.shape[0], weight.shape[1]
-            L = _lib.lib()
-            ns_tn = 0
-            if (_SPLIT_BF16 and x.dtype == torch.float32 and ctx.w_dtype == torch.float32 and dyc.data_ptr() % 16 == 0
-                    and x2.data_ptr() % 16 == 0):
-                ns_tn = L.sd_linear_wgrad_tn_slabs(T, M, N)
-            if ns_tn:
-                # round 4: the tall-skinny products with out_features >= 128 (the SegFormer head over 131072 tokens) on transposed LDS reads in
-                # split-bf16 arithmetic (csrc/wgrad_tn.hip) instead of the exact-f32 tall-skinny kernel; slabs combined by the deferred pass
-                # the bias gradient rides along as M extra floats per slab (column sums of the staged dY values): no second pass over dY
-                fuse_db = want_db and _TN_FUSED_BIAS
-                slab = M * N + (M if fuse_db else 0)
-                ws = torch.empty(ns_tn, slab, dtype=torch.float32, device=x.device)
-                _lib.check(L.sd_linear_wgrad_tn(dyc.data_ptr(), x2.data_ptr(), ws.data_ptr(), ws.numel() * 4, T, M, N, int(fuse_db), _stream_ptr()),
-                           'sd_linear_wgrad_tn')
-                buf = torch.empty(slab, dtype=torch.float32, device=x.device)
-                if ctx.defer_ok and deferred.enabled() and (ctx.defer_bias_ok or not fuse_db):
-                    deferred.add(ws, buf, slab, ns_tn)
-                else:
-                    deferred.reduce_now(ws, buf, slab, ns_tn)
-                db = buf[M * N:] if fuse_db else (deferred.column_sum(dyc, ctx.defer_bias_ok) if want_db else None)
-                return dx, buf[:M * N].view(M, N), db, None, None
-            direct = bool(L.sd_linear_wgrad_fuses_bias_dtype(_DT[x.dtype], T, M, N))
-            if not direct and x.dtype == torch.float32:
-                # fewer than 8192 tokens or a weight of more than 16 64x64 regions: no longer tall-skinny.  Round 3: split-K over the tokens
-                # on the pipelined MFMA kernel (sd_linear_wgrad_splitk), slabs combined by the deferred batched pass -- the library ran
-                # these on ~100 workgroups of 32 x 32 tiles (63 us for 1024 x 256 over 2048 tokens; profiles/r03_step_shapes.txt)
-                ns = L.sd_linear_wgrad_splitk_slabs(T, M, N) if _SPLITK_WGRAD and ctx.w_dtype == torch.float32 else 0
-                if ns:
-                    ws = torch.empty(ns, M * N, dtype=torch.float32, device=x.device)
-                    _lib.check(L.sd_linear_wgrad_splitk(dyc.data_ptr(), x2.data_ptr(), ws.data_ptr(), ws.numel() * 4, T, M, N, _stream_ptr()),
-                               'sd_linear_wgrad_splitk')
-                    buf = torch.empty(M * N, dtype=torch.float32, device=x.device)
-                    if ctx.defer_ok and deferred.enabled():
-                        deferred.add(ws, buf, M * N, ns)
-                    else:
-                        deferred.reduce_now(ws, buf, M * N, ns)
-                    dw = buf.view(M, N)
-                else:
-                    dw = (dyc.t() @ x2).to(ctx.w_dtype)
-                db = deferred.column_sum(dyc, ctx.defer_bias_ok and ctx.w_dtype == torch.float32).to(ctx.w_dtype) if want_db else None
-                return dx, dw, db, None, None
-            fuse_b = want_db and direct
-            if direct and ctx.defer_ok and deferred.enabled() and ctx.w_dtype == torch.float32:
-                # tall-skinny plan inside a deferred scope, gradients going straight to fp32 leaf parameters: leave the split-K slabs
-                # in the workspace, the scope's exit combines them together with everybody else's (segdistill_amd/deferred.py)
-                slab = M * N + (M if fuse_b else 0)
-                buf = torch.empty(slab, dtype=torch.float32, device=x.device)
-                wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
-                ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-                deferred.side_launch(lambda: _lib.check(L.sd_linear_wgrad_partials(dyc.data_ptr(), x2.data_ptr(), _DT[x.dtype], T, M, N, int(fuse_b),
-                                                                                    ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_wgrad_partials'),
-                                     dyc, x2, ws)
-                deferred.add(ws, buf, slab, L.sd_linear_wgrad_slabs(_DT[x.dtype], T, M, N))
-                dw = buf[:M * N].view(M, N)
-                if fuse_b:
-                    db = buf[M * N:]
-                elif want_db:
-                    db = deferred.column_sum(dyc, ctx.defer_bias_ok)
-                return dx, dw, db, None, None
-            if not direct and _BF16_WGRAD_LIB and x.dtype == torch.bfloat16:
-                # A/B switch: the library's bf16 GEMM for the generic (not tall-skinny) weight gradients under bf16 storage.  Measured on MI355X,
-                # config 5, same box: 515 imgs/s with it against 638 / 636 with the split-K kernel + deferred combine -- off by default
-                dw = (dyc.t() @ x2).to(ctx.w_dtype)
-                db = deferred.column_sum(dyc, ctx.defer_bias_ok and ctx.w_dtype == torch.float32).to(ctx.w_dtype) if want_db else None
-                return dx, dw, db, None, None
-            gs = 0 if direct else L.sd_linear_wgrad_generic_slabs(_DT[x.dtype], T, M, N)
-            if gs and ctx.defer_ok and deferred.enabled() and ctx.w_dtype == torch.float32:
-                # the generic split-K plan (bf16 storage: most Linears of config 5) inside a deferred scope: its slab combine joins the batched
-                # pass at the end of the backward instead of running as one more launch per layer (54 of them per config-5 step)
-                ws = torch.empty(gs, M * N, dtype=torch.float32, device=x.device)
-                _lib.check(L.sd_linear_wgrad_generic_partials(dyc.data_ptr(), x2.data_ptr(), _DT[x.dtype], T, M, N, ws.data_ptr(), ws.numel() * 4,
-                                                              _stream_ptr()), 'sd_linear_wgrad_generic_partials')
-                buf = torch.empty(M * N, dtype=torch.float32, device=x.device)
-                deferred.add(ws, buf, M * N, gs)
-                db = deferred.column_sum(dyc, ctx.defer_bias_ok) if want_db else None
-                return dx, buf.view(M, N), db, None, None
-            dw32 = torch.empty(M, N, dtype=torch.float32, device=x.device)
-            db32 = torch.empty(M, dtype=torch.float32, device=x.device) if fuse_b else None
-            wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
-            ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-            _lib.check(L.sd_linear_wgrad(dyc.data_ptr(), x2.data_ptr(), dw32.data_ptr(), None if db32 is None else db32.data_ptr(),
-                                         _DT[x.dtype], T, M, N, ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_wgrad')
-            dw = dw32.to(ctx.w_dtype)
-            if fuse_b:
-                db = db32.to(ctx.w_dtype)
+            dw, db = linear_weight_grads(x, dy2, weight.shape, ctx.w_dtype, want_db, ctx.defer_ok, ctx.defer_bias_ok)
         if want_db and db is None:
             dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
             db = deferred.column_sum(dyc, ctx.defer_bias_ok and ctx.w_dtype == torch.float32).to(ctx.w_dtype)

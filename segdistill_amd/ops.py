@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -188,6 +189,136 @@ def cgd_kl_tokens_multi(pairs, meta, return_rows=False):
     flat = [x for st in pairs for x in st]
     out = _CGDKLTokMultiFunction.apply(list(meta), *flat)
     return [(out[2 * i], out[2 * i + 1]) if return_rows else out[2 * i] for i in range(len(pairs))]
+
+
+class _AlignTokJob(C.Structure):   # include/segdistill_hip.h: sd_align_tok_job
+    _fields_ = [('X', C.c_void_p), ('W', C.c_void_p), ('bias', C.c_void_p), ('T', C.c_void_p), ('perm', C.c_void_p), ('row_lse2', C.c_void_p),
+                ('row_kl', C.c_void_p), ('loss', C.c_void_p), ('upstream', C.c_void_p), ('out', C.c_void_p), ('db_part', C.c_void_p),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('P', C.c_long), ('B', C.c_int), ('K', C.c_int), ('C', C.c_int),
+                ('g', C.c_int), ('inv_tau', C.c_float), ('loss_scale', C.c_float), ('coef', C.c_float), ('reserved', C.c_int)]
+
+
+_ALIGN_FUSED = os.environ.get('SEGDISTILL_ALIGN_FUSED', '1') == '1'     # A/B: 0 = projection as a token Linear, criterion on its stored output
+
+
+def align_cgd_tokens_supported(x, weight, t):
+    """The fused projection + criterion kernels of csrc/align_tok.hip take this entry: bf16 token-major taps [B, P, Cs] / [B, P, Ct], an fp32
+    master weight [Ct, Cs] with Cs in {64, 128, 256} and Ct a multiple of 32."""
+    if not (_ALIGN_FUSED and x.is_cuda and x.dim() == 3 and t.dim() == 3 and x.dtype == torch.bfloat16 and t.dtype == torch.bfloat16):
+        return False
+    if x.shape[:2] != t.shape[:2] or tuple(weight.shape) != (t.shape[2], x.shape[2]) or weight.dtype != torch.float32:
+        return False
+    return bool(_lib.lib().sd_align_cgd_tok_supported(x.shape[2], t.shape[2]))
+
+
+class _AlignCGDTokMultiFunction(torch.autograd.Function):
+    """n distillation entries `criterion(align(x), t)` on token-major bf16 taps, projection and criterion fused (csrc/align_tok.hip): the projected
+    feature is never written.  apply(meta, defer_ok, x_1, W_1, b_1, t_1, ...) -> (loss_1, rows_1, ...); meta = [(group_size, tau, alpha, perm or None)];
+    W_i the fp32 master weight [Ct, Cs] (its bf16 copy is the optimizer-maintained shadow), b_i fp32 [Ct] or None.
+    Forward: one scan launch + one finish launch for all entries.  Backward: one launch that recomputes the projection and writes dY (bf16) and
+    the bias gradient's per-tile column sums, then per entry dX = dY.W and the split-K weight gradient of wgrad_tn.hip."""
+
+    @staticmethod
+    def forward(ctx, meta, defer_ok, *ops_):
+        from .linear import lowp_copy
+        n = len(meta)
+        if len(ops_) != 4 * n or n == 0:
+            raise ValueError('expected (x, weight, bias, t) per entry')
+        L = _lib.lib()
+        if n > L.sd_cgd_kl_tok_max_jobs():
+            raise ValueError(f'at most {L.sd_cgd_kl_tok_max_jobs()} entries per call')
+        jobs = (_AlignTokJob * n)()
+        keep, outs, saved, info = [], [], [], []
+        for i, (g, tau, alpha, perm) in enumerate(meta):
+            x, w, b, t = ops_[4 * i:4 * i + 4]
+            _require_gpu(x, t, w)
+            if not align_cgd_tokens_supported(x, w, t):
+                raise ValueError(f'unsupported operands {tuple(x.shape)} {x.dtype} / {tuple(w.shape)} / {tuple(t.shape)} {t.dtype}')
+            x, t = x.contiguous(), t.contiguous()
+            wc = lowp_copy(w, torch.bfloat16)
+            if not wc.is_contiguous():
+                wc = wc.contiguous()
+            bb = None if b is None else b.detach().to(torch.float32).contiguous()
+            B, P, K = x.shape
+            Cc = t.shape[2]
+            g = int(g)
+            rows = B * (-(-Cc // g))
+            if perm is not None:
+                perm = perm.to(device=x.device, dtype=torch.int32).contiguous()
+                if perm.numel() != Cc:
+                    raise ValueError('perm must have C entries')
+            ws_bytes = L.sd_align_cgd_tok_workspace_bytes(B, Cc, P)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+            row_lse2 = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+            row_kl = torch.empty(rows, dtype=torch.float32, device=x.device)
+            loss = torch.empty((), dtype=torch.float32, device=x.device)
+            j = jobs[i]
+            j.X, j.W, j.bias, j.T, j.perm = x.data_ptr(), wc.data_ptr(), _ptr(bb), t.data_ptr(), _ptr(perm)
+            j.row_lse2, j.row_kl, j.loss = row_lse2.data_ptr(), row_kl.data_ptr(), loss.data_ptr()
+            j.workspace, j.workspace_bytes, j.P, j.B, j.K, j.C, j.g = ws.data_ptr(), ws_bytes, P, B, K, Cc, g
+            j.inv_tau, j.loss_scale = 1.0 / float(tau), float(alpha) / rows
+            keep += [ws, bb]
+            outs += [loss, row_kl]
+            empty = torch.empty(0, device=x.device)
+            saved += [x, wc, bb if bb is not None else empty, t, row_lse2, perm if perm is not None else empty]
+            info.append((g, float(tau), float(alpha), rows, perm is not None, bb is not None, tuple(w.shape)))
+        _lib.check(L.sd_align_cgd_tok_fwd_multi(C.cast(jobs, C.c_void_p), n, _stream_ptr()), 'sd_align_cgd_tok_fwd_multi')
+        ctx.save_for_backward(*saved)
+        ctx.info, ctx.defer_ok = info, bool(defer_ok)
+        ctx.mark_non_differentiable(*outs[1::2])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from . import deferred
+        from .linear import linear_bwd_data_bf16, linear_weight_grads
+        info, saved = ctx.info, ctx.saved_tensors
+        n = len(info)
+        L = _lib.lib()
+        jobs = (_AlignTokJob * n)()
+        work, keep = [], []
+        for i, (g, tau, alpha, rows, has_perm, has_bias, w_shape) in enumerate(info):
+            x, wc, bb, t, row_lse2, perm = saved[6 * i:6 * i + 6]
+            B, P, K = x.shape
+            Cc = t.shape[2]
+            want_db = has_bias and ctx.needs_input_grad[2 + 4 * i + 2]
+            dY = torch.empty_like(t)
+            tiles = L.sd_align_cgd_tok_tiles(B, P)
+            db_part = torch.empty(tiles, Cc, dtype=torch.float32, device=x.device) if want_db else None
+            gl = grads[2 * i]
+            up = (gl if gl is not None else torch.zeros((), device=x.device)).to(torch.float32).contiguous()
+            j = jobs[i]
+            j.X, j.W, j.bias, j.T, j.perm = x.data_ptr(), wc.data_ptr(), bb.data_ptr() if has_bias else None, t.data_ptr(), perm.data_ptr() if has_perm else None
+            j.row_lse2, j.upstream, j.out, j.db_part = row_lse2.data_ptr(), up.data_ptr(), dY.data_ptr(), _ptr(db_part)
+            j.P, j.B, j.K, j.C, j.g, j.inv_tau, j.coef = P, B, K, Cc, g, 1.0 / tau, alpha / (rows * tau)
+            work.append((x, wc, dY, db_part, tiles, w_shape))
+            keep.append(up)
+        _lib.check(L.sd_align_cgd_tok_bwd_multi(C.cast(jobs, C.c_void_p), n, _stream_ptr()), 'sd_align_cgd_tok_bwd_multi')
+        out = [None, None]
+        for i, (x, wc, dY, db_part, tiles, w_shape) in enumerate(work):
+            need = ctx.needs_input_grad[2 + 4 * i:2 + 4 * i + 4]
+            dy2 = dY.view(-1, dY.shape[-1])
+            dx = linear_bwd_data_bf16(dy2, wc).view(x.shape) if need[0] else None
+            dw = linear_weight_grads(x, dy2, w_shape, torch.float32, False, ctx.defer_ok, ctx.defer_ok)[0] if need[1] else None
+            db = None
+            if db_part is not None:
+                Cc = dY.shape[-1]
+                buf = torch.empty(Cc, dtype=torch.float32, device=x.device)
+                if ctx.defer_ok and deferred.enabled():
+                    deferred.add(db_part, buf, Cc, tiles)
+                else:
+                    deferred.reduce_now(db_part, buf, Cc, tiles)
+                db = buf.view(Cc)
+            out += [dx, dw, db, None]
+        return tuple(out)
+
+
+def align_cgd_tokens_multi(entries, meta, defer_ok=True, return_rows=False):
+    """Several fused (align + criterion) entries in one call each way: entries = [(x_i, weight_i, bias_i, t_i)], meta = [(group_size, tau, alpha,
+    perm or None)] -> [loss_i] (or [(loss_i, rows_i)]).  All entries of a call share the student width Cs."""
+    flat = [v for e in entries for v in e]
+    out = _AlignCGDTokMultiFunction.apply(list(meta), defer_ok, *flat)
+    return [(out[2 * i], out[2 * i + 1]) if return_rows else out[2 * i] for i in range(len(entries))]
 
 
 # ------------------------------------------------------------------------------------------------
