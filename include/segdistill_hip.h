@@ -365,6 +365,9 @@ size_t sd_align_cgd_tok_workspace_bytes(int B, int C, long P);
 int sd_align_cgd_tok_fwd_multi(const sd_align_tok_job *jobs, int njobs, void *stream);
 int sd_align_cgd_tok_bwd_multi(const sd_align_tok_job *jobs, int njobs, void *stream);
 int sd_linear_tok_bf16_fwd(const void *X, const void *W, const float *bias, void *Y, long tokens, int in_features, int out_features, void *stream);
+/* dX [tokens][in] = dY [tokens][out] . W [out][in] (bf16 in and out, fp32 accumulation): the projection's input gradient (autograd's
+ * `grad_output.mm(weight)` of the same Linear); the same shapes as above (sd_align_cgd_tok_supported(in, out)). */
+int sd_linear_tok_bf16_bwd_data(const void *dY, const void *W, void *dX, long tokens, int out_features, int in_features, void *stream);
 
 /* ---------------------------------------------------------------------------
  * nn.Linear on token-major activations, forward and input gradient, as exact-f32 MFMA GEMMs (csrc/token_gemm.hip):

@@ -93,7 +93,16 @@ def _bwd_data(dy2, weight):
 
 
 def linear_bwd_data_bf16(dy2, wc):
-    """dX [T, in] = dY [T, out] . W [out, in] for bf16 operands (the align projection's input gradient)."""
+    """dX [T, in] = dY [T, out] . W [out, in] for bf16 operands (the align projection's input gradient): csrc/align_tok.hip's tok_dx_kernel for the
+    projection's shapes (in <= 256), the library otherwise."""
+    T, M = dy2.shape
+    N = wc.shape[1]
+    L = _lib.lib()
+    if (dy2.is_cuda and dy2.dtype == torch.bfloat16 and wc.dtype == torch.bfloat16 and dy2.is_contiguous() and wc.is_contiguous()
+            and L.sd_align_cgd_tok_supported(N, M) and dy2.data_ptr() % 16 == 0 and wc.data_ptr() % 16 == 0):
+        dx = torch.empty(T, N, dtype=torch.bfloat16, device=dy2.device)
+        _lib.check(L.sd_linear_tok_bf16_bwd_data(dy2.data_ptr(), wc.data_ptr(), dx.data_ptr(), T, M, N, _stream_ptr()), 'sd_linear_tok_bf16_bwd_data')
+        return dx
     return dy2 @ wc
 
 

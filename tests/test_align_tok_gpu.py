@@ -3,7 +3,7 @@ opts.py:25-27 docstring, commented `self.ff` of losses.py:258,332-333,373-374, K
 
     y = x . W_bf16^T + b  (fp64 on the bf16-rounded operands; NOT rounded: the fused kernels never store it)  ->  oracle/kd_ref.rowwise_kld
 
-Covers: K in {64, 128, 256}; pad (C % g != 0); a channel permutation; ragged token tiles (P % 256, P % 64, P < 64); several images; several jobs of
+Covers: K in {64, 128, 256}; pad (C % g != 0); a channel permutation; ragged token tiles (P % 512, P % 64, P < 64); several images; several jobs of
 different size in one call (the plan's channel split of the small jobs); an upstream factor; no bias; the stored dY itself (bf16 of the fp64 value);
 the stand-alone projection (plain mode) against torch."""
 import numpy as np
@@ -16,9 +16,9 @@ pytestmark = pytest.mark.gpu
 
 CASES = [  # B, P, K, C, g, tau, alpha, perm, bias
     (1, 256, 256, 768, 8, 4.0, 3.0, False, True),      # one full tile at config 5's widths
-    (2, 300, 256, 96, 8, 4.0, 3.0, True, True),        # ragged second tile (44 rows: one wave ragged, three empty)
+    (2, 300, 256, 96, 8, 4.0, 3.0, True, True),        # a ragged tile (300 rows: four full waves, one of 44 rows, three empty)
     (1, 40, 64, 32, 1, 1.0, 1.0, False, True),         # fewer rows than one wave; CD rows (g = 1)
-    (3, 513, 128, 160, 7, 2.0, 2.0, True, False),      # pad 160 % 7, a one-row tile, no bias
+    (3, 513, 128, 160, 7, 2.0, 2.0, True, False),      # pad 160 % 7, a one-row second tile, no bias
     (1, 1024, 256, 768, 8, 4.0, 3.0, True, True),      # config 5 stage 3, B = 1
     (2, 64, 64, 64, 64, 3.0, 1.0, False, True),        # g = C
 ]
@@ -81,7 +81,7 @@ def test_fused_align_criterion_matches_oracle(case):
 
 def test_stored_dy_is_the_bf16_of_the_oracle_gradient():
     """The backward launch through the C ABI: dY [B, P, C] elementwise against the fp64 gradient (one bf16 rounding + fp32 arithmetic), the
-    per-tile column sums against the sums of the fp64 gradient over each 256-token tile."""
+    per-tile column sums against the sums of the fp64 gradient over each 512-token tile."""
     import ctypes as C
     from segdistill_amd import _lib, ops
     B, P, K, Cc, g, tau, alpha = 2, 600, 256, 128, 8, 4.0, 3.0
@@ -96,7 +96,9 @@ def test_stored_dy_is_the_bf16_of_the_oracle_gradient():
     wc = fn.saved_tensors[1]
     L = _lib.lib()
     tiles = L.sd_align_cgd_tok_tiles(B, P)
-    assert tiles == B * 3
+    per_img = L.sd_align_cgd_tok_tiles(1, P)
+    tile_rows = 512                                                  # tokens per workgroup item (csrc/align_tok.hip: kBM)
+    assert tiles == B * per_img and per_img == -(-P // tile_rows)
     dY = torch.full((B, P, Cc), float('nan'), dtype=torch.bfloat16, device=dev)
     dbp = torch.empty(tiles, Cc, dtype=torch.float32, device=dev)
     job = (ops._AlignTokJob * 1)()
@@ -112,13 +114,13 @@ def test_stored_dy_is_the_bf16_of_the_oracle_gradient():
     assert (err <= 2.0 ** -8 * np.abs(ref['dy']) + 1e-3 * np.abs(ref['dy']).max()).all()
     part = np.zeros((tiles, Cc))
     for bi in range(B):
-        for kb in range(3):
-            part[bi * 3 + kb] = ref['dy'][bi, kb * 256:(kb + 1) * 256].sum(0)
+        for kb in range(per_img):
+            part[bi * per_img + kb] = ref['dy'][bi, kb * tile_rows:(kb + 1) * tile_rows].sum(0)
     np.testing.assert_allclose(dbp.cpu().numpy(), part, rtol=2e-3, atol=2e-4 * np.abs(part).max())
 
 
 def test_several_jobs_in_one_call_match_single_calls():
-    """Config 5's four stages at B = 1 (64 + 16 + 4 + 1 tiles: the plan cuts every item into channel ranges) against one call per stage."""
+    """Config 5's four stages at B = 1 (32 + 8 + 2 + 1 tiles: the plan cuts every item into channel ranges) against one call per stage."""
     from segdistill_amd import ops
     dev = torch.device('cuda:0')
     K, C = 256, 768
@@ -188,3 +190,20 @@ def test_plain_projection_matches_torch(shape):
     got = y.double().cpu().numpy()
     assert np.isfinite(got).all()
     assert (np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 1e-4).all()
+
+
+@pytest.mark.parametrize('shape', [(1000, 768, 256), (256, 32, 64), (70, 96, 128), (4096, 768, 256)])
+def test_input_gradient_gemm_matches_torch(shape):
+    """dX = dY . W (csrc/align_tok.hip: tok_dx_kernel) against fp64 on the same bf16 operands; ragged token tiles, all three student widths."""
+    from segdistill_amd import _lib
+    T, C, N = shape
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(T + C)
+    dy = torch.randn(T, C, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(C, N, generator=g) / C ** 0.5).to(torch.bfloat16).to(dev)
+    dx = torch.full((T, N), float('nan'), dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.lib().sd_linear_tok_bf16_bwd_data(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), T, C, N, torch.cuda.current_stream().cuda_stream), 'bwd_data')
+    ref = (dy.double() @ w.double()).cpu().numpy()
+    got = dx.double().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert (np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 2e-4).all()
