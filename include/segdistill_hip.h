@@ -68,10 +68,15 @@ const char *sd_error_string(int code);
  *       into three bf16 terms -- fp32-grade results; 0 = v_mfma_f32_32x32x2_f32), "sra_bf16_mfma" (0|1, default 1: bf16-storage
  *       attention forward and backward on the bf16 matrix pipe with P / dS rounded to bf16; 0 = the f32-input MFMA kernels), "align_split_bf16"
  *       (0|1, default 1: the three fp32 products of the 1x1 align projection and of sd_linear_nchw_* in split-bf16 arithmetic),
- *       "pred_tall_tile" (0|1, default 1: sd_linear_nchw_fwd / _bwd_weight use ONE 160-row tile for 129 ... 160 output planes -- the 150
- *       classes -- instead of two 128-row tiles; same arithmetic), "ce_bwd_multiclass" (0|1, default 1: sd_ce_up_bwd handles 4 (2 at
+ *       "ce_bwd_multiclass" (0|1, default 1: sd_ce_up_bwd handles 4 (2 at
  *       factor 8) class planes per workgroup with the pixel maps loaded once per group; 0 = one class per workgroup, rounds 1-2).
- *       The sra_*, align_*, pred_* and ce_* keys select arithmetic or tiling, not workspace geometry: no workspace size depends on them. */
+ *       "wgrad_tn_ring" (0|1|2, default 1: the bf16 weight-gradient kernels of csrc/wgrad_tn.hip -- 0 register-staged tiles everywhere, 1 the LDS-DMA
+ *       ring where legal, 2 its 256 x 256 tiles wherever legal), "wgrad_slab_ratio" (per cent, default 40, 0 = no cap: the most split-K slab bytes a
+ *       bf16-storage weight gradient may write, as a share of its operand bytes).
+ *       The sra_*, align_*, ce_* and wgrad_tn_ring keys select arithmetic or tiling, not workspace geometry: no workspace size depends on them.
+ *       "wgrad_slab_ratio" IS workspace geometry: it changes what sd_linear_wgrad_generic_slabs / sd_linear_wgrad_slabs /
+ *       sd_linear_wgrad_workspace_bytes answer, so set it before any of those queries (the Python binding reads SEGDISTILL_WGRAD_SLAB_RATIO once,
+ *       when the library is loaded). */
 int sd_set_tunable(const char *key, int value);
 int sd_get_tunable(const char *key);
 

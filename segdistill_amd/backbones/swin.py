@@ -128,7 +128,7 @@ class WindowAttention(nn.Module):
         h = self.num_heads
         tbl = self.relative_position_bias_table
         qkv = self.qkv(x)
-        if (not (torch.is_grad_enabled() and qkv.requires_grad) and not (self.training and self.attn_drop.p > 0)
+        if (not (torch.is_grad_enabled() and (qkv.requires_grad or tbl.requires_grad)) and not (self.training and self.attn_drop.p > 0)
                 and window_attn.supported(qkv, n, h, c // h) and (mask is None or bw % mask.shape[0] == 0)):
             # no graph to build (the frozen teacher): one kernel over the qkv Linear's output, bias and mask read from their tables
             # (csrc/window_attn.hip) -- no [windows, heads, N, N] additive tensor, no permuted copies of q / k / v or of the output
@@ -180,6 +180,9 @@ class SwinTransformerBlock(nn.Module):
         """no graph to build, nothing stochastic, both norms on the HIP kernels: forward_fused applies"""
         return (_GATHER_WINDOWS and _FUSE_NORMS and (not self.training or isinstance(self.drop_path, nn.Identity))
                 and map_supported(x, self.norm1) and map_supported(x, self.norm2)
+                # forward_fused runs forward-only kernels around the attention / MLP modules: with ANY trainable parameter in the block (frozen
+                # norms, trainable qkv / proj / bias table / MLP) their outputs would enter those kernels and the gradients would be lost
+                and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
                 # a tapped block (Extractor hooks) must be CALLED and must return its complete output: forward_fused does neither
                 and not (self._forward_hooks or self._forward_pre_hooks or self.drop_path._forward_hooks or self.drop_path._forward_pre_hooks))
 

@@ -136,17 +136,6 @@ __global__ __launch_bounds__(64 * kNW, 2) void align_tok_kernel(const AlignTokTa
     const int rows_tile = (int)min((long)kBM, P - (long)kb * kBM);
     const int wrows = min(64, max(0, rows_tile - 64 * wave));    // valid rows of this wave (wave-uniform)
 
-    // ---- A fragments: this wave's 64 token rows, all of K, straight from global in the operand layout (lane l: row l & 31, k = 16 s + 8 (l >> 5) ..+7)
-    const bf16_t *X = tab.X[j];
-    bf16x8 af[2][KS];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const long tok = min(tok0 + 64 * wave + 32 * i + col, last_tok);         // rows past the image: clamped address, masked below
-        const bf16_t *px = X + (size_t)tok * K + 8 * h;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) af[i][s] = *reinterpret_cast<const bf16x8 *>(px + 16 * s);
-    }
-
     // ---- per-channel tables of the item's range
     float *bias_l = reinterpret_cast<float *>(lds + L::kBias);
     {
@@ -270,10 +259,26 @@ __global__ __launch_bounds__(64 * kNW, 2) void align_tok_kernel(const AlignTokTa
     issue_w(0);
     issue_t(0);
     if (nblk > 1) issue_t(1);
-    stamp(0);                                                 // prologue: X fragments requested, tables, first DMAs issued
+    // The X fragments are requested BEHIND the first blocks' DMAs (and behind the tables' loads): block 0 then waits for W(0) and T(0) only, and its
+    // MFMAs wait fragment by fragment (the compiler's own counted waits) instead of for all 2 KS loads -- the prologue was 13 % of an item.
+    // A fragments: this wave's 64 token rows, all of K, straight from global in the operand layout (lane l: row l & 31, k = 16 s + 8 (l >> 5) ..+7)
+    const bf16_t *X = tab.X[j];
+    bf16x8 af[2][KS];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long tok = min(tok0 + 64 * wave + 32 * i + col, last_tok);         // rows past the image: clamped address, masked below
+        const bf16_t *px = X + (size_t)tok * K + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) af[i][s] = *reinterpret_cast<const bf16x8 *>(px + 16 * s);
+    }
+
+    stamp(0);                                                 // prologue: tables, first DMAs issued, X fragments requested
     for (int nb = 0; nb < nblk; ++nb) {
-        // everything but the youngest T block (T(nb + 1), issued an iteration ago or in the prologue) has landed: W(nb), T(nb), the prologue's loads
-        if (MODE != MODE_PLAIN && nb + 1 < nblk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // everything but the youngest T block (T(nb + 1), issued an iteration ago or in the prologue) has landed: W(nb), T(nb)
+        if (nb == 0) {                                        // ... and, the first time, but the 2 KS fragment loads issued behind them
+            if (MODE != MODE_PLAIN && nblk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KS + 4) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KS) : "memory");
+        } else if (MODE != MODE_PLAIN && nb + 1 < nblk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(1);                                             // waited for this wave's DMAs
         __syncthreads();                                     // W(nb): everyone's part; and nobody reads W stage (nb + 1) & 1 any more

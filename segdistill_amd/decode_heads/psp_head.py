@@ -27,7 +27,9 @@ class PPM(nn.ModuleList):
         size = x.shape[2:]
         from .. import ppm
         scales = [s if isinstance(s, int) else None for s in self.pool_scales]
-        if None not in scales and ppm.supported(x, scales) and not any(b[0]._forward_hooks or b[0]._forward_pre_hooks for b in self):
+        # a tapped branch (Extractor hooks on `psp_modules.i`, the reference's child name, or on its pool) must be CALLED as a module
+        hooked = any(b._forward_hooks or b._forward_pre_hooks or b[0]._forward_hooks or b[0]._forward_pre_hooks for b in self)
+        if None not in scales and ppm.supported(x, scales) and not hooked:
             # every pool scale from ONE read of the map; in the backward dx is gathered once, without float atomics (csrc/ppm_pool.hip)
             pooled = ppm.ppm_pool(x, scales)
             return [resize(branch[1](p), size=size, mode='bilinear', align_corners=self.align_corners) for branch, p in zip(self, pooled)]

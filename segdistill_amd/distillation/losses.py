@@ -12,9 +12,11 @@ iteration :38) are taken here; everything per-pixel runs on the GPU:
   kernel (no gather copies);
 * 'pixel' rows (PD): ``ops.pix_kl``.
 
-There is no eager / CPU implementation in this module: on a CPU tensor the ops raise.
+On a CPU tensor the ops raise; the one exception is the explicit plumbing mode below (BASELINE configs[0]), which is never a fallback.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -23,6 +25,35 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..builder import DISTILL_LOSSES
+
+
+# BASELINE configs[0] ("CPU train_step via tools/train.py (plumbing, no GPU)"): an EXPLICIT opt-in (tools/train.py --cpu-plumbing, or
+# SEGDISTILL_CPU_PLUMBING=1) under which KLDLoss evaluates CPU taps with ATen ops, so that the whole harness -- config loader, registries, hooks,
+# loss naming, optimizer, checkpointing -- can be exercised on a box without a GPU.  It is never taken for CUDA tensors and never by default:
+# without the switch a CPU tap raises (tests/test_host_logic_cpu.py), and on a GPU box a missing extension still fails loudly (_lib.lib()).
+CPU_PLUMBING = os.environ.get('SEGDISTILL_CPU_PLUMBING', '0') == '1'
+
+
+def _plumbing_kld(s, t, gt, alpha, tau, resize_config, transform_config, perm):
+    """reference losses.py:101-112 on CPU tensors, op for op (resize both, gather the shuffle, -1e9 pad, rows, KLDivLoss(sum) / rows * alpha)."""
+    if resize_config:
+        size = tuple(int(v) for v in (t if resize_config.get('target', 'gt') == 'teacher' else gt).shape[2:])
+        s, t = (F.interpolate(v, size=size, mode=resize_config['mode'], align_corners=resize_config['align_corners']) for v in (s, t))
+    if perm is not None:
+        s, t = s[:, perm.long()].contiguous(), t[:, perm.long()].contiguous()
+    kind = transform_config['loss_type'] if transform_config else None
+    if kind == 'pixel':
+        s, t = (v.permute(0, 2, 3, 1).flatten(1, 2) for v in (s, t))
+    elif kind == 'channel':
+        g = transform_config['group_size']
+        n = (g - s.shape[1] % g) % g
+        if n:
+            s, t = (torch.cat([v, v.new_full((v.shape[0], n) + tuple(v.shape[2:]), -1e9)], 1) for v in (s, t))
+        s, t = (v.reshape(v.shape[0], v.shape[1] // g, -1) for v in (s, t))
+    elif kind is not None:
+        raise ValueError(f'unknown loss_type {kind!r}')
+    kl = F.kl_div(F.log_softmax(s / tau, -1), F.softmax(t / tau, -1), reduction='sum')
+    return kl / (s.numel() // s.shape[-1]) * alpha
 
 
 def _bilinear(x, size):
@@ -178,6 +209,8 @@ class KLDLoss(nn.Module):
             loss = ops.cgd_kl_tokens_multi([(x_student, x_teacher)], [meta])[0]
             return loss if alpha_t is None else loss * alpha_t
         alpha, alpha_t, perm = self._prepare(x_student, x_student.shape[1], n_iter)
+        if CPU_PLUMBING and not x_student.is_cuda and not x_teacher.is_cuda and x_student.dim() == 4:
+            return _plumbing_kld(x_student, x_teacher, gt, alpha, self.tau, self.resize_config, self.transform_config, perm)
         loss = self._device_part(x_student, x_teacher, gt, alpha, perm)
         return loss if alpha_t is None else loss * alpha_t
 

@@ -162,18 +162,24 @@ class HipAdamW(torch.optim.AdamW):
 
 def sync_derived_weights(params):
     """Copies of the weights that kernels read instead of the fp32 parameter -- pre-split bf16 planes (planes.py), bf16 shadows
-    (linear.lowp_copy) -- rewritten IN PLACE from the parameters' current values, one launch for all planes."""
+    (linear.lowp_copy) -- rewritten IN PLACE from the parameters' current values: one launch for all planes, one multi-tensor copy for all shadows."""
     from .. import planes
     params = [p for p in params if p.is_cuda]
     if not params:
         return
     planes.sync(params)
     with torch.no_grad():
+        # the bf16 shadows in ONE multi-tensor copy (a per-parameter `copy_` was one tiny launch per weight and bias: hundreds per step under
+        # bf16 storage on the torch-optimizer paths)
+        src, dst = [], []
         for p in params:
             sh = getattr(p, '_sd_shadow', None)
             if sh is not None:
-                sh[1].copy_(p)
+                src.append(p.detach())
+                dst.append(sh[1])
                 p._sd_shadow = (p._version, sh[1])
+        if dst:
+            torch._foreach_copy_(dst, src)
 
 
 def _refresh_after_step(optimizer, *_args, **_kw):

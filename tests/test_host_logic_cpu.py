@@ -609,3 +609,51 @@ def test_fuse_pairs_rule_which_criteria_may_share_a_pass(monkeypatch):
     monkeypatch.setenv('SEGDISTILL_FUSE_PAIRS', '0')
     vals, _ = run([entry('a', 'b', kld(8, True)), entry('a', 'b', kld(1, False))])
     assert calls == [] and vals == [10.0, 11.0]
+
+
+def test_cpu_plumbing_mode_is_explicit_and_matches_the_oracle():
+    """BASELINE configs[0] (CPU train_step via tools/train.py): with the explicit switch (tools/train.py --cpu-plumbing) the KLDLoss criteria
+    evaluate CPU taps with ATen ops -- value equal to the oracle's restatement of losses.py:101-112 on the very taps -- and without it they
+    raise (no silent fallback: test_sdmodule_contract_and_engine_step_cpu)."""
+    import segdistill_amd
+    from oracle import kd_ref
+    from segdistill_amd.builder import build_segmentor
+    from segdistill_amd.distillation import losses as kd_losses
+    from segdistill_amd.engine import SyntheticADE
+    from segdistill_amd.segmentors import sd_module
+    segdistill_amd.register_all()
+    sd_module.SYNTHETIC_WEIGHTS_OK = True
+    try:
+        torch.manual_seed(0)
+        model = build_segmentor(_tiny_sd_cfg())
+    finally:
+        sd_module.SYNTHETIC_WEIGHTS_OK = False
+    model.train()
+    data = SyntheticADE(1, size=(64, 64), device='cpu', pool=1)
+    batch = data.next()
+    assert kd_losses.CPU_PLUMBING is False
+    with pytest.raises(RuntimeError, match='GPU only'):
+        model.train_step(batch, None)
+    taps = {}
+    inner = model.distillation_loss.forward
+
+    def spy(sf, tf, gt, step, *rest):
+        taps['s'], taps['t'], taps['gt'] = sf['decode_head.linear_pred'].detach(), tf['decode_head.linear_pred'].detach(), gt
+        return inner(sf, tf, gt, step, *rest)
+
+    model.distillation_loss.forward = spy
+    model.cnt = 0
+    kd_losses.CPU_PLUMBING = True
+    try:
+        out = model.train_step(batch, None)
+    finally:
+        kd_losses.CPU_PLUMBING = False
+    kd = {k: v for k, v in out['log_vars'].items() if k.startswith('loss_decode_head.linear_pred<->')}
+    assert len(kd) == 2
+    out['loss'].backward()                                            # the ATen criteria are differentiable: the harness can step
+    assert model.student.decode_head.linear_pred.weight.grad is not None
+    size = tuple(taps['gt'].shape[2:])
+    want = [float(kd_ref.eager_kld(taps['s'].double(), taps['t'].double(), alpha=3, tau=4, out_size=size, loss_type='channel', group_size=8)),
+            float(kd_ref.eager_kld(taps['s'].double(), taps['t'].double(), alpha=1, tau=1, out_size=size, loss_type='channel', group_size=1))]
+    for got, ref in zip(kd.values(), want):
+        assert got == pytest.approx(ref, rel=1e-5)

@@ -72,3 +72,33 @@ def test_frozen_swin_gather_path_equals_the_module_chain(size):
     feats = net.train()(x)
     sum(f.mean() for f in feats).backward()
     assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+def test_partially_frozen_swin_keeps_the_gradients_of_its_trainable_parts():
+    """frozen patch embedding and norms, TRAINABLE attention (qkv, proj, relative-position table) and MLP, grad mode on, input without
+    a graph -- the no-graph block kernels (forward_fused, the packed window attention) must step aside: the gradients of the trainable parameters
+    equal those of the literal module chain (fast paths switched off)."""
+    import segdistill_amd
+    from segdistill_amd.backbones import swin
+    segdistill_amd.register_all()
+    torch.manual_seed(0)
+    net = swin.SwinTransformer(embed_dim=32, depths=(2, 2), num_heads=(2, 4), window_size=7, out_indices=(0, 1)).cuda().eval()
+    for name, p in net.named_parameters():
+        p.requires_grad = ('attn.' in name) or ('mlp.' in name)
+    assert any(p.requires_grad for p in net.parameters()) and not all(p.requires_grad for p in net.parameters())
+    img = torch.randn(2, 3, 112, 120, device='cuda:0')
+    grads = {}
+    for fast in (True, False):
+        swin._GATHER_WINDOWS = swin._FUSE_NORMS = fast
+        try:
+            for p in net.parameters():
+                p.grad = None
+            sum(f.square().mean() for f in net(img)).backward()
+            grads[fast] = {n: p.grad.clone() for n, p in net.named_parameters() if p.requires_grad}
+        finally:
+            swin._GATHER_WINDOWS = swin._FUSE_NORMS = True
+    assert grads[True].keys() == grads[False].keys() and len(grads[True]) > 0
+    for n in grads[False]:
+        a, b = grads[True][n], grads[False][n]
+        assert a is not None and float(b.abs().max()) > 0, n
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-9, n

@@ -33,6 +33,8 @@ def main():
     ap.add_argument('--synthetic-weights', action='store_true', help='train from random init when checkpoints named by the config are absent')
     ap.add_argument('--data-root', default=None, help='dataset directory for configs with data.train (overrides its data_root); '
                                                       'without a data.train entry synthetic ADE20K-shaped batches are used')
+    ap.add_argument('--cpu-plumbing', action='store_true', help='BASELINE configs[0]: run the harness on a box WITHOUT a GPU -- the KLDLoss criteria evaluate '
+                    'CPU taps with ATen ops (never used for CUDA tensors; without it a CPU tap raises)')
     ap.add_argument('--options', nargs='*', default=[], help='config overrides key=value (dotted keys)')
     args = ap.parse_args()
 
@@ -46,6 +48,14 @@ def main():
     if device.type == 'cuda':
         torch.cuda.set_device(device)
         torch.backends.cudnn.benchmark = True
+    if args.cpu_plumbing:
+        if device.type == 'cuda':
+            raise SystemExit('--cpu-plumbing is for boxes without a GPU; on a GPU the HIP kernels are the only path')
+        from segdistill_amd.distillation import losses as kd_losses
+        kd_losses.CPU_PLUMBING = True
+    elif device.type == 'cpu':
+        print('no GPU visible: the distillation criteria are HIP kernels and will raise on CPU taps (pass --cpu-plumbing to exercise the harness '
+              'with ATen criteria: BASELINE configs[0])', file=sys.stderr)
     cfg = Config.fromfile(args.config)
     if args.options:
         import ast
