@@ -33,6 +33,8 @@ def main():
     ap.add_argument('--synthetic-weights', action='store_true', help='train from random init when checkpoints named by the config are absent')
     ap.add_argument('--data-root', default=None, help='dataset directory for configs with data.train (overrides its data_root); '
                                                       'without a data.train entry synthetic ADE20K-shaped batches are used')
+    ap.add_argument('--deterministic', action='store_true', help='run-to-run bit-identical training (reference tools/dist_train.sh:8): MIOpen held to its '
+                    'deterministic convolution algorithms, auto-tuner off; the HIP kernels of this package are deterministic by construction')
     ap.add_argument('--cpu-plumbing', action='store_true', help='BASELINE configs[0]: run the harness on a box WITHOUT a GPU -- the KLDLoss criteria evaluate '
                     'CPU taps with ATen ops (never used for CUDA tensors; without it a CPU tap raises)')
     ap.add_argument('--options', nargs='*', default=[], help='config overrides key=value (dotted keys)')
@@ -48,6 +50,9 @@ def main():
     if device.type == 'cuda':
         torch.cuda.set_device(device)
         torch.backends.cudnn.benchmark = True
+    if args.deterministic:
+        from segdistill_amd.engine import set_deterministic
+        set_deterministic(True)
     if args.cpu_plumbing:
         if device.type == 'cuda':
             raise SystemExit('--cpu-plumbing is for boxes without a GPU; on a GPU the HIP kernels are the only path')
