@@ -341,7 +341,7 @@ def _newest_profile(pattern):
 
 
 def compose_line(*, args, world, B, dt, rank_ms, graphed, segments, trainer_bf16, arithmetic, grad_bytes, ranks_seen, backend, rccl_version,
-                 logs, allreduce_ms=None, roofline=None, cpu_baseline=None, exact_f32=None, kernels_file=None, errors=None):
+                 logs, allreduce_ms=None, syncbn_ms=None, roofline=None, cpu_baseline=None, exact_f32=None, kernels_file=None, errors=None):
     """The ONE JSON line of the contract, kept SHORT (the driver keeps only the tail of stdout: round 2's 24 KB line was lost).  Pure: the
     CPU test tests/test_bench_line_cpu.py builds it from canned leg outputs and holds it under 3500 bytes."""
     cfg_name = os.path.basename(args.config)
@@ -361,6 +361,8 @@ def compose_line(*, args, world, B, dt, rank_ms, graphed, segments, trainer_bf16
     }
     if allreduce_ms is not None:
         line['config']['grad_allreduce_ms'] = allreduce_ms
+    if syncbn_ms is not None:
+        line['config']['syncbn_collectives'] = syncbn_ms          # device time of the norms' statistics exchanges between the step's graphs
     if exact_f32 is not None:
         line['config']['value_exact_f32'] = exact_f32
     if roofline is not None:
@@ -392,6 +394,35 @@ def allreduce_probe(trainer, reps=10):
     e1.record()
     torch.cuda.synchronize()
     return round(e0.elapsed_time(e1) / reps, 4)
+
+
+def ranks_agree(ok):
+    """True only if EVERY rank says ok (one tiny all-reduce; no process group: this rank's word)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return bool(ok)
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
+def choose_graph_mode(trainer, next_batch, requested, errors):
+    """'full' -> 'hybrid' -> False (eager), the first mode that EVERY rank could set up (requested: auto | on | hybrid | off; `on` and
+    `hybrid` try that mode only).  A rank whose capture succeeded while another rank's failed drops its graphs again: all ranks of a
+    data-parallel job step the same way, and the line says which mode that was and why the better ones were not taken."""
+    plan = {'auto': ['full', 'hybrid'], 'on': ['full'], 'hybrid': ['hybrid'], 'off': []}[requested]
+    for mode in plan:
+        try:
+            ok = trainer.enable_graph(next_batch()) if mode == 'full' else trainer.enable_hybrid_graph(next_batch())
+        except Exception as e:  # noqa: BLE001 -- enable_* catch their own failures; belt and braces: the line must survive
+            ok = False
+            trainer.graph_error = f'{type(e).__name__}: {e}'
+        if ranks_agree(ok):
+            return mode
+        why = getattr(trainer, 'graph_error', None) if not ok else 'another rank could not capture'
+        errors.append(f'hip_graph {mode}: {why}')
+        trainer.disable_graph()
+    return False
 
 
 def main():
@@ -471,16 +502,17 @@ def main():
     for _ in range(n_eager_warm):            # eager warm-up first (MIOpen find, hipBLASLt heuristics, allocator)
         trainer.step(data.next())
     # auto: the whole step as hipGraphs at any world size (with ranks > 1 the capture is cut at the SyncBN collectives,
-    # engine/segments.py); a capture that fails degrades to the hybrid mode, then to eager
-    mode = args.graph if args.graph != 'auto' else 'on'
-    if mode == 'on':
-        graphed = 'full' if trainer.enable_graph(data.next()) else False
-        if not graphed and args.graph == 'auto':
-            mode = 'hybrid'
-    if mode == 'hybrid':
-        graphed = 'hybrid' if trainer.enable_hybrid_graph(data.next()) else False
-    for _ in range(args.warmup - n_eager_warm):
-        trainer.step(data.next())
+    # engine/segments.py); a capture that fails ON ANY RANK degrades every rank to the hybrid mode, then to eager
+    graphed = choose_graph_mode(trainer, data.next, args.graph, errors)
+    try:
+        for _ in range(args.warmup - n_eager_warm):
+            trainer.step(data.next())
+    except Exception as e:  # noqa: BLE001 -- a replay that fails (first RCCL run inside a segmented capture) must not cost the line
+        errors.append(f'{graphed} graph replay failed in warm-up ({type(e).__name__}: {e}); eager steps instead')
+        trainer.disable_graph()
+        graphed = False
+        for _ in range(max(1, args.warmup - n_eager_warm)):
+            trainer.step(data.next())
     dt_local = timed_steps(trainer, data, args.steps, world)
     t = torch.tensor([dt_local], device=device, dtype=torch.float64)
     rank_ms = None
@@ -504,6 +536,15 @@ def main():
     except Exception:  # noqa: BLE001
         rccl_version = None
     allreduce_ms = allreduce_probe(trainer) if dist.is_initialized() else None       # collective: all ranks
+    syncbn_ms = None
+    if dist.is_initialized() and graphed == 'full' and getattr(trainer, '_seg', None) is not None and trainer._seg.cuts:
+        # the statistics exchanges of the synchronised norms between the step's graphs: 3 more steps with HIP events around each (every rank)
+        trainer._seg.time_collectives = True
+        for _ in range(3):
+            trainer.step(data.next())
+        ms, n = trainer._seg.collective_ms()
+        trainer._seg.time_collectives = False
+        syncbn_ms = {'ms_per_step': round(ms, 4), 'collectives_per_step': n}
     if rank == 0 and allreduce_ms is not None:
         print(f'[bench] gradient exchange (pack + one all-reduce of {trainer.reducer.nbytes} bytes over {ranks_seen} ranks, {backend}): '
               f'{allreduce_ms} ms per step by HIP events; step {dt / args.steps * 1e3:.3f} ms; hip_graph={graphed}', file=sys.stderr)
@@ -530,7 +571,7 @@ def main():
             errors.append(f'cpu baseline leg: {type(e).__name__}: {e}')
         line = compose_line(args=args, world=world, B=B, dt=dt, rank_ms=rank_ms, graphed=graphed, segments=segs, trainer_bf16=trainer.bf16,
                             arithmetic=arithmetic, grad_bytes=trainer.reducer.nbytes, ranks_seen=ranks_seen, backend=backend,
-                            rccl_version=rccl_version, logs=logs, allreduce_ms=allreduce_ms, roofline=roofline, cpu_baseline=cpu,
+                            rccl_version=rccl_version, logs=logs, allreduce_ms=allreduce_ms, syncbn_ms=syncbn_ms, roofline=roofline, cpu_baseline=cpu,
                             exact_f32=exact_f32, kernels_file=kernels_file, errors=errors)
         sys.stderr.flush()
         print(json.dumps(line))

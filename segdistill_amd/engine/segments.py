@@ -92,6 +92,8 @@ class SegmentRecorder:
         self._stream_ctx = None
         self._coll_stream = None
         self.cuts = 0
+        self.time_collectives = False
+        self.collective_events = []
 
     # ---- capture / replay ---------------------------------------------------------------------------------------------
     def _begin_graph(self):
@@ -150,11 +152,33 @@ class SegmentRecorder:
         self._begin_graph()
 
     def replay(self):
+        if self.time_collectives:                      # diagnostics (bench.py's `syncbn_collectives_ms`): HIP events around every collective
+            evs = []
+            for it in self.items:
+                if isinstance(it, torch.cuda.CUDAGraph):
+                    it.replay()
+                else:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    it()
+                    e1.record()
+                    evs.append((e0, e1))
+            self.collective_events.append(evs)
+            return
         for it in self.items:
             if isinstance(it, torch.cuda.CUDAGraph):
                 it.replay()
             else:
                 it()
+
+    def collective_ms(self):
+        """Mean device time per replayed step spent in the collectives between the graphs, and how many there are (after replays with
+        `time_collectives` set; synchronises)."""
+        torch.cuda.synchronize()
+        steps = [sum(e0.elapsed_time(e1) for e0, e1 in evs) for evs in self.collective_events if evs]
+        n = len(self.collective_events[-1]) if self.collective_events else 0
+        self.collective_events = []
+        return (sum(steps) / len(steps) if steps else 0.0), n
 
     # ---- the chained SyncBatchNorm ------------------------------------------------------------------------------------
     def sync_batch_norm(self, mod, x):

@@ -158,18 +158,33 @@ class KDTrainer:
         except Exception as e:  # noqa: BLE001 -- any capture problem must degrade to eager, not kill the run
             warnings.warn(f'hipGraph capture failed ({type(e).__name__}: {e}); continuing in eager mode')
             self.graph_error = f'{type(e).__name__}: {e}'     # for callers that must say why (bench.py's line, the tests)
-            self._graph = None
-            self._seg = None
-            segments.attach(m, None)
             if hasattr(m, 'cnt') and 'cnt0' in locals():
                 m.cnt = cnt0
-            m.external_step = False
-            if hasattr(m, '_taps_override'):
-                m._taps_override = None
-            if hasattr(m, 'distillation_loss'):
-                m.distillation_loss.set_graph_safe(False)
-            torch.cuda.synchronize()
+            self.disable_graph()
             return False
+
+    def disable_graph(self):
+        """Back to eager stepping: after a failed capture, or when ANOTHER rank's capture failed -- every rank of a data-parallel job must step
+        the same way (bench.agree_on_graph_mode): a rank replaying graphs next to eager ranks would still issue the same collectives, but a
+        half-captured rank must not be left with static buffers the others do not have."""
+        m = self.model
+        self._graph = None
+        self._seg = None
+        self._t_graph = None
+        if getattr(m, '_graphed_teacher', None) is not None:      # hybrid mode's pieces
+            m._graphed_teacher = None
+        if hasattr(m, 'student') and getattr(m.student, '_graphed_backbone', None) is not None:
+            object.__setattr__(m.student, '_graphed_backbone', None)
+        segments.attach(m, None)
+        m.external_step = False
+        if hasattr(m, '_taps_override'):
+            m._taps_override = None
+        if hasattr(m, '_prefetched'):
+            m._prefetched = None
+        if hasattr(m, 'distillation_loss'):
+            m.distillation_loss.set_graph_safe(False)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
     # ---- hybrid graph mode (safe at any world size) -----------------------------------------------------------------------
     # The full-step capture above would have to record the student's SyncBatchNorm collectives (RCCL inside a hipGraph

@@ -104,3 +104,70 @@ def test_stored_step_table_is_quoted_only_for_the_tree_it_was_measured_on(tmp_pa
     assert bench.stored_step_top5() is None                    # another tree's table: dropped
     good.write_text(json.dumps([{'name': 'k', 'ms_per_step': 1.0}]))
     assert bench.stored_step_top5() is None                    # round 3's unstamped form: dropped
+
+
+# ---- N > 1: every rank must end in the SAME stepping mode, whatever fails where (VERDICT r4 item 3 i) ------------------------------------
+def _mode_worker(rank, world, port, q):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    class FakeTrainer:
+        """enable_* as KDTrainer's: True / False, never raising -- except where the scenario says a capture blows up on this rank"""
+        def __init__(self, full_ok, hybrid_ok, raises=False):
+            self.full_ok, self.hybrid_ok, self.raises, self.disabled, self.graph_error = full_ok, hybrid_ok, raises, 0, None
+
+        def enable_graph(self, batch):
+            if self.raises:
+                raise RuntimeError('capture failure injected on this rank')
+            if not self.full_ok:
+                self.graph_error = 'RuntimeError: injected'
+            return self.full_ok
+
+        def enable_hybrid_graph(self, batch):
+            return self.hybrid_ok
+
+        def disable_graph(self):
+            self.disabled += 1
+
+    out = {}
+    scenarios = {
+        'rank1_full_fails': (rank == 0, True, False),           # one rank cannot capture the whole step -> everybody hybrid
+        'rank1_full_raises': (True, True, rank == 1),            # ... even when its capture raises instead of returning False
+        'rank0_hybrid_fails_too': (False, rank == 1, False),     # nobody full, one rank not even hybrid -> everybody eager
+        'all_full': (True, True, False),
+    }
+    for name, (full_ok, hybrid_ok, raises) in scenarios.items():
+        tr, errors = FakeTrainer(full_ok, hybrid_ok, raises), []
+        mode = bench.choose_graph_mode(tr, lambda: None, 'auto', errors)
+        out[name] = (mode, tr.disabled, len(errors))
+    tr, errors = FakeTrainer(rank == 0, True), []
+    out['on_only'] = (bench.choose_graph_mode(tr, lambda: None, 'on', errors), tr.disabled, len(errors))   # --graph on: no hybrid attempt
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_all_ranks_agree_on_the_graph_mode_gloo():
+    import torch.multiprocessing as mp
+    world, port = 2, 29757
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mode_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for name in res[0]:
+        assert res[0][name][0] == res[1][name][0], (name, res)          # the same mode on both ranks
+    assert res[0]['rank1_full_fails'][0] == 'hybrid' and res[0]['rank1_full_fails'][1] == 1      # rank 0 dropped the graph it had captured
+    assert res[1]['rank1_full_raises'][0] == 'hybrid'
+    assert res[0]['rank0_hybrid_fails_too'][0] is False and res[1]['rank0_hybrid_fails_too'][1] == 2
+    assert res[0]['all_full'] == ('full', 0, 0) and res[1]['all_full'] == ('full', 0, 0)
+    assert res[0]['on_only'][0] is False and res[1]['on_only'][0] is False
