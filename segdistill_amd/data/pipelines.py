@@ -19,6 +19,10 @@ class Compose:
 
     def __init__(self, transforms):
         self.transforms = [build_from_cfg(t, PIPELINES) if isinstance(t, dict) else t for t in transforms]
+        # a Resize whose result goes straight into a RandomCrop leaves the image resize to the crop (imops.LazyResize: only the window is computed)
+        for a, b in zip(self.transforms, self.transforms[1:]):
+            if isinstance(a, Resize) and isinstance(b, RandomCrop):
+                a.crop_follows = True
 
     def __call__(self, data):
         for t in self.transforms:
@@ -116,7 +120,10 @@ class Resize:
             self._random_scale(results)
         img = results['img']
         h, w = img.shape[:2]
-        if self.keep_ratio:
+        if getattr(self, 'crop_follows', False) and img.dtype == np.uint8:
+            size = imops.rescale_size((w, h), results['scale']) if self.keep_ratio else results['scale']
+            new = imops.LazyResize(img, size)                 # computed by the RandomCrop that follows, for its window only
+        elif self.keep_ratio:
             new = imops.imrescale(img, results['scale'])
         else:
             new = imops.imresize(img, results['scale'])
@@ -147,6 +154,8 @@ class RandomCrop:
     @staticmethod
     def crop(img, box):
         y1, y2, x1, x2 = box
+        if isinstance(img, imops.LazyResize):
+            return img.region(y1, y2, x1, x2)
         return img[y1:y2, x1:x2, ...]
 
     def __call__(self, results):
@@ -154,7 +163,13 @@ class RandomCrop:
         box = self.get_crop_bbox(img)
         if self.cat_max_ratio < 1.:
             for _ in range(10):
-                labels, cnt = np.unique(self.crop(results['gt_semantic_seg'], box), return_counts=True)
+                seg = self.crop(results['gt_semantic_seg'], box)
+                if seg.dtype == np.uint8:          # the counts np.unique returns, without its sort of 262 144 labels
+                    full = np.bincount(seg.reshape(-1), minlength=256)
+                    labels = np.nonzero(full)[0]
+                    cnt = full[labels]
+                else:
+                    labels, cnt = np.unique(seg, return_counts=True)
                 cnt = cnt[labels != self.ignore_index]
                 if len(cnt) > 1 and np.max(cnt) / np.sum(cnt) < self.cat_max_ratio:
                     break
@@ -199,6 +214,11 @@ class PhotoMetricDistortion:
 
     @staticmethod
     def convert(img, alpha=1, beta=0):
+        """transforms.py:1128-1131: float32 multiply-add, clip, cast back (truncation).  For 8-bit input the 256 possible results are a table: the
+        same arithmetic per value, one gather per pixel."""
+        if img.dtype == np.uint8:
+            lut = np.clip(np.arange(256, dtype=np.float32) * alpha + beta, 0, 255).astype(np.uint8)
+            return lut[img]
         return np.clip(img.astype(np.float32) * alpha + beta, 0, 255).astype(np.uint8)
 
     def brightness(self, img):

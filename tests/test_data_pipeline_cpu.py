@@ -34,8 +34,26 @@ def test_imresize_follows_opencv_sampling():
     up = imops.imresize(img, (12, 8), 'bilinear')                    # x2: src = (dst + 0.5)/2 - 0.5, edge clamp
     assert up.shape == (8, 12)
     assert up[0, 0] == img[0, 0] and up[-1, -1] == img[-1, -1]       # clamped corners
-    assert up[0, 1] == round(0.75 * img[0, 0] + 0.25 * img[0, 1])    # lambda = .25 at dst x = 1
-    assert up[0, 2] == round(0.25 * img[0, 0] + 0.75 * img[0, 1])
+    # 8-bit images go through OpenCV's fixed-point arithmetic (11-bit coefficients, two truncating shifts, + 2 >> 2): lambda = .25 at dst x = 1
+    # gives 0.75 * 0 + 0.25 * 10 = 2.5 -> ((2048 * ((10 * 512) >> 4)) >> 16) + 2 >> 2 = (10 + 2) >> 2 = 3, and 7.5 -> (30 + 2) >> 2 = 8
+    assert up[0, 1] == 3 and up[0, 2] == 8
+    # hand-computed known answer, 4 x 4 -> 7 wide x 5 high.  Element [1][1]: fx = 1.5 * 4/7 - .5 = .35714 -> a = rint(.64286 * 2048) = 1317,
+    # b = rint(.35714 * 2048) = 731; fy = 1.5 * .8 - .5 = .7 -> c = rint(.3 * 2048) = 614, d = rint(.7 * 2048) = 1434;
+    # R0 = (3 * 1317 + 19 * 731) >> 4 = 17840 >> 4 = 1115, R1 = (67 * 1317 + 83 * 731) >> 4 = 148912 >> 4 = 9307;
+    # ((614 * 1115) >> 16) + ((1434 * 9307) >> 16) = 10 + 203 = 213; (213 + 2) >> 2 = 53   (the exact value is 53.51: the shifts truncate)
+    kat = np.arange(16, dtype=np.uint8).reshape(4, 4) * 16 + 3
+    want = [[3, 9, 18, 27, 36, 45, 51], [48, 53, 63, 72, 81, 90, 96], [99, 105, 114, 123, 132, 141, 147], [150, 156, 165, 174, 183, 192, 198],
+            [195, 201, 210, 219, 228, 237, 243]]
+    got = imops.imresize(kat, (7, 5), 'bilinear')
+    assert got.tolist() == want
+    assert np.array_equal(imops.imresize(np.stack([kat] * 3, -1), (7, 5))[..., 1], got)          # channels are independent
+    # the crop-aware form computes a window of the same resize: bit-identical to resize-then-slice
+    rng = np.random.default_rng(0)
+    big = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    full = imops.imresize(big, (91, 70))
+    lazy = imops.LazyResize(big, (91, 70))
+    assert lazy.shape == full.shape and np.array_equal(np.asarray(lazy), full)
+    assert np.array_equal(lazy.region(11, 43, 20, 91), full[11:43, 20:91]) and np.array_equal(lazy.region(60, 200, -5, 30), full[60:, :30])
     near = imops.imresize(img, (3, 2), 'nearest')                    # floor(dst * scale): rows 0,2  cols 0,2,4
     assert np.array_equal(near, img[[0, 2]][:, [0, 2, 4]])
     assert imops.rescale_size((683, 512), (2048, 512)) == (683, 512)           # short edge already at the bound
