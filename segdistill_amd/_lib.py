@@ -182,8 +182,6 @@ def lib():
         h.sd_set_tunable(b'align_split_bf16', 0)
     if os.environ.get('SEGDISTILL_WGRAD_SLAB_RATIO'):   # A/B switch: slab bytes of the bf16 split-K weight gradients as a percentage of their operand bytes (0 = no cap)
         h.sd_set_tunable(b'wgrad_slab_ratio', int(os.environ['SEGDISTILL_WGRAD_SLAB_RATIO']))
-    if os.environ.get('SEGDISTILL_PLANES_TILE') in ('64', '128'):   # A/B switch: force the row-tile height of the planes GEMMs
-        h.sd_set_tunable(b'planes_tile', int(os.environ['SEGDISTILL_PLANES_TILE']))
     return h
 
 

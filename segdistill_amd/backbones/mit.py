@@ -44,7 +44,7 @@ def _mit_init(m):
             m.bias.data.zero_()
 
 
-_LN_PATCHES = os.environ.get('SEGDISTILL_LN_PATCHES', '1') == '1'      # A/B: 0 = the SR path gathers its patches with a copy (round 2)
+_LN_PATCHES = True      # test hook: False = the SR path gathers its patches with a copy (the general path)
 
 
 class Tap(nn.Identity):
@@ -266,7 +266,7 @@ class _ConvDeferredBias(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
-_CONV_DEFERRED_BIAS = os.environ.get('SEGDISTILL_CONV_DEFERRED_BIAS', '1') == '1'
+_CONV_DEFERRED_BIAS = True      # test hook: False = ATen's per-layer reduction (the general path)
 
 
 class OverlapPatchEmbed(nn.Module):

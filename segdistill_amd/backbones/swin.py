@@ -26,7 +26,7 @@ from .. import window_attn
 from ..layers import DropPath, to_2tuple, trunc_normal_
 
 
-_GATHER_WINDOWS = os.environ.get('SEGDISTILL_SWIN_GATHER', '1') == '1'
+_GATHER_WINDOWS = True          # test hook: False = the literal pad / roll / window_partition chain (the path a trainable Swin takes)
 _FUSE_NORMS = os.environ.get('SEGDISTILL_SWIN_FUSE_NORMS', '1') == '1'      # A/B: 0 = LayerNorm, zero-row cat, index_select and add as separate kernels
 _TABLES = {}
 

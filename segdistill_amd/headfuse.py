@@ -47,8 +47,7 @@ class _UpSum(torch.autograd.Function):
         L = _lib.lib()
         grads = [dy if ctx.needs_input_grad[0] else None]
         H, W = ctx.sizes[0]
-        if (tuple(ctx.fs) == (2, 4, 8) and all(ctx.needs_input_grad[1:4]) and H % 8 == 0 and W % 8 == 0 and E % 64 == 0 and W <= 512
-                and os.environ.get('SEGDISTILL_UPSUM_BWD3', '1') == '1'):
+        if (tuple(ctx.fs) == (2, 4, 8) and all(ctx.needs_input_grad[1:4]) and H % 8 == 0 and W % 8 == 0 and E % 64 == 0 and W <= 512):
             # all three branches from one read of dy (two separable passes, csrc/headfuse.hip: sd_upsum_bwd3)
             dzs = [torch.empty(B, h * w, E, dtype=dy.dtype, device=dy.device) for (h, w) in ctx.sizes[1:]]
             wsb = L.sd_upsum_bwd3_workspace_bytes(B, H, W, E)

@@ -34,6 +34,18 @@ def main():
         torch.manual_seed(0)
         m1 = bench.build_model(cfg, dev)
     m2 = copy.deepcopy(m1)
+    # a throw-away trainer first: the FIRST encounter of every convolution / GEMM shape in a process runs the libraries' searches and fills their
+    # caches; the two compared runs below then see the same cached choices (what two separate `tools/train.py --deterministic` processes on one
+    # machine see after the first has populated MIOpen's user database)
+    m0 = copy.deepcopy(m1)
+    tr0 = KDTrainer(m0, dict(cfg.optimizer), dict(cfg.lr_config), world=1, precision=cfg.get('precision'))
+    d0 = SyntheticADE(a.batch, size=(a.size, a.size), device=dev, pool=3, seed=1)
+    if a.graph == 'full':
+        tr0.enable_graph(dict(img=d0._pool[0][0], img_metas=None, gt_semantic_seg=d0._pool[0][1]))
+    for _ in range(2):
+        tr0.step(d0.next())
+    torch.cuda.synchronize()
+    del tr0, m0, d0
     res = []
     for m in (m1, m2):
         tr = KDTrainer(m, dict(cfg.optimizer), dict(cfg.lr_config), world=1, precision=cfg.get('precision'))
