@@ -175,6 +175,20 @@ int sd_pix_kl_bwd(const void *S, const void *T, int dtype, int B, int C, int H, 
                   float inv_tau, float coef, const float *pix_lse2,
                   const float *upstream, void *dS, void *stream);
 
+/* The pixel-wise criterion with the bilinear up-sampling FUSED in (csrc/pix_up.hip): s, t are the TAPPED logits [B,C,h,w]; the class softmax runs at
+ * (H, W) = (F*h, F*w), F in {2,4,8}, align_corners=False.  Replaces losses.py:101-102 (both F.interpolate calls) PLUS losses.py:47-49,108-112
+ * (`loss_type='pixel'`: the PDLoss preset of :115-128) and, in the backward, upsample_bilinear2d_backward; nothing of size B*C*H*W is written.
+ * pix_lse2: [2][B*H*W] as sd_pix_kl_fwd (written by fwd, read by bwd); `ds` is the gradient with respect to the tap s.  A channel shuffle
+ * (losses.py:39-41) does not change a softmax over ALL channels of a pixel, so there is no permutation argument. */
+int sd_pix_kl_up_supported(int h, int w, int H, int W);
+size_t sd_pix_kl_up_workspace_bytes(int B, int h);
+int sd_pix_kl_up_fwd(const void *s, const void *t, int dtype, int B, int C, int h, int w, int H, int W,
+                     float inv_tau, float loss_scale, float *pix_lse2, float *loss,
+                     void *workspace, size_t workspace_bytes, void *stream);
+int sd_pix_kl_up_bwd(const void *s, const void *t, int dtype, int B, int C, int h, int w, int H, int W,
+                     float inv_tau, float coef, const float *pix_lse2,
+                     const float *upstream, void *ds, void *stream);
+
 /* ATLoss (losses.py:175-197: nn.MSELoss between x.mean(dim=1) maps + the class-softmax KL, tau = 1) fused into the same two
  * passes: loss = mean_{b,p}(mean_c S - mean_c T)^2 + 1/(B*H*W) * sum_pixels KL.  planes: [3][B*H*W] fp32 (base-2 lse of S and
  * T, channel-mean difference), written by fwd, read by bwd.  Workspace: sd_pix_kl_workspace_bytes. */

@@ -71,6 +71,10 @@ SIGNATURES = {
     'sd_pix_kl_workspace_bytes': (_sz, [_i] * 4),
     'sd_pix_kl_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     'sd_pix_kl_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
+    'sd_pix_kl_up_supported': (_i, [_i, _i, _i, _i]),
+    'sd_pix_kl_up_workspace_bytes': (_sz, [_i, _i]),
+    'sd_pix_kl_up_fwd': (_i, [_vp, _vp, _i] + [_i] * 6 + [_f, _f, _vp, _vp, _vp, _sz, _vp]),
+    'sd_pix_kl_up_bwd': (_i, [_vp, _vp, _i] + [_i] * 6 + [_f, _f, _vp, _vp, _vp, _vp]),
     'sd_ifvd_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'sd_ifvd_stepmask_ints': (_sz, [_i, _i, _i]),
     'sd_ifvd_counts': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -235,6 +235,11 @@ class KLDLoss(nn.Module):
             mode, ac = self.resize_config['mode'], self.resize_config['align_corners']
             fusable = mode == 'bilinear' and not ac and self.fuse_resize and \
                 ops.can_fuse_resize(x_student, x_teacher, out_size, self.transform_config)
+            if (not fusable and mode == 'bilinear' and not ac and self.fuse_resize and self.transform_config
+                    and self.transform_config.get('loss_type') == 'pixel' and ops.can_fuse_pixel_resize(x_student, x_teacher, out_size)):
+                # PDLoss (reference :115-128): class softmax at the label size straight from the taps (csrc/pix_up.hip).  A shuffle (:39-41)
+                # permutes the classes of every pixel alike and leaves a softmax over all of them unchanged: no gather
+                return ops.pix_kl_up(x_student, x_teacher, out_size, tau=self.tau, alpha=alpha)
             if not fusable:
                 from ..layers import resize        # csrc/resize.hip for contiguous NCHW maps on the GPU, ATen otherwise
                 if tuple(x_student.shape[2:]) != out_size:

@@ -498,6 +498,56 @@ def pix_kl(S, T, *, tau, alpha):
     return _PixKLFunction.apply(S, T, tau, alpha)
 
 
+def can_fuse_pixel_resize(x_student, x_teacher, out_size) -> bool:
+    """The fused-upsample pixel-wise kernels (csrc/pix_up.hip) cover this case: same tap shapes, integer factor 2 / 4 / 8 on both axes."""
+    if x_student.dim() != 4 or x_student.shape != x_teacher.shape or x_student.dtype != x_teacher.dtype:
+        return False
+    if x_student.dtype not in _DT or not x_student.is_cuda:
+        return False
+    h, w = x_student.shape[2:]
+    return bool(_lib.lib().sd_pix_kl_up_supported(int(h), int(w), int(out_size[0]), int(out_size[1])))
+
+
+class _PixKLUpFunction(torch.autograd.Function):
+    """Pixel-wise criterion (softmax over the classes of every pixel) on TAP tensors with the bilinear resize to `out_size` fused in."""
+
+    @staticmethod
+    def forward(ctx, s, t, out_size, tau, alpha):
+        _require_gpu(s, t)
+        if s.shape != t.shape or s.dim() != 4 or s.dtype != t.dtype or s.dtype not in _DT:
+            raise ValueError(f'expected equal 4-D taps of one supported dtype, got {tuple(s.shape)} {s.dtype} / {tuple(t.shape)} {t.dtype}')
+        s, t = s.contiguous(), t.contiguous()
+        B, Cc, h, w = s.shape
+        H, W = int(out_size[0]), int(out_size[1])
+        rows = B * H * W
+        L = _lib.lib()
+        wsb = L.sd_pix_kl_up_workspace_bytes(B, h)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=s.device)
+        lse2 = torch.empty(2, rows, dtype=torch.float32, device=s.device)
+        loss = torch.empty((), dtype=torch.float32, device=s.device)
+        _lib.check(L.sd_pix_kl_up_fwd(s.data_ptr(), t.data_ptr(), _DT[s.dtype], B, Cc, h, w, H, W, 1.0 / float(tau), float(alpha) / rows,
+                                      lse2.data_ptr(), loss.data_ptr(), ws.data_ptr(), wsb, _stream_ptr()), 'sd_pix_kl_up_fwd')
+        ctx.save_for_backward(s, t, lse2)
+        ctx.meta = (H, W, float(tau), float(alpha), rows)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        s, t, lse2 = ctx.saved_tensors
+        H, W, tau, alpha, rows = ctx.meta
+        B, Cc, h, w = s.shape
+        ds = torch.empty_like(s)
+        up = grad_loss.to(torch.float32).contiguous()
+        _lib.check(_lib.lib().sd_pix_kl_up_bwd(s.data_ptr(), t.data_ptr(), _DT[s.dtype], B, Cc, h, w, H, W, 1.0 / tau, alpha / (rows * tau),
+                                               lse2.data_ptr(), up.data_ptr(), ds.data_ptr(), _stream_ptr()), 'sd_pix_kl_up_bwd')
+        return ds, None, None, None, None
+
+
+def pix_kl_up(s, t, out_size, *, tau, alpha):
+    """PDLoss on the taps: class softmax at label resolution, nothing of label size materialised.  HIP only."""
+    return _PixKLUpFunction.apply(s, t, out_size, tau, alpha)
+
+
 class _ATKLFunction(torch.autograd.Function):
     """ATLoss: mean_{b,p}(mean_c S - mean_c T)^2 + 1/(B*H*W) * sum_pixels KL(softmax_C(T) || softmax_C(S)), one pass each way."""
 
