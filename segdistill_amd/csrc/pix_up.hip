@@ -40,8 +40,8 @@ __device__ __forceinline__ void pu_online2(float x, float diff, float &m, float 
 }
 
 // grid = (h + 1 gaps, B, F / QR row slices); blockDim = tap width rounded up to 64.  Gap j: output rows Y = F*j - F/2 + q (rows outside the image
-// skipped), this workgroup's q in [QR z, QR z + QR) -- QR * F <= 16 pixel states per thread; the thread's columns X = F*kx + rx.  lse2: [2][B*H*W].
-template <int F> struct PuGeo { static constexpr int QR = F == 8 ? 2 : F; };
+// skipped), this workgroup's q in [QR z, QR z + QR); the thread's columns X = F*kx + rx.  lse2: [2][B*H*W].
+template <int F> struct PuGeo { static constexpr int QR = 2; };     // rows of a gap per workgroup: 2 F pixel states per thread (F = 4: 16 states were 174 registers, two waves per SIMD, 422 us)
 
 template <typename T, int F, int NT>
 __global__ __launch_bounds__(NT) void pix_up_fwd(const T *__restrict__ s, const T *__restrict__ t, float *__restrict__ lse2, double *__restrict__ wg_sum, int C, int h, int w,
@@ -63,6 +63,7 @@ __global__ __launch_bounds__(NT) void pix_up_fwd(const T *__restrict__ s, const 
         for (int rx = 0; rx < F; ++rx) { ms[q][rx] = mt[q][rx] = kNegBig; zs[q][rx] = zt[q][rx] = a[q][rx] = 0.f; }
     const size_t plane = (size_t)h * w;
     const T *ps = s + (size_t)b * C * plane, *pt = t + (size_t)b * C * plane;
+#pragma unroll 2
     for (int c = 0; c < C; ++c) {
         float sa[F], sb[F], ta[F], tb[F];
         hrow<T, F>(ps + c * plane + (size_t)ra * w, kxc, w, sa);
@@ -281,7 +282,7 @@ int sd_pix_kl_up_fwd(const void *s, const void *t, int dtype, int B, int C, int 
     if (dtype == SD_F32) SD_PU_FWD(float);
     else SD_PU_FWD(sd::bf16_t);
 #undef SD_PU_FWD
-    hipLaunchKernelGGL(sd::pix_up_loss, dim3(1), dim3(256), 0, st, sums, loss, B * (h + 1) * (F == 8 ? 4 : 1), loss_scale);
+    hipLaunchKernelGGL(sd::pix_up_loss, dim3(1), dim3(256), 0, st, sums, loss, B * (h + 1) * (F / 2), loss_scale);
     return (int)hipGetLastError();
 }
 

@@ -170,6 +170,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+__global__ __launch_bounds__(256) void window_attn_zero_flags(int *__restrict__ flags, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) flags[i] = 0;
+}
+
 // tables [n][49][49] in the reference's orientation ([query i][key j]) -> [n][a][b][g][lane][c] as the accumulators hold them; padded positions
 // take `pad_key` (keys j >= 49) or 0 (queries i >= 49); flags[n] = 1 if the table has a nonzero entry (NULL: not wanted)
 __global__ __launch_bounds__(256) void window_attn_pack(const float *__restrict__ table, float *__restrict__ packed, int *__restrict__ flags, int n,
@@ -201,10 +206,9 @@ int sd_window_attn_pack(const float *tables, float *packed, int32_t *flags, int 
     if (count <= 0 || (long)count * sd::kPackFloats > 0x7fffffffL * 256L) return SD_E_SHAPE;
     if (reinterpret_cast<uintptr_t>(packed) & 15) return SD_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (flags) {
-        hipError_t e = hipMemsetAsync(flags, 0, sizeof(int32_t) * (size_t)count, st);
-        if (e != hipSuccess) return (int)e;
-    }
+    // the flags are cleared by a KERNEL, not by hipMemsetAsync: a pack that runs inside a hipGraph capture (a cache miss there) must not record
+    // a memset node -- memset nodes of one graph are corruptible by a concurrent memset on another stream (engine/trainer.py::_issues_memsets)
+    if (flags) hipLaunchKernelGGL(sd::window_attn_zero_flags, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, (int *)flags, count);
     const long total = (long)count * sd::kPackFloats;
     hipLaunchKernelGGL(sd::window_attn_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tables, packed, (int *)flags, count, pad_key_value);
     return (int)hipGetLastError();

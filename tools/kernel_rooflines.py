@@ -610,7 +610,91 @@ def bench_wattn(dev, reps):
     return out
 
 
+def bench_aligntok(dev, reps, B=8, K=256, C=768, g=8, stages=(16384, 4096, 1024, 256)):
+    """csrc/align_tok.hip at config 5's shapes: the fused projection + criterion forward / backward (stage 1 alone and all four stages in one
+    call), the stand-alone projection and the input-gradient GEMM.  Roof: HBM (X + T forward, X + T + dY backward, X + Y / dY + dX for the
+    GEMMs); the matrix-pipe view (2 T K C flops against dense bf16) is in the note."""
+    import ctypes as C_
+    from segdistill_amd import _lib, ops
+    L = _lib.lib()
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    xs = [torch.randn(B, P, K, device=dev, generator=gen).to(torch.bfloat16) for P in stages]
+    ts = [(2 * torch.randn(B, P, C, device=dev, generator=gen)).to(torch.bfloat16) for P in stages]
+    w = (torch.randn(C, K, device=dev, generator=gen) / K ** 0.5).to(torch.bfloat16)
+    bias = 0.1 * torch.randn(C, device=dev, generator=gen)
+    rows = B * (-(-C // g))
+    keep = []
+
+    def jobs(idx):
+        arr = (ops._AlignTokJob * len(idx))()
+        for k, i in enumerate(idx):
+            P = stages[i]
+            wsb = L.sd_align_cgd_tok_workspace_bytes(B, C, P)
+            bufs = [torch.empty(wsb, dtype=torch.uint8, device=dev), torch.zeros(rows, 2, device=dev), torch.empty(rows, device=dev), torch.empty((), device=dev),
+                    torch.empty(B, P, C, dtype=torch.bfloat16, device=dev), torch.empty(L.sd_align_cgd_tok_tiles(B, P), C, device=dev)]
+            keep.extend(bufs)
+            j = arr[k]
+            j.X, j.W, j.bias, j.T = xs[i].data_ptr(), w.data_ptr(), bias.data_ptr(), ts[i].data_ptr()
+            j.workspace, j.workspace_bytes, j.row_lse2, j.row_kl, j.loss = bufs[0].data_ptr(), wsb, bufs[1].data_ptr(), bufs[2].data_ptr(), bufs[3].data_ptr()
+            j.out, j.db_part = bufs[4].data_ptr(), bufs[5].data_ptr()
+            j.P, j.B, j.K, j.C, j.g, j.inv_tau, j.loss_scale, j.coef = P, B, K, C, g, 0.25, 3.0 / rows, 3.0 / (rows * 4.0)
+        return arr
+
+    out = []
+    for idx, tag in (([0], 'cfg5 stage 1'), (list(range(len(stages))), 'cfg5 all four stages in one call')):
+        arr = jobs(idx)
+        n = len(idx)
+        ptr = C_.cast(arr, C_.c_void_p)
+        _ok(L.sd_align_cgd_tok_fwd_multi(ptr, n, None), 'align_tok fwd')       # row constants for the backward
+        tf = _time(lambda st: _ok(L.sd_align_cgd_tok_fwd_multi(ptr, n, st), 'align_tok fwd'), reps)
+        tb = _time(lambda st: _ok(L.sd_align_cgd_tok_bwd_multi(ptr, n, st), 'align_tok bwd'), reps)
+        T = sum(B * stages[i] for i in idx)
+        flops = 2.0 * T * K * C
+        shape = [[B, stages[i], K, C] for i in idx]
+        out.append(_entry(f'align + criterion fused fwd, {tag} (bf16)', 'align_tok_kernel<16,0> + cgd_tok_finish', shape, 'bf16', tf, 'hbm', T * (K + C) * 2, HBM,
+                          note=f'{flops / (tf * 1e-3) / 1e12:.0f} TFLOP/s of {MFMA_BF16:.0f} (bf16 MFMA); Y never written'))
+        out.append(_entry(f'align + criterion fused bwd (recompute, dY, db), {tag} (bf16)', 'align_tok_kernel<16,1>', shape, 'bf16', tb, 'hbm', T * (K + 2 * C) * 2, HBM,
+                          note=f'{flops / (tb * 1e-3) / 1e12:.0f} TFLOP/s of {MFMA_BF16:.0f}'))
+    T0 = B * stages[0]
+    y = torch.empty(T0, C, dtype=torch.bfloat16, device=dev)
+    dx = torch.empty(T0, K, dtype=torch.bfloat16, device=dev)
+    x2 = xs[0].view(T0, K)
+    tp = _time(lambda st: _ok(L.sd_linear_tok_bf16_fwd(x2.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr(), T0, K, C, st), 'plain'), reps)
+    td = _time(lambda st: _ok(L.sd_linear_tok_bf16_bwd_data(y.data_ptr(), w.data_ptr(), dx.data_ptr(), T0, C, K, st), 'dx'), reps)
+    gemm_bytes, gemm_flops = T0 * (K + C) * 2, 2.0 * T0 * K * C
+    out.append(_entry('align projection alone Y = X.W^T + b, cfg5 stage 1 (bf16)', 'align_tok_kernel<16,2>', [T0, K, C], 'bf16', tp, 'hbm', gemm_bytes, HBM,
+                      note=f'{gemm_flops / (tp * 1e-3) / 1e12:.0f} TFLOP/s of {MFMA_BF16:.0f}'))
+    out.append(_entry('align input gradient dX = dY.W, cfg5 stage 1 (bf16)', 'tok_dx_kernel<8>', [T0, C, K], 'bf16', td, 'hbm', gemm_bytes, HBM,
+                      note=f'{gemm_flops / (td * 1e-3) / 1e12:.0f} TFLOP/s of {MFMA_BF16:.0f}'))
+    return out
+
+
+def bench_pixup(dev, reps, B=8, C=150, hw=128, F=4):
+    """csrc/pix_up.hip: PDLoss with the up-sampling fused, config-2 taps.  VALU-bound like R2: priced by lane-instructions (19 per interpolated
+    (s, t) pair forward, 12 backward)."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    s = 2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)
+    t = 2 * torch.randn(B, C, hw, hw, device=dev, generator=gen)
+    H = W = F * hw
+    rows = B * H * W
+    lse, loss, ds = torch.empty(2, rows, device=dev), torch.empty((), device=dev), torch.empty_like(s)
+    wsb = L.sd_pix_kl_up_workspace_bytes(B, hw)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    up = torch.ones((), device=dev)
+    tf = _time(lambda st: _ok(L.sd_pix_kl_up_fwd(s.data_ptr(), t.data_ptr(), 0, B, C, hw, hw, H, W, 1.0, 1.0 / rows, lse.data_ptr(), loss.data_ptr(),
+                                                  ws.data_ptr(), wsb, st), 'pix_up fwd'), reps)
+    tb = _time(lambda st: _ok(L.sd_pix_kl_up_bwd(s.data_ptr(), t.data_ptr(), 0, B, C, hw, hw, H, W, 1.0, 1.0 / rows, lse.data_ptr(), up.data_ptr(),
+                                                  ds.data_ptr(), st), 'pix_up bwd'), reps)
+    N = B * C * H * W
+    return [_entry('pix_kl with the x4 upsample fused, fwd (PDLoss from the taps)', 'pix_up_fwd + pix_up_loss', [B, C, hw, hw, '->', H, W], 'f32', tf, 'valu', 19 * N, VALU),
+            _entry('pix_kl with the x4 upsample fused, bwd', 'pix_up_bwd', [B, C, hw, hw, '->', H, W], 'f32', tb, 'valu', 12 * N, VALU)]
+
+
 GROUPS = {
+    'aligntok': lambda dev, reps: bench_aligntok(dev, reps),
+    'pixup': lambda dev, reps: bench_pixup(dev, reps),
     'wattn': lambda dev, reps: bench_wattn(dev, reps),
     'ppm': lambda dev, reps: bench_ppm(dev, reps),
     'wgrad_bf16': lambda dev, reps: bench_wgrad_bf16(dev, reps),
@@ -618,8 +702,8 @@ GROUPS = {
     'r1_bf16': lambda dev, reps: bench_r1(dev, reps, C=768, HW=128, dtype=torch.bfloat16),      # config 5 stage 1
     'r2': lambda dev, reps: bench_r2(dev, reps),
     'tok': lambda dev, reps: bench_tok(dev, reps),
-    # config 4 (fp32, NCHW taps) is THE user of the NCHW align kernels; config 5's token-major taps take the token Linear (library bf16 GEMM +
-    # sd_linear_wgrad) -- the bf16 NCHW entry is kept as the direct-caller reference of the C ABI
+    # config 4 (fp32, NCHW taps) is THE user of the NCHW align kernels; config 5's token-major taps take csrc/align_tok.hip (group 'aligntok');
+    # the bf16 NCHW entry is kept as the direct-caller reference of the C ABI
     'align': lambda dev, reps: (bench_align(dev, reps, 8, 128, 512, 64, torch.float32, 'cfg4 f32')
                                 + bench_align(dev, reps, 8, 256, 768, 128, torch.float32, 'C 256->768 at 128x128 f32')
                                 + bench_align(dev, reps, 8, 256, 768, 128, torch.bfloat16, 'C 256->768 at 128x128 bf16 (NCHW, direct callers)')),
