@@ -26,6 +26,7 @@ int token_gemm_tunable(const char *key, int set, int v);
 int ce_tunable(const char *key, int set, int v);
 int headfuse_tunable(const char *key, int set, int v);
 int wgrad_tn_tunable(const char *key, int set, int v);
+int tok_gemm_bf16_tunable(const char *key, int set, int v);
 // token-major -> class-planes Linear, fp32 (token_gemm.hip); the dtype-dispatching C entry points live in align1x1.hip
 size_t linear_nchw_workspace_bytes(int B, long P, int in_features, int out_features);
 int pred_splits(int B, long P);

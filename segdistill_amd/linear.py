@@ -77,7 +77,7 @@ def linear_forward(x, weight, bias):
             else:
                 w16 = frozen_derived(root, ('cast', dt, weight.data_ptr(), tuple(weight.shape), tuple(weight.stride())), lambda: weight.to(dt))
             b16 = None if bias is None else frozen_derived(bias, ('cast', dt), lambda: bias.to(dt))
-            return F.linear(x if x.dtype == dt else x.to(dt), w16, b16)
+            return linear_fwd_bf16(x if x.dtype == dt else x.to(dt), w16, b16) if dt == torch.bfloat16 else F.linear(x if x.dtype == dt else x.to(dt), w16, b16)
     return F.linear(x, weight, bias)
 
 
@@ -90,6 +90,35 @@ def _bwd_data(dy2, weight):
         if mode != 'lib':
             return token_gemm.linear_bwd_data(dy2, weight, split_bf16=(mode == 'x3'))
     return None
+
+
+# bf16 Linears (config 5): csrc/tok_gemm_bf16.hip instead of the library wherever its shape test passes; SEGDISTILL_BF16_TOK_GEMM=0: A/B switch.
+_BF16_TOK_GEMM = os.environ.get('SEGDISTILL_BF16_TOK_GEMM', '1') == '1'
+
+
+def bf16_tok_gemm_ok(tokens, k, n):
+    """The MEASURED dispatch of the bf16 forward product (tools/bf16_gemm_bench.py on MI355X; profiles/r05_bf16_gemm_bench.txt)."""
+    # ours: the latency-bound products (a few GFLOP over <= 32768 tokens, or short reductions over the high-resolution stages) -- 8192 x 320 -> 320:
+    # 6.7 vs 9.3 us, -> 1280: 14.3 vs 19.0, 2048 x 320 -> 640: 5.7 vs 7.7, 131072 x 64 -> 64: 8.8 vs 11.8; the library: the throughput-bound ones
+    # (131072 x 768 -> 768: 137 vs 221 us -- 128 x 64 tiles are LDS-fill-bound there) and long reductions over few tokens (2048 x 2048 -> 512: its
+    # split-K kernels, 12 vs 15 us)
+    if not _BF16_TOK_GEMM or 2.0 * tokens * k * n >= 9e9 or (k > 1024 and tokens < 8192):
+        return False
+    return bool(_lib.lib().sd_linear_bf16_fwd_supported(tokens, k, n))
+
+
+def linear_fwd_bf16(x, w, b=None):
+    """F.linear(x, w, b) for bf16 x [..., in] and a row-major bf16 w [out, in] (b: bf16 or fp32): fp32 accumulation, one rounding."""
+    K, N = x.shape[-1], w.shape[0]
+    if (x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.dim() == 2 and w.stride() == (K, 1) and x.is_contiguous()
+            and (b is None or (b.dtype in _DT and b.is_contiguous())) and x.numel() > 0 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0):
+        T = x.numel() // K
+        if bf16_tok_gemm_ok(T, K, N):
+            y = torch.empty(*x.shape[:-1], N, dtype=torch.bfloat16, device=x.device)
+            _lib.check(_lib.lib().sd_linear_bf16_fwd(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), 0 if b is None else _DT[b.dtype],
+                                                     y.data_ptr(), T, K, N, _stream_ptr()), 'sd_linear_bf16_fwd')
+            return y
+    return F.linear(x, w, b if b is None or b.dtype == x.dtype else b.to(x.dtype))
 
 
 def linear_bwd_data_bf16(dy2, wc):
@@ -251,7 +280,8 @@ class _TokenLinear(torch.autograd.Function):
             with torch.autocast('cuda', enabled=False):
                 xc = x.to(dt)
                 wc = lowp_copy(weight, dt)
-                y = F.linear(xc, wc, None if bias is None else lowp_copy(bias, dt))
+                bc = None if bias is None else lowp_copy(bias, dt)
+                y = linear_fwd_bf16(xc, wc, bc) if dt == torch.bfloat16 else F.linear(xc, wc, bc)
             ctx.save_for_backward(xc, wc)
         else:
             y = linear_forward(x, weight, bias)
