@@ -692,7 +692,34 @@ def bench_pixup(dev, reps, B=8, C=150, hw=128, F=4):
             _entry('pix_kl with the x4 upsample fused, bwd', 'pix_up_bwd', [B, C, hw, hw, '->', H, W], 'f32', tb, 'valu', 12 * N, VALU)]
 
 
+def bench_bf16gemm(dev, reps):
+    """csrc/tok_gemm_bf16.hip at the Segformer-B4 teacher's stage-3 / stage-2 / stage-1 shapes (config 5).  Roof: the larger of the matrix-pipe time
+    (2 T K N flops on dense bf16) and the HBM time of X + W + Y -- a few microseconds for all of them: these launches are latency-bound, the
+    fraction says how far above their roof one launch sits."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    gen = torch.Generator(device=dev).manual_seed(99)
+    out = []
+    for T, K, N, tag in ((8192, 320, 320, 'B4 stage 3 q / proj'), (8192, 320, 1280, 'B4 stage 3 fc1'), (8192, 1280, 320, 'B4 stage 3 fc2'),
+                         (2048, 320, 640, 'B4 stage 3 kv'), (32768, 128, 128, 'B4 stage 2 q / proj'), (32768, 512, 128, 'B4 stage 2 fc2'),
+                         (131072, 64, 64, 'B4 stage 1 q / proj'), (131072, 256, 64, 'B4 stage 1 fc2')):
+        x = torch.randn(T, K, device=dev, generator=gen).to(torch.bfloat16)
+        w = (torch.randn(N, K, device=dev, generator=gen) / K ** 0.5).to(torch.bfloat16)
+        b = torch.randn(N, device=dev, generator=gen).to(torch.bfloat16)
+        y = torch.empty(T, N, dtype=torch.bfloat16, device=dev)
+        t = _time(lambda st: _ok(L.sd_linear_bf16_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), _lib.SD_BF16, y.data_ptr(), T, K, N, st), 'sd_linear_bf16_fwd'), reps)
+        flops, nbytes = 2.0 * T * K * N, (T * K + N * K + T * N) * 2
+        if flops / (MFMA_BF16 * 1e12) > nbytes / (HBM * 1e9):
+            out.append(_entry(f'bf16 Linear fwd {T} x {K} -> {N} ({tag})', 'tok_gemm_bf16_kernel', [T, K, N], 'bf16', t, 'mfma', flops, MFMA_BF16,
+                              note=f'{nbytes / (t * 1e-3) / 1e9:.0f} GB/s of operands'))
+        else:
+            out.append(_entry(f'bf16 Linear fwd {T} x {K} -> {N} ({tag})', 'tok_gemm_bf16_kernel', [T, K, N], 'bf16', t, 'hbm', nbytes, HBM,
+                              note=f'{flops / (t * 1e-3) / 1e12:.0f} TFLOP/s of {MFMA_BF16:.0f}'))
+    return out
+
+
 GROUPS = {
+    'bf16gemm': lambda dev, reps: bench_bf16gemm(dev, reps),
     'aligntok': lambda dev, reps: bench_aligntok(dev, reps),
     'pixup': lambda dev, reps: bench_pixup(dev, reps),
     'wattn': lambda dev, reps: bench_wattn(dev, reps),
