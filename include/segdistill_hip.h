@@ -394,8 +394,8 @@ int sd_linear_tok_bf16_bwd_data(const void *dY, const void *W, void *dX, long to
  * fp32 accumulation, ONE rounding of (accumulator + bias) to bf16 -- what autocast's F.linear computes.  Replaces the F.linear of every q / kv /
  * proj / fc1 / fc2 of the MiT encoders (mix_transformer.py:24-27,48-55,75-84,107-133), the SR convolution as a patch GEMM (:66-70) and the MLP
  * projections of the SegFormer head (segformer_head.py:22-33) in BASELINE config 5.  _supported(): in % 64 == 0, out % 64 == 0, tokens * in and
- * out * in below 2^31 elements; operands 16-byte aligned (SD_E_ALIGN), rows dense.  Tunables (A/B): tok_gemm_bf16_bn (64 / 128 output channels
- * per tile; 0 = by shape), tok_gemm_bf16_ns (LDS ring depth 2..4; 0 = by tile).
+ * out * in below 2^31 elements; operands 16-byte aligned (SD_E_ALIGN), rows dense.  Tunable (A/B): tok_gemm_bf16_variant (index of a tile /
+ * wave-layout / ring-depth instantiation, csrc/tok_gemm_bf16.hip::launch_variant; -1 = by shape).
  */
 int sd_linear_bf16_fwd_supported(long tokens, int in_features, int out_features);
 int sd_linear_bf16_fwd(const void *X, const void *W, const void *bias, int bias_dtype, void *Y, long tokens, int in_features, int out_features,

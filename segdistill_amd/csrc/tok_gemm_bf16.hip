@@ -33,10 +33,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kBM = 128;            // tokens per tile
 constexpr int kBK = 64;             // k per step: one 128-byte line per operand row
 
-int g_force_bn = 0, g_force_ns = 0;     // A/B tunables (0 = the dispatch below)
+int g_force_variant = -1;           // A/B tunable (-1 = the dispatch below)
 
 // global -> LDS, 16 bytes per lane (align_tok.hip): M0 = wave-uniform LDS byte address of lane 0's 16 bytes, lane l lands at M0 + 16 l; the source is a
 // wave-uniform base (SGPR pair) + a per-lane unsigned byte offset.  From inline asm, so that the waits are the hand-counted ones below.
@@ -49,18 +48,31 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, int NS>
-__global__ __launch_bounds__(256, (NS * (kBM + BN) * 128 <= 80 * 1024) ? 2 : 1) void tok_gemm_bf16_kernel(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const void *__restrict__ bias,
-                                                                int bias_is_bf16, bf16_t *__restrict__ Y, long T, int N, int K, int tiles_n) {
-    constexpr int kXB = kBM * 128, kWB = BN * 128, kStage = kXB + kWB;
-    constexpr int kPieces = kStage / 1024, kPPW = kPieces / 4;      // 1 KB DMA pieces per stage / per wave: 6 (BN = 64), 8 (BN = 128)
-    constexpr int TM = BN / 64;                                      // 32-channel blocks per wave (waves: 2 token halves x 2 channel halves)
-    constexpr int kPitch = BN * 2 + 16;                              // output image: [128 tokens][BN channels] bf16, rows padded by 16 bytes
-    constexpr int kImg = kBM * kPitch;
-    constexpr int kRing = NS * kStage > kImg ? NS * kStage : kImg;
-    static_assert(kPieces % 4 == 0, "whole pieces per wave");
-    static_assert(NS >= 2 && NS <= 4, "ring depth");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[kRing + BN * 4];
+// Tile BM tokens x BN channels, WM x WN waves: a wave owns BM / WM tokens (TN blocks of 32) x BN / WN channels (TM blocks of 32).
+template <int BM, int BN, int WM, int WN, int NS>
+struct TileCfg {
+    static constexpr int NW = WM * WN, NT = 64 * NW;
+    static constexpr int TN = BM / (32 * WM), TM = BN / (32 * WN);
+    static constexpr int kXB = BM * 128, kWB = BN * 128, kStage = kXB + kWB;
+    static constexpr int kPieces = kStage / 1024, kPPW = (kPieces + NW - 1) / NW;      // 1 KB DMA pieces per stage / per wave
+    static constexpr int kPitch = BN * 2 + 16;                                         // output image rows: BN channels bf16 + 16 bytes of pad
+    static constexpr int kImg = BM * kPitch;
+    static constexpr int kRing = NS * kStage > kImg ? NS * kStage : kImg;
+    static constexpr int kLds = kRing + BN * 4;
+    static constexpr int kWgPerCu = 160 * 1024 / kLds >= 2 ? 2 : 1;
+    static constexpr int kWavesPerSimd = (kWgPerCu * NW + 3) / 4;
+    static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "whole 32 x 32 blocks per wave");
+    static_assert(NS >= 2 && NS <= 4 && (NS - 2) * kPPW <= 63, "ring depth / vmcnt range");
+    static_assert(kLds <= 160 * 1024, "LDS");
+};
+
+template <int BM, int BN, int WM, int WN, int NS>
+__global__ __launch_bounds__(64 * WM * WN, (TileCfg<BM, BN, WM, WN, NS>::kWavesPerSimd)) void tok_gemm_bf16_kernel(
+    const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const void *__restrict__ bias, int bias_is_bf16, bf16_t *__restrict__ Y, long T, int N,
+    int K, int tiles_n) {
+    typedef TileCfg<BM, BN, WM, WN, NS> C;
+    constexpr int TM = C::TM, TN = C::TN, NT = C::NT, kPPW = C::kPPW, kStage = C::kStage, kXB = C::kXB, kPitch = C::kPitch;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[C::kLds];
 
     // XCD-aware order (bijective): consecutive workgroup ids land on different XCDs; every XCD gets a contiguous band of tiles, channel tiles of one
     // token tile next to each other (they share the X rows through that XCD's L2)
@@ -69,36 +81,37 @@ __global__ __launch_bounds__(256, (NS * (kBM + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     const long tile = (xcd < rem ? xcd * (qx + 1) : rem * (qx + 1) + (xcd - rem) * qx) + id / 8;
     const long tm = tile / tiles_n;
     const int tn = (int)(tile - tm * tiles_n);
-    const long m0 = tm * kBM;
+    const long m0 = tm * BM;
     const int n0 = tn * BN;
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, h = lane >> 5;
 
     // bias table (fp32) behind the ring; visible to everybody after the first barrier of the k-loop
-    float *bias_l = reinterpret_cast<float *>(lds + kRing);
-    if (t < BN) {
+    float *bias_l = reinterpret_cast<float *>(lds + C::kRing);
+    for (int c = t; c < BN; c += NT) {
         float b = 0.f;
         if (bias) {
             if (bias_is_bf16) {
-                const uint32_t bits = (uint32_t) reinterpret_cast<const uint16_t *>(bias)[n0 + t] << 16;
+                const uint32_t bits = (uint32_t) reinterpret_cast<const uint16_t *>(bias)[n0 + c] << 16;
                 b = __builtin_bit_cast(float, bits);
             } else {
-                b = reinterpret_cast<const float *>(bias)[n0 + t];
+                b = reinterpret_cast<const float *>(bias)[n0 + c];
             }
         }
-        bias_l[t] = b;
+        bias_l[c] = b;
     }
 
-    // ---- DMA plan: piece q of a stage = physical bytes [1024 q, 1024 q + 1024) = 8 rows of one operand tile (pieces 0..15: X, the rest: W)
+    // ---- DMA plan: piece q of a stage = physical bytes [1024 q, 1024 q + 1024) = 8 rows of one operand tile (the first BM / 8 pieces: X, the rest: W);
+    // a wave beyond the stage's last piece repeats it (same bytes to the same place: every wave issues the same count, the waits are uniform)
     const unsigned lds0 = (unsigned)(uintptr_t)lds;
     unsigned src_off[kPPW];
     const long tlast = T - 1;
 #pragma unroll
     for (int u = 0; u < kPPW; ++u) {
-        const int q = wave * kPPW + u;
+        const int q = min(wave * kPPW + u, C::kPieces - 1);
         const bool is_x = q < kXB / 1024;
         const int qq = is_x ? q : q - kXB / 1024;
         const int o = 16 * lane;
@@ -110,29 +123,29 @@ __global__ __launch_bounds__(256, (NS * (kBM + BN) * 128 <= 80 * 1024) ? 2 : 1) 
     }
     auto issue = [&](int ks) {          // stage ks % NS <- k-step ks of both tiles
         const bf16_t *xk = X + (size_t)ks * kBK, *wk = W + (size_t)ks * kBK;
-        const unsigned sb = lds0 + (unsigned)(ks % NS) * (unsigned)kStage + (unsigned)(wave * kPPW) * 1024u;
+        const unsigned sb = lds0 + (unsigned)(ks % NS) * (unsigned)kStage;
 #pragma unroll
         for (int u = 0; u < kPPW; ++u) {
-            const bool is_x = wave * kPPW + u < kXB / 1024;
-            dma16(is_x ? (const void *)xk : (const void *)wk, src_off[u], __builtin_amdgcn_readfirstlane(sb + 1024u * u));
+            const int q = min(wave * kPPW + u, C::kPieces - 1);
+            dma16(q < kXB / 1024 ? (const void *)xk : (const void *)wk, src_off[u], __builtin_amdgcn_readfirstlane(sb + 1024u * (unsigned)q));
         }
     };
 
     // ---- fragment addresses: lane (r, h) reads chunk 2 s + h of row base + r; (2 s + h) ^ (r & 7) = (2 s) ^ (h ^ (r & 7))
     const unsigned lane_c = (unsigned)((r >> 1) * 256 + (((r & 1) ^ ((r >> 3) & 1)) << 7) + ((h ^ (r & 7)) << 4));
-    const unsigned xrd = lane_c + (unsigned)wm * (64 * 128);
-    const unsigned wrd = lane_c + (unsigned)kXB + (unsigned)wn * ((BN / 2) * 128);
+    const unsigned xrd = lane_c + (unsigned)wm * (TN * 32 * 128);
+    const unsigned wrd = lane_c + (unsigned)kXB + (unsigned)wn * (TM * 32 * 128);
 
-    f32x16 acc[TM][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = K / kBK;
-    __builtin_amdgcn_sched_barrier(0);      // the bias load (a compiler-counted vector-memory operation) is waited for above this line
+    __builtin_amdgcn_sched_barrier(0);      // the bias loads (compiler-counted vector-memory operations) are waited for above this line
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s);
@@ -148,15 +161,15 @@ __global__ __launch_bounds__(256, (NS * (kBM + BN) * 128 <= 80 * 1024) ? 2 : 1) 
         const unsigned char *st = lds + (size_t)(k % NS) * kStage;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bf16x8 wf[TM], xf[2];
+            bf16x8 wf[TM], xf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) wf[i] = *reinterpret_cast<const bf16x8 *>(st + ((wrd + 4096u * i) ^ (unsigned)(s << 5)));
 #pragma unroll
-            for (int j = 0; j < 2; ++j) xf[j] = *reinterpret_cast<const bf16x8 *>(st + ((xrd + 4096u * j) ^ (unsigned)(s << 5)));
+            for (int j = 0; j < TN; ++j) xf[j] = *reinterpret_cast<const bf16x8 *>(st + ((xrd + 4096u * j) ^ (unsigned)(s << 5)));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
         }
     }
     __syncthreads();                        // the ring is free (the last wait was vmcnt(0)): it becomes the output image
@@ -165,11 +178,11 @@ __global__ __launch_bounds__(256, (NS * (kBM + BN) * 128 <= 80 * 1024) ? 2 : 1) 
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int tok = wm * 64 + 32 * j + r;
+        for (int j = 0; j < TN; ++j) {
+            const int tok = wm * (TN * 32) + 32 * j + r;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int nl = wn * (BN / 2) + 32 * i + 8 * q + 4 * h;
+                const int nl = wn * (TM * 32) + 32 * i + 8 * q + 4 * h;
                 const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bias_l + nl);
                 const bf16x2 lo = __builtin_convertvector((f32x2){acc[i][j][4 * q] + b4[0], acc[i][j][4 * q + 1] + b4[1]}, bf16x2);
                 const bf16x2 hi = __builtin_convertvector((f32x2){acc[i][j][4 * q + 2] + b4[2], acc[i][j][4 * q + 3] + b4[3]}, bf16x2);
@@ -179,10 +192,8 @@ __global__ __launch_bounds__(256, (NS * (kBM + BN) * 128 <= 80 * 1024) ? 2 : 1) 
         }
     __syncthreads();
     constexpr int kCPR = BN / 8;            // 16-byte chunks per output row
-#pragma unroll
-    for (int it = 0; it < kBM * kCPR / 256; ++it) {
-        const int idx = t + 256 * it;
-        const int row = idx / kCPR, c = idx % kCPR;
+    for (int idx = t; idx < BM * kCPR; idx += NT) {
+        const int row = idx / kCPR, c = idx - row * kCPR;
         const u32x4 v = *reinterpret_cast<const u32x4 *>(lds + row * kPitch + c * 16);
         if (m0 + row < T) *reinterpret_cast<u32x4 *>(Y + (size_t)(m0 + row) * N + n0 + c * 8) = v;
     }
@@ -193,26 +204,53 @@ bool shape_ok(long T, int K, int N) {
     return T > 0 && K >= kBK && K % kBK == 0 && N >= 64 && N % 64 == 0 && (double)T * K * 2 < 4.0e9 && (double)N * K * 2 < 4.0e9;
 }
 
-template <int BN, int NS>
-int launch(const void *X, const void *W, const void *bias, int bias_is_bf16, void *Y, long T, int N, int K, hipStream_t st) {
-    const long tiles_m = (T + kBM - 1) / kBM;
-    const int tiles_n = N / BN;
+struct Args {
+    const void *X, *W, *bias;
+    int bias_is_bf16;
+    void *Y;
+    long T;
+    int N, K;
+    hipStream_t st;
+};
+
+template <int BM, int BN, int WM, int WN, int NS>
+int launch(const Args &a) {
+    if (a.N % BN) return SD_E_UNSUPPORTED;
+    const long tiles_m = (a.T + BM - 1) / BM;
+    const int tiles_n = a.N / BN;
     const long nblk = tiles_m * tiles_n;
     if (nblk > 0x7fffffffL) return SD_E_SHAPE;
-    hipLaunchKernelGGL((tok_gemm_bf16_kernel<BN, NS>), dim3((unsigned)nblk), dim3(256), 0, st, (const bf16_t *)X, (const bf16_t *)W, bias, bias_is_bf16,
-                       (bf16_t *)Y, T, N, K, tiles_n);
+    hipLaunchKernelGGL((tok_gemm_bf16_kernel<BM, BN, WM, WN, NS>), dim3((unsigned)nblk), dim3(64 * WM * WN), 0, a.st, (const bf16_t *)a.X,
+                       (const bf16_t *)a.W, a.bias, a.bias_is_bf16, (bf16_t *)a.Y, a.T, a.N, a.K, tiles_n);
     return (int)hipGetLastError();
+}
+
+// The tile variants (tools/bf16_gemm_bench.py --variants times every one that divides N)
+constexpr int kVariants = 11;
+int launch_variant(int v, const Args &a) {
+    switch (v) {
+        case 0: return launch<128, 64, 2, 2, 2>(a);
+        case 1: return launch<128, 128, 2, 2, 2>(a);
+        case 2: return launch<128, 64, 2, 2, 3>(a);
+        case 3: return launch<256, 160, 4, 1, 2>(a);
+        case 4: return launch<256, 160, 8, 1, 2>(a);
+        case 5: return launch<64, 160, 2, 1, 2>(a);
+        case 6: return launch<128, 160, 4, 1, 2>(a);
+        case 7: return launch<256, 128, 4, 2, 2>(a);
+        case 8: return launch<256, 64, 4, 1, 2>(a);
+        case 9: return launch<64, 64, 2, 1, 2>(a);
+        case 10: return launch<64, 128, 2, 2, 2>(a);
+        default: return SD_E_UNSUPPORTED;
+    }
 }
 
 }  // namespace
 
 int tok_gemm_bf16_tunable(const char *key, int set, int v) {
-    int *p = nullptr;
-    if (!strcmp(key, "tok_gemm_bf16_bn")) p = &g_force_bn;
-    else if (!strcmp(key, "tok_gemm_bf16_ns")) p = &g_force_ns;
-    if (!p) return SD_E_UNSUPPORTED;
-    if (!set) return *p;
-    *p = v;
+    if (strcmp(key, "tok_gemm_bf16_variant")) return SD_E_UNSUPPORTED;
+    if (!set) return g_force_variant;
+    if (v < -1 || v >= kVariants) return SD_E_SHAPE;
+    g_force_variant = v;
     return SD_OK;
 }
 
@@ -229,25 +267,17 @@ int sd_linear_bf16_fwd(const void *X, const void *W, const void *bias, int bias_
     if (!shape_ok(tokens, in_features, out_features)) return SD_E_UNSUPPORTED;
     if (bias && bias_dtype != SD_F32 && bias_dtype != SD_BF16) return SD_E_DTYPE;
     if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(Y)) & 15) return SD_E_ALIGN;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const int K = in_features, N = out_features;
-    const int bb = bias_dtype == SD_BF16 ? 1 : 0;
+    const Args a = {X, W, bias, bias_dtype == SD_BF16 ? 1 : 0, Y, tokens, out_features, in_features, reinterpret_cast<hipStream_t>(stream)};
+    if (g_force_variant >= 0) {
+        const int rc = launch_variant(g_force_variant, a);
+        if (rc != SD_E_UNSUPPORTED) return rc;          // a forced variant that does not divide N: the dispatch below
+    }
     // Measured (tools/bf16_gemm_bench.py, profiles/r05_bf16_gemm_bench.txt): what bounds these products is the rate at which a CU fills its LDS from
     // L2 (~70 GB/s per CU), i.e. bytes per CU and their balance over the CUs, so (a) the SHALLOW ring wins -- 48 / 64 KB of LDS = three / two workgroups
     // per CU hide more latency than a third stage in flight (8192 x 320 -> 1280: 14.3 us with two stages, 16.5 with three, 22.0 with four) -- and
     // (b) 128-channel tiles (X re-read half as often) pay from 32768 tokens on; below that 64-channel tiles spread the product over more CUs.
-    int bn = (N % 128 == 0 && tokens >= 32768) ? 128 : 64;
-    if (g_force_bn == 64 || (g_force_bn == 128 && N % 128 == 0)) bn = g_force_bn;
-    int ns = 2;
-    if (g_force_ns >= 2 && g_force_ns <= 4) ns = g_force_ns;
-    if (bn == 64) {
-        if (ns == 2) return launch<64, 2>(X, W, bias, bb, Y, tokens, N, K, st);
-        if (ns == 3) return launch<64, 3>(X, W, bias, bb, Y, tokens, N, K, st);
-        return launch<64, 4>(X, W, bias, bb, Y, tokens, N, K, st);
-    }
-    if (ns == 2) return launch<128, 2>(X, W, bias, bb, Y, tokens, N, K, st);
-    if (ns == 3) return launch<128, 3>(X, W, bias, bb, Y, tokens, N, K, st);
-    return launch<128, 4>(X, W, bias, bb, Y, tokens, N, K, st);
+    const int N = out_features;
+    return launch_variant((N % 128 == 0 && tokens >= 32768) ? 1 : 0, a);
 }
 
 }  // extern "C"

@@ -51,23 +51,24 @@ def test_forward_matches_fp64(shape, bias):
     _check(y, _ref(x, w, b), K)
 
 
-@pytest.mark.parametrize('bn,ns', [(64, 2), (64, 3), (64, 4), (128, 2), (128, 3), (128, 4)])
-def test_every_tile_and_ring_variant(bn, ns):
+@pytest.mark.parametrize('variant', range(11))
+def test_every_tile_variant(variant):
+    """Every (tile, wave layout, ring depth) instantiation, forced through the A/B tunable, on shapes its channel tile divides (a forced variant that
+    does not divide N falls back to the dispatch -- still checked)."""
     from segdistill_amd import _lib, linear
     L = _lib.lib()
     dev = torch.device('cuda:0')
-    g = torch.Generator(device='cpu').manual_seed(bn + ns)
+    g = torch.Generator(device='cpu').manual_seed(variant)
     try:
-        assert L.sd_set_tunable(b'tok_gemm_bf16_bn', bn) == 0 and L.sd_set_tunable(b'tok_gemm_bf16_ns', ns) == 0
-        for T, K, N in [(700, 320, 384), (2048, 64, 128), (300, 704, 256)]:
+        assert L.sd_set_tunable(b'tok_gemm_bf16_variant', variant) == 0
+        for T, K, N in [(700, 320, 640), (2048, 64, 1280), (300, 704, 320), (513, 128, 128)]:
             x = torch.randn(T, K, generator=g).to(dev).bfloat16()
             w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).bfloat16()
             b = torch.randn(N, generator=g).to(dev).bfloat16()
             assert linear.bf16_tok_gemm_ok(T, K, N)
             _check(linear.linear_fwd_bf16(x, w, b), _ref(x, w, b), K)
     finally:
-        L.sd_set_tunable(b'tok_gemm_bf16_bn', 0)
-        L.sd_set_tunable(b'tok_gemm_bf16_ns', 0)
+        L.sd_set_tunable(b'tok_gemm_bf16_variant', -1)
 
 
 def test_unsupported_shapes_fall_back_to_the_library():

@@ -29,8 +29,11 @@ def main():
             key = (t, k, n)
             prev = shapes.get(key, ('', 0))
             shapes[key] = (prev[0] + ('' if not prev[0] else ' + ') + f'{tag} {name}', prev[1] + cnt)
-    variants = [(64, 2), (64, 3), (64, 4), (128, 2), (128, 3), (128, 4)] if a.variants else []
-    hdr = f'{"shape":>22s} {"calls":>5s} {"library":>9s} {"ours":>9s}' + ''.join(f' {f"{bn}x{ns}":>8s}' for bn, ns in variants) + '   used by'
+    # (BM, BN, waves); index = the tunable's value (csrc/tok_gemm_bf16.hip::launch_variant)
+    names = ['128x64', '128x128', '128x64/3', '256x160', '256x160w8', '64x160', '128x160', '256x128w8', '256x64', '64x64', '64x128']
+    bns = [64, 128, 64, 160, 160, 160, 160, 128, 64, 64, 128]
+    variants = list(range(len(names))) if a.variants else []
+    hdr = f'{"shape":>22s} {"calls":>5s} {"library":>9s} {"ours":>9s}' + ''.join(f' {names[v]:>9s}' for v in variants) + '   used by'
     print(hdr)
     tot_lib = tot_ours = 0.0
     for (t, k, n), (who, cnt) in sorted(shapes.items(), key=lambda kv: (-kv[0][0], kv[0][1], kv[0][2])):
@@ -39,21 +42,19 @@ def main():
         b = torch.randn(n, device=dev).bfloat16()
         lib = timeit(lambda: F.linear(x, w, b), reps=a.reps)
         if not linear.bf16_tok_gemm_ok(t, k, n):
-            print(f'{f"{t} x {k} -> {n}":>22s} {cnt:5d} {lib:9.1f} {"-":>9s}' + ''.join(f' {"-":>8s}' for _ in variants) + f'   {who}')
+            print(f'{f"{t} x {k} -> {n}":>22s} {cnt:5d} {lib:9.1f} {"-":>9s}' + ''.join(f' {"-":>9s}' for _ in variants) + f'   {who}')
             tot_lib += lib * cnt
             tot_ours += lib * cnt
             continue
         ours = timeit(lambda: linear.linear_fwd_bf16(x, w, b), reps=a.reps)
         cols = []
-        for bn, ns in variants:
-            if n % bn:
-                cols.append(f' {"-":>8s}')
+        for v in variants:
+            if n % bns[v]:
+                cols.append(f' {"-":>9s}')
                 continue
-            L.sd_set_tunable(b'tok_gemm_bf16_bn', bn)
-            L.sd_set_tunable(b'tok_gemm_bf16_ns', ns)
-            cols.append(f' {timeit(lambda: linear.linear_fwd_bf16(x, w, b), reps=a.reps):8.1f}')
-            L.sd_set_tunable(b'tok_gemm_bf16_bn', 0)
-            L.sd_set_tunable(b'tok_gemm_bf16_ns', 0)
+            L.sd_set_tunable(b'tok_gemm_bf16_variant', v)
+            cols.append(f' {timeit(lambda: linear.linear_fwd_bf16(x, w, b), reps=a.reps):9.1f}')
+            L.sd_set_tunable(b'tok_gemm_bf16_variant', -1)
         print(f'{f"{t} x {k} -> {n}":>22s} {cnt:5d} {lib:9.1f} {ours:9.1f}' + ''.join(cols) + f'   {who}')
         tot_lib += lib * cnt
         tot_ours += ours * cnt
