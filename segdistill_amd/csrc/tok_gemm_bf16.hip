@@ -225,21 +225,18 @@ int launch(const Args &a) {
     return (int)hipGetLastError();
 }
 
-// The tile variants (tools/bf16_gemm_bench.py --variants times every one that divides N)
-constexpr int kVariants = 11;
+// The tile variants kept (tools/bf16_gemm_bench.py --variants).  Measured and dropped (profiles/r05_bf16_gemm_variants.txt): 256 x 160, 128 x 160,
+// 64 x 160, 256 x 128 and 256 x 64 tiles -- fewer, larger workgroups read fewer bytes in total but finish in ONE round, so every workgroup's output
+// stores drain together behind the last MFMA instead of under the next round's k-loop (8192 x 320 -> 1280: 13.8 - 18.4 us against 14.5; -> 320: 9.1 -
+// 13.3 against 7.3); a third ring stage buys nothing (the shallow ring's extra co-resident workgroup does more for latency).
+constexpr int kVariants = 5;
 int launch_variant(int v, const Args &a) {
     switch (v) {
         case 0: return launch<128, 64, 2, 2, 2>(a);
         case 1: return launch<128, 128, 2, 2, 2>(a);
         case 2: return launch<128, 64, 2, 2, 3>(a);
-        case 3: return launch<256, 160, 4, 1, 2>(a);
-        case 4: return launch<256, 160, 8, 1, 2>(a);
-        case 5: return launch<64, 160, 2, 1, 2>(a);
-        case 6: return launch<128, 160, 4, 1, 2>(a);
-        case 7: return launch<256, 128, 4, 2, 2>(a);
-        case 8: return launch<256, 64, 4, 1, 2>(a);
-        case 9: return launch<64, 64, 2, 1, 2>(a);
-        case 10: return launch<64, 128, 2, 2, 2>(a);
+        case 3: return launch<64, 64, 2, 1, 2>(a);
+        case 4: return launch<64, 128, 2, 2, 2>(a);
         default: return SD_E_UNSUPPORTED;
     }
 }
@@ -272,10 +269,10 @@ int sd_linear_bf16_fwd(const void *X, const void *W, const void *bias, int bias_
         const int rc = launch_variant(g_force_variant, a);
         if (rc != SD_E_UNSUPPORTED) return rc;          // a forced variant that does not divide N: the dispatch below
     }
-    // Measured (tools/bf16_gemm_bench.py, profiles/r05_bf16_gemm_bench.txt): what bounds these products is the rate at which a CU fills its LDS from
-    // L2 (~70 GB/s per CU), i.e. bytes per CU and their balance over the CUs, so (a) the SHALLOW ring wins -- 48 / 64 KB of LDS = three / two workgroups
-    // per CU hide more latency than a third stage in flight (8192 x 320 -> 1280: 14.3 us with two stages, 16.5 with three, 22.0 with four) -- and
-    // (b) 128-channel tiles (X re-read half as often) pay from 32768 tokens on; below that 64-channel tiles spread the product over more CUs.
+    // Measured (tools/bf16_gemm_bench.py, profiles/r05_bf16_gemm_bench.txt, r05_bf16_gemm_variants.txt): these launches cost a fixed ~4 us (launch, first
+    // operands, epilogue) + ~0.5 us per 64-deep k-step -- the rate at which a CU fills its LDS from L2 (~70 GB/s) over the one or two workgroups it
+    // holds -- so the tile shape moves them by a few per cent only: 128-channel tiles (X re-read half as often) from 32768 tokens on, 64-channel tiles
+    // (more workgroups in flight) below.
     const int N = out_features;
     return launch_variant((N % 128 == 0 && tokens >= 32768) ? 1 : 0, a);
 }

@@ -30,8 +30,8 @@ def main():
             prev = shapes.get(key, ('', 0))
             shapes[key] = (prev[0] + ('' if not prev[0] else ' + ') + f'{tag} {name}', prev[1] + cnt)
     # (BM, BN, waves); index = the tunable's value (csrc/tok_gemm_bf16.hip::launch_variant)
-    names = ['128x64', '128x128', '128x64/3', '256x160', '256x160w8', '64x160', '128x160', '256x128w8', '256x64', '64x64', '64x128']
-    bns = [64, 128, 64, 160, 160, 160, 160, 128, 64, 64, 128]
+    names = ['128x64', '128x128', '128x64/3', '64x64', '64x128']
+    bns = [64, 128, 64, 64, 128]
     variants = list(range(len(names))) if a.variants else []
     hdr = f'{"shape":>22s} {"calls":>5s} {"library":>9s} {"ours":>9s}' + ''.join(f' {names[v]:>9s}' for v in variants) + '   used by'
     print(hdr)
