@@ -33,10 +33,11 @@ json.dump(d, open(sys.argv[2], 'w'), indent=1)
 PY
   ) && n=$((n + 1))
 fi
-put $R/gpurun_out/ab_switches.txt $DST/${P}_ab_switches.txt
-put $R/gpurun_out/ab_round4.txt $DST/${P}_ab_round4.txt
-put $R/gpurun_out/ab_round4b.txt $DST/${P}_ab_round4_ppm.txt
-for f in $R/gpurun_out/configs/train_step_kernels_cfg*.txt $R/gpurun_out/configs/step_shapes_cfg*.txt; do
+for f in align_tok_bench.txt pix_up_bench.txt bf16_gemm_bench.txt; do
+  put $SRC/$f $DST/${P}_$f
+done
+for f in $R/gpurun_out/configs/train_step_kernels_cfg*.txt $R/gpurun_out/configs/step_shapes_cfg*.txt \
+         $SRC/prof5/train_step_kernels_cfg*.txt $SRC/prof5/step_shapes_cfg*.txt; do
   [ -e "$f" ] && put $f $DST/${P}_$(basename $f)
 done
 echo "published $n files under $DST/${P}_*"
