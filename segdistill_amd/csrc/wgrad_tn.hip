@@ -158,15 +158,16 @@ __device__ __forceinline__ void dma16(const void *gptr, unsigned lds_byte) {
 // registers, one workgroup per CU).  PMC of the IM = 1 form at 768 x 256 over 131072 tokens (profiles/r04_pmc_wgrad_tn.json): no LDS bank conflict,
 // LDS array ~12 % busy, matrix pipe 25 % busy, FETCH_SIZE = dY + X once -- the kernel runs at what ~96 KB in flight per CU buy from L2 at this
 // latency (804 MB of L2 -> CU traffic in 93 us): the big tile halves that traffic per MFMA (402 MB) instead of deepening the ring.
+// nblk / id: the number of workgroups of THIS product and this workgroup's index among them (the whole grid for a single launch; a slice of it in
+// the grouped launch below, whose slices start at multiples of 8 so that id % 8 is still the XCD the workgroup runs on)
 template <int IM>
-__global__ __launch_bounds__(256) void wgrad_tn_bf16_ring(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, float *__restrict__ C, int M,
-                                                           int N, long T, int klen, int tiles_m, int tiles_n, int nsplit) {
+__device__ __forceinline__ void wgrad_ring_body(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, float *__restrict__ C, int M, int N, long T,
+                                                int klen, int tiles_m, int tiles_n, int nsplit, long nblk, long id) {
     constexpr int BT = 128 * IM;                       // tile extent along m and along n
     constexpr int TW = 2 * IM;                         // 32-row (-column) MFMA blocks per wave and axis
     constexpr int kStage = 2 * IM * kStageBytes;       // A images, then B images
     constexpr int kDma = 4 * IM;                       // DMA instructions per wave and tile
     __shared__ __attribute__((aligned(1024))) unsigned char lds[kRing * kStage];      // 64 KB (IM = 1) / 128 KB (IM = 2)
-    const long nblk = gridDim.x, id = blockIdx.x;
     const long qd = nblk / 8, rem = nblk % 8, xcd = id % 8;
     const long L = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + id / 8;
     const int tiles = tiles_m * tiles_n;
@@ -260,6 +261,43 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_ring(const bf16_t *__restri
                 if (m < M && n < N) Cz[(size_t)m * N + n] = acc[i][j][e];
             }
         }
+}
+
+template <int IM>
+__global__ __launch_bounds__(256) void wgrad_tn_bf16_ring(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, float *__restrict__ C, int M,
+                                                           int N, long T, int klen, int tiles_m, int tiles_n, int nsplit) {
+    wgrad_ring_body<IM>(A, B, C, M, N, T, klen, tiles_m, tiles_n, nsplit, (long)gridDim.x, (long)blockIdx.x);
+}
+
+// ---- many products in ONE launch (round 5) -------------------------------------------------------------------------------------------------
+// The weight gradients of a backward are needed by nobody before the optimizer; launched one by one between the input-gradient GEMMs they sat in
+// the critical chain (54 launches of 9 ... 74 us per config-5 step, the stage 3-4 ones on 16 ... 100 workgroups) and each planned its k-splits as
+// if it had the chip to itself (~768 workgroups per product: 832 MB of slabs next to 1.48 GB of operands per step).  Deferred to the end of the
+// backward (segdistill_amd/deferred.py) they run as one launch whose k-splits are planned over ALL of them: ~1536 workgroups in total, dealt in
+// proportion to each product's tile-k-steps -- a 2048-token product gets ONE split (its gradient is written straight to its destination, no slab at
+// all), a 131072-token one ~30.  The table travels by value in the kernel arguments (safe under graph capture).
+constexpr int kMultiMax = 32;
+struct WgradMultiTable {
+    const bf16_t *A[kMultiMax], *B[kMultiMax];
+    float *C[kMultiMax];
+    long T[kMultiMax];
+    int M[kMultiMax], N[kMultiMax], klen[kMultiMax], tiles_m[kMultiMax], tiles_n[kMultiMax], nsplit[kMultiMax];
+    int blk_begin[kMultiMax + 1];       // multiples of 8
+    int nblk[kMultiMax];                // real workgroups of the job (the slice is padded up to a multiple of 8)
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void wgrad_tn_bf16_ring_multi(const WgradMultiTable t) {
+    int lo = 0, hi = t.njobs - 1;
+    while (lo < hi) {                   // wave-uniform binary search
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= t.blk_begin[mid]) lo = mid;
+        else hi = mid - 1;
+    }
+    const int j = lo;
+    const long id = (long)blockIdx.x - t.blk_begin[j];
+    if (id >= t.nblk[j]) return;        // padding of the slice
+    wgrad_ring_body<1>(t.A[j], t.B[j], t.C[j], t.M[j], t.N[j], t.T[j], t.klen[j], t.tiles_m[j], t.tiles_n[j], t.nsplit[j], (long)t.nblk[j], id);
 }
 
 // ---- fp32 storage: the same product in split-bf16 arithmetic ("bf16x3", fp32-grade: token_gemm.hip section 3.9 of DESIGN.md) ---------------
@@ -520,6 +558,81 @@ int wgrad_tn_launch(const void *dY, const void *X, float *slabs, long T, int M, 
     return (int)hipGetLastError();
 }
 
+// ---- the grouped launch: eligibility, the joint plan, the launch
+bool wgrad_tn_multi_ok(long T, int M, int N) { return M > 0 && N > 0 && M % 8 == 0 && N % 8 == 0 && T >= 3 * TBK && T % TBK == 0 && T <= 0x7fffffffL; }
+
+constexpr long kMultiTargetWgs = 1536;      // 6 per CU: three rounds of the two a CU holds (64 KB of LDS each)
+
+// k-splits of every job, planned together: work = tiles x k-steps; a workgroup should get total / kMultiTargetWgs k-steps (at least 8), every split
+// at least three k-steps (the ring's depth), and no job more slab bytes than wgrad_slab_cap allows
+void wgrad_tn_multi_plan(const long *T, const int *M, const int *N, int *nsplit, int njobs) {
+    double total = 0.0;
+    for (int j = 0; j < njobs; ++j) total += (double)((M[j] + TBM - 1) / TBM) * ((N[j] + TBN - 1) / TBN) * (double)(T[j] / TBK);
+    double per_wg = total / (double)kMultiTargetWgs;
+    if (per_wg < 8.0) per_wg = 8.0;
+    for (int j = 0; j < njobs; ++j) {
+        const long ksteps = T[j] / TBK;
+        long ns = (long)((double)ksteps / per_wg + 0.5);
+        if (ns > ksteps / 3) ns = ksteps / 3;
+        const long cap = wgrad_slab_cap(T[j], M[j], N[j], 2);
+        if (ns > cap) ns = cap;
+        if (ns > 256) ns = 256;
+        if (ns < 1) ns = 1;
+        const long kl = ((ksteps + ns - 1) / ns) * TBK;
+        nsplit[j] = (int)((T[j] + kl - 1) / kl);
+    }
+}
+
+int wgrad_tn_multi_launch(const void *const *dY, const void *const *X, float *const *slabs, const long *T, const int *M, const int *N, const int *nsplit,
+                          int njobs, hipStream_t st) {
+    // longest workgroups first: the tail of the launch is then made of short ones
+    int order[kMultiMax];
+    for (int base = 0; base < njobs; base += kMultiMax) {
+        const int n = njobs - base < kMultiMax ? njobs - base : kMultiMax;
+        for (int i = 0; i < n; ++i) order[i] = base + i;
+        for (int i = 1; i < n; ++i) {       // insertion sort by k-steps per split, descending
+            const int v = order[i];
+            const long kv = T[v] / nsplit[v];
+            int q = i - 1;
+            while (q >= 0 && T[order[q]] / nsplit[order[q]] < kv) { order[q + 1] = order[q]; --q; }
+            order[q + 1] = v;
+        }
+        WgradMultiTable t;
+        memset(&t, 0, sizeof(t));
+        long blk = 0;
+        for (int i = 0; i < n; ++i) {
+            const int j = order[i];
+            if (!wgrad_tn_multi_ok(T[j], M[j], N[j]) || nsplit[j] < 1) return SD_E_UNSUPPORTED;
+            const long ksteps = T[j] / TBK;
+            const long kl = ((ksteps + nsplit[j] - 1) / nsplit[j]) * TBK;
+            if ((T[j] + kl - 1) / kl != nsplit[j] || kl < 3 * TBK) return SD_E_SHAPE;       // not a plan of wgrad_tn_multi_plan
+            if ((reinterpret_cast<uintptr_t>(dY[j]) | reinterpret_cast<uintptr_t>(X[j]) | reinterpret_cast<uintptr_t>(slabs[j])) & 15) return SD_E_ALIGN;
+            t.A[i] = (const bf16_t *)dY[j];
+            t.B[i] = (const bf16_t *)X[j];
+            t.C[i] = slabs[j];
+            t.T[i] = T[j];
+            t.M[i] = M[j];
+            t.N[i] = N[j];
+            t.klen[i] = (int)kl;
+            t.tiles_m[i] = (M[j] + TBM - 1) / TBM;
+            t.tiles_n[i] = (N[j] + TBN - 1) / TBN;
+            t.nsplit[i] = nsplit[j];
+            const long nb = (long)t.tiles_m[i] * t.tiles_n[i] * nsplit[j];
+            if (nb > 0x3fffffffL) return SD_E_SHAPE;
+            t.nblk[i] = (int)nb;
+            t.blk_begin[i] = (int)blk;
+            blk += (nb + 7) / 8 * 8;
+            if (blk > 0x7fffffffL) return SD_E_SHAPE;
+        }
+        t.blk_begin[n] = (int)blk;
+        t.njobs = n;
+        hipLaunchKernelGGL(wgrad_tn_bf16_ring_multi, dim3((unsigned)blk), dim3(256), 0, st, t);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return SD_OK;
+}
+
 // fp32 storage: which products take wgrad_tn_x3, and with how many k-splits (0: not this kernel's)
 int wgrad_tn_x3_plan(long T, int M, int N, int *klen, int *bn) {
     if (T < 8192 || T > 0x7fffffffL || M < 128 || N < 32 || M % 8 || N % 8) return 0;          // tall-skinny, at least one full tile row of dY
@@ -571,6 +684,54 @@ int sd_linear_wgrad_tn(const float *dY, const float *X, float *slabs, size_t sla
     else SD_X3(32, 4, 1);
 #undef SD_X3
     return (int)hipGetLastError();
+}
+
+
+int sd_linear_wgrad_tn_multi_supported(long tokens, int out_features, int in_features) { return sd::wgrad_tn_multi_ok(tokens, out_features, in_features) ? 1 : 0; }
+
+int sd_linear_wgrad_tn_multi_plan(sd_wgrad_job *jobs, int njobs) {
+    if (!jobs) return SD_E_NULL;
+    if (njobs <= 0 || njobs > 4096) return SD_E_SHAPE;
+    long *T = new long[njobs];
+    int *M = new int[njobs], *N = new int[njobs], *ns = new int[njobs];
+    int rc = SD_OK;
+    for (int j = 0; j < njobs; ++j) {
+        T[j] = jobs[j].tokens, M[j] = jobs[j].out_features, N[j] = jobs[j].in_features;
+        if (!sd::wgrad_tn_multi_ok(T[j], M[j], N[j])) rc = SD_E_UNSUPPORTED;
+    }
+    if (rc == SD_OK) {
+        sd::wgrad_tn_multi_plan(T, M, N, ns, njobs);
+        for (int j = 0; j < njobs; ++j) jobs[j].nsplit = ns[j];
+    }
+    delete[] T;
+    delete[] M;
+    delete[] N;
+    delete[] ns;
+    return rc;
+}
+
+int sd_linear_wgrad_tn_multi(const sd_wgrad_job *jobs, int njobs, void *stream) {
+    if (!jobs) return SD_E_NULL;
+    if (njobs <= 0 || njobs > 4096) return SD_E_SHAPE;
+    const void **dY = new const void *[njobs], **X = new const void *[njobs];
+    float **C = new float *[njobs];
+    long *T = new long[njobs];
+    int *M = new int[njobs], *N = new int[njobs], *ns = new int[njobs];
+    int rc = SD_OK;
+    for (int j = 0; j < njobs; ++j) {
+        if (!jobs[j].dY || !jobs[j].X || !jobs[j].slabs) rc = SD_E_NULL;
+        dY[j] = jobs[j].dY, X[j] = jobs[j].X, C[j] = jobs[j].slabs;
+        T[j] = jobs[j].tokens, M[j] = jobs[j].out_features, N[j] = jobs[j].in_features, ns[j] = jobs[j].nsplit;
+    }
+    if (rc == SD_OK) rc = sd::wgrad_tn_multi_launch(dY, X, C, T, M, N, ns, njobs, static_cast<hipStream_t>(stream));
+    delete[] dY;
+    delete[] X;
+    delete[] C;
+    delete[] T;
+    delete[] M;
+    delete[] N;
+    delete[] ns;
+    return rc;
 }
 
 }  // extern "C"

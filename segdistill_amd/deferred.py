@@ -18,6 +18,7 @@ from .ops import _DT, _stream_ptr
 
 _jobs = None   # None: not deferring.  list of (partials tensor, out tensor, n, nslabs) -- the tensors are held until the flush
 _colsums = []  # column sums whose PARTIALS are deferred as well: (x2d, partials, out, rows, C, nblk), x2d kept alive until the flush
+_wgrads = []   # bf16 weight gradients whose GEMM is deferred as well: (dY, X, out, tokens, M, N), operands kept alive until the flush
 _side = {}     # device index -> the side stream the weight-gradient kernels of a scope run on
 _held = []     # operands of side-stream launches, kept alive until the join (so the allocator cannot hand their memory out earlier)
 _forked = None  # the side stream with un-joined work, if any
@@ -25,6 +26,11 @@ _forked = None  # the side stream with un-joined work, if any
 
 class _ColsumJob(C.Structure):
     _fields_ = [('x', C.c_void_p), ('partials', C.c_void_p), ('rows', C.c_long), ('C', C.c_int), ('reserved', C.c_int)]
+
+
+class _WgradJob(C.Structure):
+    _fields_ = [('dY', C.c_void_p), ('X', C.c_void_p), ('slabs', C.c_void_p), ('tokens', C.c_long), ('out_features', C.c_int), ('in_features', C.c_int),
+                ('nsplit', C.c_int), ('reserved', C.c_int)]
 
 
 class _Job(C.Structure):
@@ -39,6 +45,49 @@ def add(partials, out, n, nslabs):
     """out[i] = sum_s partials[s*n + i], i < n -- to be computed when the enclosing scope ends.  Both tensors fp32 on the GPU.
     The caller must hand autograd VIEWS of `out`, never `out` itself (see column_sum)."""
     _jobs.append((partials, out, int(n), int(nslabs)))
+
+
+# SEGDISTILL_WGRAD_GROUPED=0 (A/B): every bf16 weight gradient as its own launch inside the backward, planned on its own (rounds 2-4)
+_WGRAD_GROUPED = os.environ.get('SEGDISTILL_WGRAD_GROUPED', '1') == '1'
+
+
+def wgrad_groupable(dy2, x2, M, N):
+    """May this bf16 weight gradient dY^T . X join the scope's ONE grouped launch (csrc/wgrad_tn.hip, wgrad_tn_bf16_ring_multi)?"""
+    return (_jobs is not None and _WGRAD_GROUPED and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and dy2.is_contiguous()
+            and x2.is_contiguous() and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
+            and bool(_lib.lib().sd_linear_wgrad_tn_multi_supported(dy2.shape[0], M, N)))
+
+
+def add_wgrad(dy2, x2, M, N):
+    """dW [M, N] fp32 = dy2 [T, M]^T . x2 [T, N] (bf16), computed when the enclosing scope ends by the grouped launch -- its k-splits planned over all
+    the scope's weight gradients together -- and the scope's slab combine.  Returns a VIEW of the result buffer (see column_sum)."""
+    out = torch.empty(M * N, dtype=torch.float32, device=dy2.device)
+    _wgrads.append((dy2, x2, out, int(dy2.shape[0]), int(M), int(N)))
+    return out.view(M, N)
+
+
+def _flush_wgrads():
+    global _wgrads
+    pend, _wgrads = _wgrads, []
+    L = _lib.lib()
+    arr = (_WgradJob * len(pend))()
+    for k, (dy, x, out, T, M, N) in enumerate(pend):
+        arr[k].dY, arr[k].X, arr[k].tokens, arr[k].out_features, arr[k].in_features = dy.data_ptr(), x.data_ptr(), T, M, N
+    _lib.check(L.sd_linear_wgrad_tn_multi_plan(C.cast(arr, C.c_void_p), len(pend)), 'sd_linear_wgrad_tn_multi_plan')
+    total = sum(arr[k].nsplit * pend[k][4] * pend[k][5] for k in range(len(pend)) if arr[k].nsplit > 1)
+    ws = torch.empty(max(total, 4), dtype=torch.float32, device=pend[0][0].device)      # every slab a multiple of 64 floats: 16-byte aligned
+    off = 0
+    for k, (dy, x, out, T, M, N) in enumerate(pend):
+        ns = arr[k].nsplit
+        if ns > 1:
+            part = ws[off:off + ns * M * N]
+            off += ns * M * N
+            arr[k].slabs = part.data_ptr()
+            _jobs.append((part, out, M * N, ns))
+        else:
+            arr[k].slabs = out.data_ptr()          # one split: the product IS the gradient
+    _lib.check(L.sd_linear_wgrad_tn_multi(C.cast(arr, C.c_void_p), len(pend), _stream_ptr()), 'sd_linear_wgrad_tn_multi')
+    # (the slab views in _jobs keep `ws` alive until the combine below is enqueued; the operands in `pend` until here)
 
 
 def reduce_now(partials, out, n, nslabs):
@@ -85,6 +134,8 @@ def join():
 def flush():
     global _jobs, _colsums
     join()
+    if _wgrads:
+        _flush_wgrads()
     if _colsums:
         pend, _colsums = _colsums, []
         for dt in {p[0].dtype for p in pend}:          # one batched partials launch per storage type
@@ -120,6 +171,7 @@ def scope():
         join()
         _jobs = None
         _colsums.clear()
+        _wgrads.clear()
 
 
 def column_sum(x2d, defer_ok=True):

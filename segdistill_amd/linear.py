@@ -244,6 +244,10 @@ def linear_weight_grads(x, dy2, w_shape, w_dtype, want_db, defer_ok, defer_bias_
         dw = (dyc.t() @ x2).to(w_dtype)
         db = deferred.column_sum(dyc, defer_bias_ok and w_dtype == torch.float32).to(w_dtype) if want_db else None
         return dw, db
+    if not direct and defer_ok and w_dtype == torch.float32 and deferred.wgrad_groupable(dyc, x2, M, N):
+        # round 5: not even the GEMM runs now -- the scope's ONE grouped launch computes every such gradient, its k-splits planned over all of them
+        dw = deferred.add_wgrad(dyc, x2, M, N)
+        return dw, (deferred.column_sum(dyc, defer_bias_ok) if want_db else None)
     gs = 0 if direct else L.sd_linear_wgrad_generic_slabs(_DT[x.dtype], T, M, N)
     if gs and defer_ok and deferred.enabled() and w_dtype == torch.float32:
         # the generic split-K plan (bf16 storage: most Linears of config 5) inside a deferred scope: its slab combine joins the batched

@@ -61,5 +61,8 @@ def test_slab_budget_of_config_5_stays_under_its_operand_bytes():
     assert len(lines) > 25 and slab < op
     slab0, op0 = slab_budget.budget(**slab_budget.PRESETS['cfg5'], ratio=0, out=lambda s: None)
     assert op0 == op and slab0 > 2 * op
+    # round 5: the grouped launch's joint plan (what the step runs): a fifth of the operand bytes (<= 300 MB)
+    slab_g, op_g = slab_budget.budget(**slab_budget.PRESETS['cfg5'], out=lambda s: None, grouped=True)
+    assert op_g == op and slab_g <= 300e6 and slab_g < 0.2 * op
     slab2, op2 = slab_budget.budget(**slab_budget.PRESETS['cfg2'], out=lambda s: None)
     assert slab2 > 0 and op2 > 0
