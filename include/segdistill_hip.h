@@ -672,25 +672,26 @@ int sd_linear_wgrad_partials(const void *dY, const void *X, int dtype, long toke
 int sd_linear_wgrad_tn_slabs(long tokens, int out_features, int in_features);
 int sd_linear_wgrad_tn(const float *dY, const float *X, float *slabs, size_t slabs_bytes, long tokens, int out_features, int in_features, int with_bias,
                        void *stream);
-/* MANY bf16 weight gradients in ONE launch, their k-splits planned together (csrc/wgrad_tn.hip, round 5): the weight gradients of a backward
- * (autograd's `grad_output.t().mm(input)` of every token-major Linear; same reference lines as above), deferred to its end.
- *   _supported(): bf16 storage, out % 8 == in % 8 == 0, tokens % 32 == 0, tokens >= 96; operands 16-byte aligned.
- *   _plan():  fills job.nsplit (>= 1) for ALL jobs of the coming call: ~1536 workgroups in total, dealt by tile-k-steps, within the
- *             "wgrad_slab_ratio" cap; SD_E_UNSUPPORTED if a job is not _supported (nothing is filled then).
- *   launch:   job.slabs = nsplit * out * in floats: slab z = the product over the z-th token range; the caller sums them (sd_multi_slab_reduce,
- *             fixed order: run-to-run identical).  nsplit == 1: `slabs` IS the gradient (point it at the destination, no combine).
- *             One launch per 32 jobs. */
+/* MANY weight gradients in ONE launch, their k-splits planned together (csrc/wgrad_tn.hip, round 5): the weight gradients of a backward
+ * (autograd's `grad_output.t().mm(input)` of every token-major Linear; same reference lines as above), deferred to its end.  dtype = the storage
+ * type of dY and X: SD_BF16 -> the LDS-DMA ring kernel; SD_F32 -> split-bf16 arithmetic (wgrad_tn_x3; one launch per tile width 128 / 64 / 32).
+ *   _supported(): out % 8 == in % 8 == 0; bf16: tokens % 32 == 0 and tokens >= 96; operands 16-byte aligned.
+ *   _plan():  fills job.nsplit (>= 1) for ALL jobs of the coming call: ~1536 (bf16) / ~2304 (fp32) workgroups in total, dealt by tile-k-steps;
+ *             bf16 within the "wgrad_slab_ratio" cap.  SD_E_UNSUPPORTED if a job is not _supported (nothing is filled then).
+ *   launch:   job.slabs = nsplit slabs of out * in floats (+ out floats when with_bias: the column sums of dY over the slab's tokens = the bias
+ *             gradient; fp32 only): slab z = the product over the z-th token range; the caller sums them (sd_multi_slab_reduce, fixed order:
+ *             run-to-run identical).  nsplit == 1: `slabs` IS the gradient (point it at the destination, no combine).  One launch per 32 jobs. */
 typedef struct sd_wgrad_job {
-    const void *dY, *X;         /* [tokens][out], [tokens][in] bf16 */
+    const void *dY, *X;         /* [tokens][out], [tokens][in] */
     float *slabs;
     long tokens;
     int out_features, in_features;
     int nsplit;                 /* written by _plan, read by the launch */
-    int reserved;
+    int with_bias;
 } sd_wgrad_job;
-int sd_linear_wgrad_tn_multi_supported(long tokens, int out_features, int in_features);
-int sd_linear_wgrad_tn_multi_plan(sd_wgrad_job *jobs, int njobs);
-int sd_linear_wgrad_tn_multi(const sd_wgrad_job *jobs, int njobs, void *stream);
+int sd_linear_wgrad_tn_multi_supported(int dtype, long tokens, int out_features, int in_features);
+int sd_linear_wgrad_tn_multi_plan(sd_wgrad_job *jobs, int njobs, int dtype);
+int sd_linear_wgrad_tn_multi(const sd_wgrad_job *jobs, int njobs, int dtype, void *stream);
 int sd_linear_wgrad_generic_slabs(int dtype, long tokens, int out_features, int in_features);
 int sd_linear_wgrad_generic_partials(const void *dY, const void *X, int dtype, long tokens, int out_features, int in_features, void *workspace,
                                      size_t workspace_bytes, void *stream);

@@ -63,9 +63,9 @@ SIGNATURES = {
     'sd_linear_tok_bf16_fwd': (_i, [_vp, _vp, _vp, _vp, C.c_long, _i, _i, _vp]),
     'sd_linear_tok_bf16_bwd_data': (_i, [_vp, _vp, _vp, C.c_long, _i, _i, _vp]),
     'sd_linear_bf16_fwd_supported': (_i, [C.c_long, _i, _i]),
-    'sd_linear_wgrad_tn_multi_supported': (_i, [C.c_long, _i, _i]),
-    'sd_linear_wgrad_tn_multi_plan': (_i, [_vp, _i]),
-    'sd_linear_wgrad_tn_multi': (_i, [_vp, _i, _vp]),
+    'sd_linear_wgrad_tn_multi_supported': (_i, [_i, C.c_long, _i, _i]),
+    'sd_linear_wgrad_tn_multi_plan': (_i, [_vp, _i, _i]),
+    'sd_linear_wgrad_tn_multi': (_i, [_vp, _i, _i, _vp]),
     'sd_linear_bf16_fwd': (_i, [_vp, _vp, _vp, _i, _vp, C.c_long, _i, _i, _vp]),
     'sd_cgd_kl_up_supported': (_i, [_i, _i, _i, _i]),
     'sd_cgd_kl_up_workspace_bytes': (_sz, [_i] * 7),

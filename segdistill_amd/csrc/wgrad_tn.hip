@@ -278,12 +278,13 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_ring(const bf16_t *__restri
 // all), a 131072-token one ~30.  The table travels by value in the kernel arguments (safe under graph capture).
 constexpr int kMultiMax = 32;
 struct WgradMultiTable {
-    const bf16_t *A[kMultiMax], *B[kMultiMax];
+    const void *A[kMultiMax], *B[kMultiMax];
     float *C[kMultiMax];
     long T[kMultiMax];
     int M[kMultiMax], N[kMultiMax], klen[kMultiMax], tiles_m[kMultiMax], tiles_n[kMultiMax], nsplit[kMultiMax];
     int blk_begin[kMultiMax + 1];       // multiples of 8
     int nblk[kMultiMax];                // real workgroups of the job (the slice is padded up to a multiple of 8)
+    int bias[kMultiMax];                // fp32 form: the slab is [M x N] followed by M column sums of dY
     int njobs;
 };
 
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_ring_multi(const WgradMulti
     const int j = lo;
     const long id = (long)blockIdx.x - t.blk_begin[j];
     if (id >= t.nblk[j]) return;        // padding of the slice
-    wgrad_ring_body<1>(t.A[j], t.B[j], t.C[j], t.M[j], t.N[j], t.T[j], t.klen[j], t.tiles_m[j], t.tiles_n[j], t.nsplit[j], (long)t.nblk[j], id);
+    wgrad_ring_body<1>((const bf16_t *)t.A[j], (const bf16_t *)t.B[j], t.C[j], t.M[j], t.N[j], t.T[j], t.klen[j], t.tiles_m[j], t.tiles_n[j], t.nsplit[j], (long)t.nblk[j], id);
 }
 
 // ---- fp32 storage: the same product in split-bf16 arithmetic ("bf16x3", fp32-grade: token_gemm.hip section 3.9 of DESIGN.md) ---------------
@@ -331,15 +332,15 @@ __device__ __forceinline__ void split8_planes(const f32x4 &v0, const f32x4 &v1, 
 // BIAS: the slab of split z is [M x N] followed by M column sums of dY over the split's tokens (the Linear's bias gradient: every dY value passes
 // through the staging registers of exactly one thread of the tn == 0 workgroup of its row tile, in fp32 -- the separate pass that re-read every dY for
 // the bias gradients was 98 us per config-2 step at full HBM speed).
-template <int BN_, int WM, int WN, bool BIAS>
-__global__ __launch_bounds__(256) void wgrad_tn_x3(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, long T,
-                                                    int klen, int tiles_m, int tiles_n, int nsplit) {
+// (BIAS is a compile-time constant in the single launches and a per-job flag in the grouped one; nblk / id as in wgrad_ring_body)
+template <int BN_, int WM, int WN>
+__device__ __forceinline__ void wgrad_x3_body(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, long T,
+                                              int klen, int tiles_m, int tiles_n, int nsplit, const bool BIAS, long nblk, long id) {
     constexpr int TM = TBM / (32 * WM), TN = BN_ / (32 * WN);
     constexpr int BCH = BN_ / 8;                                     // 8-float chunks per B row
     constexpr int NB = (32 * BCH + 255) / 256;                       // B chunks per thread (1 for BN_ <= 64, 2 for 128)
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "four waves");
     __shared__ __attribute__((aligned(16))) unsigned char lds[6 * kStageBytes];        // A planes h, m, l | B planes h, m, l
-    const long nblk = gridDim.x, id = blockIdx.x;
     const long qd = nblk / 8, rem = nblk % 8, xcd = id % 8;
     const long L = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + id / 8;
     const int tiles = tiles_m * tiles_n;
@@ -478,6 +479,28 @@ __global__ __launch_bounds__(256) void wgrad_tn_x3(const float *__restrict__ A, 
     }
 }
 
+template <int BN_, int WM, int WN, bool BIAS>
+__global__ __launch_bounds__(256) void wgrad_tn_x3(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, long T,
+                                                    int klen, int tiles_m, int tiles_n, int nsplit) {
+    wgrad_x3_body<BN_, WM, WN>(A, B, C, M, N, T, klen, tiles_m, tiles_n, nsplit, BIAS, (long)gridDim.x, (long)blockIdx.x);
+}
+
+// the fp32 weight gradients of a backward in one launch per tile width (the grouped form of wgrad_tn_bf16_ring_multi above; bias: per job)
+template <int BN_, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_tn_x3_multi(const WgradMultiTable t) {
+    int lo = 0, hi = t.njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= t.blk_begin[mid]) lo = mid;
+        else hi = mid - 1;
+    }
+    const int j = lo;
+    const long id = (long)blockIdx.x - t.blk_begin[j];
+    if (id >= t.nblk[j]) return;
+    wgrad_x3_body<BN_, WM, WN>((const float *)t.A[j], (const float *)t.B[j], t.C[j], t.M[j], t.N[j], t.T[j], t.klen[j], t.tiles_m[j], t.tiles_n[j],
+                               t.nsplit[j], t.bias[j] != 0, (long)t.nblk[j], id);
+}
+
 }  // namespace
 
 // ---- plan + launcher shared with align1x1.hip (the generic weight-gradient entry points) -------------------------------------------------
@@ -558,23 +581,32 @@ int wgrad_tn_launch(const void *dY, const void *X, float *slabs, long T, int M, 
     return (int)hipGetLastError();
 }
 
-// ---- the grouped launch: eligibility, the joint plan, the launch
-bool wgrad_tn_multi_ok(long T, int M, int N) { return M > 0 && N > 0 && M % 8 == 0 && N % 8 == 0 && T >= 3 * TBK && T % TBK == 0 && T <= 0x7fffffffL; }
+// ---- the grouped launch: eligibility, the joint plan, the launch (bf16: the ring kernel, 128 x 128 tiles; fp32: wgrad_tn_x3, 128 x {128, 64, 32})
+bool wgrad_tn_multi_ok(bool bf16, long T, int M, int N) {
+    if (M <= 0 || N <= 0 || M % 8 || N % 8 || T <= 0 || T > 0x7fffffffL) return false;
+    return bf16 ? (T >= 3 * TBK && T % TBK == 0) : true;
+}
+static int x3_bn(int N) { return N > 64 ? 128 : (N > 32 ? 64 : 32); }
 
-constexpr long kMultiTargetWgs = 1536;      // 6 per CU: three rounds of the two a CU holds (64 KB of LDS each)
+// workgroups per launch group: bf16 64 KB of LDS (two per CU, three rounds), fp32 48 KB (three per CU, three rounds)
+constexpr long kMultiTargetWgs = 1536, kMultiTargetWgsF32 = 2304;
 
-// k-splits of every job, planned together: work = tiles x k-steps; a workgroup should get total / kMultiTargetWgs k-steps (at least 8), every split
-// at least three k-steps (the ring's depth), and no job more slab bytes than wgrad_slab_cap allows
-void wgrad_tn_multi_plan(const long *T, const int *M, const int *N, int *nsplit, int njobs) {
+// k-splits of every job, planned together: work = tiles x k-steps; a workgroup should get total / target k-steps (at least 8); bf16: every split at
+// least three k-steps (the ring's depth) and no job more slab bytes than wgrad_slab_cap allows; fp32: at least two k-steps, no cap (see g_slab_ratio)
+void wgrad_tn_multi_plan(bool bf16, const long *T, const int *M, const int *N, int *nsplit, int njobs) {
     double total = 0.0;
-    for (int j = 0; j < njobs; ++j) total += (double)((M[j] + TBM - 1) / TBM) * ((N[j] + TBN - 1) / TBN) * (double)(T[j] / TBK);
-    double per_wg = total / (double)kMultiTargetWgs;
+    for (int j = 0; j < njobs; ++j) {
+        const int bn = bf16 ? TBN : x3_bn(N[j]);
+        total += (double)((M[j] + TBM - 1) / TBM) * ((N[j] + bn - 1) / bn) * (double)((T[j] + TBK - 1) / TBK);
+    }
+    double per_wg = total / (double)(bf16 ? kMultiTargetWgs : kMultiTargetWgsF32);
     if (per_wg < 8.0) per_wg = 8.0;
     for (int j = 0; j < njobs; ++j) {
-        const long ksteps = T[j] / TBK;
+        const long ksteps = (T[j] + TBK - 1) / TBK;
         long ns = (long)((double)ksteps / per_wg + 0.5);
-        if (ns > ksteps / 3) ns = ksteps / 3;
-        const long cap = wgrad_slab_cap(T[j], M[j], N[j], 2);
+        const long most = ksteps / (bf16 ? 3 : 2);
+        if (ns > most) ns = most;
+        const long cap = wgrad_slab_cap(T[j], M[j], N[j], bf16 ? 2 : 4);
         if (ns > cap) ns = cap;
         if (ns > 256) ns = 256;
         if (ns < 1) ns = 1;
@@ -583,14 +615,14 @@ void wgrad_tn_multi_plan(const long *T, const int *M, const int *N, int *nsplit,
     }
 }
 
-int wgrad_tn_multi_launch(const void *const *dY, const void *const *X, float *const *slabs, const long *T, const int *M, const int *N, const int *nsplit,
-                          int njobs, hipStream_t st) {
-    // longest workgroups first: the tail of the launch is then made of short ones
+template <typename F>
+static int multi_fill_and_launch(bool bf16, const int *sel, int nsel, const void *const *dY, const void *const *X, float *const *slabs, const long *T,
+                                 const int *M, const int *N, const int *nsplit, const int *bias, int bn, F launch) {
     int order[kMultiMax];
-    for (int base = 0; base < njobs; base += kMultiMax) {
-        const int n = njobs - base < kMultiMax ? njobs - base : kMultiMax;
-        for (int i = 0; i < n; ++i) order[i] = base + i;
-        for (int i = 1; i < n; ++i) {       // insertion sort by k-steps per split, descending
+    for (int base = 0; base < nsel; base += kMultiMax) {
+        const int n = nsel - base < kMultiMax ? nsel - base : kMultiMax;
+        for (int i = 0; i < n; ++i) order[i] = sel[base + i];
+        for (int i = 1; i < n; ++i) {       // longest workgroups first (k-steps per split, descending): the launch's tail is made of short ones
             const int v = order[i];
             const long kv = T[v] / nsplit[v];
             int q = i - 1;
@@ -602,21 +634,23 @@ int wgrad_tn_multi_launch(const void *const *dY, const void *const *X, float *co
         long blk = 0;
         for (int i = 0; i < n; ++i) {
             const int j = order[i];
-            if (!wgrad_tn_multi_ok(T[j], M[j], N[j]) || nsplit[j] < 1) return SD_E_UNSUPPORTED;
-            const long ksteps = T[j] / TBK;
+            if (!wgrad_tn_multi_ok(bf16, T[j], M[j], N[j]) || nsplit[j] < 1) return SD_E_UNSUPPORTED;
+            const long ksteps = (T[j] + TBK - 1) / TBK;
             const long kl = ((ksteps + nsplit[j] - 1) / nsplit[j]) * TBK;
-            if ((T[j] + kl - 1) / kl != nsplit[j] || kl < 3 * TBK) return SD_E_SHAPE;       // not a plan of wgrad_tn_multi_plan
+            if ((T[j] + kl - 1) / kl != nsplit[j] || (bf16 && kl < 3 * TBK)) return SD_E_SHAPE;       // not a plan of wgrad_tn_multi_plan
             if ((reinterpret_cast<uintptr_t>(dY[j]) | reinterpret_cast<uintptr_t>(X[j]) | reinterpret_cast<uintptr_t>(slabs[j])) & 15) return SD_E_ALIGN;
-            t.A[i] = (const bf16_t *)dY[j];
-            t.B[i] = (const bf16_t *)X[j];
+            if (bf16 && bias[j]) return SD_E_UNSUPPORTED;
+            t.A[i] = dY[j];
+            t.B[i] = X[j];
             t.C[i] = slabs[j];
             t.T[i] = T[j];
             t.M[i] = M[j];
             t.N[i] = N[j];
             t.klen[i] = (int)kl;
             t.tiles_m[i] = (M[j] + TBM - 1) / TBM;
-            t.tiles_n[i] = (N[j] + TBN - 1) / TBN;
+            t.tiles_n[i] = (N[j] + bn - 1) / bn;
             t.nsplit[i] = nsplit[j];
+            t.bias[i] = bias[j];
             const long nb = (long)t.tiles_m[i] * t.tiles_n[i] * nsplit[j];
             if (nb > 0x3fffffffL) return SD_E_SHAPE;
             t.nblk[i] = (int)nb;
@@ -626,11 +660,37 @@ int wgrad_tn_multi_launch(const void *const *dY, const void *const *X, float *co
         }
         t.blk_begin[n] = (int)blk;
         t.njobs = n;
-        hipLaunchKernelGGL(wgrad_tn_bf16_ring_multi, dim3((unsigned)blk), dim3(256), 0, st, t);
+        launch(t, (unsigned)blk);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
     }
     return SD_OK;
+}
+
+int wgrad_tn_multi_launch(bool bf16, const void *const *dY, const void *const *X, float *const *slabs, const long *T, const int *M, const int *N,
+                          const int *nsplit, const int *bias, int njobs, hipStream_t st) {
+    int *sel = new int[njobs];
+    int rc = SD_OK;
+    if (bf16) {
+        for (int j = 0; j < njobs; ++j) sel[j] = j;
+        rc = multi_fill_and_launch(true, sel, njobs, dY, X, slabs, T, M, N, nsplit, bias, TBN, [&](const WgradMultiTable &t, unsigned blk) {
+            hipLaunchKernelGGL(wgrad_tn_bf16_ring_multi, dim3(blk), dim3(256), 0, st, t);
+        });
+    } else {
+        for (int bn = 128; bn >= 32 && rc == SD_OK; bn >>= 1) {        // one launch group per tile width
+            int n = 0;
+            for (int j = 0; j < njobs; ++j)
+                if (x3_bn(N[j]) == bn) sel[n++] = j;
+            if (!n) continue;
+            rc = multi_fill_and_launch(false, sel, n, dY, X, slabs, T, M, N, nsplit, bias, bn, [&](const WgradMultiTable &t, unsigned blk) {
+                if (bn == 128) hipLaunchKernelGGL((wgrad_tn_x3_multi<128, 2, 2>), dim3(blk), dim3(256), 0, st, t);
+                else if (bn == 64) hipLaunchKernelGGL((wgrad_tn_x3_multi<64, 2, 2>), dim3(blk), dim3(256), 0, st, t);
+                else hipLaunchKernelGGL((wgrad_tn_x3_multi<32, 4, 1>), dim3(blk), dim3(256), 0, st, t);
+            });
+        }
+    }
+    delete[] sel;
+    return rc;
 }
 
 // fp32 storage: which products take wgrad_tn_x3, and with how many k-splits (0: not this kernel's)
@@ -687,20 +747,25 @@ int sd_linear_wgrad_tn(const float *dY, const float *X, float *slabs, size_t sla
 }
 
 
-int sd_linear_wgrad_tn_multi_supported(long tokens, int out_features, int in_features) { return sd::wgrad_tn_multi_ok(tokens, out_features, in_features) ? 1 : 0; }
+int sd_linear_wgrad_tn_multi_supported(int dtype, long tokens, int out_features, int in_features) {
+    if (dtype != SD_F32 && dtype != SD_BF16) return 0;
+    return sd::wgrad_tn_multi_ok(dtype == SD_BF16, tokens, out_features, in_features) ? 1 : 0;
+}
 
-int sd_linear_wgrad_tn_multi_plan(sd_wgrad_job *jobs, int njobs) {
+int sd_linear_wgrad_tn_multi_plan(sd_wgrad_job *jobs, int njobs, int dtype) {
     if (!jobs) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
     if (njobs <= 0 || njobs > 4096) return SD_E_SHAPE;
+    const bool bf16 = dtype == SD_BF16;
     long *T = new long[njobs];
     int *M = new int[njobs], *N = new int[njobs], *ns = new int[njobs];
     int rc = SD_OK;
     for (int j = 0; j < njobs; ++j) {
         T[j] = jobs[j].tokens, M[j] = jobs[j].out_features, N[j] = jobs[j].in_features;
-        if (!sd::wgrad_tn_multi_ok(T[j], M[j], N[j])) rc = SD_E_UNSUPPORTED;
+        if (!sd::wgrad_tn_multi_ok(bf16, T[j], M[j], N[j])) rc = SD_E_UNSUPPORTED;
     }
     if (rc == SD_OK) {
-        sd::wgrad_tn_multi_plan(T, M, N, ns, njobs);
+        sd::wgrad_tn_multi_plan(bf16, T, M, N, ns, njobs);
         for (int j = 0; j < njobs; ++j) jobs[j].nsplit = ns[j];
     }
     delete[] T;
@@ -710,20 +775,21 @@ int sd_linear_wgrad_tn_multi_plan(sd_wgrad_job *jobs, int njobs) {
     return rc;
 }
 
-int sd_linear_wgrad_tn_multi(const sd_wgrad_job *jobs, int njobs, void *stream) {
+int sd_linear_wgrad_tn_multi(const sd_wgrad_job *jobs, int njobs, int dtype, void *stream) {
     if (!jobs) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
     if (njobs <= 0 || njobs > 4096) return SD_E_SHAPE;
     const void **dY = new const void *[njobs], **X = new const void *[njobs];
     float **C = new float *[njobs];
     long *T = new long[njobs];
-    int *M = new int[njobs], *N = new int[njobs], *ns = new int[njobs];
+    int *M = new int[njobs], *N = new int[njobs], *ns = new int[njobs], *bias = new int[njobs];
     int rc = SD_OK;
     for (int j = 0; j < njobs; ++j) {
         if (!jobs[j].dY || !jobs[j].X || !jobs[j].slabs) rc = SD_E_NULL;
         dY[j] = jobs[j].dY, X[j] = jobs[j].X, C[j] = jobs[j].slabs;
-        T[j] = jobs[j].tokens, M[j] = jobs[j].out_features, N[j] = jobs[j].in_features, ns[j] = jobs[j].nsplit;
+        T[j] = jobs[j].tokens, M[j] = jobs[j].out_features, N[j] = jobs[j].in_features, ns[j] = jobs[j].nsplit, bias[j] = jobs[j].with_bias;
     }
-    if (rc == SD_OK) rc = sd::wgrad_tn_multi_launch(dY, X, C, T, M, N, ns, njobs, static_cast<hipStream_t>(stream));
+    if (rc == SD_OK) rc = sd::wgrad_tn_multi_launch(dtype == SD_BF16, dY, X, C, T, M, N, ns, bias, njobs, static_cast<hipStream_t>(stream));
     delete[] dY;
     delete[] X;
     delete[] C;
@@ -731,6 +797,7 @@ int sd_linear_wgrad_tn_multi(const sd_wgrad_job *jobs, int njobs, void *stream) 
     delete[] M;
     delete[] N;
     delete[] ns;
+    delete[] bias;
     return rc;
 }
 

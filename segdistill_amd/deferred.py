@@ -30,7 +30,7 @@ class _ColsumJob(C.Structure):
 
 class _WgradJob(C.Structure):
     _fields_ = [('dY', C.c_void_p), ('X', C.c_void_p), ('slabs', C.c_void_p), ('tokens', C.c_long), ('out_features', C.c_int), ('in_features', C.c_int),
-                ('nsplit', C.c_int), ('reserved', C.c_int)]
+                ('nsplit', C.c_int), ('with_bias', C.c_int)]
 
 
 class _Job(C.Structure):
@@ -47,47 +47,56 @@ def add(partials, out, n, nslabs):
     _jobs.append((partials, out, int(n), int(nslabs)))
 
 
-# SEGDISTILL_WGRAD_GROUPED=0 (A/B): every bf16 weight gradient as its own launch inside the backward, planned on its own (rounds 2-4)
+# SEGDISTILL_WGRAD_GROUPED=0 (A/B): every weight gradient as its own launch inside the backward, planned on its own (rounds 2-4)
 _WGRAD_GROUPED = os.environ.get('SEGDISTILL_WGRAD_GROUPED', '1') == '1'
 
 
 def wgrad_groupable(dy2, x2, M, N):
-    """May this bf16 weight gradient dY^T . X join the scope's ONE grouped launch (csrc/wgrad_tn.hip, wgrad_tn_bf16_ring_multi)?"""
-    return (_jobs is not None and _WGRAD_GROUPED and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and dy2.is_contiguous()
+    """May this weight gradient dY^T . X join the scope's grouped launch (csrc/wgrad_tn.hip: wgrad_tn_bf16_ring_multi / wgrad_tn_x3_multi)?"""
+    return (_jobs is not None and _WGRAD_GROUPED and dy2.dtype == x2.dtype and dy2.dtype in _DT and dy2.is_contiguous()
             and x2.is_contiguous() and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0
-            and bool(_lib.lib().sd_linear_wgrad_tn_multi_supported(dy2.shape[0], M, N)))
+            and bool(_lib.lib().sd_linear_wgrad_tn_multi_supported(_DT[dy2.dtype], dy2.shape[0], M, N)))
 
 
-def add_wgrad(dy2, x2, M, N):
-    """dW [M, N] fp32 = dy2 [T, M]^T . x2 [T, N] (bf16), computed when the enclosing scope ends by the grouped launch -- its k-splits planned over all
-    the scope's weight gradients together -- and the scope's slab combine.  Returns a VIEW of the result buffer (see column_sum)."""
-    out = torch.empty(M * N, dtype=torch.float32, device=dy2.device)
-    _wgrads.append((dy2, x2, out, int(dy2.shape[0]), int(M), int(N)))
-    return out.view(M, N)
+def add_wgrad(dy2, x2, M, N, with_bias=False):
+    """dW [M, N] fp32 = dy2 [T, M]^T . x2 [T, N], computed when the enclosing scope ends by the grouped launch -- its k-splits planned over all the
+    scope's weight gradients together -- and the scope's slab combine.  with_bias (fp32 storage only): the column sums of dy2 (the Linear's bias
+    gradient) ride along in the slabs.  Returns VIEWS of the result buffer (see column_sum): (dW, db or None)."""
+    with_bias = bool(with_bias) and dy2.dtype == torch.float32
+    out = torch.empty(M * N + (M if with_bias else 0), dtype=torch.float32, device=dy2.device)
+    _wgrads.append((dy2, x2, out, int(dy2.shape[0]), int(M), int(N), with_bias))
+    return out[:M * N].view(M, N), (out[M * N:] if with_bias else None)
 
 
 def _flush_wgrads():
     global _wgrads
-    pend, _wgrads = _wgrads, []
+    pend_all, _wgrads = _wgrads, []
     L = _lib.lib()
-    arr = (_WgradJob * len(pend))()
-    for k, (dy, x, out, T, M, N) in enumerate(pend):
-        arr[k].dY, arr[k].X, arr[k].tokens, arr[k].out_features, arr[k].in_features = dy.data_ptr(), x.data_ptr(), T, M, N
-    _lib.check(L.sd_linear_wgrad_tn_multi_plan(C.cast(arr, C.c_void_p), len(pend)), 'sd_linear_wgrad_tn_multi_plan')
-    total = sum(arr[k].nsplit * pend[k][4] * pend[k][5] for k in range(len(pend)) if arr[k].nsplit > 1)
-    ws = torch.empty(max(total, 4), dtype=torch.float32, device=pend[0][0].device)      # every slab a multiple of 64 floats: 16-byte aligned
-    off = 0
-    for k, (dy, x, out, T, M, N) in enumerate(pend):
-        ns = arr[k].nsplit
-        if ns > 1:
-            part = ws[off:off + ns * M * N]
-            off += ns * M * N
-            arr[k].slabs = part.data_ptr()
-            _jobs.append((part, out, M * N, ns))
-        else:
-            arr[k].slabs = out.data_ptr()          # one split: the product IS the gradient
-    _lib.check(L.sd_linear_wgrad_tn_multi(C.cast(arr, C.c_void_p), len(pend), _stream_ptr()), 'sd_linear_wgrad_tn_multi')
-    # (the slab views in _jobs keep `ws` alive until the combine below is enqueued; the operands in `pend` until here)
+    for dt in (torch.bfloat16, torch.float32):      # one plan + one launch group per storage type
+        pend = [p for p in pend_all if p[0].dtype == dt]
+        if not pend:
+            continue
+        arr = (_WgradJob * len(pend))()
+        for k, (dy, x, out, T, M, N, wb) in enumerate(pend):
+            arr[k].dY, arr[k].X, arr[k].tokens, arr[k].out_features, arr[k].in_features, arr[k].with_bias = dy.data_ptr(), x.data_ptr(), T, M, N, int(wb)
+        _lib.check(L.sd_linear_wgrad_tn_multi_plan(C.cast(arr, C.c_void_p), len(pend), _DT[dt]), 'sd_linear_wgrad_tn_multi_plan')
+        # every slab is rounded up to a multiple of 4 floats: 16-byte aligned slab origins whatever M is
+        sizes = [((M * N + (M if wb else 0)) + 3) // 4 * 4 for (_, _, _, _, M, N, wb) in pend]
+        total = sum(arr[k].nsplit * sizes[k] for k in range(len(pend)) if arr[k].nsplit > 1)
+        ws = torch.empty(max(total, 4), dtype=torch.float32, device=pend[0][0].device)
+        off = 0
+        for k, (dy, x, out, T, M, N, wb) in enumerate(pend):
+            ns, n = arr[k].nsplit, M * N + (M if wb else 0)
+            if ns > 1:
+                assert n == sizes[k], 'slab size must be a multiple of 4 floats (out % 8 == 0)'
+                part = ws[off:off + ns * n]
+                off += ns * n
+                arr[k].slabs = part.data_ptr()
+                _jobs.append((part, out, n, ns))
+            else:
+                arr[k].slabs = out.data_ptr()          # one split: the product IS the gradient
+        _lib.check(L.sd_linear_wgrad_tn_multi(C.cast(arr, C.c_void_p), len(pend), _DT[dt], _stream_ptr()), 'sd_linear_wgrad_tn_multi')
+        # (the slab views in _jobs keep `ws` alive until the combine is enqueued; the operands in `pend_all` until here)
 
 
 def reduce_now(partials, out, n, nslabs):

@@ -140,6 +140,8 @@ _BF16_WGRAD_LIB = os.environ.get('SEGDISTILL_BF16_WGRAD_LIB', '0') == '1'
 # in their slabs.  Config 2, same box: 793.2 - 795.5 imgs/s with it, 787.0 / 787.1 without (profiles/r04_ab_cfg2_tn_fused_bias.txt)
 _TN_FUSED_BIAS = os.environ.get('SEGDISTILL_TN_FUSED_BIAS', '1') == '1'
 _SPLITK_WGRAD = os.environ.get('SEGDISTILL_SPLITK_WGRAD', '1') == '1'      # A/B: 0 = the library's dY^T @ X for the non-tall-skinny weight gradients
+# A/B: 0 = the fp32 weight gradients launched one by one inside the backward (rounds 2-4) instead of the scope's grouped launches (deferred.add_wgrad)
+_FP32_WGRAD_GROUPED = os.environ.get('SEGDISTILL_FP32_WGRAD_GROUPED', '1') == '1'
 
 
 def lowp_copy(t, dt):
@@ -180,6 +182,11 @@ def linear_weight_grads(x, dy2, w_shape, w_dtype, want_db, defer_ok, defer_bias_
     dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
     T, M, N = x2.shape[0], w_shape[0], w_shape[1]
     L = _lib.lib()
+    if (_SPLIT_BF16 and _FP32_WGRAD_GROUPED and x.dtype == torch.float32 and w_dtype == torch.float32 and defer_ok and (defer_bias_ok or not want_db)
+            and deferred.wgrad_groupable(dyc, x2, M, N)):
+        # round 5: every fp32 weight gradient of the backward (the transposed-read split-bf16 ones, the tall-skinny exact-f32 ones, the split-K
+        # and library ones of the few-token stages) joins the scope's grouped launches (one per tile width), bias sums riding along in the slabs
+        return deferred.add_wgrad(dyc, x2, M, N, with_bias=want_db)
     ns_tn = 0
     if (_SPLIT_BF16 and x.dtype == torch.float32 and w_dtype == torch.float32 and dyc.data_ptr() % 16 == 0
             and x2.data_ptr() % 16 == 0):
@@ -244,9 +251,9 @@ def linear_weight_grads(x, dy2, w_shape, w_dtype, want_db, defer_ok, defer_bias_
         dw = (dyc.t() @ x2).to(w_dtype)
         db = deferred.column_sum(dyc, defer_bias_ok and w_dtype == torch.float32).to(w_dtype) if want_db else None
         return dw, db
-    if not direct and defer_ok and w_dtype == torch.float32 and deferred.wgrad_groupable(dyc, x2, M, N):
+    if not direct and defer_ok and w_dtype == torch.float32 and x.dtype == torch.bfloat16 and deferred.wgrad_groupable(dyc, x2, M, N):
         # round 5: not even the GEMM runs now -- the scope's ONE grouped launch computes every such gradient, its k-splits planned over all of them
-        dw = deferred.add_wgrad(dyc, x2, M, N)
+        dw, _ = deferred.add_wgrad(dyc, x2, M, N)
         return dw, (deferred.column_sum(dyc, defer_bias_ok) if want_db else None)
     gs = 0 if direct else L.sd_linear_wgrad_generic_slabs(_DT[x.dtype], T, M, N)
     if gs and defer_ok and deferred.enabled() and w_dtype == torch.float32:

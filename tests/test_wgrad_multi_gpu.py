@@ -79,10 +79,73 @@ def test_joint_plan_cuts_the_slab_bytes():
     arr = (deferred._WgradJob * len(SHAPES))()
     for k, (T, M, N) in enumerate(SHAPES):
         arr[k].tokens, arr[k].out_features, arr[k].in_features = T, M, N
-    assert L.sd_linear_wgrad_tn_multi_plan(C.cast(arr, C.c_void_p), len(SHAPES)) == 0
+    assert L.sd_linear_wgrad_tn_multi_plan(C.cast(arr, C.c_void_p), len(SHAPES), 1) == 0
     joint = sum(arr[k].nsplit * M * N * 4 for k, (T, M, N) in enumerate(SHAPES) if arr[k].nsplit > 1)
     single = sum(max(L.sd_linear_wgrad_generic_slabs(1, T, M, N), 1) * M * N * 4 for T, M, N in SHAPES)
     wgs = sum(arr[k].nsplit * -(-M // 128) * -(-N // 128) for k, (T, M, N) in enumerate(SHAPES))
     assert joint < 0.5 * single and 512 <= wgs <= 4096
     assert all(arr[k].nsplit >= 1 for k in range(len(SHAPES)))
     assert all(arr[k].nsplit == 1 for k, (T, M, N) in enumerate(SHAPES) if T <= 2048 and M * N >= 512 * 512)
+
+
+# fp32 storage: the B0 student's Linears of BASELINE config 2 (tokens, out, in), incl. out < 128 (half-empty tile rows), the three tile widths,
+# few-token stages, a ragged token count and a bias-free product
+SHAPES_F32 = [(131072, 32, 32), (131072, 128, 32), (131072, 32, 128), (2048, 64, 32), (32768, 64, 64), (32768, 256, 64), (32768, 64, 256),
+              (8192, 160, 160), (8192, 640, 160), (8192, 160, 640), (2048, 320, 160), (2048, 256, 256), (2048, 1024, 256), (2048, 256, 1024),
+              (2048, 512, 256), (131072, 256, 32), (32768, 256, 64), (8192, 256, 160), (2048, 256, 256), (131072, 256, 256), (9001, 136, 40)]
+
+
+def _rel_l2(a, r):
+    return float(((a.double() - r) ** 2).sum().sqrt() / (r ** 2).sum().sqrt().clamp_min(1e-300))
+
+
+def test_fp32_grouped_launches_match_fp64_with_the_bias_sums_riding_along():
+    """wgrad_tn_x3_multi: one launch per tile width for all fp32 weight gradients of a scope, in split-bf16 arithmetic (fp32-grade: held to the bar of
+    tests/test_align_gpu.py::test_linear_wgrad_tn_split_bf16), bias gradients as M extra floats per slab, run-to-run identical."""
+    from segdistill_amd import deferred, linear
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(11)
+    ops = [(torch.randn(T, M, generator=g).to(dev), torch.randn(T, N, generator=g).to(dev)) for T, M, N in SHAPES_F32]
+
+    def run():
+        res = []
+        with deferred.scope():
+            for k, ((dy, x), (T, M, N)) in enumerate(zip(ops, SHAPES_F32)):
+                assert deferred.wgrad_groupable(dy, x, M, N)
+                res.append(linear.linear_weight_grads(x, dy, (M, N), torch.float32, k % 5 != 4, True, True))
+        torch.cuda.synchronize()
+        return res
+    a, b = run(), run()
+    for k, ((dy, x), (T, M, N), (dw, db), (dw2, db2)) in enumerate(zip(ops, SHAPES_F32, a, b)):
+        ref = dy.double().t() @ x.double()
+        assert dw.shape == (M, N) and _rel_l2(dw, ref) < 2e-5, (T, M, N, _rel_l2(dw, ref))
+        assert torch.equal(dw, dw2)
+        if k % 5 != 4:
+            assert db.shape == (M,) and _rel_l2(db, dy.double().sum(0)) < 2e-5 and torch.equal(db, db2)
+        else:
+            assert db is None
+
+
+def test_fp32_student_step_is_the_same_grouped_and_one_by_one(monkeypatch):
+    """A small fp32 MiT block stack, forward + backward inside a deferred scope: parameter gradients with the grouped launches (default) against
+    the one-launch-per-Linear path of rounds 2-4 -- the same values up to the k-split boundaries' summation order."""
+    from segdistill_amd import deferred, linear
+    from segdistill_amd.backbones.mit import MixVisionTransformer
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    net = MixVisionTransformer(embed_dims=(32, 64, 160, 256), num_heads=(1, 2, 5, 8), depths=(1, 1, 1, 1), sr_ratios=(8, 4, 2, 1), drop_path_rate=0.0).to(dev)
+    img = torch.randn(2, 3, 256, 256, device=dev)
+
+    def grads():
+        net.zero_grad(set_to_none=True)
+        with deferred.scope():
+            sum(f.square().mean() for f in net(img)).backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    ga = grads()
+    monkeypatch.setattr(linear, '_FP32_WGRAD_GROUPED', False)
+    gb = grads()
+    assert ga.keys() == gb.keys() and len(ga) > 40
+    for n in ga:
+        scale = float(gb[n].abs().max()) + 1e-12
+        assert float((ga[n] - gb[n]).abs().max()) <= 2e-4 * scale, n

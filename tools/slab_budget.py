@@ -54,12 +54,12 @@ def budget(dims, bf16, align, embed, batch=8, size=512, depths=(2, 2, 2, 2), sr=
             import ctypes as C
             from segdistill_amd import deferred
             idx = [k for k, (s, name, T, M, N, mult) in enumerate(rows)
-                   if not L.sd_linear_wgrad_fuses_bias_dtype(1, T, M, N) and L.sd_linear_wgrad_tn_multi_supported(T, M, N)]
+                   if not L.sd_linear_wgrad_fuses_bias_dtype(1, T, M, N) and L.sd_linear_wgrad_tn_multi_supported(1, T, M, N)]
             jobs = [k for k in idx for _ in range(rows[k][5])]
             arr = (deferred._WgradJob * len(jobs))()
             for q, k in enumerate(jobs):
                 arr[q].tokens, arr[q].out_features, arr[q].in_features = rows[k][2], rows[k][3], rows[k][4]
-            _lib.check(L.sd_linear_wgrad_tn_multi_plan(C.cast(arr, C.c_void_p), len(jobs)), 'sd_linear_wgrad_tn_multi_plan')
+            _lib.check(L.sd_linear_wgrad_tn_multi_plan(C.cast(arr, C.c_void_p), len(jobs), 1), 'sd_linear_wgrad_tn_multi_plan')
             joint = {k: arr[q].nsplit for q, k in enumerate(jobs)}
         if True:
             for k, (s, name, T, M, N, mult) in enumerate(rows):
