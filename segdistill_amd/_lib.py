@@ -191,6 +191,8 @@ def lib():
         h.sd_set_tunable(b'align_split_bf16', 0)
     if os.environ.get('SEGDISTILL_WGRAD_SLAB_RATIO'):   # A/B switch: slab bytes of the bf16 split-K weight gradients as a percentage of their operand bytes (0 = no cap)
         h.sd_set_tunable(b'wgrad_slab_ratio', int(os.environ['SEGDISTILL_WGRAD_SLAB_RATIO']))
+    if os.environ.get('SEGDISTILL_WGRAD_MULTI_WGS'):       # A/B: workgroups per grouped weight-gradient launch
+        h.sd_set_tunable(b'wgrad_multi_wgs', int(os.environ['SEGDISTILL_WGRAD_MULTI_WGS']))
     return h
 
 

@@ -510,6 +510,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_x3_multi(const WgradMultiTable t
 // fp32 storage (es == 4) is NOT capped: config 2, same box, no cap 781.6 / 784.5 imgs/s, 100 % 783.1, 60 % 780.7, 40 % 771.9, 20 % 744.6 -- its
 // split-bf16 / f32-MFMA weight-gradient kernels need the parallelism more than they pay for the slabs.
 int g_slab_ratio = 40;
+int g_multi_wgs = 0;        // tunable "wgrad_multi_wgs" (A/B): workgroups per grouped launch, 0 = kMultiTargetWgs / kMultiTargetWgsF32 below
 long wgrad_slab_cap(long T, int M, int N, int es) {
     if (es != 2 || g_slab_ratio <= 0) return 1L << 40;
     const long cap = (long)((double)g_slab_ratio * 0.01 * (double)T * (M + N) * 2.0 / ((double)M * N * 4.0));
@@ -557,6 +558,12 @@ int wgrad_tn_tunable(const char *key, int set, int v) {
         g_slab_ratio = v;
         return SD_OK;
     }
+    if (!strcmp(key, "wgrad_multi_wgs")) {
+        if (!set) return g_multi_wgs;
+        if (v < 0 || v > 65536) return SD_E_SHAPE;
+        g_multi_wgs = v;
+        return SD_OK;
+    }
     if (strcmp(key, "wgrad_tn_ring")) return SD_E_UNSUPPORTED;
     if (!set) return g_wgrad_ring;
     if (v < 0 || v > 2) return SD_E_SHAPE;
@@ -599,7 +606,7 @@ void wgrad_tn_multi_plan(bool bf16, const long *T, const int *M, const int *N, i
         const int bn = bf16 ? TBN : x3_bn(N[j]);
         total += (double)((M[j] + TBM - 1) / TBM) * ((N[j] + bn - 1) / bn) * (double)((T[j] + TBK - 1) / TBK);
     }
-    double per_wg = total / (double)(bf16 ? kMultiTargetWgs : kMultiTargetWgsF32);
+    double per_wg = total / (double)(g_multi_wgs > 0 ? (long)g_multi_wgs : (bf16 ? kMultiTargetWgs : kMultiTargetWgsF32));
     if (per_wg < 8.0) per_wg = 8.0;
     for (int j = 0; j < njobs; ++j) {
         const long ksteps = (T[j] + TBK - 1) / TBK;

@@ -94,9 +94,14 @@ def test_graph_replay_matches_eager(mode):
         assert ref.distillation_loss.criteria[0].alpha == pytest.approx(gra.distillation_loss.criteria[0].alpha)
         perms.append(pe)
     assert perms[2] is not None                 # iteration 3 drew a permutation
-    # after 7 optimizer steps the two students still agree closely
-    num = sum(float((a - b).pow(2).sum()) for a, b in zip(ref.student.parameters(), gra.student.parameters()))
-    den = sum(float(a.pow(2).sum()) for a in ref.student.parameters())
+    # after 7 optimizer steps the two students still agree closely.  Left out: parameters whose gradient is mathematically ZERO -- a bias in front
+    # of a normalisation (the head's linear_c*.proj.bias before linear_fuse's BatchNorm, and backbone.norm4.bias feeding only linear_c4): what
+    # arrives there is rounding noise (|g| ~ 1e-9 next to 1e-3 for the weights), AdamW normalises it to full-size steps of noise-determined sign,
+    # and the hybrid mode's graphed backbone sums its weight gradients in another order than the eager step's grouped launches (round 5)
+    pairs = [(a, b) for a, b in zip(ref.student.parameters(), gra.student.parameters()) if a.grad is None or float(a.grad.abs().max()) > 1e-7]
+    assert len(pairs) >= len(list(ref.student.parameters())) - 8
+    num = sum(float((a - b).pow(2).sum()) for a, b in pairs)
+    den = sum(float(a.pow(2).sum()) for a, _ in pairs)
     assert (num / den) ** 0.5 < 3e-4
 
 
