@@ -676,7 +676,7 @@ int sd_linear_wgrad_tn(const float *dY, const float *X, float *slabs, size_t sla
  * (autograd's `grad_output.t().mm(input)` of every token-major Linear; same reference lines as above), deferred to its end.  dtype = the storage
  * type of dY and X: SD_BF16 -> the LDS-DMA ring kernel; SD_F32 -> split-bf16 arithmetic (wgrad_tn_x3; one launch per tile width 128 / 64 / 32).
  *   _supported(): out % 8 == in % 8 == 0; bf16: tokens % 32 == 0 and tokens >= 96; operands 16-byte aligned.
- *   _plan():  fills job.nsplit (>= 1) for ALL jobs of the coming call: ~1536 (bf16) / ~2304 (fp32) workgroups in total, dealt by tile-k-steps;
+ *   _plan():  fills job.nsplit (>= 1) for ALL jobs of the coming call: ~1536 (bf16) / ~3072 (fp32) workgroups in total, dealt by tile-k-steps;
  *             bf16 within the "wgrad_slab_ratio" cap.  SD_E_UNSUPPORTED if a job is not _supported (nothing is filled then).
  *   launch:   job.slabs = nsplit slabs of out * in floats (+ out floats when with_bias: the column sums of dY over the slab's tokens = the bias
  *             gradient; fp32 only): slab z = the product over the z-th token range; the caller sums them (sd_multi_slab_reduce, fixed order:

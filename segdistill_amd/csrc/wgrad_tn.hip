@@ -595,8 +595,8 @@ bool wgrad_tn_multi_ok(bool bf16, long T, int M, int N) {
 }
 static int x3_bn(int N) { return N > 64 ? 128 : (N > 32 ? 64 : 32); }
 
-// workgroups per launch group: bf16 64 KB of LDS (two per CU, three rounds), fp32 48 KB (three per CU, three rounds)
-constexpr long kMultiTargetWgs = 1536, kMultiTargetWgsF32 = 2304;
+// workgroups per launch group: bf16 64 KB of LDS (two per CU, three rounds), fp32 48 KB (three per CU, four rounds: 1024 / 1536 / 2304 / 3072 / 4608 measured at 827.6 / 836.0 / 833.5 / 842.1 / 837.9 imgs/s on config 2, same box)
+constexpr long kMultiTargetWgs = 1536, kMultiTargetWgsF32 = 3072;
 
 // k-splits of every job, planned together: work = tiles x k-steps; a workgroup should get total / target k-steps (at least 8); bf16: every split at
 // least three k-steps (the ring's depth) and no job more slab bytes than wgrad_slab_cap allows; fp32: at least two k-steps, no cap (see g_slab_ratio)
