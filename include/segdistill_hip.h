@@ -454,6 +454,16 @@ int sd_linear_patch_fwd(const float *X, const float *W, const float *bias /* or 
  */
 size_t sd_dwconv3x3_workspace_bytes(int dtype, int B, int H, int W, int C);
 int sd_dwconv3x3_wgrad_slabs(int dtype, int B, int H, int W, int C);
+/* the partials of MANY depth-wise convolutions in ONE launch per 24 jobs (round 5: the filter gradients of a backward, deferred to its end):
+ * job.partials receives what sd_dwconv3x3_bwd_weight(dw = NULL) leaves in its workspace -- [sd_dwconv3x3_wgrad_slabs()][9*C + C] floats
+ * (partials_bytes >= that) -- for sd_multi_slab_reduce. */
+typedef struct sd_dw_wgrad_job {
+    const void *x, *dy;         /* [B, H*W, C] tokens of the conv's input / of the gradient of its output */
+    float *partials;
+    size_t partials_bytes;
+    int B, H, W, C;
+} sd_dw_wgrad_job;
+int sd_dwconv3x3_wgrad_multi(const sd_dw_wgrad_job *jobs, int njobs, int dtype, void *stream);
 
 int sd_dwconv3x3_fwd(const void *x, const float *w, const float *bias /* or NULL */, void *y,
                      int dtype, int B, int H, int W, int C, void *stream);

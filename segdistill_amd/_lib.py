@@ -112,6 +112,7 @@ SIGNATURES = {
     'sd_linear_wgrad': (_i, [_vp, _vp, _vp, _vp, _i, C.c_long, _i, _i, _vp, _sz, _vp]),
     'sd_dwconv3x3_workspace_bytes': (_sz, [_i] * 5),
     'sd_dwconv3x3_wgrad_slabs': (_i, [_i] * 5),
+    'sd_dwconv3x3_wgrad_multi': (_i, [_vp, _i, _i, _vp]),
     'sd_dwconv3x3_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'sd_dwconv3x3_gelu_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'sd_dwconv3x3_gelu_fwd_train': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

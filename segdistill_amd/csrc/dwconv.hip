@@ -20,6 +20,9 @@
 // block and pass -- 16 tiny kernels per step of Segformer-B0).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
+
+#include <type_traits>
 
 #include "cgd_device.h"
 
@@ -205,17 +208,19 @@ __global__ __launch_bounds__(256) void dw3x3_fwd(const T *__restrict__ x, const 
 // RY segments; each thread walks its segment with a sliding 3x3 window (loads for column ix+2 are issued one
 // iteration ahead of their use: 4 vector loads + 9 vector FMAs per pixel) and the RY threads of a channel
 // vector are combined through LDS.  part layout: [gridDim.y][10][C]  (k = 0..8 taps, k = 9 bias).
+// (gx x gy workgroups, this one the lin-th of them: the whole grid in the single launch, a slice of it -- starting at a multiple of 8, so that
+// lin % 8 is still the XCD -- in the grouped launch below)
 template <typename T>
-__global__ __launch_bounds__(256) void dw3x3_wgrad_partials(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part,
-                                                             int nsegs, int nseg, int SEG, int H, int W, int C, int LX, int RY) {
+__device__ __forceinline__ void dw3x3_wgrad_body(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part, int nsegs, int nseg, int SEG,
+                                                 int H, int W, int C, int LX, int RY, unsigned gx, unsigned gy, unsigned lin) {
     constexpr int N = CV<T>::N;
     extern __shared__ float red[];  // [RY][10][LX*N]
     const int lx = threadIdx.x % LX, ry = threadIdx.x / LX;
     // XCD-aware order (see dw3x3_fwd): consecutive segment groups -- neighbouring image rows -- stay on one XCD's L2
-    const unsigned total = gridDim.x * gridDim.y, q8 = total / 8, r8 = total % 8;
-    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin % 8;
+    const unsigned total = gx * gy, q8 = total / 8, r8 = total % 8;
+    const unsigned xcd = lin % 8;
     const unsigned item = xcd * q8 + (xcd < r8 ? xcd : r8) + lin / 8;
-    const unsigned bx = item % gridDim.x, by = item / gridDim.x;
+    const unsigned bx = item % gx, by = item / gx;
     const int c = (bx * LX + lx) * N;
     const int sid = by * RY + ry;
     const bool live = (c < C) && (sid < nsegs);
@@ -294,6 +299,38 @@ __global__ __launch_bounds__(256) void dw3x3_wgrad_partials(const T *__restrict_
         const int cc = bx * LC + col;
         if (cc < C) part[(size_t)by * 10 * C + (k < 9 ? cc * 9 + k : 9 * C + cc)] = s;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dw3x3_wgrad_partials(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part,
+                                                             int nsegs, int nseg, int SEG, int H, int W, int C, int LX, int RY) {
+    dw3x3_wgrad_body<T>(x, dy, part, nsegs, nseg, SEG, H, W, C, LX, RY, gridDim.x, gridDim.y, blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// The filter gradients of ALL depth-wise convolutions of a backward in one launch (round 5; deferred to the backward's end like the Linear weight
+// gradients -- csrc/wgrad_tn.hip, segdistill_amd/deferred.py): eight launches of 128 ... 512 workgroups per Segformer-B0 step become one.
+constexpr int kDwMultiMax = 24;
+struct DwMultiTable {
+    const void *x[kDwMultiMax], *dy[kDwMultiMax];
+    float *part[kDwMultiMax];
+    int nsegs[kDwMultiMax], nseg[kDwMultiMax], H[kDwMultiMax], W[kDwMultiMax], C[kDwMultiMax], LX[kDwMultiMax], RY[kDwMultiMax], gx[kDwMultiMax],
+        gy[kDwMultiMax];
+    int blk_begin[kDwMultiMax + 1];     // multiples of 8
+    int njobs;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void dw3x3_wgrad_partials_multi(const DwMultiTable t) {
+    int lo = 0, hi = t.njobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= t.blk_begin[mid]) lo = mid;
+        else hi = mid - 1;
+    }
+    const int j = lo;
+    const unsigned lin = blockIdx.x - (unsigned)t.blk_begin[j];
+    if (lin >= (unsigned)(t.gx[j] * t.gy[j])) return;       // padding of the slice (uniform over the workgroup: no barrier is skipped by a part of it)
+    dw3x3_wgrad_body<T>((const T *)t.x[j], (const T *)t.dy[j], t.part[j], t.nsegs[j], t.nseg[j], 32, t.H[j], t.W[j], t.C[j], t.LX[j], t.RY[j],
+                        (unsigned)t.gx[j], (unsigned)t.gy[j], lin);
 }
 
 // out[o] = sum_p part[p][o], o < 10*C (9*C weight-gradient entries in conv layout, then C bias sums).  grid: ceil(10*C / 64);
@@ -383,10 +420,59 @@ int wgrad_launch(const void *x, const void *dy, float *dw, float *db, void *ws, 
     return (int)hipGetLastError();
 }
 
+template <typename T>
+int wgrad_multi_launch(const sd_dw_wgrad_job *jobs, int njobs, hipStream_t st) {
+    static_assert(kSeg == 32, "the grouped kernel passes SEG = 32");
+    for (int base = 0; base < njobs; base += kDwMultiMax) {
+        const int n = njobs - base < kDwMultiMax ? njobs - base : kDwMultiMax;
+        DwMultiTable t;
+        memset(&t, 0, sizeof(t));
+        long blk = 0;
+        size_t lds = 0;
+        for (int i = 0; i < n; ++i) {
+            const sd_dw_wgrad_job &q = jobs[base + i];
+            int rc = check_dw(q.x, q.dy, std::is_same<T, float>::value ? SD_F32 : SD_BF16, q.B, q.H, q.W, q.C);
+            if (rc) return rc;
+            if (!q.partials) return SD_E_NULL;
+            const WgGeo g = wgrad_geo<T>(q.B, q.H, q.W, q.C);
+            if (q.partials_bytes < (size_t)g.gy * 10 * q.C * sizeof(float) || (reinterpret_cast<uintptr_t>(q.partials) & 15)) return SD_E_WORKSPACE;
+            t.x[i] = q.x, t.dy[i] = q.dy, t.part[i] = q.partials;
+            t.nsegs[i] = g.nsegs, t.nseg[i] = g.nseg, t.H[i] = q.H, t.W[i] = q.W, t.C[i] = q.C, t.LX[i] = g.LX, t.RY[i] = g.RY, t.gx[i] = g.gx, t.gy[i] = g.gy;
+            t.blk_begin[i] = (int)blk;
+            blk += ((long)g.gx * g.gy + 7) / 8 * 8;
+            if (blk > 0x7fffffffL) return SD_E_SHAPE;
+            if (g.lds > lds) lds = g.lds;
+        }
+        t.blk_begin[n] = (int)blk;
+        t.njobs = n;
+        if (lds > 64 * 1024) {
+            static bool raised = false;
+            if (!raised) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&dw3x3_wgrad_partials_multi<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   96 * 1024);
+                if (e != hipSuccess) return (int)e;
+                raised = true;
+            }
+        }
+        hipLaunchKernelGGL((dw3x3_wgrad_partials_multi<T>), dim3((unsigned)blk), dim3(256), lds, st, t);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+    }
+    return SD_OK;
+}
+
 }  // namespace
 }  // namespace sd
 
 extern "C" {
+
+int sd_dwconv3x3_wgrad_multi(const sd_dw_wgrad_job *jobs, int njobs, int dtype, void *stream) {
+    if (!jobs) return SD_E_NULL;
+    if (njobs <= 0 || njobs > 4096) return SD_E_SHAPE;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return dtype == SD_F32 ? sd::wgrad_multi_launch<float>(jobs, njobs, st) : sd::wgrad_multi_launch<sd::bf16_t>(jobs, njobs, st);
+}
 
 int sd_dwconv3x3_wgrad_slabs(int dtype, int B, int H, int W, int C) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;

@@ -19,6 +19,7 @@ from .ops import _DT, _stream_ptr
 _jobs = None   # None: not deferring.  list of (partials tensor, out tensor, n, nslabs) -- the tensors are held until the flush
 _colsums = []  # column sums whose PARTIALS are deferred as well: (x2d, partials, out, rows, C, nblk), x2d kept alive until the flush
 _wgrads = []   # bf16 weight gradients whose GEMM is deferred as well: (dY, X, out, tokens, M, N), operands kept alive until the flush
+_dw_wgrads = []  # depth-wise 3x3 filter gradients whose partials launch is deferred: (x, dy, ws, B, H, W, C), grouped into one launch at the flush
 _side = {}     # device index -> the side stream the weight-gradient kernels of a scope run on
 _held = []     # operands of side-stream launches, kept alive until the join (so the allocator cannot hand their memory out earlier)
 _forked = None  # the side stream with un-joined work, if any
@@ -31,6 +32,11 @@ class _ColsumJob(C.Structure):
 class _WgradJob(C.Structure):
     _fields_ = [('dY', C.c_void_p), ('X', C.c_void_p), ('slabs', C.c_void_p), ('tokens', C.c_long), ('out_features', C.c_int), ('in_features', C.c_int),
                 ('nsplit', C.c_int), ('with_bias', C.c_int)]
+
+
+class _DwWgradJob(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('dy', C.c_void_p), ('partials', C.c_void_p), ('partials_bytes', C.c_size_t), ('B', C.c_int), ('H', C.c_int),
+                ('W', C.c_int), ('C', C.c_int)]
 
 
 class _Job(C.Structure):
@@ -99,6 +105,24 @@ def _flush_wgrads():
         # (the slab views in _jobs keep `ws` alive until the combine is enqueued; the operands in `pend_all` until here)
 
 
+def add_dw_wgrad(x, dy, ws, B, H, W, Cc):
+    """The partials launch of a depth-wise 3 x 3 filter gradient (csrc/dwconv.hip), deferred: all of a scope's run as ONE launch when it ends
+    (the caller registers the combine of `ws` with add() as before)."""
+    _dw_wgrads.append((x, dy, ws, int(B), int(H), int(W), int(Cc)))
+
+
+def _flush_dw_wgrads():
+    global _dw_wgrads
+    pend, _dw_wgrads = _dw_wgrads, []
+    for dt in {p[0].dtype for p in pend}:
+        group = [p for p in pend if p[0].dtype == dt]
+        arr = (_DwWgradJob * len(group))()
+        for k, (x, dy, ws, B, H, W, Cc) in enumerate(group):
+            arr[k].x, arr[k].dy, arr[k].partials, arr[k].partials_bytes = x.data_ptr(), dy.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size()
+            arr[k].B, arr[k].H, arr[k].W, arr[k].C = B, H, W, Cc
+        _lib.check(_lib.lib().sd_dwconv3x3_wgrad_multi(C.cast(arr, C.c_void_p), len(group), _DT[dt], _stream_ptr()), 'sd_dwconv3x3_wgrad_multi')
+
+
 def reduce_now(partials, out, n, nslabs):
     """out[i] = sum_s partials[s*n + i] at once (one launch of the batched kernel with a single job)."""
     job = (_Job * 1)()
@@ -145,6 +169,8 @@ def flush():
     join()
     if _wgrads:
         _flush_wgrads()
+    if _dw_wgrads:
+        _flush_dw_wgrads()
     if _colsums:
         pend, _colsums = _colsums, []
         for dt in {p[0].dtype for p in pend}:          # one batched partials launch per storage type
@@ -181,6 +207,7 @@ def scope():
         _jobs = None
         _colsums.clear()
         _wgrads.clear()
+        _dw_wgrads.clear()
 
 
 def column_sum(x2d, defer_ok=True):

@@ -57,7 +57,11 @@ class _DWConv3x3Tokens(torch.autograd.Function):
                 _lib.check(L.sd_dwconv3x3_bwd_weight(x.data_ptr(), dy.data_ptr(), None if later else buf.data_ptr(),
                                                      None if later else buf[9 * C:].data_ptr(), _DT[x.dtype], B, H, W, C, ws.data_ptr(), wsb,
                                                      _stream_ptr()), 'sd_dwconv3x3_bwd_weight')
-            if later:   # partials only, off the critical chain: side stream, combined when the scope ends
+            if later and deferred._WGRAD_GROUPED:
+                # round 5: not even the partials are launched now -- all depth-wise filter gradients of the backward run as ONE launch at its end
+                deferred.add_dw_wgrad(x, dy, ws, B, H, W, C)
+                deferred.add(ws, buf, 10 * C, L.sd_dwconv3x3_wgrad_slabs(_DT[x.dtype], B, H, W, C))
+            elif later:   # partials only, off the critical chain: side stream, combined when the scope ends
                 deferred.side_launch(launch, x, dy, ws)
                 deferred.add(ws, buf, 10 * C, L.sd_dwconv3x3_wgrad_slabs(_DT[x.dtype], B, H, W, C))
             else:

@@ -151,3 +151,42 @@ def test_fp32_student_step_is_the_same_grouped_and_one_by_one(monkeypatch):
         # (the patch-embed convolutions' filter gradients come from MIOpen kernels that accumulate with atomics: two runs of the SAME path differ
         # in the last bits, and what reaches them here went through every layer above)
         assert float((ga[n] - gb[n]).abs().max()) <= (2e-3 if ga[n].dim() == 4 else 2e-4) * scale, n
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_depthwise_filter_gradients_grouped_equal_the_single_launches(dtype):
+    """csrc/dwconv.hip::dw3x3_wgrad_partials_multi: the depth-wise 3 x 3 filter / bias gradients of a scope (Mix-FFN, mix_transformer.py:376-387) in
+    ONE launch -- the same workgroup program per job as the single launch, hence bit-identical gradients; shapes of all four MiT stages + a ragged one."""
+    from segdistill_amd import deferred, dwconv
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(21)
+    cases = [(2, 64, 64, 128), (2, 32, 32, 256), (2, 16, 16, 640), (2, 8, 8, 1024), (1, 5, 7, 40), (3, 16, 16, 64)]
+    mods = []
+    for B, H, W, C in cases:
+        w = torch.randn(C, 1, 3, 3, generator=g).to(dev).requires_grad_(True)
+        b = torch.randn(C, generator=g).to(dev).requires_grad_(True)
+        x = torch.randn(B, H * W, C, generator=g).to(dev).to(dtype)
+        gy = torch.randn(B, H * W, C, generator=g).to(dev).to(dtype)
+        mods.append((w, b, x, gy, H, W))
+
+    def run(grouped):
+        for w, b, *_ in mods:
+            w.grad = b.grad = None
+        deferred._WGRAD_GROUPED = grouped           # False: every partials launch on its own inside the backward (same combine at the scope's end)
+        with deferred.scope():
+            for w, b, x, gy, H, W in mods:
+                with torch.autocast('cuda', dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+                    y = dwconv.dwconv3x3_tokens(x, w, b, H, W)
+                y.backward(gy.to(y.dtype))
+        torch.cuda.synchronize()
+        return [(w.grad.clone(), b.grad.clone()) for w, b, *_ in mods]
+    try:
+        a, c = run(True), run(False)
+    finally:
+        deferred._WGRAD_GROUPED = True
+    for (wa, ba), (wc, bc), (w, b, x, gy, H, W) in zip(a, c, mods):
+        assert torch.equal(wa, wc) and torch.equal(ba, bc)
+        B, C = x.shape[0], x.shape[2]
+        ref = torch.nn.grad.conv2d_weight(x.double().transpose(1, 2).reshape(B, C, H, W), (C, 1, 3, 3), gy.double().transpose(1, 2).reshape(B, C, H, W),
+                                          padding=1, groups=C)
+        assert float((wa.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) * (1 if dtype == torch.float32 else 4)
