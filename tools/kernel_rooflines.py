@@ -559,6 +559,60 @@ def bench_wgrad_bf16(dev, reps):
     return out
 
 
+def bench_wgrad_multi(dev, reps):
+    """The grouped weight-gradient launches (round 5; csrc/wgrad_tn.hip wgrad_tn_x3_multi / wgrad_tn_bf16_ring_multi + multi_slab_reduce): every
+    token-major Linear of the student of config 2 (Segformer-B0, fp32, bias sums in the slabs) resp. config 5 (B1, bf16) in one deferred scope.
+    Roof: HBM -- every dY and X once + the slabs written and read back."""
+    import ctypes as C_
+    from segdistill_amd import _lib, deferred
+    from tools.slab_budget import PRESETS
+    L = _lib.lib()
+    out = []
+    for tag, preset, dt, code in (('config 2 (B0 student, fp32, bias sums riding along)', 'cfg2', torch.float32, 0),
+                                  ('config 5 (B1 student + align, bf16)', 'cfg5', torch.bfloat16, 1)):
+        pr = PRESETS[preset]
+        dims, embed, align = pr['dims'], pr['embed'], pr['align']
+        shapes = []
+        for s_, c in enumerate(dims):
+            t = 8 * (512 // (4 << s_)) ** 2
+            tk = t // (8, 4, 2, 1)[s_] ** 2
+            layers = [(t, c, c), (tk, 2 * c, c), (t, c, c), (t, 4 * c, c), (t, c, 4 * c)]
+            shapes += layers * 2 + [(t, embed, c)] + ([(t, align, embed)] if align else [])
+        shapes = [(T, M, N) for T, M, N in shapes if L.sd_linear_wgrad_tn_multi_supported(code, T, M, N)]
+        gen = torch.Generator(device=dev).manual_seed(17)
+        ops_ = [(torch.randn(T, M, device=dev, generator=gen).to(dt), torch.randn(T, N, device=dev, generator=gen).to(dt)) for T, M, N in shapes]
+        wb = dt == torch.float32
+        arr = (deferred._WgradJob * len(shapes))()
+        for k, ((dy, x), (T, M, N)) in enumerate(zip(ops_, shapes)):
+            arr[k].dY, arr[k].X, arr[k].tokens, arr[k].out_features, arr[k].in_features, arr[k].with_bias = dy.data_ptr(), x.data_ptr(), T, M, N, int(wb)
+        _ok(L.sd_linear_wgrad_tn_multi_plan(C_.cast(arr, C_.c_void_p), len(shapes), code), 'plan')
+        sizes = [M * N + (M if wb else 0) for T, M, N in shapes]
+        outs = [torch.empty(n, device=dev) for n in sizes]
+        ws = torch.empty(sum(arr[k].nsplit * sizes[k] for k in range(len(shapes)) if arr[k].nsplit > 1) + 4, device=dev)
+        red, off = [], 0
+        for k in range(len(shapes)):
+            if arr[k].nsplit > 1:
+                arr[k].slabs = ws[off:].data_ptr()
+                red.append((ws[off:].data_ptr(), outs[k].data_ptr(), sizes[k], arr[k].nsplit))
+                off += arr[k].nsplit * sizes[k]
+            else:
+                arr[k].slabs = outs[k].data_ptr()
+        jobs = (deferred._Job * len(red))()
+        for k, (p_, o_, n_, ns_) in enumerate(red):
+            jobs[k].partials, jobs[k].out, jobs[k].n, jobs[k].nslabs = p_, o_, n_, ns_
+
+        def run(st):
+            _ok(L.sd_linear_wgrad_tn_multi(C_.cast(arr, C_.c_void_p), len(shapes), code, st), 'wgrad multi')
+            _ok(L.sd_multi_slab_reduce(C_.cast(jobs, C_.c_void_p), len(red), st), 'slab reduce')
+        t = _time(run, reps)
+        es = 4 if wb else 2
+        slab = sum(arr[k].nsplit * sizes[k] * 4 for k in range(len(shapes)) if arr[k].nsplit > 1)
+        nbytes = sum(float(T) * (M + N) * es for T, M, N in shapes) + 2.0 * slab
+        out.append(_entry(f'all {len(shapes)} Linear weight gradients of one backward, grouped: {tag}', 'wgrad_tn_*_multi + multi_slab_reduce',
+                          [len(shapes)], 'f32' if wb else 'bf16', t, 'hbm', nbytes, HBM, note=f'{slab / 1e6:.0f} MB of slabs written + read back'))
+    return out
+
+
 def bench_ppm(dev, reps):
     """All adaptive average pools of a PPM in one pass each way (csrc/ppm_pool.hip): the PSPNet-R18 student's [8, 512, 64, 64] map and the
     ResNet-101 teacher's [2, 2048, 64, 64] (config 1).  HBM-bound: forward reads the map once, backward writes it once."""
@@ -719,6 +773,7 @@ def bench_bf16gemm(dev, reps):
 
 
 GROUPS = {
+    'wgradmulti': lambda dev, reps: bench_wgrad_multi(dev, reps),
     'bf16gemm': lambda dev, reps: bench_bf16gemm(dev, reps),
     'aligntok': lambda dev, reps: bench_aligntok(dev, reps),
     'pixup': lambda dev, reps: bench_pixup(dev, reps),

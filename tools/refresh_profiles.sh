@@ -59,7 +59,7 @@ done
 fi
 if want 5; then
 echo "[5] kernel rooflines: trace + PMC passes" | tee -a $OUT/progress.txt
-for g in r1 tok aligntok bf16gemm r2 ce align sra optim dw ln upsum resize gemm pred ifvd pix pixup at wgrad_bf16 ppm wattn; do
+for g in r1 tok aligntok bf16gemm wgradmulti r2 ce align sra optim dw ln upsum resize gemm pred ifvd pix pixup at wgrad_bf16 ppm wattn; do
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kr_$g -o k -- python3 $R/tools/kernel_rooflines.py --only $g > $OUT/kernels_$g.txt 2>/dev/null )
   cp $(find /tmp/kr_$g -name '*kernel_stats.csv' | head -1) $OUT/kernels_${g}_stats.csv 2>/dev/null
 done
