@@ -146,12 +146,16 @@ def test_fp32_student_step_is_the_same_grouped_and_one_by_one(monkeypatch):
     monkeypatch.setattr(linear, '_FP32_WGRAD_GROUPED', False)
     gb = grads()
     assert ga.keys() == gb.keys() and len(ga) > 40
+    # rel-L2 per tensor.  Two runs of the SAME path already differ in the last bits (MIOpen's patch-embed convolution kernels accumulate with atomics),
+    # so: 1e-3, and tensors whose gradient is noise-level next to the others (a bias in front of a normalisation) are left out
+    top = max(float(g.norm()) for g in gb.values())
+    checked = 0
     for n in ga:
-        scale = float(gb[n].abs().max()) + 1e-12
-        # (the patch-embed convolutions' filter gradients come from MIOpen kernels that accumulate with atomics: two runs of the SAME path differ
-        # in the last bits, and what reaches them here went through every layer above)
-        assert float((ga[n] - gb[n]).abs().max()) <= (2e-3 if ga[n].dim() == 4 else 2e-4) * scale, n
-
+        if float(gb[n].norm()) < 1e-5 * top:
+            continue
+        checked += 1
+        assert float((ga[n] - gb[n]).norm()) <= 1e-3 * float(gb[n].norm()), n
+    assert checked > 40
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_depthwise_filter_gradients_grouped_equal_the_single_launches(dtype):
