@@ -72,8 +72,12 @@ const char *sd_error_string(int code);
  *       factor 8) class planes per workgroup with the pixel maps loaded once per group; 0 = one class per workgroup, rounds 1-2).
  *       "wgrad_tn_ring" (0|1|2, default 1: the bf16 weight-gradient kernels of csrc/wgrad_tn.hip -- 0 register-staged tiles everywhere, 1 the LDS-DMA
  *       ring where legal, 2 its 256 x 256 tiles wherever legal), "wgrad_slab_ratio" (per cent, default 40, 0 = no cap: the most split-K slab bytes a
- *       bf16-storage weight gradient may write, as a share of its operand bytes).
- *       The sra_*, align_*, ce_* and wgrad_tn_ring keys select arithmetic or tiling, not workspace geometry: no workspace size depends on them.
+ *       bf16-storage weight gradient may write, as a share of its operand bytes), "wgrad_multi_wgs" (0 = default: workgroups per launch group
+ *       that sd_linear_wgrad_tn_multi_plan deals out -- 1536 for bf16, 3072 for fp32 storage; planning only: set it before _plan),
+ *       "tok_gemm_bf16_variant" (-1 = by shape; 0..4 force a tile / ring variant of sd_linear_bf16_fwd), "planes_tile" (0 = by shape; 128 / 64: row
+ *       tile of the split-bf16 planes GEMM).
+ *       The sra_*, align_*, ce_*, wgrad_tn_ring, tok_gemm_bf16_variant and planes_tile keys select arithmetic or tiling, not workspace geometry: no
+ *       workspace size depends on them.
  *       "wgrad_slab_ratio" IS workspace geometry: it changes what sd_linear_wgrad_generic_slabs / sd_linear_wgrad_slabs /
  *       sd_linear_wgrad_workspace_bytes answer, so set it before any of those queries (the Python binding reads SEGDISTILL_WGRAD_SLAB_RATIO once,
  *       when the library is loaded). */
