@@ -693,7 +693,7 @@ int sd_linear_wgrad_tn(const float *dY, const float *X, float *slabs, size_t sla
  *   _plan():  fills job.nsplit (>= 1) for ALL jobs of the coming call: ~1536 (bf16) / ~3072 (fp32) workgroups in total, dealt by tile-k-steps;
  *             bf16 within the "wgrad_slab_ratio" cap.  SD_E_UNSUPPORTED if a job is not _supported (nothing is filled then).
  *   launch:   job.slabs = nsplit slabs of out * in floats (+ out floats when with_bias: the column sums of dY over the slab's tokens = the bias
- *             gradient; fp32 only): slab z = the product over the z-th token range; the caller sums them (sd_multi_slab_reduce, fixed order:
+ *             gradient): slab z = the product over the z-th token range; the caller sums them (sd_multi_slab_reduce, fixed order:
  *             run-to-run identical).  nsplit == 1: `slabs` IS the gradient (point it at the destination, no combine).  One launch per 32 jobs. */
 typedef struct sd_wgrad_job {
     const void *dY, *X;         /* [tokens][out], [tokens][in] */

@@ -162,7 +162,9 @@ __device__ __forceinline__ void dma16(const void *gptr, unsigned lds_byte) {
 // the grouped launch below, whose slices start at multiples of 8 so that id % 8 is still the XCD the workgroup runs on)
 template <int IM>
 __device__ __forceinline__ void wgrad_ring_body(const bf16_t *__restrict__ A, const bf16_t *__restrict__ B, float *__restrict__ C, int M, int N, long T,
-                                                int klen, int tiles_m, int tiles_n, int nsplit, long nblk, long id) {
+                                                int klen, int tiles_m, int tiles_n, int nsplit, long nblk, long id, const bool BIAS = false) {
+    // BIAS (IM = 1 only): the slab is [M x N] followed by M column sums of A = dY over the split's tokens -- the Linear's bias gradient, taken from the
+    // tiles the tn == 0 workgroups stage anyway (the batched column-sum pass re-read every dY: 0.11 ms per config-5 step)
     constexpr int BT = 128 * IM;                       // tile extent along m and along n
     constexpr int TW = 2 * IM;                         // 32-row (-column) MFMA blocks per wave and axis
     constexpr int kStage = 2 * IM * kStageBytes;       // A images, then B images
@@ -217,6 +219,7 @@ __device__ __forceinline__ void wgrad_ring_body(const bf16_t *__restrict__ A, co
                 dma16(gb[im][u] + (size_t)kc * TBK * N, __builtin_amdgcn_readfirstlane(st + (unsigned)(IM + im) * kStageBytes + la[u]));
             }
     };
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (nk > 0) {
         issue(0);
         issue(1);
@@ -228,6 +231,18 @@ __device__ __forceinline__ void wgrad_ring_body(const bf16_t *__restrict__ A, co
         __builtin_amdgcn_sched_barrier(0);
         issue(kt + 3);
         const unsigned char *sa = lds + (size_t)(kt % kRing) * kStage, *sb = sa + IM * kStageBytes;
+        if (IM == 1 && BIAS && tn == 0) {
+            // thread t: chunk t % 16 (8 columns) of rows 2 (t / 16), + 1 of the 32-row tile
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(sa + swz(2 * (t >> 4) + u, t & 15));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bsum[2 * e] += __uint_as_float(v[e] << 16);
+                    bsum[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u);
+                }
+            }
+        }
 #pragma unroll
         for (int s = 0; s < TBK / 16; ++s) {
             bf16x8 fa[TW], fb[TW];
@@ -248,7 +263,20 @@ __device__ __forceinline__ void wgrad_ring_body(const bf16_t *__restrict__ A, co
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tail's placeholder DMAs must not land after the workgroup's LDS is gone
-    float *Cz = C + (size_t)split * M * N;
+    float *Cz = C + (size_t)split * ((size_t)M * N + (BIAS ? M : 0));
+    if (IM == 1 && BIAS && tn == 0) {
+        __syncthreads();                                 // every wave is done with the ring: 8 KB of it become the fold buffer [16 row pairs][128 columns]
+        float *red = reinterpret_cast<float *>(lds);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(t >> 4) * TBM + 8 * (t & 15) + e] = bsum[e];
+        __syncthreads();
+        if (t < TBM) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v += red[q * TBM + t];
+            if (m0 + t < M) Cz[(size_t)M * N + m0 + t] = v;
+        }
+    }
     const int col = lane & 31;
 #pragma unroll
     for (int i = 0; i < TW; ++i)
@@ -298,7 +326,8 @@ __global__ __launch_bounds__(256) void wgrad_tn_bf16_ring_multi(const WgradMulti
     const int j = lo;
     const long id = (long)blockIdx.x - t.blk_begin[j];
     if (id >= t.nblk[j]) return;        // padding of the slice
-    wgrad_ring_body<1>((const bf16_t *)t.A[j], (const bf16_t *)t.B[j], t.C[j], t.M[j], t.N[j], t.T[j], t.klen[j], t.tiles_m[j], t.tiles_n[j], t.nsplit[j], (long)t.nblk[j], id);
+    wgrad_ring_body<1>((const bf16_t *)t.A[j], (const bf16_t *)t.B[j], t.C[j], t.M[j], t.N[j], t.T[j], t.klen[j], t.tiles_m[j], t.tiles_n[j], t.nsplit[j], (long)t.nblk[j], id,
+                       t.bias[j] != 0);
 }
 
 // ---- fp32 storage: the same product in split-bf16 arithmetic ("bf16x3", fp32-grade: token_gemm.hip section 3.9 of DESIGN.md) ---------------
@@ -646,7 +675,6 @@ static int multi_fill_and_launch(bool bf16, const int *sel, int nsel, const void
             const long kl = ((ksteps + nsplit[j] - 1) / nsplit[j]) * TBK;
             if ((T[j] + kl - 1) / kl != nsplit[j] || (bf16 && kl < 3 * TBK)) return SD_E_SHAPE;       // not a plan of wgrad_tn_multi_plan
             if ((reinterpret_cast<uintptr_t>(dY[j]) | reinterpret_cast<uintptr_t>(X[j]) | reinterpret_cast<uintptr_t>(slabs[j])) & 15) return SD_E_ALIGN;
-            if (bf16 && bias[j]) return SD_E_UNSUPPORTED;
             t.A[i] = dY[j];
             t.B[i] = X[j];
             t.C[i] = slabs[j];

@@ -66,9 +66,8 @@ def wgrad_groupable(dy2, x2, M, N):
 
 def add_wgrad(dy2, x2, M, N, with_bias=False):
     """dW [M, N] fp32 = dy2 [T, M]^T . x2 [T, N], computed when the enclosing scope ends by the grouped launch -- its k-splits planned over all the
-    scope's weight gradients together -- and the scope's slab combine.  with_bias (fp32 storage only): the column sums of dy2 (the Linear's bias
-    gradient) ride along in the slabs.  Returns VIEWS of the result buffer (see column_sum): (dW, db or None)."""
-    with_bias = bool(with_bias) and dy2.dtype == torch.float32
+    scope's weight gradients together -- and the scope's slab combine.  with_bias: the column sums of dy2 (the Linear's bias gradient) ride along in the slabs.  Returns VIEWS of the result buffer (see column_sum): (dW, db or None)."""
+    with_bias = bool(with_bias)
     out = torch.empty(M * N + (M if with_bias else 0), dtype=torch.float32, device=dy2.device)
     _wgrads.append((dy2, x2, out, int(dy2.shape[0]), int(M), int(N), with_bias))
     return out[:M * N].view(M, N), (out[M * N:] if with_bias else None)

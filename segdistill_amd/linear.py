@@ -253,6 +253,8 @@ def linear_weight_grads(x, dy2, w_shape, w_dtype, want_db, defer_ok, defer_bias_
         return dw, db
     if not direct and defer_ok and w_dtype == torch.float32 and x.dtype == torch.bfloat16 and deferred.wgrad_groupable(dyc, x2, M, N):
         # round 5: not even the GEMM runs now -- the scope's ONE grouped launch computes every such gradient, its k-splits planned over all of them
+        if want_db and defer_bias_ok:       # the bias gradient rides along in the slabs (no second pass over dY)
+            return deferred.add_wgrad(dyc, x2, M, N, with_bias=True)
         dw, _ = deferred.add_wgrad(dyc, x2, M, N)
         return dw, (deferred.column_sum(dyc, defer_bias_ok) if want_db else None)
     gs = 0 if direct else L.sd_linear_wgrad_generic_slabs(_DT[x.dtype], T, M, N)

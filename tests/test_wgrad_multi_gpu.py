@@ -147,15 +147,10 @@ def test_fp32_student_step_is_the_same_grouped_and_one_by_one(monkeypatch):
     gb = grads()
     assert ga.keys() == gb.keys() and len(ga) > 40
     # rel-L2 per tensor.  Two runs of the SAME path already differ in the last bits (MIOpen's patch-embed convolution kernels accumulate with atomics),
-    # so: 1e-3, and tensors whose gradient is noise-level next to the others (a bias in front of a normalisation) are left out
+    # so: 1e-3, plus an absolute floor for tensors whose gradient is noise-level next to the others (a bias in front of a normalisation)
     top = max(float(g.norm()) for g in gb.values())
-    checked = 0
     for n in ga:
-        if float(gb[n].norm()) < 1e-5 * top:
-            continue
-        checked += 1
-        assert float((ga[n] - gb[n]).norm()) <= 1e-3 * float(gb[n].norm()), n
-    assert checked > 40
+        assert float((ga[n] - gb[n]).norm()) <= 1e-3 * float(gb[n].norm()) + 1e-7 * top, n
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_depthwise_filter_gradients_grouped_equal_the_single_launches(dtype):
