@@ -4,7 +4,12 @@ The LayerNorm and Linear weight-gradient kernels produce per-workgroup partial s
 launch each (~65 per backward of Segformer-B0).  Inside ``scope()`` they leave the slabs in their workspace and register a job
 here; the scope's exit combines ALL jobs in one launch per 80 (``sd_multi_slab_reduce``).  Valid because nothing reads those
 gradients before the optimizer: a call site opts in only when its result goes straight to a leaf parameter's ``.grad`` (no cast,
-no stacking, no accumulation into an existing gradient).  Outside a scope every op combines its partials at once, as before."""
+no stacking, no accumulation into an existing gradient).  Outside a scope every op combines its partials at once, as before.
+
+Round 5: the weight-gradient GEMMs themselves are deferred too.  ``add_wgrad`` / ``add_dw_wgrad`` only REGISTER a Linear's / a depth-wise
+convolution's filter gradient (operands held alive, results handed out as views of buffers that are written at the flush); the scope's exit
+plans the k-splits of all of them together and computes them in grouped launches (csrc/wgrad_tn.hip ``sd_linear_wgrad_tn_multi``, csrc/dwconv.hip
+``sd_dwconv3x3_wgrad_multi``), then runs the one slab combine.  DESIGN 3.5b."""
 from __future__ import annotations
 
 import contextlib
@@ -66,7 +71,8 @@ def wgrad_groupable(dy2, x2, M, N):
 
 def add_wgrad(dy2, x2, M, N, with_bias=False):
     """dW [M, N] fp32 = dy2 [T, M]^T . x2 [T, N], computed when the enclosing scope ends by the grouped launch -- its k-splits planned over all the
-    scope's weight gradients together -- and the scope's slab combine.  with_bias: the column sums of dy2 (the Linear's bias gradient) ride along in the slabs.  Returns VIEWS of the result buffer (see column_sum): (dW, db or None)."""
+    scope's weight gradients together -- and the scope's slab combine.  with_bias: the column sums of dy2 (the Linear's bias gradient) ride along in
+    the slabs.  Returns VIEWS of the result buffer (see column_sum): (dW, db or None)."""
     with_bias = bool(with_bias)
     out = torch.empty(M * N + (M if with_bias else 0), dtype=torch.float32, device=dy2.device)
     _wgrads.append((dy2, x2, out, int(dy2.shape[0]), int(M), int(N), with_bias))
