@@ -10,6 +10,8 @@ student fwd + frozen-teacher fwd + distillation loss (HIP kernels) + supervised 
 flat-buffer gradient all-reduce (RCCL) + fused AdamW step + LR update.  Workload at N=1: BASELINE
 config 2 (Segformer-B0 <- B2, CGD group 8, T 4, bs 8, 512x512, 150 classes), fp32 as the reference.
 
+After the warm-up the timed region (EXACTLY K steps, barrier + synchronize on both sides, max over ranks) is run --repeats times (3) back
+to back: `value` / `ms_per_step` are the MEDIAN region, `value_min` / `value_max` the slowest / fastest, so a box's spread is in the line.
 Rank 0 prints ONE SHORT JSON line (< 3.5 KB: the driver keeps only the tail of stdout) with, besides the contract fields:
   roofline      the HBM-bound CGD kernels (R1 fwd+bwd) at the config-2 operand shape, timed with HIP
                 events in this same process: achieved = 5*N*4 bytes / (t_fwd + t_bwd);
@@ -17,6 +19,7 @@ Rank 0 prints ONE SHORT JSON line (< 3.5 KB: the driver keeps only the tail of s
                 a bounded sample (N=1 only);
   config.arithmetic / config.value_exact_f32   the shipped fp32 mode computes its GEMM-shaped products as split-bf16
                 (fp32-grade by test); the same workload on exact-f32 MFMA is measured by a child run (N=1 only).
+  config.value_deterministic   the same workload under `--deterministic` (the reference's only launch mode, tools/dist_train.sh:8), child run.
 --kernel-rooflines additionally writes the per-kernel-family table to a side file (roofline.kernels_file).
 """
 from __future__ import annotations
@@ -245,13 +248,15 @@ def kernel_roofline_entries(groups=('r2', 'r1_bf16', 'tok', 'align', 'ce', 'pix'
     return out
 
 
-def exact_f32_child(argv_base, steps, warmup, timeout=420):
-    """The same workload with every split-bf16 product switched back to exact-f32 MFMA (SEGDISTILL_SPLIT_BF16=0), in a CHILD process started
-    before this one touches the GPU.  Returns (imgs/s or None, note)."""
+def variant_child(argv_base, steps, warmup, env_extra=None, flags=(), timeout=420):
+    """The same workload in a CHILD process started before this one touches the GPU, with a switch flipped: every split-bf16 product back on
+    exact-f32 MFMA (SEGDISTILL_SPLIT_BF16=0 -> config.value_exact_f32), or the reference's launch mode `--deterministic`
+    (tools/dist_train.sh:8 -> config.value_deterministic).  Returns (imgs/s or None, note)."""
     import subprocess
-    env = dict(os.environ, SEGDISTILL_SPLIT_BF16='0', SEGDISTILL_BENCH_CHILD='1')
+    env = dict(os.environ, SEGDISTILL_BENCH_CHILD='1', **(env_extra or {}))
     cmd = [sys.executable, os.path.abspath(__file__)] + argv_base + ['--steps', str(steps), '--warmup', str(warmup), '--no-roofline',
-                                                                     '--no-cpu-baseline', '--no-exact-f32']
+                                                                     '--no-cpu-baseline', '--no-exact-f32', '--no-deterministic-child',
+                                                                     '--repeats', '1'] + list(flags)
     try:
         r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -260,6 +265,14 @@ def exact_f32_child(argv_base, steps, warmup, timeout=420):
         return float(json.loads(lines[-1])['value']), None
     except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
         return None, f'{type(e).__name__}: {str(e)[:120]}'
+
+
+def exact_f32_child(argv_base, steps, warmup, timeout=420):
+    return variant_child(argv_base, steps, warmup, env_extra={'SEGDISTILL_SPLIT_BF16': '0'}, timeout=timeout)
+
+
+def deterministic_child(argv_base, steps, warmup, timeout=420):
+    return variant_child(argv_base, steps, warmup, flags=('--deterministic',), timeout=timeout)
 
 
 def _usable_cores():
@@ -341,11 +354,15 @@ def _newest_profile(pattern):
 
 
 def compose_line(*, args, world, B, dt, rank_ms, graphed, segments, trainer_bf16, arithmetic, grad_bytes, ranks_seen, backend, rccl_version,
-                 logs, allreduce_ms=None, syncbn_ms=None, roofline=None, cpu_baseline=None, exact_f32=None, kernels_file=None, errors=None):
+                 logs, allreduce_ms=None, syncbn_ms=None, roofline=None, cpu_baseline=None, exact_f32=None, kernels_file=None, errors=None,
+                 dts=None, deterministic=None, value_deterministic=None, allreduce_exposed_ms=None, peak_mem_gb=None):
     """The ONE JSON line of the contract, kept SHORT (the driver keeps only the tail of stdout: round 2's 24 KB line was lost).  Pure: the
     CPU test tests/test_bench_line_cpu.py builds it from canned leg outputs and holds it under 3500 bytes."""
     cfg_name = os.path.basename(args.config)
     is_cfg2 = 'cfg2' in cfg_name
+    # `dt` is the MEDIAN of the timed regions (each exactly `steps` steps, barrier + synchronize on both sides, max over ranks); `dts` lists
+    # them all, so the spread of the box rides along in the one record that counts (VERDICT r5)
+    dts = sorted(dts) if dts else [dt]
     line = {
         'metric': 'imgs/sec/node KD train_step, ' + ('Segformer-B2->B0 512x512' if is_cfg2 else cfg_name),
         'value': round(world * B * args.steps / dt, 3), 'unit': 'imgs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -359,8 +376,20 @@ def compose_line(*, args, world, B, dt, rank_ms, graphed, segments, trainer_bf16
                    'rccl_version': rccl_version, 'rank_ms_per_step': rank_ms},
         'final_log_vars': {k: round(v, 5) for k, v in list(logs.items())[:8]},
     }
+    if len(dts) > 1:
+        line['value_min'] = round(world * B * args.steps / dts[-1], 3)
+        line['value_max'] = round(world * B * args.steps / dts[0], 3)
+        line['timed_regions'] = len(dts)
+    if deterministic:
+        line['config']['deterministic'] = True
+    if peak_mem_gb is not None:
+        line['config']['peak_mem_gb'] = peak_mem_gb       # torch.cuda.max_memory_allocated over warm-up + timed regions (this rank)
+    if value_deterministic is not None:
+        line['config']['value_deterministic'] = value_deterministic
     if allreduce_ms is not None:
         line['config']['grad_allreduce_ms'] = allreduce_ms
+    if allreduce_exposed_ms is not None:
+        line['config']['grad_allreduce_exposed_ms'] = allreduce_exposed_ms
     if syncbn_ms is not None:
         line['config']['syncbn_collectives'] = syncbn_ms          # device time of the norms' statistics exchanges between the step's graphs
     if exact_f32 is not None:
@@ -438,6 +467,12 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-exact-f32', action='store_true', help='skip the exact-f32 A/B child run (config.value_exact_f32)')
     ap.add_argument('--exact-f32-steps', type=int, default=0, help='timed steps of the exact-f32 A/B child (default: min(steps, 10))')
+    ap.add_argument('--repeats', type=int, default=3,
+                    help='timed regions of EXACTLY --steps steps each, back to back; value / ms_per_step = the median region, value_min / value_max '
+                         'the slowest / fastest one')
+    ap.add_argument('--deterministic', action='store_true',
+                    help="the reference's launch mode (tools/dist_train.sh:8): engine.set_deterministic -- MIOpen held to its deterministic algorithms")
+    ap.add_argument('--no-deterministic-child', action='store_true', help='skip the --deterministic child run (config.value_deterministic)')
     ap.add_argument('--kernel-rooflines', action='store_true',
                     help='N=1 only: also time every hand-written kernel family against its own bound (tools/kernel_rooflines.py, child processes '
                          'started before this process touches the GPU); the table goes to a SIDE FILE named by roofline.kernels_file')
@@ -473,9 +508,15 @@ def main():
         exact_f32, err = exact_f32_child(base, args.exact_f32_steps or min(args.steps, 10), min(args.warmup, 4))
         if err:
             errors.append('exact-f32 A/B: ' + err)
+    value_deterministic = None
+    if single and not args.deterministic and not args.no_deterministic_child:
+        base = ['--config', args.config, '--kd-path', args.kd_path, '--graph', args.graph] + (['--batch', str(args.batch)] if args.batch else [])
+        value_deterministic, err = deterministic_child(base, min(args.steps, 10), min(args.warmup, 4))
+        if err:
+            errors.append('deterministic child: ' + err)
 
     from segdistill_amd.config import Config
-    from segdistill_amd.engine import KDTrainer, SyntheticADE, init_distributed
+    from segdistill_amd.engine import KDTrainer, SyntheticADE, init_distributed, set_deterministic
     rank, local, world = init_distributed()
     if world != args.gpus:
         raise SystemExit(f'[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)')
@@ -483,6 +524,8 @@ def main():
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     torch.backends.cudnn.benchmark = True
+    if args.deterministic:
+        set_deterministic(True)
 
     cfg = Config.fromfile(args.config)
     B = args.batch or int(cfg.data.samples_per_gpu)
@@ -504,25 +547,38 @@ def main():
     # auto: the whole step as hipGraphs at any world size (with ranks > 1 the capture is cut at the SyncBN collectives,
     # engine/segments.py); a capture that fails ON ANY RANK degrades every rank to the hybrid mode, then to eager
     graphed = choose_graph_mode(trainer, data.next, args.graph, errors)
+    replay_failed = None
     try:
         for _ in range(args.warmup - n_eager_warm):
             trainer.step(data.next())
     except Exception as e:  # noqa: BLE001 -- a replay that fails (first RCCL run inside a segmented capture) must not cost the line
-        errors.append(f'{graphed} graph replay failed in warm-up ({type(e).__name__}: {e}); eager steps instead')
+        replay_failed = f'{type(e).__name__}: {e}'
+    if world > 1 and replay_failed is not None:
+        # a rank that raised in the middle of a step has not issued the step's remaining collectives: its peers are blocked in them, and a
+        # rank that carried on alone (eager) would never meet them again -- say why and leave; never re-exec, never hang
+        print(f'[bench] rank {rank}: {graphed} graph replay failed in warm-up ({replay_failed}); exiting', file=sys.stderr)
+        sys.stderr.flush()
+        os._exit(3)
+    if replay_failed is not None:
+        errors.append(f'{graphed} graph replay failed in warm-up ({replay_failed}); eager steps instead')
         trainer.disable_graph()
         graphed = False
         for _ in range(max(1, args.warmup - n_eager_warm)):
             trainer.step(data.next())
-    dt_local = timed_steps(trainer, data, args.steps, world)
-    t = torch.tensor([dt_local], device=device, dtype=torch.float64)
-    rank_ms = None
-    if dist.is_initialized():
-        every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
-        dist.all_gather(every, t)
-        per = [float(x.item()) / args.steps * 1e3 for x in every]
-        rank_ms = {'min': round(min(per), 3), 'max': round(max(per), 3)}
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    # the timed regions: each EXACTLY args.steps steps between barrier + synchronize, max over ranks; the line's value is the median region
+    dts, rank_ms = [], None
+    for _ in range(max(1, args.repeats)):
+        dt_local = timed_steps(trainer, data, args.steps, world)
+        t = torch.tensor([dt_local], device=device, dtype=torch.float64)
+        if dist.is_initialized():
+            every = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+            dist.all_gather(every, t)
+            per = [float(x.item()) / args.steps * 1e3 for x in every]
+            rank_ms = {'min': round(min(per), 3), 'max': round(max(per), 3)}
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dts.append(float(t.item()))
+    dt = sorted(dts)[len(dts) // 2]
+    peak_mem_gb = round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 3)
     logs = trainer.log_values()
     # how many ranks really took part: an all-reduce of ones over the process group the gradients went through
     ranks_seen, backend = 1, None
@@ -572,7 +628,8 @@ def main():
         line = compose_line(args=args, world=world, B=B, dt=dt, rank_ms=rank_ms, graphed=graphed, segments=segs, trainer_bf16=trainer.bf16,
                             arithmetic=arithmetic, grad_bytes=trainer.reducer.nbytes, ranks_seen=ranks_seen, backend=backend,
                             rccl_version=rccl_version, logs=logs, allreduce_ms=allreduce_ms, syncbn_ms=syncbn_ms, roofline=roofline, cpu_baseline=cpu,
-                            exact_f32=exact_f32, kernels_file=kernels_file, errors=errors)
+                            exact_f32=exact_f32, kernels_file=kernels_file, errors=errors, dts=dts, deterministic=args.deterministic,
+                            value_deterministic=value_deterministic, peak_mem_gb=peak_mem_gb)
         sys.stderr.flush()
         print(json.dumps(line))
         sys.stdout.flush()

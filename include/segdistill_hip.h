@@ -774,6 +774,23 @@ int sd_linear_nchw_bwd_weight(const void *dY, const void *X, float *dW, float *d
                               void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Overlapping patch embedding as window gather + token GEMM (round 6).
+ * Replaces the nn.Conv2d of OverlapPatchEmbed (mix_transformer.py:185-215: kernel 7 / stride 4 / pad 3 for stage 1, 3 / 2 / 1 for
+ * stages 2-4, followed by flatten(2).transpose(1, 2)): MIOpen's filter-gradient kernels for these shapes accumulate with float atomics and its
+ * deterministic mode (the reference always launches with --deterministic, tools/dist_train.sh:8) falls back to naive kernels, 11x the step.
+ * sd_im2col_tokens gathers the k x k windows of a map x (logical [B, Cin, H, W] with ELEMENT strides sb, sc, sy, sx -- a channels-last view of
+ * tokens or a contiguous NCHW image) into col [B * Ho * Wo][Kp], column (ky * k + kx) * Cin + ci (the order of a channels-last filter),
+ * Kp = k * k * Cin rounded up to a multiple of 8, the surplus columns and the out-of-image taps zero; Ho = (H + 2 pad - k) / stride + 1.
+ * The three products then run on the token-major Linear entry points (sd_linear_fwd* / sd_linear_bwd_data* / sd_linear_wgrad_tn_multi).
+ * sd_col2im_tokens is the transposed gather (the convolution's input gradient from dcol): dx [B][H][W][Cin] contiguous, every element the
+ * fp32 sum, in fixed order, of the <= ceil(k / stride)^2 windows covering it; needs Cin % (16 / element size) == 0 (SD_E_UNSUPPORTED otherwise).
+ * col / dcol / dx 16-byte aligned.  Deterministic, no atomics, no workspace.
+ */
+int sd_im2col_tokens(const void *x, void *col, int dtype, int B, int H, int W, int Cin, long sb, long sc, long sy, long sx, int k, int stride, int pad,
+                     int Ho, int Wo, int Kp, void *stream);
+int sd_col2im_tokens(const void *dcol, void *dx, int dtype, int B, int H, int W, int Cin, int k, int stride, int pad, int Ho, int Wo, int Kp, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Bilinear resize of contiguous NCHW maps, forward and backward (round 3).
  * Replaces F.interpolate(x, size, mode='bilinear', align_corners) as the reference's networks call it through
  * mmseg/ops/wrappers.py:6-28 -- PSPHead's pooled branches (psp_head.py:52-58), UPerHead's top-down path and level fusion

@@ -39,6 +39,8 @@ SIGNATURES = {
     'sd_cgd_kl_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'sd_cgd_kl_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'sd_cgd_kl_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'sd_im2col_tokens': (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _i, _i, _i, _vp]),
+    'sd_col2im_tokens': (_i, [_vp, _vp, _i] + [_i] * 10 + [_vp]),
     'sd_linear_wgrad_tn_slabs': (_i, [C.c_long, _i, _i]),
     'sd_linear_wgrad_tn': (_i, [_vp, _vp, _vp, _sz, C.c_long, _i, _i, _i, _vp]),
     'sd_ppm_pool_supported': (_i, [_i, _i, _vp, _i]),

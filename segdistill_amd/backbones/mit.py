@@ -282,6 +282,11 @@ class OverlapPatchEmbed(nn.Module):
 
     def forward(self, x):
         p = self.proj
+        from .. import patch_embed as hip_pe
+        if hip_pe.supported(x, p):
+            # MI355X path (csrc/patch_embed.hip): window gather + token GEMM -- deterministic filter gradients, the output already token-major
+            tokens, hw = hip_pe.patch_embed_tokens(x, p)
+            return self.norm(tokens), hw
         if (x.is_cuda and torch.is_autocast_enabled() and p.weight.dtype == torch.float32 and not p.weight.requires_grad
                 and (p.bias is None or not p.bias.requires_grad) and not (p._forward_hooks or p._forward_pre_hooks)):
             # frozen network under low-precision storage (the config-5 teacher): autocast would cast filter and bias again on every call --

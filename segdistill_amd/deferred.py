@@ -28,6 +28,63 @@ _dw_wgrads = []  # depth-wise 3x3 filter gradients whose partials launch is defe
 _side = {}     # device index -> the side stream the weight-gradient kernels of a scope run on
 _held = []     # operands of side-stream launches, kept alive until the join (so the allocator cannot hand their memory out earlier)
 _forked = None  # the side stream with un-joined work, if any
+_held_ptrs = set()   # storages of the operands a scope keeps alive for its deferred launches (dY / X of every registered weight gradient)
+_held_bytes = 0
+partial_flushes = 0  # diagnostic: how many times a scope ran its grouped launches early because the budget below was reached
+
+# deferring the weight-gradient GEMMs keeps every Linear's dY and saved X (and every depth-wise convolution's x / dy) alive until the
+# scope ends, where rounds 2-4 freed them as the backward progressed.  The budget bounds that: once the registered operands exceed it, the
+# grouped launches registered SO FAR run at once (their results are only read after the scope's combine, so an early launch is always valid)
+# and the operands are released.  Default: 1/8 of the device memory (36 GB on MI355X; config 2 holds 1.9 GB, config 5 3.3 GB: never reached
+# by the BASELINE configs).  SEGDISTILL_WGRAD_HELD_MB overrides it (0: flush at every registration = the pre-round-5 memory profile).
+_HELD_BUDGET_MB = os.environ.get('SEGDISTILL_WGRAD_HELD_MB')
+
+
+def held_budget_bytes(device=None):
+    if _HELD_BUDGET_MB is not None:
+        return int(float(_HELD_BUDGET_MB) * (1 << 20))
+    try:
+        return torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).total_memory // 8
+    except Exception:  # noqa: BLE001 -- no GPU (CPU tests of the bookkeeping)
+        return 1 << 62
+
+
+def held_bytes():
+    return _held_bytes
+
+
+def _note_held(*tensors):
+    """Account the operands a registration keeps alive; when the scope's budget is reached, run the grouped launches registered so far."""
+    global _held_bytes
+    for t in tensors:
+        if t is None:
+            continue
+        try:
+            key = t.untyped_storage().data_ptr()
+            nbytes = t.untyped_storage().nbytes()
+        except Exception:  # noqa: BLE001
+            key, nbytes = t.data_ptr(), t.numel() * t.element_size()
+        if key not in _held_ptrs:
+            _held_ptrs.add(key)
+            _held_bytes += nbytes
+    if _held_bytes > held_budget_bytes(tensors[0].device if tensors and tensors[0].is_cuda else None):
+        global partial_flushes
+        partial_flushes += 1
+        flush_operands()
+
+
+def flush_operands():
+    """Run every deferred launch that holds operands (weight-gradient GEMMs, depth-wise filter partials, column-sum partials) NOW; their slab
+    combines stay with the scope's exit.  Safe at any point inside a scope: nobody reads these gradients before the scope ends."""
+    global _held_bytes
+    if _wgrads:
+        _flush_wgrads()
+    if _dw_wgrads:
+        _flush_dw_wgrads()
+    if _colsums:
+        _flush_colsums()
+    _held_ptrs.clear()
+    _held_bytes = 0
 
 
 class _ColsumJob(C.Structure):
@@ -76,7 +133,9 @@ def add_wgrad(dy2, x2, M, N, with_bias=False):
     with_bias = bool(with_bias)
     out = torch.empty(M * N + (M if with_bias else 0), dtype=torch.float32, device=dy2.device)
     _wgrads.append((dy2, x2, out, int(dy2.shape[0]), int(M), int(N), with_bias))
-    return out[:M * N].view(M, N), (out[M * N:] if with_bias else None)
+    views = out[:M * N].view(M, N), (out[M * N:] if with_bias else None)
+    _note_held(dy2, x2)
+    return views
 
 
 def _flush_wgrads():
@@ -114,6 +173,7 @@ def add_dw_wgrad(x, dy, ws, B, H, W, Cc):
     """The partials launch of a depth-wise 3 x 3 filter gradient (csrc/dwconv.hip), deferred: all of a scope's run as ONE launch when it ends
     (the caller registers the combine of `ws` with add() as before)."""
     _dw_wgrads.append((x, dy, ws, int(B), int(H), int(W), int(Cc)))
+    _note_held(x, dy)
 
 
 def _flush_dw_wgrads():
@@ -169,23 +229,23 @@ def join():
     _held.clear()
 
 
+def _flush_colsums():
+    global _colsums
+    pend, _colsums = _colsums, []
+    for dt in {p[0].dtype for p in pend}:          # one batched partials launch per storage type
+        group = [p for p in pend if p[0].dtype == dt]
+        arr = (_ColsumJob * len(group))()
+        for k, (x, part, out, rows, Cc, nblk) in enumerate(group):
+            arr[k].x, arr[k].partials, arr[k].rows, arr[k].C = x.data_ptr(), part.data_ptr(), rows, Cc
+        _lib.check(_lib.lib().sd_multi_colsum_partials(C.cast(arr, C.c_void_p), len(group), _DT[dt], _stream_ptr()), 'sd_multi_colsum_partials')
+    for (x, part, out, rows, Cc, nblk) in pend:
+        _jobs.append((part, out, Cc, nblk))
+
+
 def flush():
-    global _jobs, _colsums
+    global _jobs
     join()
-    if _wgrads:
-        _flush_wgrads()
-    if _dw_wgrads:
-        _flush_dw_wgrads()
-    if _colsums:
-        pend, _colsums = _colsums, []
-        for dt in {p[0].dtype for p in pend}:          # one batched partials launch per storage type
-            group = [p for p in pend if p[0].dtype == dt]
-            arr = (_ColsumJob * len(group))()
-            for k, (x, part, out, rows, Cc, nblk) in enumerate(group):
-                arr[k].x, arr[k].partials, arr[k].rows, arr[k].C = x.data_ptr(), part.data_ptr(), rows, Cc
-            _lib.check(_lib.lib().sd_multi_colsum_partials(C.cast(arr, C.c_void_p), len(group), _DT[dt], _stream_ptr()), 'sd_multi_colsum_partials')
-        for (x, part, out, rows, Cc, nblk) in pend:
-            _jobs.append((part, out, Cc, nblk))
+    flush_operands()
     if not _jobs:
         return
     jobs, _jobs = _jobs, []
@@ -213,6 +273,8 @@ def scope():
         _colsums.clear()
         _wgrads.clear()
         _dw_wgrads.clear()
+        _held_ptrs.clear()
+        globals()['_held_bytes'] = 0
 
 
 def column_sum(x2d, defer_ok=True):
@@ -230,6 +292,7 @@ def column_sum(x2d, defer_ok=True):
         # nothing at all is launched now: the matrix is kept alive and its columns are summed, together with everybody else's, when the
         # scope ends (one partials launch + the shared combine) -- the per-layer launch leaves the backward's critical chain
         _colsums.append((x2d, part, out, rows, Cc, nblk))
+        _note_held(x2d)
         # hand out a VIEW: autograd's AccumulateGrad keeps ("steals") a gradient tensor only if nobody else references that tensor
         # object, and clones it otherwise -- a clone taken before the flush would freeze the not-yet-written values.  The job list holds
         # `out`; a view is its own tensor object on the same storage.  (Every deferring op returns views of its job's buffer.)

@@ -51,6 +51,18 @@ def test_line_is_short_and_carries_the_contract_fields():
     assert d['roofline']['frac'] == 0.8052 and d['roofline']['kernels_file'] == 'gpurun_out/bench_kernels.json'
     assert 'model' not in d['config'] and d['vs_baseline'] is None and d['dtype'] == 'f32'
     assert 'kernels' not in d['roofline']       # the per-family table lives in the side file only
+    assert 'value_min' not in d                 # one timed region: no spread fields
+
+
+def test_median_of_three_regions_and_the_deterministic_figure_ride_along():
+    d = _line(dt=0.221, dts=[0.225, 0.219, 0.221], value_deterministic=801.2, allreduce_exposed_ms=0.05, allreduce_ms=0.2)
+    assert len(json.dumps(d)) < 3500
+    assert d['value'] == round(8 * 20 / 0.221, 3) and d['timed_regions'] == 3
+    assert d['value_min'] == round(8 * 20 / 0.225, 3) and d['value_max'] == round(8 * 20 / 0.219, 3)
+    assert d['value_min'] <= d['value'] <= d['value_max']
+    assert d['config']['value_deterministic'] == 801.2 and 'deterministic' not in d['config']
+    assert d['config']['grad_allreduce_exposed_ms'] == 0.05
+    assert _line(deterministic=True)['config']['deterministic'] is True
 
 
 def test_multi_rank_line_explains_itself():
@@ -72,7 +84,7 @@ def test_main_prints_exactly_one_stdout_line_and_children_run_before_the_gpu_is_
     assert len(to_stdout) == 1 and 'json.dumps(line)' in ast.unparse(to_stdout[0])
     # every child-process leg sits above the first call that initialises HIP in the parent
     first_gpu = min(n.lineno for n in ast.walk(main) if isinstance(n, ast.Call) and ast.unparse(n.func) in ('init_distributed', 'torch.cuda.set_device'))
-    for name in ('kernel_roofline_entries', 'exact_f32_child'):
+    for name in ('kernel_roofline_entries', 'exact_f32_child', 'deterministic_child'):
         calls = [n.lineno for n in ast.walk(main) if isinstance(n, ast.Call) and getattr(n.func, 'id', None) == name]
         assert calls and max(calls) < first_gpu, name
 

@@ -189,3 +189,25 @@ def test_depthwise_filter_gradients_grouped_equal_the_single_launches(dtype):
         ref = torch.nn.grad.conv2d_weight(x.double().transpose(1, 2).reshape(B, C, H, W), (C, 1, 3, 3), gy.double().transpose(1, 2).reshape(B, C, H, W),
                                           padding=1, groups=C)
         assert float((wa.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) * (1 if dtype == torch.float32 else 4)
+
+
+def test_held_operand_budget_flushes_early_and_changes_no_bit(monkeypatch):
+    """the operands a scope keeps alive for its grouped launches are bounded (deferred.held_budget_bytes); past the budget the launches
+    registered so far run at once.  A zero budget (every registration flushes = rounds 2-4's memory profile) must give the very same bits for the
+    one-split products and fp64-grade values for all, and the bookkeeping must return to zero when the scope ends."""
+    from segdistill_amd import deferred
+    dev = torch.device('cuda:0')
+    shapes = SHAPES[:10]
+    ops = _operands(dev, shapes, seed=3)
+    before = deferred.partial_flushes
+    a = _grouped(ops, shapes)
+    assert deferred.partial_flushes == before and deferred.held_bytes() == 0          # the default budget is never reached here
+    monkeypatch.setattr(deferred, '_HELD_BUDGET_MB', '64')
+    b = _grouped(ops, shapes)
+    assert deferred.partial_flushes > before and deferred.held_bytes() == 0
+    for (dy, x), (T, M, N), (dw, db), (dw2, db2) in zip(ops, shapes, a, b):
+        ref = dy.double().t() @ x.double()
+        scale = float(ref.abs().max()) + 1e-12
+        assert float((dw2.double() - ref).abs().max()) <= 2e-5 * scale * max(1.0, (T / 4096) ** 0.5), (T, M, N)
+        assert float((dw2.double() - dw.double()).abs().max()) <= 2e-5 * scale * max(1.0, (T / 4096) ** 0.5)
+        assert torch.allclose(db, db2, rtol=1e-5, atol=1e-4)
