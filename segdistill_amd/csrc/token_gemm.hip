@@ -227,7 +227,19 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
         if (BT) store_ktile<BN>(fbt, buf + A_ELEMS);
         else store_ntile<BN>(fbn, buf + A_ELEMS);
     };
+#ifdef SD_DIAG_NOPROLOGUE
+    // diagnostic A/B build only (tools/gemm_nosplit_probe.py; WRONG numerics): the first tile's operands are NOT requested and not waited for --
+    // the time this build saves is an upper bound on what a persistent tile loop can buy by requesting the next tile's first operands under the
+    // current tile's epilogue (profiles/r06_gemm_noprologue_probe.txt: 3.5 %)
+    if constexpr (BFRAG) {
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) fa.v[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+    } else {
+        load_tiles(0);
+    }
+#else
     load_tiles(0);
+#endif
     if (FULLK && !BFRAG) wait_loads();
     if (!BFRAG) {
         store_tiles(lds);
@@ -388,8 +400,13 @@ __global__ __launch_bounds__(256) void token_gemm_f32(const float *__restrict__ 
         // 56.1 vs 46.9 at 320 -> 1280 over 8192; the lower-priority wave's split instructions starve and its own MFMAs start late.)
         APl PA0, PA1;
         BPl B0, B1;
+#ifdef SD_DIAG_NOPROLOGUE
+#pragma unroll
+        for (int j = 0; j < TN; ++j) B0.h[j] = B0.m[j] = B0.l[j] = bf16x8{};
+#else
         load_b(B0, 0);                                  // (the A tile of step 0 was requested above)
         wait_vm(std::integral_constant<int, 0>{});
+#endif
         store_tiles(lds);
         if (nk > 1) load_tiles(BK);                     // A(1): consumed in the middle of step 0
         __syncthreads();

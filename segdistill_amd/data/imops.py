@@ -18,12 +18,14 @@ def rescale_size(old_wh, scale):
 
 
 def _linear_taps(n_out, n_in):
-    """cv2 INTER_LINEAR sampling: src = (dst + 0.5) * n_in / n_out - 0.5; left of the first centre -> tap 0 with weight 0, right of the last ->
-    the last sample."""
-    s = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5
+    """cv2 INTER_LINEAR sampling as OpenCV 4.x computes it (imgproc/resize.cpp, restated from the published source -- cv2 is not in this image, so
+    NOT verified against it): scale = 1 / (n_out / n_in) in double, fx = (float)((dst + 0.5) * scale - 0.5), sx = floor(fx), fx -= sx in float32;
+    left of the first centre -> tap 0 with weight 0; at or right of the last sample -> the last sample with weight 0 (a + b = 2048 exactly there)."""
+    scale = 1.0 / (n_out / n_in)
+    s = ((np.arange(n_out, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
     i0 = np.floor(s).astype(np.int64)
-    lam = s - i0
-    lam = np.where(i0 < 0, 0.0, lam)            # cv2: sx < 0 -> fx = 0, sx = 0
+    lam = (s - i0.astype(np.float32)).astype(np.float32)
+    lam = np.where((i0 < 0) | (i0 >= n_in - 1), np.float32(0.0), lam)
     i0 = np.clip(i0, 0, n_in - 1)
     i1 = np.clip(i0 + 1, 0, n_in - 1)
     return i0, i1, lam
@@ -95,12 +97,13 @@ def _resize_linear_u8(img, y0, y1, ly, x0, x1, lx):
       horizontal    R[y][X] = S[y][x0] * a_X + S[y][x1] * b_X                                        (int32, no shift)
       vertical      D[Y][X] = (((c_Y * (R[y0][X] >> 4)) >> 16) + ((d_Y * (R[y1][X] >> 4)) >> 16) + 2) >> 2
     Integer numpy throughout: ~4x faster than the float64 form it replaces (the training feed resizes every image, local_configs/_base_/datasets/
-    ade20k_repeat.py:7-18), and bit-exact to what the reference's pipeline computes on the same JPEG."""
-    scale = float(1 << _COEF_BITS)
+    ade20k_repeat.py:7-18).  Restated from the published algorithm, not verified against cv2: a one-LSB difference on rare pixels cannot be ruled out."""
+    scale = np.float32(1 << _COEF_BITS)             # float32 throughout, as cbuf[] / saturate_cast<short>(cbuf * INTER_RESIZE_COEF_SCALE) are
+    lx, ly = lx.astype(np.float32), ly.astype(np.float32)
     bx = np.rint(lx * scale).astype(np.int32)
-    ax = np.rint((1.0 - lx) * scale).astype(np.int32)
+    ax = np.rint((np.float32(1.0) - lx) * scale).astype(np.int32)
     by = np.rint(ly * scale).astype(np.int32)
-    ay = np.rint((1.0 - ly) * scale).astype(np.int32)
+    ay = np.rint((np.float32(1.0) - ly) * scale).astype(np.int32)
     src = img if img.ndim == 3 else img[:, :, None]
     r_lo, r_hi = (int(y0.min()), int(y1.max()) + 1) if len(y0) else (0, 0)         # source rows this window reads
     s32 = src[r_lo:r_hi].astype(np.int32)

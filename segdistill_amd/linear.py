@@ -121,13 +121,20 @@ def linear_fwd_bf16(x, w, b=None):
     return F.linear(x, w, b if b is None or b.dtype == x.dtype else b.to(x.dtype))
 
 
+# Stand-alone the library is ahead at 256 input features (62.0 vs 73.6 us over 131072 tokens, profiles/r06_tok_dx_bench.txt), but INSIDE the config-5
+# step the kernel is not behind (753.0 with it vs 746.8 / 749.1 imgs/s with the library, same box, profiles/r06_ab_cfg5_tok_dx.txt): it stays.
+_TOK_DX_MAX_IN = int(os.environ.get('SEGDISTILL_TOK_DX_MAX_IN', '256'))     # A/B: 128 = the library for config 5's projection shape
+
+
 def linear_bwd_data_bf16(dy2, wc):
-    """dX [T, in] = dY [T, out] . W [out, in] for bf16 operands (the align projection's input gradient): csrc/align_tok.hip's tok_dx_kernel for the
-    projection's shapes (in <= 256), the library otherwise."""
+    """dX [T, in] = dY [T, out] . W [out, in] for bf16 operands (the align projection's input gradient).  MEASURED dispatch
+    (tools/tok_dx_bench.py on MI355X, profiles/r06_tok_dx_bench.txt): csrc/align_tok.hip's tok_dx_kernel for the projection's shapes (768 -> 64:
+    13-39 us against the library's 23-42, 768 -> 128: 18-47 vs 23-47; 768 -> 256: 73.6 vs 62.0 stand-alone, level inside the step), the library
+    otherwise."""
     T, M = dy2.shape
     N = wc.shape[1]
     L = _lib.lib()
-    if (dy2.is_cuda and dy2.dtype == torch.bfloat16 and wc.dtype == torch.bfloat16 and dy2.is_contiguous() and wc.is_contiguous()
+    if (_TOK_DX_MAX_IN >= N and dy2.is_cuda and dy2.dtype == torch.bfloat16 and wc.dtype == torch.bfloat16 and dy2.is_contiguous() and wc.is_contiguous()
             and L.sd_align_cgd_tok_supported(N, M) and dy2.data_ptr() % 16 == 0 and wc.data_ptr() % 16 == 0):
         dx = torch.empty(T, N, dtype=torch.bfloat16, device=dy2.device)
         _lib.check(L.sd_linear_tok_bf16_bwd_data(dy2.data_ptr(), wc.data_ptr(), dx.data_ptr(), T, M, N, _stream_ptr()), 'sd_linear_tok_bf16_bwd_data')

@@ -179,10 +179,13 @@ def test_bf16_generic_weight_gradient_defers_its_combine(T, M, N):
 
 
 @pytest.mark.parametrize('scoped', [True, False])
-def test_patch_embed_conv_bias_gradient_through_the_column_sum_pass(scoped):
+def test_patch_embed_conv_bias_gradient_through_the_column_sum_pass(scoped, monkeypatch):
     """backbones/mit.py::_ConvDeferredBias: the patch-embed convolution whose bias gradient is a column sum of the channels-last incoming gradient
-    (batched with the Linears' inside a deferred scope) -- against nn.Conv2d's own backward: same input gradient, filter and bias gradients to rounding."""
-    from segdistill_amd import deferred
+    (batched with the Linears' inside a deferred scope) -- against nn.Conv2d's own backward: same input gradient, filter and bias gradients to rounding.
+    Round 6: this is the path BEHIND the window-gather + token-GEMM form (csrc/patch_embed.hip, tests/test_patch_embed_gpu.py), taken when that form is
+    switched off or the projection is tapped -- so it is switched off here."""
+    from segdistill_amd import deferred, patch_embed
+    monkeypatch.setattr(patch_embed, '_ENABLED', False)
     from segdistill_amd.backbones import mit
     dev = torch.device('cuda:0')
     torch.manual_seed(2)

@@ -55,6 +55,21 @@ def test_deterministic_switch_makes_graph_replay_bit_identical():
     assert 'deterministic=True steps=5: 0 of' in r.stdout, r.stdout[-1000:]
 
 
+@pytest.mark.parametrize('cfg', ['cfg2_segformer_b2_b0_cgd', 'cfg5_segformer_b4_b1_multistage_bf16'])
+def test_default_step_is_bit_identical_without_the_switch(cfg):
+    """Round 6: no MIOpen convolution is left in the SegFormer configs' step (the patch embeddings are window gather + token GEMM,
+    csrc/patch_embed.hip), so two runs from one seed agree bit for bit WITHOUT --deterministic -- the reference needs the switch
+    (tools/dist_train.sh:8) and pays for it with MIOpen's naive kernels."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'determinism_probe.py'), '--config', os.path.join(root, 'configs', 'kd', cfg + '.py'),
+                        '--size', '256', '--steps', '5'], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'deterministic=False steps=5: 0 of' in r.stdout, r.stdout[-1000:]
+
+
 @pytest.mark.parametrize('mode', ['full', 'hybrid', 'eager_prefetch'])
 def test_graph_replay_matches_eager(mode):
     from segdistill_amd.engine import KDTrainer, SyntheticADE
@@ -98,8 +113,16 @@ def test_graph_replay_matches_eager(mode):
     # of a normalisation (the head's linear_c*.proj.bias before linear_fuse's BatchNorm, and backbone.norm4.bias feeding only linear_c4): what
     # arrives there is rounding noise (|g| ~ 1e-9 next to 1e-3 for the weights), AdamW normalises it to full-size steps of noise-determined sign,
     # and the hybrid mode's graphed backbone sums its weight gradients in another order than the eager step's grouped launches (round 5)
-    pairs = [(a, b) for a, b in zip(ref.student.parameters(), gra.student.parameters()) if a.grad is None or float(a.grad.abs().max()) > 1e-7]
-    assert len(pairs) >= len(list(ref.student.parameters())) - 8
+    # The exclusion is BY NAME (a magnitude threshold would silently drop a real divergence in a small-gradient parameter), and the named
+    # gradients are checked to be noise next to their layer's weight gradient.
+    zero_grad = {f'decode_head.linear_c{i}.proj.bias' for i in (1, 2, 3, 4)} | {'backbone.norm4.bias'}
+    named_r, named_g = dict(ref.student.named_parameters()), dict(gra.student.named_parameters())
+    assert zero_grad <= set(named_r)
+    for n in zero_grad:
+        w = named_r[n.replace('.bias', '.weight')]
+        if named_r[n].grad is not None and w.grad is not None:
+            assert float(named_r[n].grad.abs().max()) <= 1e-4 * float(w.grad.abs().max()) + 1e-7, n
+    pairs = [(named_r[n], named_g[n]) for n in named_r if n not in zero_grad]
     num = sum(float((a - b).pow(2).sum()) for a, b in pairs)
     den = sum(float(a.pow(2).sum()) for a, _ in pairs)
     assert (num / den) ** 0.5 < 3e-4
