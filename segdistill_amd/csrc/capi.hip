@@ -33,6 +33,7 @@ int sd_set_tunable(const char *key, int value) {
     if (rc == SD_E_UNSUPPORTED) rc = sd::headfuse_tunable(key, 1, value);
     if (rc == SD_E_UNSUPPORTED) rc = sd::wgrad_tn_tunable(key, 1, value);
     if (rc == SD_E_UNSUPPORTED) rc = sd::tok_gemm_bf16_tunable(key, 1, value);
+    if (rc == SD_E_UNSUPPORTED) rc = sd::align_stream_tunable(key, 1, value);
     return rc;
 }
 
@@ -46,6 +47,7 @@ int sd_get_tunable(const char *key) {
     if (rc == SD_E_UNSUPPORTED) rc = sd::headfuse_tunable(key, 0, 0);
     if (rc == SD_E_UNSUPPORTED) rc = sd::wgrad_tn_tunable(key, 0, 0);
     if (rc == SD_E_UNSUPPORTED) rc = sd::tok_gemm_bf16_tunable(key, 0, 0);
+    if (rc == SD_E_UNSUPPORTED) rc = sd::align_stream_tunable(key, 0, 0);
     return rc;
 }
 

@@ -27,6 +27,9 @@ int ce_tunable(const char *key, int set, int v);
 int headfuse_tunable(const char *key, int set, int v);
 int wgrad_tn_tunable(const char *key, int set, int v);
 int tok_gemm_bf16_tunable(const char *key, int set, int v);
+int align_stream_tunable(const char *key, int set, int v);
+// the NCHW align projection's forward for Cs <= 128 with W resident in registers (align_stream.hip); SD_E_UNSUPPORTED: not its shape
+int align_f32_fwd_stream(const float *X, const float *W, const float *bias, float *Y, int B, int Cs, int Ct, long P, hipStream_t st);
 // token-major -> class-planes Linear, fp32 (token_gemm.hip); the dtype-dispatching C entry points live in align1x1.hip
 size_t linear_nchw_workspace_bytes(int B, long P, int in_features, int out_features);
 int pred_splits(int B, long P);

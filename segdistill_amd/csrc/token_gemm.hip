@@ -1025,6 +1025,11 @@ int dispatch(const float *A, const float *Bm, float *C, const float *bias, const
 int g_align_split_bf16 = 1;   // tunable "align_split_bf16": the three align products in split-bf16 arithmetic (same error bound as f32 MFMA)
 
 int align_f32_fwd(const float *X, const float *W, const float *bias, float *Y, int B, int Cs, int Ct, long P, hipStream_t st) {
+    if (g_align_split_bf16) {
+        // short reductions (Cs <= 128): the streaming kernel with W resident in registers (csrc/align_stream.hip); SD_E_UNSUPPORTED = not its shape
+        const int rc = align_f32_fwd_stream(X, W, bias, Y, B, Cs, Ct, P, st);
+        if (rc != SD_E_UNSUPPORTED) return rc;
+    }
     if (g_align_split_bf16 && Cs % 32 == 0)
         return launch_epi<128, 128, 2, 2, false, 0, true, true, true>(W, X, Y, bias, nullptr, Ct, (int)P, Cs, Cs, P, P, st, B, 0L, (long)Cs * P,
                                                                       (long)Ct * P);

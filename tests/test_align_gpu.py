@@ -56,6 +56,44 @@ def test_align1x1_fwd_bwd(case, dtype):
     assert _err(bg.grad, db_ref) < 2e-5
 
 
+@pytest.mark.parametrize('case', [(8, 128, 512, 64, 64),     # BASELINE config 4: [8,128,64,64] -> 512 channels
+                                  (2, 128, 512, 10, 10),     # a ragged last pixel tile (P = 100 = 64 + 36), one tile per workgroup
+                                  (3, 48, 200, 12, 20),      # K = 48 (three k-steps), channel count not a multiple of 32 / 128
+                                  (1, 16, 32, 2, 2),         # one pixel group
+                                  (2, 96, 160, 36, 36)])     # P = 1296 = 20 tiles + 16 pixels
+def test_streaming_forward_matches_fp64_and_the_generic_kernel(case):
+    """csrc/align_stream.hip (round 6): the forward with W resident in registers, through the C ABI -- against fp64 (bound of the exact-f32 path)
+    and against the generic pipelined GEMM it replaces (tunable align_stream = 0): same split-bf16 arithmetic, different summation order."""
+    from segdistill_amd import _lib
+    L = _lib.lib()
+    B, Cs, Ct, h, w = case
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(Cs * 7 + Ct)
+    x = torch.randn(B, Cs, h, w, generator=g).to(dev)
+    wt = (torch.randn(Ct, Cs, generator=g) / Cs ** 0.5).to(dev)
+    b = torch.randn(Ct, generator=g).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    assert L.sd_get_tunable(b'align_stream') == 1
+    try:
+        for flag in (1, 0):
+            assert L.sd_set_tunable(b'align_stream', flag) == 0
+            y = torch.full((B, Ct, h, w), float('nan'), device=dev)
+            assert L.sd_align1x1_fwd(x.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), 0, B, Cs, Ct, h, w, st) == 0
+            torch.cuda.synchronize()
+            outs.append(y)
+    finally:
+        L.sd_set_tunable(b'align_stream', 1)
+    ref = F.conv2d(x.double(), wt.double()[:, :, None, None], b.double())
+    assert not torch.isnan(outs[0]).any()
+    assert _err(outs[0], ref) < 2e-5 and _err(outs[1], ref) < 2e-5
+    assert _err(outs[0], outs[1].double()) < 1e-5
+    # no bias: the accumulators start from zero
+    y = torch.empty(B, Ct, h, w, device=dev)
+    assert L.sd_align1x1_fwd(x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), 0, B, Cs, Ct, h, w, st) == 0
+    assert _err(y, F.conv2d(x.double(), wt.double()[:, :, None, None])) < 2e-5
+
+
 def test_align1x1_asymmetric_identity():
     """A = I with an asymmetric B catches a transposed C write (cdna guide, MFMA section)."""
     from segdistill_amd.align import align1x1
