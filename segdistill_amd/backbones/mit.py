@@ -44,6 +44,10 @@ def _mit_init(m):
             m.bias.data.zero_()
 
 
+# batch slices the deep stages (3, 4) of a FROZEN encoder are cut into (MixVisionTransformer.forward_features); A/B: SEGDISTILL_DEEP_CHUNKS=1
+DEEP_CHUNKS = int(os.environ.get('SEGDISTILL_DEEP_CHUNKS', '2'))
+_DEEP_CHUNKS_F32 = os.environ.get('SEGDISTILL_DEEP_CHUNKS_F32', '0') == '1'      # A/B: the slices under fp32 storage too
+
 _LN_PATCHES = True      # test hook: False = the SR path gathers its patches with a copy (the general path)
 
 
@@ -362,16 +366,72 @@ class MixVisionTransformer(nn.Module):
         for i, b in enumerate(active):
             b._dp_pending = [table[2 * i], table[2 * i + 1]]
 
+    def _stage(self, s, x):
+        x, hw = getattr(self, f'patch_embed{s}')(x)
+        x = _run_stage(x, hw, list(getattr(self, f'block{s}')), getattr(self, f'norm{s}'))
+        return x, hw
+
+    def _deep_stages_observed(self):
+        """True when a hook sits on any module of stages 3-4 (a tap there must see ONE call with the whole batch)."""
+        cached = getattr(self, '_deep_mods', None)
+        if cached is None:
+            cached = [m for s in (3, 4) for top in (getattr(self, f'patch_embed{s}'), getattr(self, f'block{s}'), getattr(self, f'norm{s}'))
+                      for m in top.modules()]
+            object.__setattr__(self, '_deep_mods', cached)
+        return any(m._forward_hooks or m._forward_pre_hooks for m in cached)
+
     def forward_features(self, x):
         feats = []
         self._draw_drop_path(x)
+        # MI355X (round 6): a FROZEN encoder (no graph to build: the teacher) runs its deep stages -- 2048-8192 tokens per kernel, 5-15 us each,
+        # most of the 256 CUs idle -- as DEEP_CHUNKS concurrent chains over slices of the batch, each on a stream forked from / joined into the
+        # calling one (inside a capture: parallel branches of the hipGraph).  Per-image arithmetic: nothing in these stages mixes images.
+        # MEASURED (profiles/r06_ab_deep_chunks.txt, same box): config 5 (bf16 storage, 30 + 2 deep blocks of the B4 teacher) 735 -> 759 imgs/s with
+        # two slices; config 2 (fp32, B2 teacher) 792 -> 778: at half the tokens the fp32 Linears fall out of the split-bf16 planes kernels'
+        # dispatch (linear._gemm_mode) -- so fp32 storage keeps one chain; four slices lose everywhere (559 / 642).
+        n = DEEP_CHUNKS
+        split = (n > 1 and x.is_cuda and not torch.is_grad_enabled() and not self.training and x.shape[0] % n == 0 and x.shape[0] >= 2 * n
+                 and (torch.is_autocast_enabled() or _DEEP_CHUNKS_F32) and not self._deep_stages_observed())
         for s in range(1, 5):
-            x, hw = getattr(self, f'patch_embed{s}')(x)
-            x = _run_stage(x, hw, list(getattr(self, f'block{s}')), getattr(self, f'norm{s}'))
+            if split and s == 3:
+                break
+            x, hw = self._stage(s, x)
             # logically [B,C,H,W] like the reference (:340,:347,...), but as a channels-last VIEW of the tokens on the GPU:
             # the next stage's conv and the head consume it without the two transpose copies per stage
             x = nchw_view_of_tokens(x, hw) if x.is_cuda else x.reshape(x.shape[0], hw[0], hw[1], -1).permute(0, 3, 1, 2).contiguous()
             feats.append(x)
+        if not split:
+            return feats
+        cur = torch.cuda.current_stream(x.device)
+        streams = getattr(self, '_chunk_streams', None)
+        if streams is None or len(streams) < n - 1 or streams[0].device != x.device:
+            streams = [torch.cuda.Stream(device=x.device) for _ in range(n - 1)]
+            object.__setattr__(self, '_chunk_streams', streams)
+        fork = torch.cuda.Event()
+        fork.record(cur)
+        outs, joins = [], []
+        for i, piece in enumerate(x.chunk(n)):
+            st = cur if i == 0 else streams[i - 1]
+            if i:
+                st.wait_event(fork)
+            with torch.cuda.stream(st):
+                toks = []
+                y = piece
+                for s in (3, 4):
+                    t, hw = self._stage(s, y)
+                    toks.append((t, hw))
+                    y = nchw_view_of_tokens(t, hw)
+                outs.append(toks)
+                if i:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    joins.append(ev)
+        for ev in joins:
+            cur.wait_event(ev)
+        for k in range(2):
+            for o in outs[1:]:
+                o[k][0].record_stream(cur)            # allocated on a slice's stream, read by the concatenation on the calling one
+            feats.append(nchw_view_of_tokens(torch.cat([o[k][0] for o in outs], 0), outs[0][k][1]))
         return feats
 
     def forward(self, x):
