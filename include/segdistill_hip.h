@@ -426,26 +426,6 @@ int sd_linear_bwd_data(const void *dY, const float *W, long w_row_stride, void *
                        int mode, void *stream);
 
 /* ---------------------------------------------------------------------------
- * Forward of a Linear with a LONG reduction axis and a small output: Y [rows][out] (fp32) = X [rows][in] . W[out][in]^T + bias.
- * Used for the SR-attention spatial reduction (mix_transformer.py:86-88,112-116: Conv2d(dim, dim, r, stride=r) ==
- * Linear over r*r*dim patch features, in = up to 4096, out = dim, rows = B*256): the reduction axis is split over
- * workgroups (f32 MFMA partial slabs in `workspace`, deterministic combine that also adds the bias).
- */
-size_t sd_linear_longk_workspace_bytes(int rows, int out_features, int in_features);
-
-int sd_linear_longk_fwd(const void *X, const float *W, const float *bias /* or NULL */, float *Y, int dtype,
-                        int rows, int out_features, int in_features,
-                        void *workspace, size_t workspace_bytes, void *stream);
-
-/* The same product with the patch gather folded into the kernel: X is the token-major image [B, H*Wd, channels] (fp32), row
- * (b, py, px) of the implied [B*(H/r)*(Wd/r), r*r*channels] operand is the r x r patch at (py*r, px*r) in (ky, kx, channel)
- * order -- what mix_transformer.py:112-116 feeds its strided conv, without materialising the patch matrix.  W [out, r*r*channels]
- * in the same order.  Workspace: sd_linear_longk_workspace_bytes(B*(H/r)*(Wd/r), out_features, r*r*channels).
- * SD_E_UNSUPPORTED unless H % r == Wd % r == 0 and (r*channels) % 16 == 0. */
-int sd_linear_patch_fwd(const float *X, const float *W, const float *bias /* or NULL */, float *Y, int B, int H, int Wd, int channels, int r,
-                        int out_features, void *workspace, size_t workspace_bytes, void *stream);
-
-/* ---------------------------------------------------------------------------
  * Depth-wise 3x3 convolution (stride 1, zero pad 1) on TOKEN-MAJOR activations [B, H*W, C]: the
  * DWConv inside every MiT Mix-FFN (mix_transformer.py:376-387: transpose to NCHW ->
  * nn.Conv2d(dim, dim, 3, 1, 1, groups=dim) -> flatten/transpose back; called from Mlp.forward :48-55).

@@ -106,9 +106,6 @@ SIGNATURES = {
     'sd_linear_wgrad_splitk_slabs': (_i, [C.c_long, _i, _i]),
     'sd_linear_wgrad_splitk': (_i, [_vp, _vp, _vp, _sz, C.c_long, _i, _i, _vp]),
     'sd_linear_wgrad_workspace_bytes': (_sz, [C.c_long, _i, _i]),
-    'sd_linear_longk_workspace_bytes': (_sz, [_i, _i, _i]),
-    'sd_linear_longk_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
-    'sd_linear_patch_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     'sd_linear_wgrad_fuses_bias': (_i, [C.c_long, _i, _i]),
     'sd_linear_wgrad_fuses_bias_dtype': (_i, [_i, C.c_long, _i, _i]),
     'sd_linear_wgrad': (_i, [_vp, _vp, _vp, _vp, _i, C.c_long, _i, _i, _vp, _sz, _vp]),

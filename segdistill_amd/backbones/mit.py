@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from ..builder import BACKBONES
 from ..layers import DropPath, frozen_derived, nchw_view_of_tokens, tokens_of, trunc_normal_
 from ..layernorm import (HipLayerNorm, add_layernorm, add_layernorm_patches, add_layernorm_supported, layernorm_patches, patch_supported)
-from ..linear import call_linear, longk_linear, patch_linear_forward, patch_linear_supported
+from ..linear import call_linear, sr_patch_linear
 
 
 def _mit_init(m):
@@ -125,8 +125,7 @@ class SRAttention(nn.Module):
         (csrc/layernorm.hip, patch form) and its backward gathers the patch-order gradient -- no gather copy, no scatter copy + add."""
         conv = getattr(self, 'sr', None)
         return (_LN_PATCHES and self.sr_ratio > 1 and not (conv._forward_hooks or conv._forward_pre_hooks)
-                and conv.weight.is_contiguous(memory_format=torch.channels_last) and patch_supported(x, hw, self.sr_ratio)
-                and not patch_linear_supported(x, hw, self.sr_ratio, conv.weight))
+                and conv.weight.is_contiguous(memory_format=torch.channels_last) and patch_supported(x, hw, self.sr_ratio))
 
     def _spatial_reduce(self, x, hw, patches=None):
         """The SR conv has kernel == stride == r, i.e. it is a Linear over non-overlapping r x r patches.  On token-major
@@ -139,17 +138,14 @@ class SRAttention(nn.Module):
             return conv(x.transpose(1, 2).reshape(b, c, H, W)).flatten(2).transpose(1, 2)
         cl = conv.weight.is_contiguous(memory_format=torch.channels_last)
         if patches is not None:          # already gathered by the LayerNorm that produced x
-            return longk_linear(patches, conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c), conv.bias, weight_is_view=True)
-        if cl and patch_linear_supported(x, hw, r, conv.weight):
-            # frozen network: the gather happens inside the GEMM's operand staging (csrc/align1x1.hip: gemm_nt_patch), no patch copy
-            return patch_linear_forward(x, hw, r, conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c), conv.bias)
+            return sr_patch_linear(patches, conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c), conv.bias, weight_is_view=True)
         patches = x.reshape(b, H // r, r, W // r, r, c).permute(0, 1, 3, 2, 4, 5).reshape(b, (H // r) * (W // r), r * r * c)
         # (ky, kx, cin) order to match the patches; the re-layout is cached for a frozen network
         if cl:
             w2 = conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c)     # a view: the storage already has this order
-            return longk_linear(patches, w2, conv.bias, weight_is_view=True)
+            return sr_patch_linear(patches, w2, conv.bias, weight_is_view=True)
         w2 = frozen_derived(conv.weight, 'sr_patch', lambda: conv.weight.permute(0, 2, 3, 1).reshape(conv.out_channels, r * r * c).contiguous())
-        return longk_linear(patches, w2, conv.bias)
+        return sr_patch_linear(patches, w2, conv.bias)
 
     def forward(self, x, hw, patches=None):
         from .. import sra as hip_sra

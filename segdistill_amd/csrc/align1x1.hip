@@ -64,18 +64,11 @@ __device__ __forceinline__ void stage(float (*dst)[PITCH], const T *__restrict__
     }
 }
 
-// Row m of a GATHERED A operand is a non-overlapping r x r patch of a token-major image [B][H][W][c] (the MiT spatial-reduction conv,
-// kernel == stride == r, as a Linear): `seg` = r*c consecutive elements per image row of the patch, r such runs `seg_stride` = W*c apart.
-struct PatchMap {
-    int seg, rows_per_image, patches_per_row;
-    long seg_stride, image_stride, patch_row_stride, patch_col_stride;
-};
-
 // C_z[M x N] (+)= A_z . B_z over k in [k_begin, k_end);  z = blockIdx.z = batch*nsplit + split.
-template <typename TA, typename TB, typename TC, bool A_KMAJOR, bool B_KMAJOR, bool GATHER_A = false>
+template <typename TA, typename TB, typename TC, bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256) void gemm_mfma_f32(const TA *__restrict__ A, const TB *__restrict__ B, TC *__restrict__ C,
                                                       const float *__restrict__ bias, int M, int N, int K, long lda, long ldb, long ldc,
-                                                      long strideA, long strideB, long strideC, int nsplit, int klen, PatchMap pm = PatchMap{}) {
+                                                      long strideA, long strideB, long strideC, int nsplit, int klen) {
     __shared__ float As[BK][PITCH];
     __shared__ float Bs[BK][PITCH];
     const int z = blockIdx.z, batch = z / nsplit, split = z - batch * nsplit;
@@ -100,26 +93,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32(const TA *__restrict__ A, c
     // issuing f32 MFMAs on zero padding would make a 32x32 weight gradient MFMA-bound instead of HBM-bound)
     const bool am0 = m0 + wm < M, am1 = m0 + wm + 32 < M;
     const bool bn0 = n0 + wn < N, bn1 = n0 + wn + 32 < N;
-    // GATHER_A (X-major A only): this thread's staging row (t/2) starts at its patch origin; a BK-aligned k run never leaves a segment
-    long a_row_off = 0;
-    if constexpr (GATHER_A) {
-        static_assert(!A_KMAJOR, "gathered A is X-major");
-        const int m = min(m0 + (int)(threadIdx.x >> 1), M - 1);
-        const int img = m / pm.rows_per_image, rem = m - img * pm.rows_per_image;
-        const int py = rem / pm.patches_per_row, px = rem - py * pm.patches_per_row;
-        a_row_off = (long)img * pm.image_stride + (long)py * pm.patch_row_stride + (long)px * pm.patch_col_stride;
-    }
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        if constexpr (GATHER_A) {
-            const int x = threadIdx.x >> 1, kb = (threadIdx.x & 1) * 8;
-            const bool xin = (m0 + x) < M;
-            const int k = k0 + kb, sg = k / pm.seg;
-            const TA *row = A + a_row_off + (long)sg * pm.seg_stride + (k - sg * pm.seg);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) As[kb + i][x] = (xin && k + i < k_end) ? ld1<TA>(row + i) : 0.f;
-        } else {
-            stage<TA, A_KMAJOR>(As, A, lda, m0, M, k0, k_end);
-        }
+        stage<TA, A_KMAJOR>(As, A, lda, m0, M, k0, k_end);
         stage<TB, B_KMAJOR>(Bs, B, ldb, n0, N, k0, k_end);
         __syncthreads();
         if (am0 && bn0) {
@@ -666,53 +641,6 @@ __global__ __launch_bounds__(256) void slab_reduce_bias(const float *__restrict_
     }
 }
 
-int longk_splits(int M, int N, int K) {
-    const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    long nsplit = 512 / tiles;
-    if (nsplit > K / 64) nsplit = K / 64;
-    return (int)(nsplit < 1 ? 1 : nsplit);
-}
-
-template <typename T>
-int gemm_nt_longk(const void *X, const void *W, const float *bias, float *Y, void *ws, size_t ws_bytes, int M, int N, int K, hipStream_t st) {
-    int nsplit = longk_splits(M, N, K);
-    const int klen = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
-    nsplit = (K + klen - 1) / klen;
-    const long slab = (long)M * N;
-    if (ws_bytes < (size_t)nsplit * slab * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
-    float *slabs = static_cast<float *>(ws);
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nsplit);
-    launch_gemm<T, float, float, false, false>(grid, st, (const T *)X, (const float *)W, slabs, nullptr, M,
-                       N, K, (long)K, (long)K, (long)N, 0L, 0L, slab, nsplit, klen);
-    hipLaunchKernelGGL(slab_reduce_bias, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, slabs, Y, bias, slab, nsplit, N);
-    return (int)hipGetLastError();
-}
-
-// Y[rows x N] = patches(X) . W[N x K]^T + bias, rows = B*(H/r)*(Wd/r), K = r*r*c in (ky, kx, channel) order; X token-major [B][H*Wd][c].
-// The same split-K protocol as gemm_nt_longk with the patch gather folded into the A staging (no [rows x K] copy of the activations).
-int gemm_nt_patch(const float *X, const float *W, const float *bias, float *Y, void *ws, size_t ws_bytes, int B, int H, int Wd, int c, int r, int N,
-                  hipStream_t st) {
-    const int M = B * (H / r) * (Wd / r), K = r * r * c;
-    int nsplit = longk_splits(M, N, K);
-    const int klen = ((K + nsplit - 1) / nsplit + BK - 1) / BK * BK;
-    nsplit = (K + klen - 1) / klen;
-    const long slab = (long)M * N;
-    if (ws_bytes < (size_t)nsplit * slab * sizeof(float) || (reinterpret_cast<uintptr_t>(ws) & 15)) return SD_E_WORKSPACE;
-    float *slabs = static_cast<float *>(ws);
-    PatchMap pm;
-    pm.seg = r * c;
-    pm.rows_per_image = (H / r) * (Wd / r);
-    pm.patches_per_row = Wd / r;
-    pm.seg_stride = (long)Wd * c;
-    pm.image_stride = (long)H * Wd * c;
-    pm.patch_row_stride = (long)r * Wd * c;
-    pm.patch_col_stride = (long)r * c;
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nsplit);
-    hipLaunchKernelGGL((gemm_mfma_f32<float, float, float, false, false, true>), grid, dim3(256), 0, st, X, W, slabs, (const float *)nullptr, M, N, K,
-                       (long)K, (long)K, (long)N, 0L, 0L, slab, nsplit, klen, pm);
-    hipLaunchKernelGGL(slab_reduce_bias, dim3((unsigned)((slab + 15) / 16)), dim3(256), 0, st, slabs, Y, bias, slab, nsplit, N);
-    return (int)hipGetLastError();
-}
 
 int check_align(const void *a, const void *b, const void *c, int dtype, int B, int Cs, int Ct, int h, int w) {
     if (!a || !b || !c) return SD_E_NULL;
@@ -737,29 +665,6 @@ size_t sd_linear_wgrad_workspace_bytes(long tokens, int out_features, int in_fea
     const sd::WgradPlan p = sd::linear_wgrad_plan(tokens, out_features, in_features), q = sd::linear_wgrad_plan(tokens, out_features, in_features, true);
     const int nslabs = p.nslabs > q.nslabs ? p.nslabs : q.nslabs;    // either storage type
     return (size_t)nslabs * ((size_t)out_features * in_features + out_features) * sizeof(float) + 16;
-}
-
-size_t sd_linear_longk_workspace_bytes(int rows, int out_features, int in_features) {
-    if (rows <= 0 || out_features <= 0 || in_features <= 0) return 0;
-    return (size_t)sd::longk_splits(rows, out_features, in_features) * rows * out_features * sizeof(float) + 16;
-}
-
-int sd_linear_longk_fwd(const void *X, const float *W, const float *bias, float *Y, int dtype, int rows, int out_features, int in_features,
-                        void *workspace, size_t workspace_bytes, void *stream) {
-    if (!X || !W || !Y || !workspace) return SD_E_NULL;
-    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
-    if (rows <= 0 || out_features <= 0 || in_features <= 0) return SD_E_SHAPE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == SD_F32) return sd::gemm_nt_longk<float>(X, W, bias, Y, workspace, workspace_bytes, rows, out_features, in_features, st);
-    return sd::gemm_nt_longk<sd::bf16_t>(X, W, bias, Y, workspace, workspace_bytes, rows, out_features, in_features, st);
-}
-
-int sd_linear_patch_fwd(const float *X, const float *W, const float *bias, float *Y, int B, int H, int Wd, int channels, int r, int out_features,
-                        void *workspace, size_t workspace_bytes, void *stream) {
-    if (!X || !W || !Y || !workspace) return SD_E_NULL;
-    if (B <= 0 || H <= 0 || Wd <= 0 || channels <= 0 || r <= 0 || out_features <= 0) return SD_E_SHAPE;
-    if (H % r || Wd % r || (r * channels) % 16) return SD_E_UNSUPPORTED;     // whole patches; a 16-element k run stays inside one patch row
-    return sd::gemm_nt_patch(X, W, bias, Y, workspace, workspace_bytes, B, H, Wd, channels, r, out_features, static_cast<hipStream_t>(stream));
 }
 
 size_t sd_linear_nchw_workspace_bytes(int B, long P, int in_features, int out_features) {

@@ -1,8 +1,10 @@
 """nn.Linear on token-major activations.  Forward and input gradient: the measured three-way dispatch of `_gemm_mode` below (csrc/token_gemm.hip
 in split-bf16 or exact-f32 arithmetic, or the library GEMM); weight gradient dW = dY^T . X -- tall-skinny at the high-resolution MiT stages,
-where the library kernels ran 30x off the HBM roofline (profiles/r01_train_step_kernels_*.txt) -- by the split-K MFMA kernel
-(csrc/align1x1.hip: sd_linear_wgrad) with its slabs combined by the deferred batched reduction; the class-plane `linear_pred`
-(sd_linear_nchw_*) and the optional long-K / patch forms live here too."""
+where the library kernels ran 30x off the HBM roofline (profiles/r01_train_step_kernels_*.txt) -- by the grouped launches of csrc/wgrad_tn.hip /
+the split-K MFMA kernel (csrc/align1x1.hip: sd_linear_wgrad) with the slabs combined by the deferred batched reduction; the class-plane
+`linear_pred` (sd_linear_nchw_*) lives here too.  (Rounds 1-5 carried two opt-in forms of the SR conv -- a split-K long-K forward and the patch
+gather folded into the GEMM's staging -- and a library switch for the bf16 weight gradients; all three measured slower in the step
+(docs/history) and were removed in round 6.)"""
 from __future__ import annotations
 
 import os
@@ -15,14 +17,6 @@ from .ops import _DT, _stream_ptr
 
 MIN_TOKENS = 1     # every training Linear: below 8192 tokens dW is the library's GEMM, but the bias gradient still avoids ATen's
                    # memset + multi-block sum(0) pair (deferred.column_sum)
-# A/B on MI355X (config 2, same box, 30 steps): 19.9 ms/step with the split-K kernel vs 19.4 ms with the library GEMM -- the
-# library's un-split 64-workgroup kernel is slow in isolation (183 us) but leaves the chip to the concurrently running
-# student/teacher stream, while the split-K version occupies all CUs.  Kept as an opt-in (SEGDISTILL_LONGK=1).
-_LONGK_ENABLED = os.environ.get('SEGDISTILL_LONGK') == '1'
-# The frozen network's SR conv with the patch gather inside the GEMM (patch_linear_forward) removes the [rows, r*r*C] copy, but as a split-K
-# kernel it hits the same wall: A/B on MI355X (config 2, same box, 30 steps, twice): 659.5 / 662.8 imgs/s with it, 670.8 / 671.3 without.
-# Opt-in (SEGDISTILL_PATCH_GEMM=1).
-_PATCH_GEMM = os.environ.get('SEGDISTILL_PATCH_GEMM') == '1'
 
 
 # Forward and input gradient of fp32 Linears: the library GEMM, or the kernels of csrc/token_gemm.hip in one of two arithmetic modes.
@@ -142,7 +136,6 @@ def linear_bwd_data_bf16(dy2, wc):
     return dy2 @ wc
 
 
-_BF16_WGRAD_LIB = os.environ.get('SEGDISTILL_BF16_WGRAD_LIB', '0') == '1'
 # A/B: 0 = the bias gradient of the transposed-read fp32 weight gradients from the batched column-sum pass (a second read of dY) instead of riding along
 # in their slabs.  Config 2, same box: 793.2 - 795.5 imgs/s with it, 787.0 / 787.1 without (profiles/r04_ab_cfg2_tn_fused_bias.txt)
 _TN_FUSED_BIAS = os.environ.get('SEGDISTILL_TN_FUSED_BIAS', '1') == '1'
@@ -179,112 +172,147 @@ def lowp_copy(t, dt):
     return val
 
 
+class _WgradCall:
+    """One weight-gradient product dW [M, N] = dy^T . x over T tokens, with what its caller allows (plan_weight_grad -> a launch below)."""
+    __slots__ = ('x', 'dy', 'T', 'M', 'N', 'w_dtype', 'want_db', 'defer_ok', 'defer_bias_ok', 'n_tn', 'n_splitk', 'n_generic', 'direct')
+
+
+def plan_weight_grad(c):
+    """The kernel family that computes this product -- the MEASURED order of preference (profiles/r0N_wgrad_*bench.txt, r05_ab_cfg*_wgrad_grouped):
+       'grouped'    registered with the backward's grouped launches (csrc/wgrad_tn.hip *_multi): fp32 and bf16 leaves inside a deferred scope
+       'tn'         one launch of the transposed-read split-bf16 kernel (fp32, out_features >= 128 over many tokens)
+       'splitk'     fp32, few tokens or a large weight: split-K on the pipelined MFMA kernel     'library'  what is left of those
+       'direct'     the tall-skinny exact-f32 kernel with its slabs left to the scope's combine
+       'generic'    bf16 storage outside the grouped launch: the generic split-K plan, slabs to the scope's combine
+       'oneshot'    sd_linear_wgrad with its own combine (no scope, or gradients that are read at once)"""
+    L = _lib.lib()
+    f32 = c.x.dtype == torch.float32 and c.w_dtype == torch.float32
+    if (_SPLIT_BF16 and _FP32_WGRAD_GROUPED and f32 and c.defer_ok and (c.defer_bias_ok or not c.want_db)
+            and deferred.wgrad_groupable(c.dy, c.x, c.M, c.N)):
+        return 'grouped'
+    if _SPLIT_BF16 and f32 and c.dy.data_ptr() % 16 == 0 and c.x.data_ptr() % 16 == 0:
+        c.n_tn = L.sd_linear_wgrad_tn_slabs(c.T, c.M, c.N)
+        if c.n_tn:
+            return 'tn'
+    c.direct = bool(L.sd_linear_wgrad_fuses_bias_dtype(_DT[c.x.dtype], c.T, c.M, c.N))
+    if not c.direct and c.x.dtype == torch.float32:
+        c.n_splitk = L.sd_linear_wgrad_splitk_slabs(c.T, c.M, c.N) if _SPLITK_WGRAD and c.w_dtype == torch.float32 else 0
+        return 'splitk' if c.n_splitk else 'library'
+    if c.direct and c.defer_ok and deferred.enabled() and c.w_dtype == torch.float32:
+        return 'direct'
+    if (not c.direct and c.defer_ok and c.w_dtype == torch.float32 and c.x.dtype == torch.bfloat16
+            and deferred.wgrad_groupable(c.dy, c.x, c.M, c.N)):
+        return 'grouped'
+    c.n_generic = 0 if c.direct else L.sd_linear_wgrad_generic_slabs(_DT[c.x.dtype], c.T, c.M, c.N)
+    if c.n_generic and c.defer_ok and deferred.enabled() and c.w_dtype == torch.float32:
+        return 'generic'
+    return 'oneshot'
+
+
+def _wg_grouped(c):
+    # not even the GEMM runs now: the scope's grouped launches compute every such gradient, their k-splits planned over all of them; the bias
+    # gradient rides along in the slabs when the caller lets it wait as well (no second pass over dY)
+    if c.x.dtype == torch.float32 or (c.want_db and c.defer_bias_ok):
+        return deferred.add_wgrad(c.dy, c.x, c.M, c.N, with_bias=c.want_db)
+    dw, _ = deferred.add_wgrad(c.dy, c.x, c.M, c.N)
+    return dw, (deferred.column_sum(c.dy, c.defer_bias_ok) if c.want_db else None)
+
+
+def _wg_tn(c):
+    # the tall-skinny products with out_features >= 128 (the SegFormer head over 131072 tokens) on transposed LDS reads in split-bf16
+    # arithmetic (csrc/wgrad_tn.hip); the bias gradient rides along as M extra floats per slab (column sums of the staged dY values)
+    L, M, N = _lib.lib(), c.M, c.N
+    fuse_db = c.want_db and _TN_FUSED_BIAS
+    slab = M * N + (M if fuse_db else 0)
+    ws = torch.empty(c.n_tn, slab, dtype=torch.float32, device=c.x.device)
+    _lib.check(L.sd_linear_wgrad_tn(c.dy.data_ptr(), c.x.data_ptr(), ws.data_ptr(), ws.numel() * 4, c.T, M, N, int(fuse_db), _stream_ptr()),
+               'sd_linear_wgrad_tn')
+    buf = torch.empty(slab, dtype=torch.float32, device=c.x.device)
+    if c.defer_ok and deferred.enabled() and (c.defer_bias_ok or not fuse_db):
+        deferred.add(ws, buf, slab, c.n_tn)
+    else:
+        deferred.reduce_now(ws, buf, slab, c.n_tn)
+    db = buf[M * N:] if fuse_db else (deferred.column_sum(c.dy, c.defer_bias_ok) if c.want_db else None)
+    return buf[:M * N].view(M, N), db
+
+
+def _wg_splitk(c):
+    # fewer than 8192 tokens or a weight of more than 16 64x64 regions: split-K over the tokens on the pipelined MFMA kernel, slabs combined by the
+    # deferred batched pass -- the library ran these on ~100 workgroups of 32 x 32 tiles (63 us for 1024 x 256 over 2048 tokens)
+    L, M, N = _lib.lib(), c.M, c.N
+    ws = torch.empty(c.n_splitk, M * N, dtype=torch.float32, device=c.x.device)
+    _lib.check(L.sd_linear_wgrad_splitk(c.dy.data_ptr(), c.x.data_ptr(), ws.data_ptr(), ws.numel() * 4, c.T, M, N, _stream_ptr()), 'sd_linear_wgrad_splitk')
+    buf = torch.empty(M * N, dtype=torch.float32, device=c.x.device)
+    if c.defer_ok and deferred.enabled():
+        deferred.add(ws, buf, M * N, c.n_splitk)
+    else:
+        deferred.reduce_now(ws, buf, M * N, c.n_splitk)
+    db = deferred.column_sum(c.dy, c.defer_bias_ok and c.w_dtype == torch.float32).to(c.w_dtype) if c.want_db else None
+    return buf.view(M, N), db
+
+
+def _wg_library(c):
+    dw = (c.dy.t() @ c.x).to(c.w_dtype)
+    db = deferred.column_sum(c.dy, c.defer_bias_ok and c.w_dtype == torch.float32).to(c.w_dtype) if c.want_db else None
+    return dw, db
+
+
+def _wg_direct(c):
+    # tall-skinny plan inside a deferred scope, gradients going straight to fp32 leaf parameters: the split-K slabs stay in the workspace,
+    # the scope's exit combines them together with everybody else's (segdistill_amd/deferred.py)
+    L, M, N, x2, dyc = _lib.lib(), c.M, c.N, c.x, c.dy
+    fuse_b = c.want_db
+    slab = M * N + (M if fuse_b else 0)
+    buf = torch.empty(slab, dtype=torch.float32, device=x2.device)
+    wsb = L.sd_linear_wgrad_workspace_bytes(c.T, M, N)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x2.device)
+    deferred.side_launch(lambda: _lib.check(L.sd_linear_wgrad_partials(dyc.data_ptr(), x2.data_ptr(), _DT[x2.dtype], c.T, M, N, int(fuse_b),
+                                                                        ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_wgrad_partials'),
+                         dyc, x2, ws)
+    deferred.add(ws, buf, slab, L.sd_linear_wgrad_slabs(_DT[x2.dtype], c.T, M, N))
+    return buf[:M * N].view(M, N), (buf[M * N:] if fuse_b else None)
+
+
+def _wg_generic(c):
+    # the generic split-K plan (bf16 storage) inside a deferred scope: its slab combine joins the batched pass at the end of the backward
+    L, M, N = _lib.lib(), c.M, c.N
+    ws = torch.empty(c.n_generic, M * N, dtype=torch.float32, device=c.x.device)
+    _lib.check(L.sd_linear_wgrad_generic_partials(c.dy.data_ptr(), c.x.data_ptr(), _DT[c.x.dtype], c.T, M, N, ws.data_ptr(), ws.numel() * 4,
+                                                  _stream_ptr()), 'sd_linear_wgrad_generic_partials')
+    buf = torch.empty(M * N, dtype=torch.float32, device=c.x.device)
+    deferred.add(ws, buf, M * N, c.n_generic)
+    return buf.view(M, N), (deferred.column_sum(c.dy, c.defer_bias_ok) if c.want_db else None)
+
+
+def _wg_oneshot(c):
+    L, M, N = _lib.lib(), c.M, c.N
+    fuse_b = c.want_db and c.direct
+    dw32 = torch.empty(M, N, dtype=torch.float32, device=c.x.device)
+    db32 = torch.empty(M, dtype=torch.float32, device=c.x.device) if fuse_b else None
+    wsb = L.sd_linear_wgrad_workspace_bytes(c.T, M, N)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=c.x.device)
+    _lib.check(L.sd_linear_wgrad(c.dy.data_ptr(), c.x.data_ptr(), dw32.data_ptr(), None if db32 is None else db32.data_ptr(),
+                                 _DT[c.x.dtype], c.T, M, N, ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_wgrad')
+    return dw32.to(c.w_dtype), (db32.to(c.w_dtype) if fuse_b else None)
+
+
+_WGRAD_LAUNCH = {'grouped': _wg_grouped, 'tn': _wg_tn, 'splitk': _wg_splitk, 'library': _wg_library, 'direct': _wg_direct, 'generic': _wg_generic,
+                 'oneshot': _wg_oneshot}
+
+
 def linear_weight_grads(x, dy2, w_shape, w_dtype, want_db, defer_ok, defer_bias_ok):
     """dW [out, in] (fp32 slabs combined at once or by the deferred pass) and, when it rides along or is cheap to take here, the bias gradient of a
-    token-major Linear: x [..., in] as saved by the forward, dy2 [tokens, out] in x's dtype.  -> (dw, db or None)."""
-    dw = db = None
+    token-major Linear: x [..., in] as saved by the forward, dy2 [tokens, out] in x's dtype.  -> (dw, db or None: the caller then sums dy2's
+    columns itself).  Two steps: plan_weight_grad picks the kernel family, _WGRAD_LAUNCH[plan] runs it."""
+    c = _WgradCall()
     x2 = x.reshape(-1, x.shape[-1])
-    if not x2.is_contiguous():
-        x2 = x2.contiguous()
-    dyc = dy2 if dy2.is_contiguous() else dy2.contiguous()
-    T, M, N = x2.shape[0], w_shape[0], w_shape[1]
-    L = _lib.lib()
-    if (_SPLIT_BF16 and _FP32_WGRAD_GROUPED and x.dtype == torch.float32 and w_dtype == torch.float32 and defer_ok and (defer_bias_ok or not want_db)
-            and deferred.wgrad_groupable(dyc, x2, M, N)):
-        # round 5: every fp32 weight gradient of the backward (the transposed-read split-bf16 ones, the tall-skinny exact-f32 ones, the split-K
-        # and library ones of the few-token stages) joins the scope's grouped launches (one per tile width), bias sums riding along in the slabs
-        return deferred.add_wgrad(dyc, x2, M, N, with_bias=want_db)
-    ns_tn = 0
-    if (_SPLIT_BF16 and x.dtype == torch.float32 and w_dtype == torch.float32 and dyc.data_ptr() % 16 == 0
-            and x2.data_ptr() % 16 == 0):
-        ns_tn = L.sd_linear_wgrad_tn_slabs(T, M, N)
-    if ns_tn:
-        # round 4: the tall-skinny products with out_features >= 128 (the SegFormer head over 131072 tokens) on transposed LDS reads in
-        # split-bf16 arithmetic (csrc/wgrad_tn.hip) instead of the exact-f32 tall-skinny kernel; slabs combined by the deferred pass
-        # the bias gradient rides along as M extra floats per slab (column sums of the staged dY values): no second pass over dY
-        fuse_db = want_db and _TN_FUSED_BIAS
-        slab = M * N + (M if fuse_db else 0)
-        ws = torch.empty(ns_tn, slab, dtype=torch.float32, device=x.device)
-        _lib.check(L.sd_linear_wgrad_tn(dyc.data_ptr(), x2.data_ptr(), ws.data_ptr(), ws.numel() * 4, T, M, N, int(fuse_db), _stream_ptr()),
-                   'sd_linear_wgrad_tn')
-        buf = torch.empty(slab, dtype=torch.float32, device=x.device)
-        if defer_ok and deferred.enabled() and (defer_bias_ok or not fuse_db):
-            deferred.add(ws, buf, slab, ns_tn)
-        else:
-            deferred.reduce_now(ws, buf, slab, ns_tn)
-        db = buf[M * N:] if fuse_db else (deferred.column_sum(dyc, defer_bias_ok) if want_db else None)
-        return buf[:M * N].view(M, N), db
-    direct = bool(L.sd_linear_wgrad_fuses_bias_dtype(_DT[x.dtype], T, M, N))
-    if not direct and x.dtype == torch.float32:
-        # fewer than 8192 tokens or a weight of more than 16 64x64 regions: no longer tall-skinny.  Round 3: split-K over the tokens
-        # on the pipelined MFMA kernel (sd_linear_wgrad_splitk), slabs combined by the deferred batched pass -- the library ran
-        # these on ~100 workgroups of 32 x 32 tiles (63 us for 1024 x 256 over 2048 tokens; profiles/r03_step_shapes.txt)
-        ns = L.sd_linear_wgrad_splitk_slabs(T, M, N) if _SPLITK_WGRAD and w_dtype == torch.float32 else 0
-        if ns:
-            ws = torch.empty(ns, M * N, dtype=torch.float32, device=x.device)
-            _lib.check(L.sd_linear_wgrad_splitk(dyc.data_ptr(), x2.data_ptr(), ws.data_ptr(), ws.numel() * 4, T, M, N, _stream_ptr()),
-                       'sd_linear_wgrad_splitk')
-            buf = torch.empty(M * N, dtype=torch.float32, device=x.device)
-            if defer_ok and deferred.enabled():
-                deferred.add(ws, buf, M * N, ns)
-            else:
-                deferred.reduce_now(ws, buf, M * N, ns)
-            dw = buf.view(M, N)
-        else:
-            dw = (dyc.t() @ x2).to(w_dtype)
-        db = deferred.column_sum(dyc, defer_bias_ok and w_dtype == torch.float32).to(w_dtype) if want_db else None
-        return dw, db
-    fuse_b = want_db and direct
-    if direct and defer_ok and deferred.enabled() and w_dtype == torch.float32:
-        # tall-skinny plan inside a deferred scope, gradients going straight to fp32 leaf parameters: leave the split-K slabs
-        # in the workspace, the scope's exit combines them together with everybody else's (segdistill_amd/deferred.py)
-        slab = M * N + (M if fuse_b else 0)
-        buf = torch.empty(slab, dtype=torch.float32, device=x.device)
-        wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-        deferred.side_launch(lambda: _lib.check(L.sd_linear_wgrad_partials(dyc.data_ptr(), x2.data_ptr(), _DT[x.dtype], T, M, N, int(fuse_b),
-                                                                            ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_wgrad_partials'),
-                             dyc, x2, ws)
-        deferred.add(ws, buf, slab, L.sd_linear_wgrad_slabs(_DT[x.dtype], T, M, N))
-        dw = buf[:M * N].view(M, N)
-        if fuse_b:
-            db = buf[M * N:]
-        elif want_db:
-            db = deferred.column_sum(dyc, defer_bias_ok)
-        return dw, db
-    if not direct and _BF16_WGRAD_LIB and x.dtype == torch.bfloat16:
-        # A/B switch: the library's bf16 GEMM for the generic (not tall-skinny) weight gradients under bf16 storage.  Measured on MI355X,
-        # config 5, same box: 515 imgs/s with it against 638 / 636 with the split-K kernel + deferred combine -- off by default
-        dw = (dyc.t() @ x2).to(w_dtype)
-        db = deferred.column_sum(dyc, defer_bias_ok and w_dtype == torch.float32).to(w_dtype) if want_db else None
-        return dw, db
-    if not direct and defer_ok and w_dtype == torch.float32 and x.dtype == torch.bfloat16 and deferred.wgrad_groupable(dyc, x2, M, N):
-        # round 5: not even the GEMM runs now -- the scope's ONE grouped launch computes every such gradient, its k-splits planned over all of them
-        if want_db and defer_bias_ok:       # the bias gradient rides along in the slabs (no second pass over dY)
-            return deferred.add_wgrad(dyc, x2, M, N, with_bias=True)
-        dw, _ = deferred.add_wgrad(dyc, x2, M, N)
-        return dw, (deferred.column_sum(dyc, defer_bias_ok) if want_db else None)
-    gs = 0 if direct else L.sd_linear_wgrad_generic_slabs(_DT[x.dtype], T, M, N)
-    if gs and defer_ok and deferred.enabled() and w_dtype == torch.float32:
-        # the generic split-K plan (bf16 storage: most Linears of config 5) inside a deferred scope: its slab combine joins the batched
-        # pass at the end of the backward instead of running as one more launch per layer (54 of them per config-5 step)
-        ws = torch.empty(gs, M * N, dtype=torch.float32, device=x.device)
-        _lib.check(L.sd_linear_wgrad_generic_partials(dyc.data_ptr(), x2.data_ptr(), _DT[x.dtype], T, M, N, ws.data_ptr(), ws.numel() * 4,
-                                                      _stream_ptr()), 'sd_linear_wgrad_generic_partials')
-        buf = torch.empty(M * N, dtype=torch.float32, device=x.device)
-        deferred.add(ws, buf, M * N, gs)
-        db = deferred.column_sum(dyc, defer_bias_ok) if want_db else None
-        return buf.view(M, N), db
-    dw32 = torch.empty(M, N, dtype=torch.float32, device=x.device)
-    db32 = torch.empty(M, dtype=torch.float32, device=x.device) if fuse_b else None
-    wsb = L.sd_linear_wgrad_workspace_bytes(T, M, N)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-    _lib.check(L.sd_linear_wgrad(dyc.data_ptr(), x2.data_ptr(), dw32.data_ptr(), None if db32 is None else db32.data_ptr(),
-                                 _DT[x.dtype], T, M, N, ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_wgrad')
-    dw = dw32.to(w_dtype)
-    if fuse_b:
-        db = db32.to(w_dtype)
-    return dw, db
+    c.x = x2 if x2.is_contiguous() else x2.contiguous()
+    c.dy = dy2 if dy2.is_contiguous() else dy2.contiguous()
+    c.T, c.M, c.N = c.x.shape[0], w_shape[0], w_shape[1]
+    c.w_dtype, c.want_db, c.defer_ok, c.defer_bias_ok = w_dtype, want_db, defer_ok, defer_bias_ok
+    c.n_tn = c.n_splitk = c.n_generic = 0
+    c.direct = False
+    return _WGRAD_LAUNCH[plan_weight_grad(c)](c)
 
 
 class _TokenLinear(torch.autograd.Function):
@@ -349,38 +377,6 @@ def call_linear(module, x):
     if module._forward_hooks or module._forward_pre_hooks:
         return module(x)
     return token_linear(x, module.weight, module.bias, defer_ok=True)
-
-
-class _LongKLinear(torch.autograd.Function):
-    """y = x . W^T + b for a long reduction axis and a small output (SR-attention patch projection): split-K MFMA forward;
-    the two backward products are ordinary library GEMMs."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        x2 = x.reshape(-1, x.shape[-1])
-        if not x2.is_contiguous():
-            x2 = x2.contiguous()
-        w = weight.contiguous()
-        M, K, N = x2.shape[0], x2.shape[1], w.shape[0]
-        L = _lib.lib()
-        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-        wsb = L.sd_linear_longk_workspace_bytes(M, N, K)
-        ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-        b = None if bias is None else bias.detach().float().contiguous()
-        _lib.check(L.sd_linear_longk_fwd(x2.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), _DT[x2.dtype], M, N, K,
-                                         ws.data_ptr(), wsb, _stream_ptr()), 'sd_linear_longk_fwd')
-        ctx.save_for_backward(x2, w)
-        ctx.shape, ctx.has_bias = x.shape, bias is not None
-        return y.to(x.dtype).reshape(*x.shape[:-1], N)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x2, w = ctx.saved_tensors
-        dy2 = dy.reshape(-1, dy.shape[-1])
-        dx = (dy2 @ w).reshape(ctx.shape) if ctx.needs_input_grad[0] else None
-        dw = (dy2.t() @ x2) if ctx.needs_input_grad[1] else None
-        db = deferred.column_sum(dy2.contiguous(), False).to(dy2.dtype) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return dx, dw, db
 
 
 class _LinearToPlanes(torch.autograd.Function):
@@ -448,36 +444,8 @@ def linear_to_planes(x, weight, bias=None):
     return _LinearToPlanes.apply(x, weight, bias)
 
 
-def patch_linear_supported(x, hw, r, weight, enabled=None):
-    """The SR patch projection straight from the tokens (sd_linear_patch_fwd): fp32, no graph to build (the frozen teacher), whole patches."""
-    return ((_PATCH_GEMM if enabled is None else enabled) and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 3 and x.is_contiguous()
-            and not torch.is_autocast_enabled() and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad))
-            and hw[0] % r == 0 and hw[1] % r == 0 and (r * x.shape[-1]) % 16 == 0 and weight.shape[0] <= 512
-            and x.shape[0] * (hw[0] // r) * (hw[1] // r) <= 16384)
-
-
-def patch_linear_forward(x, hw, r, weight, bias=None):
-    """y[b, (py, px), :] = W . patch(x, py, px) + bias for the r x r patches of tokens x [B, H*W, C]; W [out, r*r*C] in (ky, kx, c) order."""
-    B, _, c = x.shape
-    H, W = hw
-    L = _lib.lib()
-    rows, N, K = B * (H // r) * (W // r), weight.shape[0], r * r * c
-    w = weight if weight.is_contiguous() else weight.contiguous()
-    y = torch.empty(B, rows // B, N, dtype=torch.float32, device=x.device)
-    wsb = L.sd_linear_longk_workspace_bytes(rows, N, K)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
-    b = None if bias is None else bias.detach().float().contiguous()
-    _lib.check(L.sd_linear_patch_fwd(x.data_ptr(), w.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), B, H, W, c, r, N, ws.data_ptr(), wsb,
-                                     _stream_ptr()), 'sd_linear_patch_fwd')
-    return y
-
-
-def longk_linear(x, weight, bias=None, weight_is_view=False):
-    """F.linear for in_features >= 1024 with few rows/outputs on the GPU (fp32 weights); otherwise F.linear."""
-    rows = x.numel() // x.shape[-1]
-    if (_LONGK_ENABLED and x.is_cuda and x.dtype in _DT and weight.dtype == torch.float32 and x.shape[-1] >= 1024 and weight.shape[0] <= 512 and rows <= 16384
-            and not torch.is_autocast_enabled()):
-        return _LongKLinear.apply(x, weight, bias)
-    # `weight` is a view of the conv filter (channels-last storage) or the caller's re-laid-out copy of it: the gradient of a copy is read
-    # by the copy's backward at once, so only a view may be deferred; the bias is the leaf itself
-    return token_linear(x, weight, bias, defer_ok=weight_is_view, defer_bias_ok=True)
+def sr_patch_linear(patches, weight, bias=None, weight_is_view=False):
+    """The spatial-reduction conv of the MiT attention (kernel == stride == r: a Linear over r x r patches, mix_transformer.py:86-88,112-116) on
+    the gathered patch matrix.  `weight` is a view of the conv filter (channels-last storage) or the caller's re-laid-out copy of it: the gradient
+    of a copy is read by the copy's backward at once, so only a view may be deferred; the bias is the leaf itself."""
+    return token_linear(patches, weight, bias, defer_ok=weight_is_view, defer_bias_ok=True)

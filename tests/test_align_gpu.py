@@ -214,12 +214,10 @@ def test_token_linear_autograd_matches_f_linear():
         assert _err(a, r) < 1e-4
 
 
-@pytest.mark.parametrize('shape', [(2048, 64, 4096), (2048, 32, 2048), (2048, 128, 2048), (500, 37, 1030), (2048, 320, 1280)])
-def test_longk_linear(shape):
-    """split-K forward of the SR patch projection vs fp64; autograd through it vs F.linear."""
-    from segdistill_amd import linear as lin
-    from segdistill_amd.linear import longk_linear
-    lin._LONGK_ENABLED = True   # opt-in path (off by default, see linear.py)
+@pytest.mark.parametrize('shape', [(2048, 64, 4096), (2048, 32, 2048), (500, 37, 1030), (2048, 320, 1280)])
+def test_sr_patch_linear(shape):
+    """The SR patch projection (a Linear over the gathered r x r patches, reduction axis up to 4096) through token_linear vs fp64, forward and gradients."""
+    from segdistill_amd.linear import sr_patch_linear
     M, N, K = shape
     g = torch.Generator().manual_seed(M + N)
     x = torch.randn(4, M // 4, K, generator=g)
@@ -227,7 +225,7 @@ def test_longk_linear(shape):
     b = torch.randn(N, generator=g)
     dev = torch.device('cuda:0')
     xg, wg, bg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
-    y = longk_linear(xg, wg, bg)
+    y = sr_patch_linear(xg, wg, bg)
     ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
     assert _err(y, ref) < 2e-5
     y.square().mean().backward()

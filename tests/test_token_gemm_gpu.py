@@ -93,32 +93,6 @@ def test_token_linear_autograd_uses_the_kernels_and_matches_torch():
         assert _rel(token_linear(x, w.detach(), b.detach()), y64.detach()) < 3e-6
 
 
-@pytest.mark.parametrize('case', [(2, 64, 64, 32, 8, 32), (1, 32, 48, 64, 4, 64), (2, 16, 16, 320, 2, 320), (8, 128, 128, 64, 8, 64), (1, 24, 8, 40, 2, 24)])
-def test_patch_linear_gathers_inside_the_gemm(case):
-    """sd_linear_patch_fwd (the frozen network's spatial-reduction conv as a Linear over r x r patches, gather folded into the operand staging)
-    against the explicit patch matrix times the weight in fp64, and against the strided Conv2d the reference runs (mix_transformer.py:86-88)."""
-    from segdistill_amd import linear
-    B, H, W, c, r, N = case
-    g = torch.Generator().manual_seed(H * W + c)
-    x = torch.randn(B, H * W, c, generator=g)
-    conv_w = torch.randn(N, c, r, r, generator=g) * (r * r * c) ** -0.5
-    bias = torch.randn(N, generator=g)
-    dev = torch.device('cuda:0')
-    w2 = conv_w.permute(0, 2, 3, 1).reshape(N, r * r * c)
-    xd, wd, bd = x.to(dev), w2.contiguous().to(dev), bias.to(dev)
-    with torch.no_grad():
-        assert linear.patch_linear_supported(xd, (H, W), r, wd, enabled=True)
-        y = linear.patch_linear_forward(xd, (H, W), r, wd, bd)
-    patches = x.double().reshape(B, H // r, r, W // r, r, c).permute(0, 1, 3, 2, 4, 5).reshape(B, -1, r * r * c)
-    ref = patches @ w2.double().t() + bias.double()
-    assert y.shape == ref.shape
-    err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
-    assert err < 2e-6, err
-    conv = torch.nn.functional.conv2d(x.double().transpose(1, 2).reshape(B, c, H, W), conv_w.double(), bias.double(), stride=r)
-    assert float((conv.flatten(2).transpose(1, 2) - ref).abs().max()) < 1e-9
-    assert not linear.patch_linear_supported(xd.clone().requires_grad_(True), (H, W), r, wd, enabled=True)     # a graph to build: the copy route
-
-
 # (.., 256 / 768, 19): <= 32 classes is ONE k-step of the input-gradient product = a single LDS staging buffer, smaller than the row-major
 # epilogue image of wave 3 (round-2 advisor finding: rows 28-31 of its blocks were dropped when in_features > 64)
 @pytest.mark.parametrize('case', [(2, 1024, 256, 150), (1, 4096, 64, 19), (3, 260, 32, 150), (8, 16384, 256, 150), (2, 1024, 256, 19), (1, 512, 768, 19),
