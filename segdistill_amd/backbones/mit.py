@@ -47,6 +47,7 @@ def _mit_init(m):
 # batch slices the deep stages (3, 4) of a FROZEN encoder are cut into (MixVisionTransformer.forward_features); A/B: SEGDISTILL_DEEP_CHUNKS=1
 DEEP_CHUNKS = int(os.environ.get('SEGDISTILL_DEEP_CHUNKS', '2'))
 _DEEP_CHUNKS_F32 = os.environ.get('SEGDISTILL_DEEP_CHUNKS_F32', '0') == '1'      # A/B: the slices under fp32 storage too
+_DEEP_FROM = int(os.environ.get('SEGDISTILL_DEEP_FROM', '2'))          # first sliced stage (measured on config 5: 3 -> 782, 2 -> 790, 1 -> 791, 4 -> 749 imgs/s)
 
 _LN_PATCHES = True      # test hook: False = the SR path gathers its patches with a copy (the general path)
 
@@ -371,7 +372,7 @@ class MixVisionTransformer(nn.Module):
         """True when a hook sits on any module of stages 3-4 (a tap there must see ONE call with the whole batch)."""
         cached = getattr(self, '_deep_mods', None)
         if cached is None:
-            cached = [m for s in (3, 4) for top in (getattr(self, f'patch_embed{s}'), getattr(self, f'block{s}'), getattr(self, f'norm{s}'))
+            cached = [m for s in range(_DEEP_FROM, 5) for top in (getattr(self, f'patch_embed{s}'), getattr(self, f'block{s}'), getattr(self, f'norm{s}'))
                       for m in top.modules()]
             object.__setattr__(self, '_deep_mods', cached)
         return any(m._forward_hooks or m._forward_pre_hooks for m in cached)
@@ -379,7 +380,7 @@ class MixVisionTransformer(nn.Module):
     def forward_features(self, x):
         feats = []
         self._draw_drop_path(x)
-        # MI355X (round 6): a FROZEN encoder (no graph to build: the teacher) runs its deep stages -- 2048-8192 tokens per kernel, 5-15 us each,
+        # MI355X (round 6): a FROZEN encoder (no graph to build: the teacher) runs its deep stages (2-4) -- 2048-32768 tokens per kernel, 5-15 us each,
         # most of the 256 CUs idle -- as DEEP_CHUNKS concurrent chains over slices of the batch, each on a stream forked from / joined into the
         # calling one (inside a capture: parallel branches of the hipGraph).  Per-image arithmetic: nothing in these stages mixes images.
         # MEASURED (profiles/r06_ab_deep_chunks.txt, same box): config 5 (bf16 storage, 30 + 2 deep blocks of the B4 teacher) 735 -> 759 imgs/s with
@@ -389,7 +390,7 @@ class MixVisionTransformer(nn.Module):
         split = (n > 1 and x.is_cuda and not torch.is_grad_enabled() and not self.training and x.shape[0] % n == 0 and x.shape[0] >= 2 * n
                  and (torch.is_autocast_enabled() or _DEEP_CHUNKS_F32) and not self._deep_stages_observed())
         for s in range(1, 5):
-            if split and s == 3:
+            if split and s == _DEEP_FROM:
                 break
             x, hw = self._stage(s, x)
             # logically [B,C,H,W] like the reference (:340,:347,...), but as a channels-last VIEW of the tokens on the GPU:
@@ -413,7 +414,7 @@ class MixVisionTransformer(nn.Module):
             with torch.cuda.stream(st):
                 toks = []
                 y = piece
-                for s in (3, 4):
+                for s in range(_DEEP_FROM, 5):
                     t, hw = self._stage(s, y)
                     toks.append((t, hw))
                     y = nchw_view_of_tokens(t, hw)
@@ -424,7 +425,7 @@ class MixVisionTransformer(nn.Module):
                     joins.append(ev)
         for ev in joins:
             cur.wait_event(ev)
-        for k in range(2):
+        for k in range(5 - _DEEP_FROM):
             for o in outs[1:]:
                 o[k][0].record_stream(cur)            # allocated on a slice's stream, read by the concatenation on the calling one
             feats.append(nchw_view_of_tokens(torch.cat([o[k][0] for o in outs], 0), outs[0][k][1]))

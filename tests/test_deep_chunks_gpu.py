@@ -1,4 +1,4 @@
-"""A frozen MiT encoder runs its deep stages (3, 4) as two concurrent chains over slices of the batch (backbones/mit.py::forward_features, round 6;
+"""A frozen MiT encoder runs its deep stages (2-4) as two concurrent chains over slices of the batch (backbones/mit.py::forward_features, round 6;
 reference mix_transformer.py:336-365 runs the four stages in sequence): same features as the one-chain forward, eager and inside a captured
 hipGraph (the slices become parallel branches), and never when a hook watches a module of those stages or a graph is being built for autograd."""
 import pytest
@@ -32,7 +32,7 @@ def test_sliced_deep_stages_match_the_single_chain(amp, monkeypatch):
         assert a.shape == b.shape
         tol = 2e-2 if amp else 2e-5          # the Linears may take another tile (another summation order) at half the tokens
         assert float((a - b).abs().max()) <= tol * (float(a.abs().max()) + 1e-6)
-    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])       # stages 1-2 are not sliced
+    assert torch.equal(outs[1][0], outs[2][0])       # stage 1 is not sliced
 
 
 def test_sliced_forward_inside_a_captured_graph_and_the_guards(monkeypatch):
