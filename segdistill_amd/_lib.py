@@ -193,6 +193,12 @@ def lib():
         h.sd_set_tunable(b'wgrad_slab_ratio', int(os.environ['SEGDISTILL_WGRAD_SLAB_RATIO']))
     if os.environ.get('SEGDISTILL_WGRAD_MULTI_WGS'):       # A/B: workgroups per grouped weight-gradient launch
         h.sd_set_tunable(b'wgrad_multi_wgs', int(os.environ['SEGDISTILL_WGRAD_MULTI_WGS']))
+    # A/B: any tunable of the header by name, SEGDISTILL_TUNABLES="wgrad_x3_ring=0,align_stream=0" (benchmarking only, like sd_set_tunable itself)
+    for kv in filter(None, os.environ.get('SEGDISTILL_TUNABLES', '').split(',')):
+        k, _, v = kv.partition('=')
+        rc = h.sd_set_tunable(k.strip().encode(), int(v))
+        if rc != 0:
+            raise SegDistillLibError(f'SEGDISTILL_TUNABLES: sd_set_tunable({k!r}, {v}) -> {rc}')
     return h
 
 
