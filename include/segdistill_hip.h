@@ -75,7 +75,8 @@ const char *sd_error_string(int code);
  *       bf16-storage weight gradient may write, as a share of its operand bytes), "wgrad_multi_wgs" (0 = default: workgroups per launch group
  *       that sd_linear_wgrad_tn_multi_plan deals out -- 1536 for bf16, 3072 for fp32 storage; planning only: set it before _plan),
  *       "tok_gemm_bf16_variant" (-1 = by shape; 0..4 force a tile / ring variant of sd_linear_bf16_fwd), "planes_tile" (0 = by shape; 128 / 64: row
- *       tile of the split-bf16 planes GEMM).
+ *       tile of the split-bf16 planes GEMM), "align_stream" (0|1, default 1: sd_align1x1_fwd with Cs <= 128 on the streaming kernel of
+ *       csrc/align_stream.hip -- W resident in registers -- instead of the generic pipelined GEMM).
  *       The sra_*, align_*, ce_*, wgrad_tn_ring, tok_gemm_bf16_variant and planes_tile keys select arithmetic or tiling, not workspace geometry: no
  *       workspace size depends on them.
  *       "wgrad_slab_ratio" IS workspace geometry: it changes what sd_linear_wgrad_generic_slabs / sd_linear_wgrad_slabs /

@@ -29,11 +29,17 @@ def _as_list(v):
     return list(v) if isinstance(v, (list, tuple)) else [v]
 
 
+class TapsComplete(Exception):
+    """Raised by the teacher's LAST tap once every tapped teacher feature of the step is in hand (Extractor.stop_teacher_after_taps): the frozen
+    network's remaining layers feed nothing -- the caller (SDModule._teacher_forward) catches it and skips them."""
+
+
 class Extractor(nn.Module):
     def __init__(self, student, teacher, distillation, verbose=False):
         super().__init__()
         self.student_features = {}
         self.teacher_features = {}
+        self.stop_teacher_after_taps = False     # armed by SDModule around a frozen teacher's forward-only pass
         want_s, want_t = [], []
         for entry in distillation:
             want_s += _as_list(entry['student_layer'])
@@ -53,6 +59,8 @@ class Extractor(nn.Module):
     def _store(self, module, inputs, output, name, kind):
         if self.training:
             (self.student_features if kind == 'student' else self.teacher_features)[name] = output
+            if kind == 'teacher' and self.stop_teacher_after_taps and len(self.teacher_features) == len(set(self.hooked['teacher'])):
+                raise TapsComplete
 
     def clear(self):
         self.student_features.clear()

@@ -52,6 +52,9 @@ def _strip_missing_pretrained(cfg):
     return cfg
 
 
+_EARLY_EXIT = os.environ.get('SEGDISTILL_TEACHER_EARLY_EXIT', '1') == '1'      # A/B: 0 = the frozen teacher always runs to its last layer
+
+
 @SEGMENTORS.register_module()
 class SDModule(BaseSegmentor):
     def __init__(self, cfg_s, cfg_t, train_cfg, test_cfg, distillation, s_pretrain=None, t_pretrain=None,
@@ -107,7 +110,19 @@ class SDModule(BaseSegmentor):
             if self.teacher_train_mode:
                 self.teacher(img, img_metas, return_loss=True, gt_semantic_seg=gt_semantic_seg)  # reference behaviour
             else:
-                self.teacher.forward_features_only(img, run_aux=self._teacher_needs_aux)
+                # the frozen teacher stops at its last tap (round 6): what comes behind feeds nothing -- config 5 taps decode_head.linear_c1..4, so
+                # the E = 768 head fusion, its four fuse GEMMs over 131072 tokens and linear_pred (0.7 ms of a 6.3 ms teacher forward) are skipped;
+                # a tap on the LAST module (configs 1-3: the logits) skips nothing.  The reference runs the whole forward_train of the teacher and
+                # discards its loss (SD_structure.py:70-75): outputs nobody reads.
+                from ..distillation.opts import TapsComplete
+                ex = self.extractor
+                ex.stop_teacher_after_taps = _EARLY_EXIT and ex.training and not ex.teacher_features
+                try:
+                    self.teacher.forward_features_only(img, run_aux=self._teacher_needs_aux)
+                except TapsComplete:
+                    pass
+                finally:
+                    ex.stop_teacher_after_taps = False
 
     # ---- teacher taps: inline, side-stream, graphed, or PREFETCHED for the next batch -------------------------------------
     # The teacher is frozen, so its features for batch k+1 do not depend on the optimizer step of iteration k: a trainer
