@@ -755,6 +755,16 @@ int sd_linear_nchw_bwd_weight(const void *dY, const void *X, float *dW, float *d
                               void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * Eval-mode BatchNorm (+ residual add) (+ ReLU) of a frozen convolutional network, one in-place pass over a contiguous NCHW fp32 map (round 6):
+ *   y[b, c, p] = act(x[b, c, p] * scale[c] + shift[c] (+ residual[b, c, p])),  scale = gamma / sqrt(running_var + eps), shift = beta - mean * scale.
+ * Replaces `relu(bn(conv(x)))` and `out += identity; relu(out)` of the reference's BasicBlock / Bottleneck (backbones/resnet.py:18-100) and the
+ * norm -> act of ConvModule (psp_head.py:38-44,84-91; uper_head.py:30-75) for a teacher in eval mode: three launches and passes become one.
+ * planes = B * C; y may alias x (in place) or residual; residual NULL = none.
+ */
+int sd_affine_act_nchw(const float *x, const float *residual, float *y, const float *scale, const float *shift, long planes, int C, long HW, int relu,
+                       void *stream);
+
+/* ---------------------------------------------------------------------------
  * Overlapping patch embedding as window gather + token GEMM (round 6).
  * Replaces the nn.Conv2d of OverlapPatchEmbed (mix_transformer.py:185-215: kernel 7 / stride 4 / pad 3 for stage 1, 3 / 2 / 1 for
  * stages 2-4, followed by flatten(2).transpose(1, 2)): MIOpen's filter-gradient kernels for these shapes accumulate with float atomics and its

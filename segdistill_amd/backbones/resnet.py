@@ -10,6 +10,7 @@ Out of scope and rejected loudly: DCN, plugins, gradient checkpointing.
 """
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
 
@@ -35,8 +36,37 @@ class _Residual(nn.Module):
     norm3 = property(lambda self: self._norm(3))
 
     def forward(self, x):
+        if self._frozen_fast(x):
+            return self._forward_frozen(x)
         shortcut = x if self.downsample is None else self.downsample(x)
         return self.relu(self.body(x) + shortcut)
+
+    # ---- frozen network (the teacher): conv -> [eval BatchNorm (+ shortcut) + ReLU as ONE in-place pass] (csrc/affine_act.hip) ----
+    def _pairs(self):
+        n = 3 if hasattr(self, 'conv3') else 2
+        return [(getattr(self, f'conv{i}'), self._norm(i)) for i in range(1, n + 1)]
+
+    def _frozen_fast(self, x):
+        from .. import affine_act
+        if self.training or torch.is_grad_enabled() or not (x.is_cuda and x.dtype == torch.float32):
+            return False
+        mods = [self, self.relu] + [m for pair in self._pairs() for m in pair]
+        return affine_act._ENABLED and not any(m._forward_hooks or m._forward_pre_hooks for m in mods)
+
+    def _forward_frozen(self, x):
+        from .. import affine_act
+        shortcut = x if self.downsample is None else affine_act.run_frozen_sequential(self.downsample, x)
+        pairs = self._pairs()
+        y = x
+        for i, (conv, norm) in enumerate(pairs):
+            y = conv(y)
+            last = i == len(pairs) - 1
+            if affine_act.usable(y, norm):
+                y = affine_act.eval_norm_act_(y, norm, True, shortcut if last else None)
+            else:
+                y = norm(y)
+                y = self.relu(y + shortcut) if last else self.relu(y)
+        return y
 
 
 class BasicBlock(_Residual):
@@ -202,7 +232,11 @@ class ResNet(nn.Module):
                     constant_init(m.norm2, 0)
 
     def forward(self, x):
-        x = self.stem(x) if self.deep_stem else self.relu(self.norm1(self.conv1(x)))
+        if self.deep_stem and not self.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32:
+            from .. import affine_act
+            x = affine_act.run_frozen_sequential(self.stem, x)        # frozen network: conv -> [BatchNorm + ReLU in one pass] x 3
+        else:
+            x = self.stem(x) if self.deep_stem else self.relu(self.norm1(self.conv1(x)))
         x = self.maxpool(x)
         outs = []
         for i, name in enumerate(self.res_layers):

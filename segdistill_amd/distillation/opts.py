@@ -45,10 +45,12 @@ class Extractor(nn.Module):
             want_s += _as_list(entry['student_layer'])
             want_t += _as_list(entry['teacher_layer'])
         self.hooked = {'student': [], 'teacher': []}
+        self._hook_ids = {}
         for kind, net, wanted in (('teacher', teacher, want_t), ('student', student, want_s)):
             for name, module in net.named_modules():
                 if name in wanted:
-                    module.register_forward_hook(partial(self._store, name=name, kind=kind))
+                    handle = module.register_forward_hook(partial(self._store, name=name, kind=kind))
+                    self._hook_ids[(kind, name)] = handle.id
                     self.hooked[kind].append(name)
                     if verbose:
                         print(f'{kind}_layer :{name} hooked!!!!')
@@ -60,6 +62,12 @@ class Extractor(nn.Module):
         if self.training:
             (self.student_features if kind == 'student' else self.teacher_features)[name] = output
             if kind == 'teacher' and self.stop_teacher_after_taps and len(self.teacher_features) == len(set(self.hooked['teacher'])):
+                # hooks that were registered on this module AFTER ours (somebody else watching the same tap) still see the call
+                mine, after = self._hook_ids.get((kind, name)), False
+                for hid, hook in list(module._forward_hooks.items()):
+                    if after:
+                        hook(module, inputs, output)
+                    after = after or hid == mine
                 raise TapsComplete
 
     def clear(self):

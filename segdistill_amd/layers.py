@@ -129,6 +129,11 @@ class ConvModule(nn.Module):
     def forward(self, x):
         x = self.conv(x)
         if self.with_norm:
+            if not torch.is_grad_enabled() and x.is_cuda and not (self.with_activation and (self.activate._forward_hooks or self.activate._forward_pre_hooks)):
+                from . import affine_act
+                if affine_act.usable(x, self.norm):
+                    # frozen network in eval mode: BatchNorm + ReLU as one in-place pass over the conv's output (csrc/affine_act.hip)
+                    return affine_act.eval_norm_act_(x, self.norm, self.with_activation)
             x = self.norm(x)
         if self.with_activation:
             x = self.activate(x)
