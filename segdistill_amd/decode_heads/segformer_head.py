@@ -10,6 +10,8 @@ SegFormerHead :37-98).  Quirks kept on purpose:
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -30,6 +32,10 @@ class MLP(nn.Module):
 
     def forward(self, x):
         return call_linear(self.proj, tokens_of(x))          # split-K weight gradient at 16384+ tokens per image (linear.py)
+
+
+# A/B: 0 = the training head runs linear_c_i and its linear_fuse block as two GEMMs per branch (rounds 1-5)
+_FOLD_TRAIN = os.environ.get('SEGDISTILL_HEAD_FOLD_TRAIN', '1') == '1'
 
 
 @HEADS.register_module()
@@ -67,7 +73,14 @@ class SegFormerHead(BaseDecodeHead):
         n, size = c1.shape[0], c1.shape[2:]
         w = self.linear_fuse.conv.weight  # [E, 4E, 1, 1], input channel blocks ordered (c4, c3, c2, c1)
         e = w.shape[0]
-        fold = (not self.training) and not any(m._forward_hooks or m.proj._forward_hooks for _, m in self._branches(feats))
+        hooked = any(m._forward_hooks or m.proj._forward_hooks for _, m in self._branches(feats))
+        fold = (not self.training) and not hooked
+        # round 6: the same composition while TRAINING (nobody taps linear_c1..4: configs 2 / 3): W_i P_i is a 256 x 256 x Cin product made anew
+        # every step INSIDE the autograd graph -- its gradient flows to both factors through two products of the same size -- and the branch is
+        # ONE token GEMM Cin -> E each way instead of two (forward, input gradient, weight gradient): the four E x E fuse products over 131072 /
+        # 32768 / 8192 / 2048 tokens (68 GF per step with their gradients) disappear.  Equal to the two-GEMM form up to fp32 rounding.
+        fold_train = (_FOLD_TRAIN and self.training and torch.is_grad_enabled() and not hooked and c1.is_cuda and w.requires_grad
+                      and not torch.is_autocast_enabled())
         zs, sizes = [], []
         # the four [E, E] input-channel blocks as ONE unbind of a strided view: no copy forward, and the backward stacks the four block
         # gradients with one kernel (per-block slicing made autograd zero-fill and add four full-size [E, 4E] gradients)
@@ -81,6 +94,9 @@ class SegFormerHead(BaseDecodeHead):
                 w_fold = frozen_derived(w, ('fold_w', i), lambda: (wi @ wp).contiguous(), wp)          # [E, Cin]: the layout of a Linear weight
                 b_fold = frozen_derived(w, ('fold_b', i), lambda: wi @ bp, bp)
                 z = linear_forward(tokens.reshape(-1, tokens.shape[-1]), w_fold, b_fold)              # measured dispatch: library / MFMA kernels
+            elif fold_train:
+                wp, bp = mlp.proj.weight, mlp.proj.bias
+                z = token_linear(tokens.reshape(-1, tokens.shape[-1]), wi @ wp, None if bp is None else wi @ bp, defer_ok=False)
             else:
                 z = token_linear(mlp(feat).reshape(-1, e), wi)        # module call keeps forward hooks (taps) alive
             zs.append(z.reshape(n, -1, e))                            # token-major [B, h_i*w_i, E]

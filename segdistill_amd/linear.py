@@ -47,11 +47,17 @@ def _gemm_mode(tokens, k, n):
     return 'lib'
 
 
+def _planes_ok(weight):
+    """Pre-split planes are kept per PARAMETER (refreshed in place by the optimizer): a frozen weight, a trainable leaf, or a view of one.  A
+    temporary that autograd made this step (a product of two parameters) would register a new entry every step."""
+    return planes.supported(weight) and (not weight.requires_grad or weight.is_leaf or (weight._base is not None and weight._base.is_leaf))
+
+
 def linear_forward(x, weight, bias):
     """x . W^T + bias without autograd bookkeeping (frozen networks, and the forward of _TokenLinear): the measured three-way dispatch."""
     if x.dtype == torch.float32 and token_gemm.supported(x, weight):
         mode = _gemm_mode(x.numel() // x.shape[-1], x.shape[-1], weight.shape[0])
-        if mode == 'x3' and planes.supported(weight):
+        if mode == 'x3' and _planes_ok(weight):
             # the weight's bf16 planes are split ONCE per optimizer step (never, for a frozen weight), not in every k-step (planes.py)
             return token_gemm.linear_fwd_planes(x, weight, planes.get(weight, 'fwd'), bias)
         if mode != 'lib':
@@ -79,7 +85,7 @@ def _bwd_data(dy2, weight):
     """dy2 [T, N] . W [N, K] -> [T, K] (None: not ours, use the library)."""
     if dy2.dtype == torch.float32 and weight.dtype == torch.float32 and dy2.is_cuda and weight.dim() == 2:
         mode = _gemm_mode(dy2.shape[0], weight.shape[0], weight.shape[1])
-        if mode == 'x3' and planes.supported(weight):
+        if mode == 'x3' and _planes_ok(weight):
             return token_gemm.linear_bwd_data_planes(dy2, weight, planes.get(weight, 'bwd'))
         if mode != 'lib':
             return token_gemm.linear_bwd_data(dy2, weight, split_bf16=(mode == 'x3'))
