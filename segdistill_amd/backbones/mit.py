@@ -88,6 +88,9 @@ class MixFFN(nn.Module):
         if (not torch.is_grad_enabled() and isinstance(self.act, nn.GELU) and getattr(self.act, 'approximate', 'none') == 'none'
                 and hip_dw.supported(h, conv.weight)
                 and not (self.dwconv._forward_hooks or conv._forward_hooks or self.act._forward_hooks)):
+            from .. import mixffn
+            if not (self.training and self.drop.p > 0) and mixffn.usable(h, conv, self.fc2, hw):
+                return mixffn.tail(h, conv, self.fc2, hw)                                         # frozen: conv + GELU + fc2 in one kernel
             h = hip_dw.dwconv3x3_gelu_tokens_inference(h, conv.weight, conv.bias, hw[0], hw[1])   # frozen-teacher path
         elif (isinstance(self.act, nn.GELU) and getattr(self.act, 'approximate', 'none') == 'none' and hip_dw.supported(h, conv.weight)
               and not (self.dwconv._forward_hooks or conv._forward_hooks or self.act._forward_hooks)):

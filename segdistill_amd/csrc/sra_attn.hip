@@ -1254,13 +1254,15 @@ __global__ __launch_bounds__(256) void sra_dkv_reduce(const float *__restrict__ 
     VecIO<T>::store1(o, a.x); VecIO<T>::store1(o + 1, a.y); VecIO<T>::store1(o + 2, a.z); VecIO<T>::store1(o + 3, a.w);
 }
 
+int g_sra_wide_min = 1024;   // tunable "sra_wide_min": 8-wave workgroups (256 queries) from this many queries per (image, head) on
+int g_sra_dkv_wgs = 256;     // tunable "sra_dkv_wgs": workgroups the dK/dV pass spreads its query chunks over (one per CU: r06_ab_sra_tiles.txt)
 struct SraPlan {
     int nchunk, qchunk;
 };
 SraPlan sra_plan(int B, int N, int KV, int heads) {
     SraPlan p;
     const long groups = (long)B * heads;
-    long want = (512 + groups - 1) / groups;            // ~2 workgroups per CU
+    long want = (g_sra_dkv_wgs + groups - 1) / groups;
     const long most = (N + 127) / 128;                  // at least 128 queries (4 LDS tiles) per workgroup
     if (want > most) want = most;
     if (want < 1) want = 1;
@@ -1287,7 +1289,7 @@ int sra_check(const void *q, const void *kv, const void *o, int dtype, int B, in
     return SD_OK;
 }
 
-inline bool sra_wide(int N) { return N >= 1024; }   // 8-wave workgroups once there are enough queries to fill them
+inline bool sra_wide(int N) { return N >= g_sra_wide_min; }   // 8-wave workgroups once there are enough queries to fill them
 
 template <typename T, int D, int NW, int QT>
 int sra_fwd_launch_nw(const void *q, const void *kv, void *out, float *lse, int B, int N, int KV, int heads, float scale, hipStream_t st) {
@@ -1438,9 +1440,15 @@ int sra_tunable(const char *key, int set, int v) {
     int *p = nullptr;
     if (!strcmp(key, "sra_split_bf16")) p = &g_sra_split_bf16;
     else if (!strcmp(key, "sra_bf16_mfma")) p = &g_sra_bf16_mfma;
+    bool flag = true;
+    if (!p) {
+        flag = false;
+        if (!strcmp(key, "sra_wide_min")) p = &g_sra_wide_min;
+        else if (!strcmp(key, "sra_dkv_wgs")) p = &g_sra_dkv_wgs;
+    }
     if (!p) return SD_E_UNSUPPORTED;
     if (set) {
-        if (v != 0 && v != 1) return SD_E_SHAPE;
+        if (flag ? (v != 0 && v != 1) : (v < 1 || v > (1 << 20))) return SD_E_SHAPE;
         *p = v;
         return SD_OK;
     }
