@@ -778,6 +778,21 @@ int sd_mixffn_tail_f32(const float *h, const float *dw_weight, const float *dw_b
                        int H, int W, int hidden, int out_features, void *stream);
 
 /* ---------------------------------------------------------------------------
+ * The tail of a frozen SegFormer head in one pass (round 6), fp32:
+ *   logits [B, classes, H, W] = W_p . relu(scale * (z1 + up2(z2) + up4(z3) + up8(z4) + fuse_bias) + shift) + pred_bias
+ * z1 [B, H*W, E], z2 [B, (H/2)(W/2), E], z3 [B, (H/4)(W/4), E], z4 [B, (H/8)(W/8), E]: the per-branch results of the fuse conv, token-major
+ * (what sd_upsum_affine_fwd takes); scale / shift [E]: the eval-mode BatchNorm of `linear_fuse` as an affine map; pred_row_planes: `linear_pred`'s
+ * weight [classes, E] pre-split by sd_presplit_multi (row_planes, sd_presplit_rows_bytes).  Replaces, for a head in eval mode without autograd
+ * (the teacher), `_c = self.linear_fuse(torch.cat([...], dim=1)); x = self.dropout(_c); x = self.linear_pred(x)` (segformer_head.py:93-96): the
+ * summed, normalised map [B, H*W, E] is never written.  Interpolation / sum / affine / ReLU as sd_upsum_affine_fwd, the product as
+ * sd_linear_nchw_fwd_planes.  _supported(): H % 8 == 0, W % 32 == 0, E % 32 == 0, E <= 1024, classes <= 160, H * W * E < 2^30.
+ */
+int sd_head_tail_supported(int H, int W, int E, int classes);
+int sd_head_tail_f32(const float *z1, const float *z2, const float *z3, const float *z4, const float *fuse_bias /* or NULL */, const float *scale,
+                     const float *shift, const void *pred_row_planes, const float *pred_bias /* or NULL */, float *logits, int B, int H, int W, int E,
+                     int classes, void *stream);
+
+/* ---------------------------------------------------------------------------
  * Overlapping patch embedding as window gather + token GEMM (round 6).
  * Replaces the nn.Conv2d of OverlapPatchEmbed (mix_transformer.py:185-215: kernel 7 / stride 4 / pad 3 for stage 1, 3 / 2 / 1 for
  * stages 2-4, followed by flatten(2).transpose(1, 2)): MIOpen's filter-gradient kernels for these shapes accumulate with float atomics and its

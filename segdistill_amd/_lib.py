@@ -39,6 +39,8 @@ SIGNATURES = {
     'sd_cgd_kl_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'sd_cgd_kl_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'sd_cgd_kl_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    'sd_head_tail_supported': (_i, [_i, _i, _i, _i]),
+    'sd_head_tail_f32': (_i, [_vp] * 10 + [_i] * 5 + [_vp]),
     'sd_mixffn_tail_supported': (_i, [_i, _i, _i, _i]),
     'sd_mixffn_tail_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'sd_affine_act_nchw': (_i, [_vp, _vp, _vp, _vp, _vp, C.c_long, _i, C.c_long, _i, _vp]),

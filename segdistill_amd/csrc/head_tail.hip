@@ -1,0 +1,320 @@
+// head_tail.hip -- the tail of a FROZEN SegFormer head in one pass (round 6), fp32 token-major branch maps in, class planes out:
+//   logits [B, classes, H, W] = W_p . relu( scale * (z1 + up2(z2) + up4(z3) + up8(z4) + b_f) + shift ) + b_p
+// reference segformer_head.py:75-98 (`_c = self.linear_fuse(torch.cat([_c4, _c3, _c2, _c1], dim=1)); x = self.dropout(_c); x = self.linear_pred(x)`)
+// for a head in eval mode nobody differentiates through (the teacher).  decode_heads/segformer_head.py already runs the fuse conv per branch at
+// native resolution (z_i = W_i c_i); as two kernels the summed, normalised map [B, H W, E] -- 403 MB at E = 768, 8 x 128 x 128 -- is written by
+// csrc/headfuse.hip::upsum_fwd_strip and read back by the linear_pred product.  Here it only exists as a workgroup's LDS tile.
+// Arithmetic: the interpolation / sum / affine / ReLU operation for operation as upsum_fwd_strip (same clamped taps, same fmaf order), the product
+// in split-bf16 arithmetic as csrc/token_gemm.hip (three bf16 planes per operand, six products, small terms first, fp32 accumulation, k
+// ascending); W_p arrives pre-split as row-major planes [3][classes][E] (sd_presplit_multi, row_planes -- what sd_linear_nchw_fwd_planes takes).
+//
+// A workgroup (256 threads) owns 4 rows x 32 columns of one image (128 pixels) and walks E in chunks of 32 channels:
+//   * W_p's chunk [160 rows][32 k] x 3 planes goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers; the 80-byte row pitch is
+//     kept by letting every fifth lane of a 1 KB run land on the 16 bytes of padding), issued at the top of the chunk under the sum stage;
+//   * sum stage: thread -> (4 channels, 4 consecutive pixels of one row): z1 (4 vectors) and the x2 branch (2 x 4) are requested a chunk ahead,
+//     the x4 / x8 branches (6 + 4 vectors, L2-resident maps) at the top of the chunk; 16 results split into the pixel tile [3][128 px][32 k];
+//   * matrix stage: wave w = tile row w (32 consecutive pixels) against all 160 class rows: D[class][pixel] has the PIXEL on the lane, so every
+//     store instruction writes two full 128-byte lines of the class planes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "sd_common.h"
+
+namespace sd {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kTH = 4, kTW = 32, kTM = kTH * kTW;   // pixel tile: 4 rows x 32 columns
+constexpr int kKC = 32;                             // channels per chunk
+constexpr int kPitch = 2 * kKC + 16;                // 80 bytes per LDS row
+constexpr int kPPlane = kTM * kPitch;               // 10240
+constexpr int kRows = 160;                          // class rows of the product (5 MFMA row blocks)
+constexpr int kWPlane = kRows * kPitch;             // 12800
+constexpr int kWRuns = (3 * kWPlane + 1023) / 1024;  // 1 KB DMA runs covering the three W planes: 38 (the last one half used)
+constexpr int kWRunsPerWave = (kWRuns + 3) / 4;     // 10
+
+__device__ __forceinline__ void split2(float x0, float x1, bf16x2 &h, bf16x2 &m, bf16x2 &l) {
+    const f32x2 v = {x0, x1};
+    h = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
+    m = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+    l = __builtin_convertvector(r2, bf16x2);
+}
+
+// a 16-byte load the compiler neither sinks nor reorders (wave-uniform base + 32-bit byte offset per lane), waited for by wait_loads(); "+v": the
+// destination is the loop-carried variable's own register (tools/asm_pending_audit.py)
+__device__ __forceinline__ void pinned_load16(f32x4 &v, const void *base, unsigned off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(v) : "v"(off), "s"(base) : "memory");
+}
+// global -> LDS, 16 bytes per lane (tok_gemm_bf16.hip): M0 = wave-uniform LDS byte address of lane 0's 16 bytes, lane l lands at M0 + 16 l
+__device__ __forceinline__ void dma16(const void *base, unsigned lane_off, unsigned lds_byte) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base), "s"(lds_byte) : "memory");
+}
+__device__ __forceinline__ void wait_loads() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// one coarse branch of csrc/headfuse.hip::add_branch_strip on already loaded taps: vertical lerp of NC columns, then the four pixels
+template <int F, int NC>
+__device__ __forceinline__ void add_branch(float (&acc)[4][4], const f32x4 (&top)[NC], const f32x4 (&bot)[NC], float ly, const float (&lx)[4]) {
+    float col[NC][4];
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) col[j][i] = fmaf(ly, bot[j][i] - top[j][i], top[j][i]);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        constexpr int kOff2[4] = {0, 1, 1, 2}, kOff4[4] = {0, 0, 1, 1};
+        const int o = F == 2 ? kOff2[p] : (F == 4 ? kOff4[p] : 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[p][i] += fmaf(lx[p], col[o + 1][i] - col[o][i], col[o][i]);
+    }
+}
+
+// per-thread geometry of one coarse branch: byte offsets of its two (clamped) tap rows and NC (clamped) tap columns, and the lerp weights
+template <int F, int NC> struct Branch {
+    unsigned row0, row1, colo[NC];
+    float ly, lx[4];
+    __device__ __forceinline__ void init(int Y, int X0, int H, int W, int E, int c) {
+        const int h = H / F, w = W / F;
+        const float sy = (Y + 0.5f) / F - 0.5f;
+        const int y0u = (int)floorf(sy);
+        ly = sy - (float)y0u;
+        const int y0 = min(max(y0u, 0), h - 1), y1 = min(max(y0u + 1, 0), h - 1);
+        const int base = (int)floorf((X0 + 0.5f) / F - 0.5f);
+        row0 = ((unsigned)(y0 * w) * (unsigned)E + (unsigned)c) * 4u;
+        row1 = ((unsigned)(y1 * w) * (unsigned)E + (unsigned)c) * 4u;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) colo[j] = (unsigned)min(max(base + j, 0), w - 1) * (unsigned)E * 4u;
+        // frac((X0 + p + 0.5) / F - 0.5) for X0 % 4 == 0: constants for F = 2, 4; two cases for F = 8 (what add_branch_strip computes, same values)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            constexpr float k2[4] = {0.75f, 0.25f, 0.75f, 0.25f}, k4[4] = {0.625f, 0.875f, 0.125f, 0.375f};
+            lx[p] = F == 2 ? k2[p] : (F == 4 ? k4[p] : ((X0 & 4) ? 0.0625f : 0.5625f) + 0.125f * p);
+        }
+    }
+};
+
+// grid.x = B * (H / 4) * (W / 32) (XCD-remapped: consecutive tiles of an image share one L2)
+__global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__ z1, const float *__restrict__ z2, const float *__restrict__ z3,
+                                                       const float *__restrict__ z4, const float *__restrict__ fbias,
+                                                       const float *__restrict__ scale, const float *__restrict__ shift,
+                                                       const unsigned char *__restrict__ wplanes, const float *__restrict__ pbias,
+                                                       float *__restrict__ out, int H, int W, int E, int classes, int tiles_x,
+                                                       int tiles_per_img) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // pixel planes [3][128][80 B] | W planes [3][160][80 B] (+ slack to 38 KB) | scale, shift, bias [E]
+    unsigned char *ldsP = lds, *ldsW = lds + 3 * kPPlane;
+    float *ldsS = reinterpret_cast<float *>(lds + 3 * kPPlane + kWRuns * 1024), *ldsH = ldsS + E, *ldsB = ldsH + E;
+    const long nblk = gridDim.x, id = blockIdx.x;
+    const long qd = nblk / 8, rem = nblk % 8, xcd = id % 8;
+    const long L = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + id / 8;
+    const int b = (int)(L / tiles_per_img), tr = (int)(L % tiles_per_img);
+    const int y0 = (tr / tiles_x) * kTH, x0 = (tr % tiles_x) * kTW;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int col = lane & 31, kg = lane >> 5;
+
+    // ---- sum-stage geometry: thread -> (channel quad c4, tile row r, 4 pixels from column xs) ----
+    const int c4 = t & 7, strip = t >> 3;
+    const int r = strip >> 3, xs = (strip & 7) * 4;
+    const int Y = y0 + r, X0 = x0 + xs;
+    const size_t HW = (size_t)H * W;
+    const float *z1b = z1 + (size_t)b * HW * E, *z2b = z2 + (size_t)b * (HW / 4) * E, *z3b = z3 + (size_t)b * (HW / 16) * E,
+                *z4b = z4 + (size_t)b * (HW / 64) * E;
+    const unsigned o1 = (((unsigned)(Y * W + X0)) * (unsigned)E + 4u * c4) * 4u;
+    Branch<2, 4> g2;
+    Branch<4, 3> g3;
+    Branch<8, 2> g4;
+    g2.init(Y, X0, H, W, E, 4 * c4);
+    g3.init(Y, X0, H, W, E, 4 * c4);
+    g4.init(Y, X0, H, W, E, 4 * c4);
+
+    // ---- W_p by LDS-DMA: wave w issues the 1 KB runs w, w + 4, ...; lane l of run u lands at LDS byte o = 1024 u + 16 l of the W region
+    //      [3 planes][160 rows][80 B]: plane o / 12800, row (o % 12800) / 80, 16-byte piece (o % 80) / 16 -- piece 4 is the row's padding (any
+    //      valid source); class rows beyond `classes` repeat the last one (their products are never stored) ----
+    unsigned wsrc[kWRunsPerWave];
+#pragma unroll
+    for (int i = 0; i < kWRunsPerWave; ++i) {
+        const int o = min(1024 * (wave + 4 * i) + 16 * lane, 3 * kWPlane - 16);
+        const int pl = o / kWPlane, ro = o % kWPlane, row = ro / kPitch, pc = min((ro % kPitch) >> 4, 3);
+        wsrc[i] = (((unsigned)pl * (unsigned)classes + (unsigned)min(row, classes - 1)) * (unsigned)E + 8u * pc) * 2u;
+    }
+
+    // per-channel tables once per workgroup
+    for (int i = t; i < E / 4; i += 256) {
+        reinterpret_cast<f32x4 *>(ldsS)[i] = reinterpret_cast<const f32x4 *>(scale)[i];
+        reinterpret_cast<f32x4 *>(ldsH)[i] = reinterpret_cast<const f32x4 *>(shift)[i];
+        reinterpret_cast<f32x4 *>(ldsB)[i] = fbias ? reinterpret_cast<const f32x4 *>(fbias)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // accumulators: D row = class 32 mt + (e & 3) + 8 (e >> 2) + 4 kg
+    f32x16 acc[5];
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
+
+    // requested a chunk ahead: z1 (4), the x2 branch (2 x 4), W_p's pieces (8)
+    f32x4 q1[4], q2t[4], q2b[4], t3[3], b3[3], t4[2], b4[2];
+    {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q1[i] = z, q2t[i] = z, q2b[i] = z;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t3[i] = z, b3[i] = z;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) t4[i] = z, b4[i] = z;
+    }
+    auto request = [&](int kc) {
+        const unsigned cbb = (unsigned)(kc * kKC) * 4u;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) pinned_load16(q1[p], z1b, o1 + (unsigned)p * (unsigned)E * 4u + cbb);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pinned_load16(q2t[j], z2b, g2.row0 + g2.colo[j] + cbb);
+            pinned_load16(q2b[j], z2b, g2.row1 + g2.colo[j] + cbb);
+        }
+    };
+    request(0);
+    __syncthreads();                                     // tables visible
+    wait_loads();
+
+    const int nchunk = E / kKC;
+    for (int kc = 0; kc < nchunk; ++kc) {
+        const int cb = kc * kKC + 4 * c4;
+        // -- W_p chunk -> LDS by DMA (the barrier at the end of the previous iteration freed both tiles); in flight under the sum stage --
+        {
+            const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ldsW);      // LDS byte address of the W region
+#pragma unroll
+            for (int i = 0; i < kWRunsPerWave; ++i)
+                if (wave + 4 * i < kWRuns) dma16(wplanes, wsrc[i] + (unsigned)(kc * kKC) * 2u, wbase + 1024u * (unsigned)(wave + 4 * i));
+        }
+        // -- the x4 / x8 taps: small L2-resident maps, requested here (same scalar-base + 32-bit-offset form), used after z1 and the x2 branch --
+        {
+            const unsigned cbb = (unsigned)(kc * kKC) * 4u;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                pinned_load16(t3[j], z3b, g3.row0 + g3.colo[j] + cbb);
+                pinned_load16(b3[j], z3b, g3.row1 + g3.colo[j] + cbb);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                pinned_load16(t4[j], z4b, g4.row0 + g4.colo[j] + cbb);
+                pinned_load16(b4[j], z4b, g4.row1 + g4.colo[j] + cbb);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // -- z1 + bias, then the branches in upsum_fwd_strip's order --
+        const f32x4 fb = *reinterpret_cast<const f32x4 *>(ldsB + cb);
+        float a[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[p][i] = q1[p][i] + fb[i];
+        add_branch<2, 4>(a, q2t, q2b, g2.ly, g2.lx);
+        wait_loads();                                    // x4 / x8 taps (and the W chunk, older) have landed
+        add_branch<4, 3>(a, t3, b3, g3.ly, g3.lx);
+        add_branch<8, 2>(a, t4, b4, g4.ly, g4.lx);
+        // every register of this chunk's request has been consumed: the next chunk's goes out now
+        __builtin_amdgcn_sched_barrier(0);
+        request(kc + 1 < nchunk ? kc + 1 : kc);          // (past the last chunk: a repeat, never used)
+        __builtin_amdgcn_sched_barrier(0);
+        // -- affine + ReLU, split, pixel tile --
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(ldsS + cb), sh = *reinterpret_cast<const f32x4 *>(ldsH + cb);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float g[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = fmaxf(fmaf(a[p][i], sc[i], sh[i]), 0.f);
+            bf16x2 h0, m0, l0, h1, m1, l1;
+            split2(g[0], g[1], h0, m0, l0);
+            split2(g[2], g[3], h1, m1, l1);
+            const bf16x4 hh = {h0[0], h0[1], h1[0], h1[1]}, mm = {m0[0], m0[1], m1[0], m1[1]}, ll = {l0[0], l0[1], l1[0], l1[1]};
+            unsigned char *q = ldsP + (32 * r + xs + p) * kPitch + 8 * c4;
+            *reinterpret_cast<uint2 *>(q) = __builtin_bit_cast(uint2, hh);
+            *reinterpret_cast<uint2 *>(q + kPPlane) = __builtin_bit_cast(uint2, mm);
+            *reinterpret_cast<uint2 *>(q + 2 * kPPlane) = __builtin_bit_cast(uint2, ll);
+        }
+        __syncthreads();
+        // -- matrix stage: A = W_p rows (classes), B = this wave's 32 pixels --
+#pragma unroll
+        for (int s = 0; s < kKC / 16; ++s) {
+            const unsigned char *qb = ldsP + (32 * wave + col) * kPitch + 32 * s + 16 * kg;
+            const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(qb), bm = *reinterpret_cast<const bf16x8 *>(qb + kPPlane),
+                         bl = *reinterpret_cast<const bf16x8 *>(qb + 2 * kPPlane);
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) {
+                const unsigned char *qa = ldsW + (32 * mt + col) * kPitch + 32 * s + 16 * kg;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(qa), am = *reinterpret_cast<const bf16x8 *>(qa + kWPlane),
+                             al = *reinterpret_cast<const bf16x8 *>(qa + 2 * kWPlane);
+                f32x16 c = acc[mt];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);      // small terms first (token_gemm.hip's order)
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                acc[mt] = c;
+            }
+        }
+        // the wait sits here, not at the loop top: whatever copies the compiler makes of the loop-carried request registers at the back edge read
+        // arrived data (tools/asm_pending_audit.py)
+        wait_loads();
+        __syncthreads();                                 // this chunk's fragment reads are done: the tiles may be overwritten
+    }
+    // ---- epilogue: class planes; lane = pixel x0 + col of row y0 + wave ----
+    float *ob = out + (size_t)b * classes * HW + (size_t)(y0 + wave) * W + x0 + col;
+#pragma unroll
+    for (int mt = 0; mt < 5; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int cls = 32 * mt + (e & 3) + 8 * (e >> 2) + 4 * kg;
+            if (cls < classes) ob[(size_t)cls * HW] = acc[mt][e] + (pbias ? pbias[cls] : 0.f);
+        }
+}
+
+}  // namespace
+}  // namespace sd
+
+extern "C" {
+
+int sd_head_tail_supported(int H, int W, int E, int classes) {
+    return (H > 0 && W > 0 && H % 8 == 0 && W % sd::kTW == 0 && E % sd::kKC == 0 && E <= 1024 && classes >= 1 && classes <= sd::kRows &&
+            (long)H * W * E < (1L << 30))
+               ? 1
+               : 0;
+}
+
+int sd_head_tail_f32(const float *z1, const float *z2, const float *z3, const float *z4, const float *fuse_bias /* or NULL */, const float *scale,
+                     const float *shift, const void *pred_row_planes, const float *pred_bias /* or NULL */, float *logits, int B, int H, int W, int E,
+                     int classes, void *stream) {
+    if (!z1 || !z2 || !z3 || !z4 || !scale || !shift || !pred_row_planes || !logits) return SD_E_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || E <= 0 || classes <= 0) return SD_E_SHAPE;
+    if (!sd_head_tail_supported(H, W, E, classes)) return SD_E_UNSUPPORTED;
+    if ((long)B * (H / sd::kTH) * (W / sd::kTW) > 0x7fffffffL) return SD_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(z1) | reinterpret_cast<uintptr_t>(z2) | reinterpret_cast<uintptr_t>(z3) | reinterpret_cast<uintptr_t>(z4) |
+         reinterpret_cast<uintptr_t>(fuse_bias) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
+         reinterpret_cast<uintptr_t>(pred_row_planes) | reinterpret_cast<uintptr_t>(logits)) & 15)
+        return SD_E_ALIGN;
+    const int tx = W / sd::kTW, tpi = tx * (H / sd::kTH);
+    const size_t ldsb = (size_t)3 * sd::kPPlane + (size_t)sd::kWRuns * 1024 + (size_t)12 * E;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sd::head_tail_x3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(sd::head_tail_x3, dim3((unsigned)((long)B * tpi)), dim3(256), ldsb, static_cast<hipStream_t>(stream), z1, z2, z3, z4, fuse_bias,
+                       scale, shift, static_cast<const unsigned char *>(pred_row_planes), pred_bias, logits, H, W, E, classes, tx, tpi);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

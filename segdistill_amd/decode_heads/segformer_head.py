@@ -66,9 +66,8 @@ class SegFormerHead(BaseDecodeHead):
     def _branches(self, feats):
         return ((feats[3], self.linear_c4), (feats[2], self.linear_c3), (feats[1], self.linear_c2), (feats[0], self.linear_c1))
 
-    def _fused_sum(self, feats, fold_norm=False):
-        """-> (y, normed): the summed branch maps, and whether the eval-mode norm + ReLU were already applied in the same pass."""
-        from .. import headfuse
+    def _branch_maps(self, feats):
+        """-> (zs, sizes, n, size, e): the fuse conv applied per branch at native resolution, token-major [B, h_i*w_i, E], finest (c1) first."""
         c1 = feats[0]
         n, size = c1.shape[0], c1.shape[2:]
         w = self.linear_fuse.conv.weight  # [E, 4E, 1, 1], input channel blocks ordered (c4, c3, c2, c1)
@@ -101,7 +100,16 @@ class SegFormerHead(BaseDecodeHead):
                 z = token_linear(mlp(feat).reshape(-1, e), wi)        # module call keeps forward hooks (taps) alive
             zs.append(z.reshape(n, -1, e))                            # token-major [B, h_i*w_i, E]
             sizes.append(tuple(feat.shape[2:]))
-        zs, sizes = zs[::-1], sizes[::-1]                             # finest (c1) first
+        return zs[::-1], sizes[::-1], n, size, e
+
+    def _fused_sum(self, feats, fold_norm=False):
+        """-> (y, normed): the summed branch maps, and whether the eval-mode norm + ReLU were already applied in the same pass."""
+        from .. import headfuse
+        zs, sizes, n, size, e = self._branch_maps(feats)
+        return self._sum_of(zs, sizes, n, size, e, fold_norm)
+
+    def _sum_of(self, zs, sizes, n, size, e, fold_norm):
+        from .. import headfuse
         bias = self.linear_fuse.conv.bias
         if fold_norm and headfuse.supported(zs, sizes):
             # frozen network: sum + eval-mode BatchNorm (an affine map per channel) + ReLU in ONE pass; finish() is told to skip them
@@ -140,8 +148,36 @@ class SegFormerHead(BaseDecodeHead):
             if self.dropout is not None:
                 fused = self.dropout(fused)
             return self._predict(fused)
+        if self._can_fold_norm() and self._can_fuse_pred():
+            # frozen network (round 6): sum + norm + ReLU + linear_pred in ONE kernel -- the summed [B, HW, E] map is never written
+            from .. import headfuse
+            zs, sizes, n, size, e = self._branch_maps(feats)
+            pred = self.linear_pred
+            if headfuse.head_tail_supported(zs, sizes, pred.out_channels):
+                norm = fuse.norm
+                scale = frozen_derived(norm.weight, 'bn_scale', lambda: (norm.weight * torch.rsqrt(norm.running_var + norm.eps)).float(),
+                                       norm.running_var)
+                shift = frozen_derived(norm.bias, 'bn_shift', lambda: (norm.bias - norm.running_mean * scale).float(), norm.running_mean,
+                                       norm.running_var, norm.weight)
+                out = headfuse.head_tail(zs, sizes, fuse.conv.bias, scale, shift, pred.weight.view(pred.out_channels, e), pred.bias)
+                for hook in pred._forward_hooks.values():       # THE tap of every shipped KD config: fired by hand (its input no longer exists)
+                    r = hook(pred, (None,), out)
+                    if r is not None:
+                        out = r
+                return out
+            y, normed = self._sum_of(zs, sizes, n, size, e, True)
+            return self.finish(y, normed)
         y, normed = self._fused_sum(feats, fold_norm=self._can_fold_norm())
         return self.finish(y, normed)
+
+    def _can_fuse_pred(self):
+        """linear_pred can join the frozen head's fused pass: a 1x1 conv on a leaf weight nobody differentiates, no dropout in effect, nobody
+        observing the fused map (a tap on linear_fuse / dropout) or linear_pred's input."""
+        pred, fuse, drop = self.linear_pred, self.linear_fuse, self.dropout
+        return (isinstance(pred, nn.Conv2d) and pred.kernel_size == (1, 1) and pred.groups == 1 and not pred.weight.requires_grad
+                and pred.weight.is_contiguous() and pred.weight.dtype == torch.float32
+                and not (pred._forward_pre_hooks or fuse._forward_hooks or fuse._forward_pre_hooks)
+                and (drop is None or not (drop.training and drop.p > 0) and not (drop._forward_hooks or drop._forward_pre_hooks)))
 
     def _can_fold_norm(self):
         """Eval-mode BatchNorm with running statistics + ReLU, no gradient wanted, nobody hooking either module."""

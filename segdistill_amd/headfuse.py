@@ -87,3 +87,37 @@ def upsum_affine_inference(zs, bias, sizes, scale, shift, relu=True):
                                         fs[2], _stream_ptr())
     _lib.check(rc, 'sd_upsum_affine_fwd')
     return y
+
+
+_HEAD_TAIL = os.environ.get('SEGDISTILL_HEAD_TAIL', '1') == '1'      # A/B: 0 = upsum_affine_inference, then the linear_pred product
+
+
+def head_tail_supported(zs, sizes, classes):
+    """The frozen head's sum + norm + ReLU + linear_pred as ONE kernel (csrc/head_tail.hip): fp32 token-major branch maps of the SegFormer
+    geometry (factors 2, 4, 8), no autograd, no autocast."""
+    if not (_HEAD_TAIL and supported(zs, sizes) and zs[0].dtype == torch.float32 and not torch.is_grad_enabled() and not torch.is_autocast_enabled()):
+        return False
+    (H, W) = sizes[0]
+    if [H // h for (h, w) in sizes[1:]] != [2, 4, 8]:
+        return False
+    return bool(_lib.lib().sd_head_tail_supported(int(H), int(W), int(zs[0].shape[-1]), int(classes)))
+
+
+def head_tail(zs, sizes, fuse_bias, scale, shift, pred_weight2d, pred_bias):
+    """-> logits [B, classes, H, W] = W_p . relu(scale * (z1 + up(z2) + up(z3) + up(z4) + fuse_bias) + shift) + pred_bias; the summed map is never
+    written.  pred_weight2d: linear_pred's weight as [classes, E] (a view of the frozen parameter: its row planes are cached on it)."""
+    from . import planes
+    zs = [z.contiguous() for z in zs]
+    B, _, E = zs[0].shape
+    (H, W) = sizes[0]
+    classes = pred_weight2d.shape[0]
+    rows = planes.get(pred_weight2d, 'rows')
+    fb = None if fuse_bias is None else fuse_bias.detach().float().contiguous()
+    pb = None if pred_bias is None else pred_bias.detach().float().contiguous()
+    sc, sh = scale.detach().float().contiguous(), shift.detach().float().contiguous()
+    out = torch.empty(B, classes, H, W, dtype=torch.float32, device=zs[0].device)
+    rc = _lib.lib().sd_head_tail_f32(zs[0].data_ptr(), zs[1].data_ptr(), zs[2].data_ptr(), zs[3].data_ptr(), None if fb is None else fb.data_ptr(),
+                                     sc.data_ptr(), sh.data_ptr(), rows.data_ptr(), None if pb is None else pb.data_ptr(), out.data_ptr(), B, int(H),
+                                     int(W), E, classes, _stream_ptr())
+    _lib.check(rc, 'sd_head_tail_f32')
+    return out

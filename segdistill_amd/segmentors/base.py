@@ -19,6 +19,20 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+def _mean(value):
+    """value.mean() of a large GPU map as two single-block-per-output sums.  ATen's one-pass mean of >= 2^15 elements is a multi-block reduction
+    whose semaphores are zeroed by hipMemsetAsync -- in a captured step the ONLY memset node left (the profiler finds `aten::mean` and nothing
+    else), and a memset node of a replayed hipGraph is not safe on ROCm 7.x: an eager hipMemsetAsync issued between two replays (a `torch.equal`,
+    an evaluation hook) can leave the node zeroing nothing from then on -- the logged `decode.loss_seg` then read 0.0115 instead of 4.82 on every
+    later step (tests/test_graph_gpu.py).  Plain differentiable ops: the gradient arrives as ONE value broadcast over the map
+    (all strides 0), which the fused CE backward takes as a scalar instead of reading a dense 1/N map."""
+    if value.is_cuda and value.numel() >= 8192 and value.is_contiguous() and value.is_floating_point():
+        for group in (1024, 512, 256):
+            if value.numel() % group == 0:
+                return value.reshape(-1, group).sum(1).sum() / value.numel()
+    return value.mean()
+
+
 def parse_losses(losses, want_host_values=True, extra=None):
     """-> (loss tensor, OrderedDict name -> float | 0-dim tensor).
 
@@ -31,9 +45,9 @@ def parse_losses(losses, want_host_values=True, extra=None):
     log_vars = OrderedDict()
     for name, value in losses.items():
         if isinstance(value, torch.Tensor):
-            log_vars[name] = value.mean()
+            log_vars[name] = _mean(value)
         elif isinstance(value, list):
-            log_vars[name] = sum(v.mean() for v in value)
+            log_vars[name] = sum(_mean(v) for v in value)
         else:
             raise TypeError(f'{name} is not a tensor or list of tensors')
     loss = sum(v for k, v in log_vars.items() if 'loss' in k)

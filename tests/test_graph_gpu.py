@@ -210,3 +210,56 @@ def test_a_torch_optimizer_keeps_derived_weights_fresh(mode, monkeypatch):
         for k in ve:
             if 'acc' not in k:
                 assert vg[k] == pytest.approx(ve[k], abs=3e-4 * max(1.0, abs(ve[k]))), (it, k, ve[k], vg[k])
+
+
+def test_step_issues_no_memset_and_replays_survive_eager_memsets():
+    """ROCm 7.x: a memset NODE of a replayed hipGraph stops zeroing once eager hipMemsetAsync calls have been issued between replays (round 6: one
+    `torch.equal` between two steps made every later `decode.loss_seg` read 0.0115 instead of 4.82 -- aten::mean's semaphores were no longer
+    cleared).  The step therefore issues NO memset at all (segmentors/base.py::_mean), and replays keep matching the eager run whatever is memset
+    in between."""
+    import ctypes
+    from segdistill_amd.engine import KDTrainer, SyntheticADE
+    from segdistill_amd.engine.trainer import _issues_memsets
+    opt = dict(type='AdamW', lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+    ref = _model()
+    gra = copy.deepcopy(ref)
+    t_e, t_g = KDTrainer(ref, opt, None), KDTrainer(gra, opt, None)
+    size = (256, 256)
+    data_e = SyntheticADE(2, size=size, device='cuda:0', pool=3, seed=1)
+    data_g = SyntheticADE(2, size=size, device='cuda:0', pool=3, seed=1)
+    probe = copy.deepcopy(ref)
+    t_p = KDTrainer(probe, opt, None)
+    batch = SyntheticADE(2, size=size, device='cuda:0', pool=1, seed=1).next()
+    t_p.step(batch)
+    assert not _issues_memsets(lambda: t_p.step(batch)), 'the KD step issues a hipMemset again: it would be a memset node of the captured step'
+    del t_p, probe
+    example = dict(img=data_g._pool[0][0], img_metas=None, gt_semantic_seg=data_g._pool[0][1])
+    assert t_g.enable_graph(example)
+    hip = ctypes.CDLL('libamdhip64.so')
+    scratch = torch.zeros(1 << 16, dtype=torch.uint8, device='cuda:0')
+    for it in range(6):
+        torch.manual_seed(100 + it)
+        t_e.step(data_e.next())
+        torch.manual_seed(100 + it)
+        t_g.step(data_g.next())
+        torch.cuda.synchronize()
+        for _ in range(it):                               # 0, 1, 2, ... eager memsets between replays: every phase of the runtime's staging ring
+            hip.hipMemsetAsync(ctypes.c_void_p(scratch.data_ptr()), 0, ctypes.c_size_t(64), None)
+        assert bool(torch.equal(scratch[:64], torch.zeros_like(scratch[:64])))     # an eager multi-block reduction on top
+        ve, vg = t_e.log_values(), t_g.log_values()
+        for k in ve:
+            if 'acc' not in k:
+                assert vg[k] == pytest.approx(ve[k], abs=3e-4 * max(1.0, abs(ve[k]))), (it, k, ve[k], vg[k])
+
+
+def test_memset_free_mean_matches_aten():
+    from segdistill_amd.segmentors.base import _mean
+    torch.manual_seed(3)
+    for shape in ((2, 256, 256), (8, 512, 512), (3, 100, 100), (5,)):
+        x = torch.randn(*shape, device='cuda:0', requires_grad=True)
+        y = x.detach().clone().requires_grad_(True)
+        a, b = _mean(x), y.mean()
+        assert float((a - b).abs()) <= 2e-7 * max(1.0, float(b.abs())) + 1e-8
+        a.backward()
+        b.backward()
+        assert float((x.grad - y.grad).abs().max()) <= 1e-7 * float(y.grad.abs().max())

@@ -69,7 +69,7 @@ def audit(asm_path):
             continue
         if in_asm:
             if VM.match(l):
-                is_load = '_load' in l and ' lds' not in l
+                is_load = '_load' in l and ' lds' not in l and '_load_lds' not in l      # LDS-DMA: the VGPR operand is an address, nothing lands in it
                 pending.append((regs_of(l.split(None, 1)[1].split(',')[0]) if is_load else set(), ln))
             continue
         live = set().union(*[r for r, _ in pending]) if pending else set()
