@@ -16,12 +16,13 @@ from .optim import PolyLR, build_optimizer, sync_derived_weights
 def _issues_memsets(fn):
     """True if running `fn` enqueues any hipMemset command (seen through the torch profiler).
 
-    Why it matters (DESIGN section 3.8; ROCm 7.x runtime bundled with PyTorch 2.10): a memset NODE inside a
+    Why it matters (DESIGN section 3.11; ROCm 7.x runtime bundled with PyTorch 2.10): a memset NODE inside a
     replayed hipGraph takes its fill pattern from a staging area shared with every other memset on the device; a
     hipMemsetAsync issued on ANOTHER stream while the node is pending makes the node write garbage (kernel-argument
     words of the other memset) instead of its value.  Two pieces of work may therefore only overlap on different
     streams if at most one of them contains memsets.  The MiT/ResNet/Swin teacher forward contains none (checked here
-    at capture time); the student's fwd+bwd contains ~30 (zero-initialised autograd buffers)."""
+    at capture time); the student's fwd+bwd contained ~30 in round 1 (zero-initialised autograd buffers) and none since round 6 (segmentors/base.py::_mean
+    removed the last one, aten::mean's semaphore clear)."""
     from torch.profiler import ProfilerActivity, profile
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:

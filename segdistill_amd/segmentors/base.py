@@ -24,7 +24,7 @@ def _mean(value):
     whose semaphores are zeroed by hipMemsetAsync -- in a captured step the ONLY memset node left (the profiler finds `aten::mean` and nothing
     else), and a memset node of a replayed hipGraph is not safe on ROCm 7.x: an eager hipMemsetAsync issued between two replays (a `torch.equal`,
     an evaluation hook) can leave the node zeroing nothing from then on -- the logged `decode.loss_seg` then read 0.0115 instead of 4.82 on every
-    later step (DESIGN section 3.8; tests/test_graph_gpu.py).  Plain differentiable ops: the gradient arrives as ONE value broadcast over the map
+    later step (DESIGN section 3.11; tests/test_graph_gpu.py).  Plain differentiable ops: the gradient arrives as ONE value broadcast over the map
     (all strides 0), which the fused CE backward takes as a scalar instead of reading a dense 1/N map."""
     if value.is_cuda and value.numel() >= 8192 and value.is_contiguous() and value.is_floating_point():
         for group in (1024, 512, 256):
