@@ -768,14 +768,16 @@ int sd_affine_act_nchw(const float *x, const float *residual, float *y, const fl
  * The second half of a frozen Mix-FFN in one pass (round 6):  y = fc2(GELU(dwconv3x3(h) + dw_bias)) + fc2_bias  on token-major fp32 activations,
  * h [B, H*W, hidden] (fc1's output) -> y [B, H*W, out_features].  Replaces `x = self.dwconv(x, H, W); x = self.act(x); x = self.fc2(x)` of the
  * reference's Mlp (mix_transformer.py:20-55) for a network in eval mode without autograd (the teacher): the activated hidden map -- the block's
- * largest tensor -- is never written.  Convolution and GELU as sd_dwconv3x3_gelu_fwd, the product in split-bf16 arithmetic as sd_linear_fwd.
- * dw_weight [hidden][9] (nn.Conv2d's [hidden, 1, 3, 3]), fc2_weight [out_features][hidden]; all operands fp32, 16-byte aligned (SD_E_ALIGN).
+ * largest tensor -- is never written.  Convolution and GELU as sd_dwconv3x3_gelu_fwd.  dtype SD_F32: h, y fp32, the product in split-bf16 arithmetic as
+ * sd_linear_fwd; SD_BF16 (the network under bf16 autocast): h, y bf16, the activated map and fc2's weight rounded to bf16 as the two-kernel route does,
+ * fp32 accumulation + bias, one rounding.  dw_weight [hidden][9] (nn.Conv2d's [hidden, 1, 3, 3]), fc2_weight [out_features][hidden], biases: fp32;
+ * everything 16-byte aligned (SD_E_ALIGN).
  * _supported(): H % 8 == 0, W % 16 == 0, hidden % 32 == 0, out_features 64 or 128, H * W * hidden < 2^30; else SD_E_UNSUPPORTED (run the two
  * kernels).
  */
 int sd_mixffn_tail_supported(int H, int W, int hidden, int out_features);
-int sd_mixffn_tail_f32(const float *h, const float *dw_weight, const float *dw_bias, const float *fc2_weight, const float *fc2_bias, float *y, int B,
-                       int H, int W, int hidden, int out_features, void *stream);
+int sd_mixffn_tail(const void *h, const float *dw_weight, const float *dw_bias, const float *fc2_weight, const float *fc2_bias, void *y, int dtype, int B,
+                   int H, int W, int hidden, int out_features, void *stream);
 
 /* ---------------------------------------------------------------------------
  * The tail of a frozen SegFormer head in one pass (round 6), fp32:

@@ -42,7 +42,7 @@ SIGNATURES = {
     'sd_head_tail_supported': (_i, [_i, _i, _i, _i]),
     'sd_head_tail_f32': (_i, [_vp] * 10 + [_i] * 5 + [_vp]),
     'sd_mixffn_tail_supported': (_i, [_i, _i, _i, _i]),
-    'sd_mixffn_tail_f32': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'sd_mixffn_tail': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'sd_affine_act_nchw': (_i, [_vp, _vp, _vp, _vp, _vp, C.c_long, _i, C.c_long, _i, _vp]),
     'sd_im2col_tokens': (_i, [_vp, _vp, _i, _i, _i, _i, _i, C.c_long, C.c_long, C.c_long, C.c_long, _i, _i, _i, _i, _i, _i, _vp]),
     'sd_col2im_tokens': (_i, [_vp, _vp, _i] + [_i] * 10 + [_vp]),

@@ -18,6 +18,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "sd_common.h"
 
 namespace sd {
@@ -63,8 +65,12 @@ __device__ __forceinline__ void split2(float x0, float x1, bf16x2 &h, bf16x2 &m,
 // explicit s_waitcnt of wait_loads(); tools/asm_pending_audit.py checks that nothing touches the destination registers in between
 // ("+v": the destination IS the loop-carried variable's register -- with "=v" the compiler defines a fresh value and copies it into the loop
 // variable right behind the request, i.e. before the data has arrived)
-__device__ __forceinline__ void pinned_load16(f32x4 &v, const float *base, unsigned off) {
+__device__ __forceinline__ void pinned_load16(f32x4 &v, const void *base, unsigned off) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(v) : "v"(off), "s"(base) : "memory");
+}
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pinned_load8(u32x2 &v, const void *base, unsigned off) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(v) : "v"(off), "s"(base) : "memory");
 }
 __device__ __forceinline__ void wait_loads() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -72,16 +78,21 @@ __device__ __forceinline__ void wait_loads() {
 }
 
 // grid.x = B * (H / 8) * (W / 16) (XCD-remapped: consecutive logical patches of an image share one L2)
-template <int NT>   // Cout = 32 NT
-__global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void mixffn_tail_x3(const float *__restrict__ h, const float *__restrict__ dww,
+// T = float: h, Y fp32, the product in split-bf16 arithmetic (NP = 3 planes per operand, six products).  T = bf16_t (the network under bf16 autocast):
+// h, Y bf16, the activated map and fc2's weight rounded to bf16 -- exactly what the two-kernel route hands the bf16 GEMM -- one plane, one product.
+template <int NT, typename T>   // Cout = 32 NT
+__global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void mixffn_tail_x3(const T *__restrict__ h, const float *__restrict__ dww,
                                                                        const float *__restrict__ dwb, const float *__restrict__ W2,
-                                                                       const float *__restrict__ b2, float *__restrict__ Y, int H, int W, int Ch,
+                                                                       const float *__restrict__ b2, T *__restrict__ Y, int H, int W, int Ch,
                                                                        int patches_x, int patches_per_img) {
     constexpr int COUT = 32 * NT;
     constexpr int kBPlane = COUT * kPitch;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // A planes [3][128][80 B] | B planes [3][COUT][80 B] | taps [Ch][9] | bias [Ch]
-    unsigned char *ldsA = lds, *ldsB = lds + 3 * kAPlane;
-    float *ldsT = reinterpret_cast<float *>(lds + 3 * kAPlane + 3 * kBPlane), *ldsBias = ldsT + 9 * Ch;
+    constexpr bool F32 = sizeof(T) == 4;
+    constexpr int NP = F32 ? 3 : 1;
+    constexpr unsigned ES = sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // A planes [NP][128][80 B] | B planes [NP][COUT][80 B] | taps [Ch][9] | bias [Ch]
+    unsigned char *ldsA = lds, *ldsB = lds + NP * kAPlane;
+    float *ldsT = reinterpret_cast<float *>(lds + NP * kAPlane + NP * kBPlane), *ldsBias = ldsT + 9 * Ch;
     const long nblk = gridDim.x, id = blockIdx.x;
     const long qd = nblk / 8, rem = nblk % 8, xcd = id % 8;
     const long L = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + id / 8;
@@ -94,17 +105,17 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void mixffn_tail_x3(const flo
     const int c4 = t & 7, strip = t >> 3;
     const int r = strip >> 2, xs = (strip & 3) * 4;
     const int yy = y0 + r, xx = x0 + xs;
-    const float *hb = h + (size_t)b * H * W * Ch;      // wave-uniform; the lane's part of the address is a 32-bit byte offset (H W Ch < 2^30)
+    const T *hb = h + (size_t)b * H * W * Ch;          // wave-uniform; the lane's part of the address is a 32-bit byte offset (H W Ch < 2^30)
     unsigned roff[3], coff[6];
     bool rok[3];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = yy + ky - 1;
         rok[ky] = iy >= 0 && iy < H;
-        roff[ky] = ((unsigned)(min(max(iy, 0), H - 1) * W) * (unsigned)Ch + 4u * c4) * 4u;
+        roff[ky] = ((unsigned)(min(max(iy, 0), H - 1) * W) * (unsigned)Ch + 4u * c4) * ES;
     }
 #pragma unroll
-    for (int j = 0; j < 6; ++j) coff[j] = (unsigned)min(max(xx + j - 1, 0), W - 1) * (unsigned)Ch * 4u;
+    for (int j = 0; j < 6; ++j) coff[j] = (unsigned)min(max(xx + j - 1, 0), W - 1) * (unsigned)Ch * ES;
     const bool lok = xx >= 1, rgt = xx + 4 < W;        // halo columns inside the image row
 
     // ---- fc2 weight staging: thread -> (output channel n = t >> 2 (+ 64 per round), 8 k from 8 (t & 3)) ----
@@ -127,22 +138,27 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void mixffn_tail_x3(const flo
     // the global operands of one chunk: 18 input vectors and this thread's piece of fc2's weight chunk.  Requested a chunk AHEAD -- right after the
     // previous chunk's convolution has consumed these registers -- so that their latency runs under the GELU / split / LDS / matrix stages instead
     // of in front of every chunk.
-    f32x4 raw[3][6], w2r[2 * RD];
+    typedef typename std::conditional<F32, f32x4, u32x2>::type raw_t;      // 4 channels of one pixel
+    raw_t raw[3][6];
+    f32x4 w2r[2 * RD];
     {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) raw[ky][j] = z;
+            for (int j = 0; j < 6; ++j) raw[ky][j] = raw_t{};
 #pragma unroll
         for (int i = 0; i < 2 * RD; ++i) w2r[i] = z;
     }
     auto request = [&](int kc) {
-        const unsigned cbb = (unsigned)(kc * kKC) * 4u;
+        const unsigned cbb = (unsigned)(kc * kKC) * 4u, cbe = (unsigned)(kc * kKC) * ES;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) pinned_load16(raw[ky][j], hb, roff[ky] + coff[j] + cbb);
+            for (int j = 0; j < 6; ++j) {
+                if constexpr (F32) pinned_load16(raw[ky][j], hb, roff[ky] + coff[j] + cbe);
+                else pinned_load8(raw[ky][j], hb, roff[ky] + coff[j] + cbe);
+            }
 #pragma unroll
         for (int rd = 0; rd < RD; ++rd) {
             const unsigned o = w2off + (unsigned)(64 * rd) * (unsigned)Ch * 4u + cbb;
@@ -183,7 +199,14 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void mixffn_tail_x3(const flo
         for (int ky = 0; ky < 3; ++ky) {
             f32x4 cv[6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j) cv[j] = raw[ky][j];
+            for (int j = 0; j < 6; ++j) {
+                if constexpr (F32) cv[j] = raw[ky][j];
+                else {
+                    const u32x2 v = raw[ky][j];
+                    cv[j] = f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16),
+                                  __uint_as_float(v[1] & 0xffff0000u)};
+                }
+            }
             if (!lok) cv[0] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (!rgt) cv[5] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -214,7 +237,7 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void mixffn_tail_x3(const flo
             if (wn + 64 * rd < COUT) {
                 unsigned char *q = ldsB + (wn + 64 * rd) * kPitch + 2 * wk;
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8 *>(q + pl * kBPlane) = bp[pl];
+                for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<bf16x8 *>(q + pl * kBPlane) = bp[pl];
             }
         }
         // every register of this chunk's request has been consumed: the next chunk's goes out now
@@ -233,27 +256,32 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void mixffn_tail_x3(const flo
             const bf16x4 hh = {h0[0], h0[1], h1[0], h1[1]}, mm = {m0[0], m0[1], m1[0], m1[1]}, ll = {l0[0], l0[1], l1[0], l1[1]};
             unsigned char *q = ldsA + (16 * r + xs + p) * kPitch + 8 * c4;
             *reinterpret_cast<uint2 *>(q) = __builtin_bit_cast(uint2, hh);
-            *reinterpret_cast<uint2 *>(q + kAPlane) = __builtin_bit_cast(uint2, mm);
-            *reinterpret_cast<uint2 *>(q + 2 * kAPlane) = __builtin_bit_cast(uint2, ll);
+            if constexpr (F32) {
+                *reinterpret_cast<uint2 *>(q + kAPlane) = __builtin_bit_cast(uint2, mm);
+                *reinterpret_cast<uint2 *>(q + 2 * kAPlane) = __builtin_bit_cast(uint2, ll);
+            }
         }
         __syncthreads();
         // -- matrix stage --
 #pragma unroll
         for (int s = 0; s < kKC / 16; ++s) {
             const unsigned char *qa = ldsA + (32 * wave + col) * kPitch + 32 * s + 16 * kg;
-            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(qa), am = *reinterpret_cast<const bf16x8 *>(qa + kAPlane),
-                         al = *reinterpret_cast<const bf16x8 *>(qa + 2 * kAPlane);
+            const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(qa);
+            bf16x8 am = ah, al = ah;
+            if constexpr (F32) am = *reinterpret_cast<const bf16x8 *>(qa + kAPlane), al = *reinterpret_cast<const bf16x8 *>(qa + 2 * kAPlane);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const unsigned char *qb = ldsB + (32 * nt + col) * kPitch + 32 * s + 16 * kg;
-                const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(qb), bm = *reinterpret_cast<const bf16x8 *>(qb + kBPlane),
-                             bl = *reinterpret_cast<const bf16x8 *>(qb + 2 * kBPlane);
+                const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(qb);
                 f32x16 c = acc[nt];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);      // small terms first (token_gemm.hip's order)
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                if constexpr (F32) {
+                    const bf16x8 bm = *reinterpret_cast<const bf16x8 *>(qb + kBPlane), bl = *reinterpret_cast<const bf16x8 *>(qb + 2 * kBPlane);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);      // small terms first (token_gemm.hip's order)
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
                 acc[nt] = c;
             }
@@ -264,31 +292,36 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void mixffn_tail_x3(const flo
         __syncthreads();                                 // this chunk's fragment reads are done: the tiles may be overwritten
     }
     // ---- epilogue: D row m = 32 wave + (e & 3) + 8 (e >> 2) + 4 kg -> patch pixel (m >> 4, m & 15); column 32 nt + col ----
-    float *Yb = Y + (size_t)b * H * W * COUT;
+    T *Yb = Y + (size_t)b * H * W * COUT;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int m = 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * kg;
-        float *yo = Yb + ((size_t)(y0 + (m >> 4)) * W + x0 + (m & 15)) * COUT + col;
+        T *yo = Yb + ((size_t)(y0 + (m >> 4)) * W + x0 + (m & 15)) * COUT + col;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) yo[32 * nt] = acc[nt][e];
+        for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (F32) yo[32 * nt] = acc[nt][e];
+            else yo[32 * nt].bits = f32_to_bf16(acc[nt][e]);
+        }
     }
 }
 
-template <int NT>
-int launch_tail(const float *h, const float *dww, const float *dwb, const float *W2, const float *b2, float *Y, int B, int H, int W, int Ch,
+template <int NT, typename T>
+int launch_tail(const void *h, const float *dww, const float *dwb, const float *W2, const float *b2, void *Y, int B, int H, int W, int Ch,
                 hipStream_t st) {
+    constexpr int NP = sizeof(T) == 4 ? 3 : 1;
     const int px = W / kPW, ppi = px * (H / kPH);
-    const size_t ldsb = (size_t)3 * kAPlane + (size_t)3 * 32 * NT * kPitch + (size_t)40 * Ch;
+    const size_t ldsb = (size_t)NP * kAPlane + (size_t)NP * 32 * NT * kPitch + (size_t)40 * Ch;
     if (ldsb > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mixffn_tail_x3<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&mixffn_tail_x3<NT, T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
             raised = true;
         }
     }
     if (ldsb > 160 * 1024) return SD_E_UNSUPPORTED;
-    hipLaunchKernelGGL((mixffn_tail_x3<NT>), dim3((unsigned)((long)B * ppi)), dim3(256), ldsb, st, h, dww, dwb, W2, b2, Y, H, W, Ch, px, ppi);
+    hipLaunchKernelGGL((mixffn_tail_x3<NT, T>), dim3((unsigned)((long)B * ppi)), dim3(256), ldsb, st, (const T *)h, dww, dwb, W2, b2, (T *)Y, H, W, Ch, px,
+                       ppi);
     return (int)hipGetLastError();
 }
 
@@ -304,9 +337,10 @@ int sd_mixffn_tail_supported(int H, int W, int hidden, int out_features) {
                : 0;
 }
 
-int sd_mixffn_tail_f32(const float *h, const float *dw_weight, const float *dw_bias, const float *fc2_weight, const float *fc2_bias, float *y, int B,
-                       int H, int W, int hidden, int out_features, void *stream) {
+int sd_mixffn_tail(const void *h, const float *dw_weight, const float *dw_bias, const float *fc2_weight, const float *fc2_bias, void *y, int dtype, int B,
+                   int H, int W, int hidden, int out_features, void *stream) {
     if (!h || !dw_weight || !dw_bias || !fc2_weight || !fc2_bias || !y) return SD_E_NULL;
+    if (dtype != SD_F32 && dtype != SD_BF16) return SD_E_DTYPE;
     if (B <= 0 || H <= 0 || W <= 0 || hidden <= 0 || out_features <= 0) return SD_E_SHAPE;
     if (!sd_mixffn_tail_supported(H, W, hidden, out_features)) return SD_E_UNSUPPORTED;
     if ((long)B * (H / sd::kPH) * (W / sd::kPW) > 0x7fffffffL) return SD_E_SHAPE;
@@ -314,8 +348,11 @@ int sd_mixffn_tail_f32(const float *h, const float *dw_weight, const float *dw_b
          reinterpret_cast<uintptr_t>(fc2_weight) | reinterpret_cast<uintptr_t>(fc2_bias) | reinterpret_cast<uintptr_t>(y)) & 15)
         return SD_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    return out_features == 64 ? sd::launch_tail<2>(h, dw_weight, dw_bias, fc2_weight, fc2_bias, y, B, H, W, hidden, st)
-                              : sd::launch_tail<4>(h, dw_weight, dw_bias, fc2_weight, fc2_bias, y, B, H, W, hidden, st);
+    if (dtype == SD_F32)
+        return out_features == 64 ? sd::launch_tail<2, float>(h, dw_weight, dw_bias, fc2_weight, fc2_bias, y, B, H, W, hidden, st)
+                                  : sd::launch_tail<4, float>(h, dw_weight, dw_bias, fc2_weight, fc2_bias, y, B, H, W, hidden, st);
+    return out_features == 64 ? sd::launch_tail<2, sd::bf16_t>(h, dw_weight, dw_bias, fc2_weight, fc2_bias, y, B, H, W, hidden, st)
+                              : sd::launch_tail<4, sd::bf16_t>(h, dw_weight, dw_bias, fc2_weight, fc2_bias, y, B, H, W, hidden, st);
 }
 
 }  // extern "C"

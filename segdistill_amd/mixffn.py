@@ -1,8 +1,9 @@
 """The second half of a frozen Mix-FFN as one kernel (csrc/mixffn_tail.hip): fc2(GELU(dwconv3x3(h) + b)) on token-major fp32 activations.
 
 reference mix_transformer.py:20-55 (`x = self.dwconv(x, H, W); x = self.act(x); x = self.drop(x); x = self.fc2(x)`), eval mode, no autograd
-(the teacher's stages 1-2): the activated hidden map is never written.  Same convolution / GELU arithmetic as dwconv.py's inference kernel, the
-product in split-bf16 arithmetic as linear.py's fp32 kernels."""
+(the teacher's stages 1-2): the activated hidden map is never written.  Same convolution / GELU arithmetic as dwconv.py's inference kernel; fp32
+storage: the product in split-bf16 arithmetic as linear.py's fp32 kernels; bf16 activations under autocast: a bf16 product on the weight's bf16
+rounding with fp32 accumulation, as the bf16 GEMM of the two-kernel route."""
 from __future__ import annotations
 
 import os
@@ -11,7 +12,7 @@ import torch
 
 from . import _lib
 from .layers import frozen_derived
-from .ops import _stream_ptr
+from .ops import _DT, _stream_ptr
 
 _ENABLED = os.environ.get('SEGDISTILL_MIXFFN_TAIL', '1') == '1'      # A/B: 0 = the depthwise kernel, then the GEMM
 _MIN_TOKENS = int(os.environ.get('SEGDISTILL_MIXFFN_TAIL_MIN_TOKENS', '16384'))   # below: too few 128-token patches to fill the CUs
@@ -19,7 +20,11 @@ _MIN_TOKENS = int(os.environ.get('SEGDISTILL_MIXFFN_TAIL_MIN_TOKENS', '16384')) 
 
 def usable(h, conv, fc2, hw):
     """h: fc1's fp32 output [B, H*W, hidden] on the GPU with autograd off; conv the depthwise 3x3 (+ bias), fc2 the output Linear (+ bias)."""
-    if not (_ENABLED and h.is_cuda and h.dtype == torch.float32 and h.dim() == 3 and not torch.is_grad_enabled() and not torch.is_autocast_enabled()):
+    if not (_ENABLED and h.is_cuda and h.dim() == 3 and not torch.is_grad_enabled()):
+        return False
+    # fp32 storage without autocast, or bf16 activations under bf16 autocast (fc2 would then run as a bf16 product on the weight's bf16 rounding)
+    amp = torch.is_autocast_enabled()
+    if not ((h.dtype == torch.float32 and not amp) or (h.dtype == torch.bfloat16 and amp and torch.get_autocast_gpu_dtype() == torch.bfloat16)):
         return False
     if conv.bias is None or fc2.bias is None or conv.weight.dtype != torch.float32 or fc2.weight.dtype != torch.float32:
         return False
@@ -38,8 +43,8 @@ def tail(h, conv, fc2, hw):
            else frozen_derived(conv.weight, 'dw_taps', lambda: conv.weight.detach().reshape(C, 9).float().contiguous()))
     w2 = fc2.weight.detach()
     w2 = w2 if w2.is_contiguous() else w2.contiguous()
-    y = torch.empty(B, N, fc2.out_features, dtype=torch.float32, device=h.device)
-    rc = _lib.lib().sd_mixffn_tail_f32(h.data_ptr(), w_t.data_ptr(), conv.bias.detach().data_ptr(), w2.data_ptr(), fc2.bias.detach().data_ptr(),
-                                       y.data_ptr(), B, int(hw[0]), int(hw[1]), C, fc2.out_features, _stream_ptr())
-    _lib.check(rc, 'sd_mixffn_tail_f32')
+    y = torch.empty(B, N, fc2.out_features, dtype=h.dtype, device=h.device)
+    rc = _lib.lib().sd_mixffn_tail(h.data_ptr(), w_t.data_ptr(), conv.bias.detach().data_ptr(), w2.data_ptr(), fc2.bias.detach().data_ptr(),
+                                   y.data_ptr(), _DT[h.dtype], B, int(hw[0]), int(hw[1]), C, fc2.out_features, _stream_ptr())
+    _lib.check(rc, 'sd_mixffn_tail')
     return y

@@ -16,19 +16,22 @@ from segdistill_amd.linear import call_linear  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--B', type=int, default=8)
+    ap.add_argument('--dtype', default='f32')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     print(f'{"map":>12} {"dim":>4} | {"dw+gelu":>8} {"fc2":>7} {"sum":>7} | {"fused":>7} | HBM floor (h in + y out at 6.3 TB/s)')
     for side, dim in ((128, 64), (64, 128), (32, 64), (32, 128)):
         m = MixFFN(dim, 4 * dim).to(dev).eval()
         conv = m.dwconv.dwconv
-        with torch.no_grad():
+        amp = torch.autocast('cuda', dtype=torch.bfloat16, enabled=a.dtype == 'bf16')
+        with torch.no_grad(), amp:
             h = torch.randn(a.B, side * side, 4 * dim, device=dev)
+            h = h.bfloat16() if a.dtype == 'bf16' else h
             g = hip_dw.dwconv3x3_gelu_tokens_inference(h, conv.weight, conv.bias, side, side)
             t_dw = timeit(lambda: hip_dw.dwconv3x3_gelu_tokens_inference(h, conv.weight, conv.bias, side, side))
             t_fc = timeit(lambda: call_linear(m.fc2, g))
             t_f = timeit(lambda: mixffn.tail(h, conv, m.fc2, (side, side)))
-        floor = (h.numel() + h.numel() // 4) * 4 / 6.3e6
+        floor = (h.numel() + h.numel() // 4) * h.element_size() / 6.3e6
         print(f'{a.B}x{side}x{side:<5} {dim:>4} | {t_dw:8.1f} {t_fc:7.1f} {t_dw + t_fc:7.1f} | {t_f:7.1f} | {floor:6.1f}')
 
 
