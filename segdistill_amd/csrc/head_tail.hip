@@ -63,6 +63,19 @@ __device__ __forceinline__ void wait_loads() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+#ifdef SD_HEAD_TAIL_STAMPS
+// diagnostic build only (tools/head_tail_bench.py --stamps): s_memtime sums per phase of wave 0 of logical workgroup 0
+__device__ unsigned long long g_head_tail_stamps[16];
+#define SD_ST(i)                                                        \
+    do {                                                                \
+        const unsigned long long tnow = __builtin_amdgcn_s_memtime();   \
+        ph[i] += tnow - tlast;                                          \
+        tlast = tnow;                                                   \
+    } while (0)
+#else
+#define SD_ST(i)
+#endif
+
 // one coarse branch of csrc/headfuse.hip::add_branch_strip on already loaded taps: vertical lerp of NC columns, then the four pixels
 template <int F, int NC>
 __device__ __forceinline__ void add_branch(float (&acc)[4][4], const f32x4 (&top)[NC], const f32x4 (&bot)[NC], float ly, const float (&lx)[4]) {
@@ -182,10 +195,24 @@ __global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__
             pinned_load16(q2t[j], z2b, g2.row0 + g2.colo[j] + cbb);
             pinned_load16(q2b[j], z2b, g2.row1 + g2.colo[j] + cbb);
         }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            pinned_load16(t3[j], z3b, g3.row0 + g3.colo[j] + cbb);
+            pinned_load16(b3[j], z3b, g3.row1 + g3.colo[j] + cbb);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            pinned_load16(t4[j], z4b, g4.row0 + g4.colo[j] + cbb);
+            pinned_load16(b4[j], z4b, g4.row1 + g4.colo[j] + cbb);
+        }
     };
     request(0);
     __syncthreads();                                     // tables visible
     wait_loads();
+#ifdef SD_HEAD_TAIL_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tlast;
+#endif
 
     const int nchunk = E / kKC;
     for (int kc = 0; kc < nchunk; ++kc) {
@@ -197,21 +224,7 @@ __global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__
             for (int i = 0; i < kWRunsPerWave; ++i)
                 if (wave + 4 * i < kWRuns) dma16(wplanes, wsrc[i] + (unsigned)(kc * kKC) * 2u, wbase + 1024u * (unsigned)(wave + 4 * i));
         }
-        // -- the x4 / x8 taps: small L2-resident maps, requested here (same scalar-base + 32-bit-offset form), used after z1 and the x2 branch --
-        {
-            const unsigned cbb = (unsigned)(kc * kKC) * 4u;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                pinned_load16(t3[j], z3b, g3.row0 + g3.colo[j] + cbb);
-                pinned_load16(b3[j], z3b, g3.row1 + g3.colo[j] + cbb);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                pinned_load16(t4[j], z4b, g4.row0 + g4.colo[j] + cbb);
-                pinned_load16(b4[j], z4b, g4.row1 + g4.colo[j] + cbb);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        SD_ST(0);                                        // W chunk DMA issued
         // -- z1 + bias, then the branches in upsum_fwd_strip's order --
         const f32x4 fb = *reinterpret_cast<const f32x4 *>(ldsB + cb);
         float a[4][4];
@@ -220,13 +233,17 @@ __global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[p][i] = q1[p][i] + fb[i];
         add_branch<2, 4>(a, q2t, q2b, g2.ly, g2.lx);
-        wait_loads();                                    // x4 / x8 taps (and the W chunk, older) have landed
         add_branch<4, 3>(a, t3, b3, g3.ly, g3.lx);
         add_branch<8, 2>(a, t4, b4, g4.ly, g4.lx);
         // every register of this chunk's request has been consumed: the next chunk's goes out now
         __builtin_amdgcn_sched_barrier(0);
+#ifdef SD_HEAD_TAIL_STAMPS
+        asm volatile("" ::"v"(a[0][0]), "v"(a[3][3]));
+#endif
+        SD_ST(1);                                        // sum stage
         request(kc + 1 < nchunk ? kc + 1 : kc);          // (past the last chunk: a repeat, never used)
         __builtin_amdgcn_sched_barrier(0);
+        SD_ST(2);                                        // requests issued
         // -- affine + ReLU, split, pixel tile --
         const f32x4 sc = *reinterpret_cast<const f32x4 *>(ldsS + cb), sh = *reinterpret_cast<const f32x4 *>(ldsH + cb);
 #pragma unroll
@@ -243,7 +260,11 @@ __global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__
             *reinterpret_cast<uint2 *>(q + kPPlane) = __builtin_bit_cast(uint2, mm);
             *reinterpret_cast<uint2 *>(q + 2 * kPPlane) = __builtin_bit_cast(uint2, ll);
         }
+        SD_ST(3);                                        // affine + split + LDS stores
+        asm volatile("s_waitcnt vmcnt(22)" ::: "memory");   // the W chunk has landed: it is older than the 22 requests of the next chunk, which stay in flight
+        SD_ST(4);                                        // wait for the W chunk
         __syncthreads();
+        SD_ST(5);                                        // barrier 1
         // -- matrix stage: A = W_p rows (classes), B = this wave's 32 pixels --
 #pragma unroll
         for (int s = 0; s < kKC / 16; ++s) {
@@ -265,11 +286,24 @@ __global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__
                 acc[mt] = c;
             }
         }
+#ifdef SD_HEAD_TAIL_STAMPS
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[4][15]));
+#endif
+        SD_ST(6);                                        // fragment reads + MFMAs
         // the wait sits here, not at the loop top: whatever copies the compiler makes of the loop-carried request registers at the back edge read
         // arrived data (tools/asm_pending_audit.py)
         wait_loads();
         __syncthreads();                                 // this chunk's fragment reads are done: the tiles may be overwritten
+        SD_ST(7);                                        // wait for the next chunk's operands + barrier 2
     }
+#ifdef SD_HEAD_TAIL_STAMPS
+    if (L == 0 && t == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_head_tail_stamps[i] = ph[i];
+        g_head_tail_stamps[8] = __builtin_amdgcn_s_memtime() - tstart;
+        g_head_tail_stamps[9] = (unsigned long long)nchunk;
+    }
+#endif
     // ---- epilogue: class planes; lane = pixel x0 + col of row y0 + wave ----
     float *ob = out + (size_t)b * classes * HW + (size_t)(y0 + wave) * W + x0 + col;
 #pragma unroll
@@ -285,6 +319,12 @@ __global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__
 }  // namespace sd
 
 extern "C" {
+
+#ifdef SD_HEAD_TAIL_STAMPS
+int sd_debug_head_tail_stamps(unsigned long long *out16) {       // diagnostic build only (not in the header)
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(sd::g_head_tail_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
 
 int sd_head_tail_supported(int H, int W, int E, int classes) {
     return (H > 0 && W > 0 && H % 8 == 0 && W % sd::kTW == 0 && E % sd::kKC == 0 && E <= 1024 && classes >= 1 && classes <= sd::kRows &&

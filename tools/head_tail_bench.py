@@ -37,5 +37,30 @@ def main():
         print(f'{a.B}x{side}x{side:<5} {E:>4} | {t_s:8.1f} {t_p:7.1f} {t_s + t_p:7.1f} | {t_f:7.1f} | {mf:6.1f} {hb:6.1f}')
 
 
+def stamps():
+    # a -DSD_HEAD_TAIL_STAMPS build: make -C segdistill_amd/csrc OUTDIR=../lib_ab EXTRA=-DSD_HEAD_TAIL_STAMPS; SEGDISTILL_LIB=.../lib_ab/libsegdistill_hip.so
+    import ctypes as C
+    from segdistill_amd import _lib
+    raw = C.CDLL(_lib.LIB_PATH)
+    dev = torch.device('cuda:0')
+    side, E, B = 128, 768, 8
+    sizes = [(side, side), (side // 2, side // 2), (side // 4, side // 4), (side // 8, side // 8)]
+    with torch.no_grad():
+        zs = [torch.randn(B, h * w, E, device=dev) for (h, w) in sizes]
+        scale, shift = torch.rand(E, device=dev) + 0.5, torch.randn(E, device=dev)
+        wp, bp = torch.randn(150, E, device=dev) / E ** 0.5, torch.randn(150, device=dev)
+        for _ in range(3):
+            headfuse.head_tail(zs, sizes, None, scale, shift, wp, bp)
+    torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 16)()
+    assert raw.sd_debug_head_tail_stamps(buf) == 0
+    n = max(1, buf[9])
+    names = ['W chunk DMA issued', 'sum stage', 'requests issued', 'affine + split + LDS stores', 'wait for the W chunk', 'barrier 1', 'fragment reads + MFMAs',
+             'wait for operands + barrier 2']
+    print(f'wave 0 of workgroup 0, {n} chunks, s_memtime ticks (100 MHz): total {buf[8]}')
+    for i, nm in enumerate(names):
+        print(f'  {nm:32s} {buf[i]:8d} ticks  ({buf[i] / n:8.1f} per chunk)')
+
+
 if __name__ == '__main__':
-    main()
+    stamps() if '--stamps' in sys.argv else main()
