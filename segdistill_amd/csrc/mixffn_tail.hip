@@ -77,6 +77,19 @@ __device__ __forceinline__ void wait_loads() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+#ifdef SD_MIXFFN_TAIL_STAMPS
+// diagnostic build only (tools/mixffn_tail_bench.py --stamps): s_memtime sums per phase of wave 0 of logical workgroup 0
+__device__ unsigned long long g_mixffn_tail_stamps[16];
+#define SD_ST(i)                                                        \
+    do {                                                                \
+        const unsigned long long tnow = __builtin_amdgcn_s_memtime();   \
+        ph[i] += tnow - tlast;                                          \
+        tlast = tnow;                                                   \
+    } while (0)
+#else
+#define SD_ST(i)
+#endif
+
 // grid.x = B * (H / 8) * (W / 16) (XCD-remapped: consecutive logical patches of an image share one L2)
 // T = float: h, Y fp32, the product in split-bf16 arithmetic (NP = 3 planes per operand, six products).  T = bf16_t (the network under bf16 autocast):
 // h, Y bf16, the activated map and fc2's weight rounded to bf16 -- exactly what the two-kernel route hands the bf16 GEMM -- one plane, one product.
@@ -171,6 +184,10 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void mixffn_tail_x3(const T *
     wait_loads();
 
     const int nchunk = Ch / kKC;
+#ifdef SD_MIXFFN_TAIL_STAMPS
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tlast;
+#endif
     for (int kc = 0; kc < nchunk; ++kc) {
         // taps of a row outside the image are zeroed (branch-free: the halo rows are clamped, valid addresses)
         float wreg[36];
@@ -218,6 +235,10 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void mixffn_tail_x3(const T *
                     for (int i = 0; i < 4; ++i) a[p][i] = fmaf(wreg[9 * i + k], cv[p + kx][i], a[p][i]);
             }
         }
+#ifdef SD_MIXFFN_TAIL_STAMPS
+        asm volatile("" ::"v"(a[0][0]), "v"(a[3][3]));
+#endif
+        SD_ST(0);                                        // taps from LDS + convolution
         // -- fc2 weight chunk: split, straight into the B tile (the barrier at the end of the previous iteration freed both tiles) --
 #pragma unroll
         for (int rd = 0; rd < RD; ++rd) {
@@ -242,8 +263,10 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void mixffn_tail_x3(const T *
         }
         // every register of this chunk's request has been consumed: the next chunk's goes out now
         __builtin_amdgcn_sched_barrier(0);
+        SD_ST(1);                                        // weight chunk split + LDS stores
         request(kc + 1 < nchunk ? kc + 1 : kc);          // (past the last chunk: a repeat, never used -- the loop body stays branch-free)
         __builtin_amdgcn_sched_barrier(0);
+        SD_ST(2);                                        // requests issued
         // -- GELU, split, A tile: pixel by pixel --
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -261,7 +284,9 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void mixffn_tail_x3(const T *
                 *reinterpret_cast<uint2 *>(q + 2 * kAPlane) = __builtin_bit_cast(uint2, ll);
             }
         }
+        SD_ST(3);                                        // GELU + split + LDS stores
         __syncthreads();
+        SD_ST(4);                                        // barrier 1
         // -- matrix stage --
 #pragma unroll
         for (int s = 0; s < kKC / 16; ++s) {
@@ -286,11 +311,25 @@ __global__ __launch_bounds__(256, NT <= 2 ? 2 : 1) void mixffn_tail_x3(const T *
                 acc[nt] = c;
             }
         }
+#ifdef SD_MIXFFN_TAIL_STAMPS
+        asm volatile("" ::"v"(acc[0][0]), "v"(acc[NT - 1][15]));
+#endif
+        SD_ST(5);                                        // fragment reads + MFMAs
         // the wait sits HERE, not at the loop top: whatever copies the compiler makes of the loop-carried request registers at the back edge then read
         // arrived data (tools/asm_pending_audit.py)
         wait_loads();
+        SD_ST(6);                                        // wait for the next chunk's operands
         __syncthreads();                                 // this chunk's fragment reads are done: the tiles may be overwritten
+        SD_ST(7);                                        // barrier 2
     }
+#ifdef SD_MIXFFN_TAIL_STAMPS
+    if (L == 0 && t == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_mixffn_tail_stamps[i] = ph[i];
+        g_mixffn_tail_stamps[8] = __builtin_amdgcn_s_memtime() - tstart;
+        g_mixffn_tail_stamps[9] = (unsigned long long)nchunk;
+    }
+#endif
     // ---- epilogue: D row m = 32 wave + (e & 3) + 8 (e >> 2) + 4 kg -> patch pixel (m >> 4, m & 15); column 32 nt + col ----
     T *Yb = Y + (size_t)b * H * W * COUT;
 #pragma unroll
@@ -329,6 +368,12 @@ int launch_tail(const void *h, const float *dww, const float *dwb, const float *
 }  // namespace sd
 
 extern "C" {
+
+#ifdef SD_MIXFFN_TAIL_STAMPS
+int sd_debug_mixffn_tail_stamps(unsigned long long *out16) {       // diagnostic build only (not in the header)
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(sd::g_mixffn_tail_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
 
 int sd_mixffn_tail_supported(int H, int W, int hidden, int out_features) {
     return (H > 0 && W > 0 && H % sd::kPH == 0 && W % sd::kPW == 0 && hidden % sd::kKC == 0 && (out_features == 64 || out_features == 128) &&

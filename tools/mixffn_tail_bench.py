@@ -35,5 +35,28 @@ def main():
         print(f'{a.B}x{side}x{side:<5} {dim:>4} | {t_dw:8.1f} {t_fc:7.1f} {t_dw + t_fc:7.1f} | {t_f:7.1f} | {floor:6.1f}')
 
 
+def stamps():
+    # a -DSD_MIXFFN_TAIL_STAMPS build: make -C segdistill_amd/csrc OUTDIR=../lib_ab EXTRA=-DSD_MIXFFN_TAIL_STAMPS; SEGDISTILL_LIB=.../lib_ab/libsegdistill_hip.so
+    import ctypes as C
+    from segdistill_amd import _lib
+    raw = C.CDLL(_lib.LIB_PATH)
+    dev = torch.device('cuda:0')
+    for side, dim in ((128, 64), (64, 128)):
+        m = MixFFN(dim, 4 * dim).to(dev).eval()
+        with torch.no_grad():
+            h = torch.randn(8, side * side, 4 * dim, device=dev)
+            for _ in range(3):
+                mixffn.tail(h, m.dwconv.dwconv, m.fc2, (side, side))
+        torch.cuda.synchronize()
+        buf = (C.c_ulonglong * 16)()
+        assert raw.sd_debug_mixffn_tail_stamps(buf) == 0
+        n = max(1, buf[9])
+        names = ['taps + convolution', 'weight chunk split + stores', 'requests issued', 'GELU + split + LDS stores', 'barrier 1', 'fragment reads + MFMAs',
+                 'wait for operands', 'barrier 2']
+        print(f'8x{side}x{side} dim {dim}: wave 0 of workgroup 0, {n} chunks, s_memtime ticks: total {buf[8]}')
+        for i, nm in enumerate(names):
+            print(f'  {nm:32s} {buf[i]:8d} ticks  ({buf[i] / n:8.1f} per chunk)')
+
+
 if __name__ == '__main__':
-    main()
+    stamps() if '--stamps' in sys.argv else main()
