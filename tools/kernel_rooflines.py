@@ -772,7 +772,48 @@ def bench_bf16gemm(dev, reps):
     return out
 
 
+def bench_tails(dev, reps, B=8):
+    """The frozen teacher's two tail kernels (round 6): Mix-FFN tail at the stage-1 / stage-2 maps of Segformer-B2 (fp32) and B4 (bf16), graded on HBM
+    (h in + y out: what a one-pass kernel has to move); the SegFormer head tail at E = 768, graded on the matrix pipe (160 class rows, 6 products)."""
+    from segdistill_amd import _lib, planes
+    L = _lib.lib()
+    out = []
+    for side, dim in ((128, 64), (64, 128)):
+        for dt, code in ((torch.float32, 0), (torch.bfloat16, 1)):
+            C = 4 * dim
+            h = torch.randn(B, side * side, C, device=dev).to(dt)
+            w = torch.randn(C, 9, device=dev) / 3
+            b = torch.randn(C, device=dev)
+            w2 = torch.randn(dim, C, device=dev) / C ** 0.5
+            b2 = torch.randn(dim, device=dev)
+            y = torch.empty(B, side * side, dim, device=dev, dtype=dt)
+            t = _time(lambda st: _ok(L.sd_mixffn_tail(h.data_ptr(), w.data_ptr(), b.data_ptr(), w2.data_ptr(), b2.data_ptr(), y.data_ptr(), code, B, side, side,
+                                                      C, dim, st), 'mixffn tail'), reps)
+            nb = (h.numel() + y.numel()) * h.element_size()
+            out.append(_entry(f'Mix-FFN tail (dw3x3 + GELU + fc2), {side}x{side}, {C} -> {dim}, {"f32" if code == 0 else "bf16"}', 'mixffn_tail_x3',
+                              [B, side, side, C, dim], 'f32 (split-bf16)' if code == 0 else 'bf16', t, 'hbm', nb, HBM,
+                              'VALU-paced (GELU): profiles/r06_mixffn_tail_stamps.txt'))
+    side, E, N = 128, 768, 150
+    sizes = [(side, side), (side // 2, side // 2), (side // 4, side // 4), (side // 8, side // 8)]
+    zs = [torch.randn(B, hh * ww, E, device=dev) for (hh, ww) in sizes]
+    scale, shift = torch.rand(E, device=dev) + 0.5, torch.randn(E, device=dev)
+    wp = torch.randn(N, E, device=dev) / E ** 0.5
+    bp = torch.randn(N, device=dev)
+    pr = planes.get(wp, 'rows')
+    lo = torch.empty(B, N, side, side, device=dev)
+    t = _time(lambda st: _ok(L.sd_head_tail_f32(zs[0].data_ptr(), zs[1].data_ptr(), zs[2].data_ptr(), zs[3].data_ptr(), None, scale.data_ptr(),
+                                                shift.data_ptr(), pr.data_ptr(), bp.data_ptr(), lo.data_ptr(), B, side, side, E, N, st), 'head tail'), reps)
+    e = _entry(f'SegFormer head tail (sum + norm + ReLU + linear_pred), E = {E}', 'head_tail_x3', [B, side, side, E, N], 'f32 (split-bf16)', t, 'mfma',
+               2.0 * B * side * side * E * N, MFMA_BF16 / 6, 'bound: dense bf16 peak / 6 cross products; profiles/r06_head_tail_stamps.txt')
+    nb = (zs[0].numel() + lo.numel()) * 4
+    e['hbm_GBps'] = round(nb / (t * 1e-3) / 1e9, 1)
+    e['hbm_frac'] = round(nb / (t * 1e-3) / 1e9 / HBM, 4)
+    out.append(e)
+    return out
+
+
 GROUPS = {
+    'tails': lambda dev, reps: bench_tails(dev, reps),
     'wgradmulti': lambda dev, reps: bench_wgrad_multi(dev, reps),
     'bf16gemm': lambda dev, reps: bench_bf16gemm(dev, reps),
     'aligntok': lambda dev, reps: bench_aligntok(dev, reps),

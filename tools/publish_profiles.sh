@@ -33,7 +33,7 @@ json.dump(d, open(sys.argv[2], 'w'), indent=1)
 PY
   ) && n=$((n + 1))
 fi
-for f in align_tok_bench.txt pix_up_bench.txt bf16_gemm_bench.txt; do
+for f in align_tok_bench.txt pix_up_bench.txt bf16_gemm_bench.txt mixffn_tail_bench.txt head_tail_bench.txt overlap_probe.txt; do
   put $SRC/$f $DST/${P}_$f
 done
 for f in $R/gpurun_out/configs/train_step_kernels_cfg*.txt $R/gpurun_out/configs/step_shapes_cfg*.txt \

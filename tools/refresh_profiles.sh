@@ -7,6 +7,7 @@
 #   4 other_configs.txt       the other BASELINE configs, graph and hybrid mode
 #   5 kernels_*.csv / pmc_*.json   rocprofv3 of tools/kernel_rooflines.py: kernel trace, then FETCH_SIZE / WRITE_SIZE / SQ_* in SEPARATE --pmc passes
 #   6 gemm_bench.txt          token-major Linear products: library vs csrc/token_gemm.hip, device time
+#   7 step_gap_probe.txt      unprofiled GPU start -> end of a step;   8 kernels_tails.txt / pmc_tails.json / *_tail_bench.txt / overlap_probe.txt (round 6)
 # rocprofv3 is always given the python program directly after `--`.
 set -u
 R=$(pwd)
@@ -73,6 +74,21 @@ for g in r2 ce; do
   ( cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pvf_$g -o p -- python3 $R/tools/kernel_rooflines.py --only $g > /dev/null 2>&1 )
   python tools/pmc_summary.py /tmp/pv_$g /tmp/pvf_$g --out $OUT/pmc_valu_$g.json > /dev/null
 done
+fi
+if want 8; then
+echo "[8] the frozen teacher's tail kernels: trace + PMC passes" | tee -a $OUT/progress.txt
+g=tails
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kr_$g -o k -- python3 $R/tools/kernel_rooflines.py --only $g > $OUT/kernels_$g.txt 2>/dev/null )
+cp $(find /tmp/kr_$g -name '*kernel_stats.csv' | head -1) $OUT/kernels_${g}_stats.csv 2>/dev/null
+( cd /tmp && rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$g -o p -- python3 $R/tools/kernel_rooflines.py --only $g > /dev/null 2>&1 )
+( cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$g -o p -- python3 $R/tools/kernel_rooflines.py --only $g > /dev/null 2>&1 )
+( cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pv_$g -o p -- python3 $R/tools/kernel_rooflines.py --only $g > /dev/null 2>&1 )
+python tools/pmc_summary.py /tmp/pf_$g /tmp/pw_$g /tmp/pv_$g --match "tail_x3" --out $OUT/pmc_$g.json > /dev/null
+python tools/mixffn_tail_bench.py 2>/dev/null | grep -v amdgpu.ids > $OUT/mixffn_tail_bench.txt
+python tools/mixffn_tail_bench.py --dtype bf16 2>/dev/null | grep -v amdgpu.ids >> $OUT/mixffn_tail_bench.txt
+python tools/head_tail_bench.py 2>/dev/null | grep -v amdgpu.ids > $OUT/head_tail_bench.txt
+python tools/overlap_probe.py 2>/dev/null | grep "full step" > $OUT/overlap_probe.txt
+python tools/overlap_probe.py --config configs/kd/cfg5_segformer_b4_b1_multistage_bf16.py 2>/dev/null | grep "full step" >> $OUT/overlap_probe.txt
 fi
 if want 6; then
 echo "[6] gemm bench" | tee -a $OUT/progress.txt
