@@ -66,9 +66,13 @@ __device__ __forceinline__ int key_of(int px) {
 
 // a 16-byte load the compiler neither sinks nor reorders (waited for by the explicit s_waitcnt below): wave-uniform base in scalar registers + a
 // 32-bit byte offset per lane -- one VGPR of address per request instead of two per row
+// hazard (gfx9): a VALU instruction that WRITES an SGPR (the v_readlane that restores a spilled base pointer, a v_readfirstlane) followed by a
+// vector-memory instruction that READS it needs 5 wait states; hipcc inserts them for its own instructions, not in front of inline asm -- the load
+// then goes to a stale address (round 6: a memory fault in head_tail.hip as soon as a spilled pointer was involved).  Every asm load with a
+// scalar operand therefore carries its own wait states (tools/asm_sgpr_hazard_scan.py checks the built code).
 __device__ __forceinline__ f32x4 pinned_load16(const float *base, unsigned off) {
     f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
     return v;
 }
 __device__ __forceinline__ void wait_loads() {

@@ -50,8 +50,12 @@ enum { MODE_FWD = 0, MODE_BWD = 1, MODE_PLAIN = 2 };
 // Issued from inline asm so that hipcc does not put `s_waitcnt vmcnt(0)` in front of every LDS read that follows (wgrad_tn.hip); the waits are
 // written by hand below.  M0 is reserved in LLVM and nothing else in these kernels uses it.
 // Address = wave-uniform base (SGPR pair) + per-lane unsigned 32-bit byte offset: one VGPR per DMA instruction instead of a 64-bit pointer.
+// hazard (gfx9): a VALU instruction that WRITES an SGPR (the v_readlane that restores a spilled base pointer, a v_readfirstlane) followed by a
+// vector-memory instruction that READS it needs 5 wait states; hipcc inserts them for its own instructions, not in front of inline asm -- the load
+// then goes to a stale address (round 6: a memory fault in head_tail.hip as soon as a spilled pointer was involved).  Every asm load with a
+// scalar operand therefore carries its own wait states (tools/asm_sgpr_hazard_scan.py checks the built code).
 __device__ __forceinline__ void dma16(const void *base, unsigned lane_off, unsigned lds_byte) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base), "s"(lds_byte) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base), "s"(lds_byte) : "memory");
 }
 
 struct AlignTokTable {

@@ -11,8 +11,11 @@
 // A workgroup (256 threads) owns 4 rows x 32 columns of one image (128 pixels) and walks E in chunks of 32 channels:
 //   * W_p's chunk [160 rows][32 k] x 3 planes goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers; the 80-byte row pitch is
 //     kept by letting every fifth lane of a 1 KB run land on the 16 bytes of padding), issued at the top of the chunk under the sum stage;
-//   * sum stage: thread -> (4 channels, 4 consecutive pixels of one row): z1 (4 vectors) and the x2 branch (2 x 4) are requested a chunk ahead,
-//     the x4 / x8 branches (6 + 4 vectors, L2-resident maps) at the top of the chunk; 16 results split into the pixel tile [3][128 px][32 k];
+//   * the coarse branches' taps of the tile and chunk -- 4 x 18, 3 x 10 and 2 x 6 coarse pixels, 14.6 KB -- are parked in LDS by DMA a chunk ahead (under
+//     the matrix stage): read from global memory per thread they were 72 KB of loads per chunk and workgroup for that footprint, a third of a wave's
+//     chunk spent waiting to issue them (profiles/r06_head_tail_stamps.txt);
+//   * sum stage: thread -> (4 channels, 4 consecutive pixels of one row): z1 (4 vectors) and the chunk's scale / shift / bias requested a chunk ahead
+//     into registers, the 18 tap vectors read from LDS; 16 results split into the pixel tile [3][128 px][32 k];
 //   * matrix stage: wave w = tile row w (32 consecutive pixels) against all 160 class rows: D[class][pixel] has the PIXEL on the lane, so every
 //     store instruction writes two full 128-byte lines of the class planes.
 #include <hip/hip_runtime.h>
@@ -51,12 +54,21 @@ __device__ __forceinline__ void split2(float x0, float x1, bf16x2 &h, bf16x2 &m,
 
 // a 16-byte load the compiler neither sinks nor reorders (wave-uniform base + 32-bit byte offset per lane), waited for by wait_loads(); "+v": the
 // destination is the loop-carried variable's own register (tools/asm_pending_audit.py)
+// hazard (gfx9): a VALU instruction that WRITES an SGPR (the v_readlane that restores a spilled base pointer, a v_readfirstlane) followed by a
+// vector-memory instruction that READS it needs 5 wait states; hipcc inserts them for its own instructions, not in front of inline asm -- the load
+// then goes to a stale address (round 6: a memory fault in head_tail.hip as soon as a spilled pointer was involved).  Every asm load with a
+// scalar operand therefore carries its own wait states (tools/asm_sgpr_hazard_scan.py checks the built code).
 __device__ __forceinline__ void pinned_load16(f32x4 &v, const void *base, unsigned off) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(v) : "v"(off), "s"(base) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "+v"(v) : "v"(off), "s"(base) : "memory");
 }
 // global -> LDS, 16 bytes per lane (tok_gemm_bf16.hip): M0 = wave-uniform LDS byte address of lane 0's 16 bytes, lane l lands at M0 + 16 l
 __device__ __forceinline__ void dma16(const void *base, unsigned lane_off, unsigned lds_byte) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base), "s"(lds_byte) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base), "s"(lds_byte) : "memory");
+}
+__device__ __forceinline__ const void *uniform_ptr(const void *p) {       // a wave-uniform pointer the compiler holds in vector registers -> scalar
+    const unsigned long long v = (unsigned long long)(uintptr_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const void *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ void wait_loads() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -93,29 +105,10 @@ __device__ __forceinline__ void add_branch(float (&acc)[4][4], const f32x4 (&top
     }
 }
 
-// per-thread geometry of one coarse branch: byte offsets of its two (clamped) tap rows and NC (clamped) tap columns, and the lerp weights
-template <int F, int NC> struct Branch {
-    unsigned row0, row1, colo[NC];
-    float ly, lx[4];
-    __device__ __forceinline__ void init(int Y, int X0, int H, int W, int E, int c) {
-        const int h = H / F, w = W / F;
-        const float sy = (Y + 0.5f) / F - 0.5f;
-        const int y0u = (int)floorf(sy);
-        ly = sy - (float)y0u;
-        const int y0 = min(max(y0u, 0), h - 1), y1 = min(max(y0u + 1, 0), h - 1);
-        const int base = (int)floorf((X0 + 0.5f) / F - 0.5f);
-        row0 = ((unsigned)(y0 * w) * (unsigned)E + (unsigned)c) * 4u;
-        row1 = ((unsigned)(y1 * w) * (unsigned)E + (unsigned)c) * 4u;
-#pragma unroll
-        for (int j = 0; j < NC; ++j) colo[j] = (unsigned)min(max(base + j, 0), w - 1) * (unsigned)E * 4u;
-        // frac((X0 + p + 0.5) / F - 0.5) for X0 % 4 == 0: constants for F = 2, 4; two cases for F = 8 (what add_branch_strip computes, same values)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            constexpr float k2[4] = {0.75f, 0.25f, 0.75f, 0.25f}, k4[4] = {0.625f, 0.875f, 0.125f, 0.375f};
-            lx[p] = F == 2 ? k2[p] : (F == 4 ? k4[p] : ((X0 & 4) ? 0.0625f : 0.5625f) + 0.125f * p);
-        }
-    }
-};
+// coarse-branch taps of one tile and chunk, parked in LDS (128 bytes = 32 channels per coarse pixel; rows x columns the tile's 4 x 32 pixels can touch):
+constexpr int kT2R = 4, kT2C = 18, kT3R = 3, kT3C = 10, kT4R = 2, kT4C = 6;
+constexpr int kT2Off = 0, kT3Off = kT2R * kT2C * 128, kT4Off = kT3Off + kT3R * kT3C * 128, kTapBytes = kT4Off + kT4R * kT4C * 128;   // 9216, 13056, 14592
+constexpr int kTapRuns = 9 + 4 + 2;                  // 1 KB DMA runs (8 coarse pixels each): x2 72 px, x4 30 px (last run 6 px), x8 12 px (last run 4 px)
 
 // grid.x = B * (H / 4) * (W / 32) (XCD-remapped: consecutive tiles of an image share one L2)
 __global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__ z1, const float *__restrict__ z2, const float *__restrict__ z3,
@@ -124,9 +117,11 @@ __global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__
                                                        const unsigned char *__restrict__ wplanes, const float *__restrict__ pbias,
                                                        float *__restrict__ out, int H, int W, int E, int classes, int tiles_x,
                                                        int tiles_per_img) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // pixel planes [3][128][80 B] | W planes [3][160][80 B] (+ slack to 38 KB) | scale, shift, bias [E]
-    unsigned char *ldsP = lds, *ldsW = lds + 3 * kPPlane;
-    float *ldsS = reinterpret_cast<float *>(lds + 3 * kPPlane + kWRuns * 1024), *ldsH = ldsS + E, *ldsB = ldsH + E;
+    // pixel planes [3][128][80 B] | W planes [3][classes][80 B] | taps [14592 B].  (Fragment reads of class rows classes .. 159 run into the next
+    // plane / the taps region: their products are never stored.)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int wplane = classes * kPitch;
+    unsigned char *ldsP = lds, *ldsW = lds + 3 * kPPlane, *ldsT = ldsW + 3 * wplane;
     const long nblk = gridDim.x, id = blockIdx.x;
     const long qd = nblk / 8, rem = nblk % 8, xcd = id % 8;
     const long L = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + id / 8;
@@ -143,30 +138,59 @@ __global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__
     const float *z1b = z1 + (size_t)b * HW * E, *z2b = z2 + (size_t)b * (HW / 4) * E, *z3b = z3 + (size_t)b * (HW / 16) * E,
                 *z4b = z4 + (size_t)b * (HW / 64) * E;
     const unsigned o1 = (((unsigned)(Y * W + X0)) * (unsigned)E + 4u * c4) * 4u;
-    Branch<2, 4> g2;
-    Branch<4, 3> g3;
-    Branch<8, 2> g4;
-    g2.init(Y, X0, H, W, E, 4 * c4);
-    g3.init(Y, X0, H, W, E, 4 * c4);
-    g4.init(Y, X0, H, W, E, 4 * c4);
+    // origins of the parked tap regions (un-clamped coarse coordinates of slot (0, 0)); y0 % 4 == 0, x0 % 32 == 0
+    const int oy2 = y0 / 2 - 1, ox2 = x0 / 2 - 1, oy3 = y0 / 4 - 1, ox3 = x0 / 4 - 1, oy4 = (y0 & 4) ? y0 / 8 : y0 / 8 - 1, ox4 = x0 / 8 - 1;
+    // this thread's taps inside them: csrc/headfuse.hip::add_branch_strip's (un-clamped) top-left tap minus the origin, and its vertical weight
+    //   x2: floor((Y + .5) / 2 - .5) - oy2 = (r + 1) >> 1, weight .75 / .25;  x4: r >> 1, weights .625 .875 .125 .375;  x8: 0, (.0625 | .5625) + r / 8
+    const unsigned ta2 = (unsigned)(kT2Off + (((r + 1) >> 1) * kT2C + xs / 2) * 128 + 16 * c4);
+    const unsigned ta3 = (unsigned)(kT3Off + ((r >> 1) * kT3C + xs / 4) * 128 + 16 * c4);
+    const unsigned ta4 = (unsigned)(kT4Off + ((int)floorf((xs + 0.5f) / 8 - 0.5f) + 1) * 128 + 16 * c4);
+    const float ly2 = (r & 1) ? 0.25f : 0.75f;
+    const float ly3 = r == 0 ? 0.625f : (r == 1 ? 0.875f : (r == 2 ? 0.125f : 0.375f));
+    const float ly4 = ((y0 & 4) ? 0.0625f : 0.5625f) + 0.125f * r;
+    const float lx2[4] = {0.75f, 0.25f, 0.75f, 0.25f}, lx3[4] = {0.625f, 0.875f, 0.125f, 0.375f};
+    float lx4[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) lx4[p] = ((X0 & 4) ? 0.0625f : 0.5625f) + 0.125f * p;
 
     // ---- W_p by LDS-DMA: wave w issues the 1 KB runs w, w + 4, ...; lane l of run u lands at LDS byte o = 1024 u + 16 l of the W region
-    //      [3 planes][160 rows][80 B]: plane o / 12800, row (o % 12800) / 80, 16-byte piece (o % 80) / 16 -- piece 4 is the row's padding (any
-    //      valid source); class rows beyond `classes` repeat the last one (their products are never stored) ----
+    //      [3 planes][classes rows][80 B]: plane o / (80 classes), row (o % (80 classes)) / 80, 16-byte piece (o % 80) / 16 -- piece 4 is the row's
+    //      padding (any valid source); lanes beyond the region are switched off ----
+    const int wbytes = 3 * wplane, wruns = (wbytes + 1023) / 1024;
     unsigned wsrc[kWRunsPerWave];
 #pragma unroll
     for (int i = 0; i < kWRunsPerWave; ++i) {
-        const int o = min(1024 * (wave + 4 * i) + 16 * lane, 3 * kWPlane - 16);
-        const int pl = o / kWPlane, ro = o % kWPlane, row = ro / kPitch, pc = min((ro % kPitch) >> 4, 3);
-        wsrc[i] = (((unsigned)pl * (unsigned)classes + (unsigned)min(row, classes - 1)) * (unsigned)E + 8u * pc) * 2u;
+        const int oraw = 1024 * (wave + 4 * i) + 16 * lane, o = min(oraw, wbytes - 16);
+        const int pl = o / wplane, ro = o % wplane, row = ro / kPitch, pc = min((ro % kPitch) >> 4, 3);
+        wsrc[i] = (((unsigned)pl * (unsigned)classes + (unsigned)row) * (unsigned)E + 8u * pc) * 2u;
     }
-
-    // per-channel tables once per workgroup
-    for (int i = t; i < E / 4; i += 256) {
-        reinterpret_cast<f32x4 *>(ldsS)[i] = reinterpret_cast<const f32x4 *>(scale)[i];
-        reinterpret_cast<f32x4 *>(ldsH)[i] = reinterpret_cast<const f32x4 *>(shift)[i];
-        reinterpret_cast<f32x4 *>(ldsB)[i] = fbias ? reinterpret_cast<const f32x4 *>(fbias)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- the taps by LDS-DMA: run u = wave + 4 i: 0..8 the x2 map, 9..12 x4, 13..14 x8; lane -> (coarse pixel 8 (run in map) + (lane >> 3), 16-byte
+    //      piece lane & 7); the slot's content is the map at the CLAMPED coordinates (what add_branch_strip loads) ----
+    unsigned tsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = wave + 4 * i;
+        const int rig = u < 9 ? u : (u < 13 ? u - 9 : u - 13), nc = u < 9 ? kT2C : (u < 13 ? kT3C : kT4C), np = u < 9 ? kT2R * kT2C : (u < 13 ? kT3R * kT3C : kT4R * kT4C);
+        const int f = u < 9 ? 2 : (u < 13 ? 4 : 8), oy = u < 9 ? oy2 : (u < 13 ? oy3 : oy4), ox = u < 9 ? ox2 : (u < 13 ? ox3 : ox4);
+        const int px = 8 * rig + (lane >> 3), pxc = min(px, np - 1);
+        const int cy = min(max(oy + pxc / nc, 0), H / f - 1), cx = min(max(ox + pxc % nc, 0), W / f - 1);
+        tsrc[i] = (((unsigned)(cy * (W / f) + cx)) * (unsigned)E + 4u * (lane & 7)) * 4u;
     }
+    auto dma_taps = [&](int kc) {
+        const unsigned tbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ldsT), cbb = (unsigned)(kc * kKC) * 4u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = wave + 4 * i;                   // wave-uniform: one of the three branches per run
+            const int px = lane >> 3;
+            if (u < 9) {
+                dma16(z2b, tsrc[i] + cbb, __builtin_amdgcn_readfirstlane(tbase + (unsigned)(kT2Off + 1024 * u)));
+            } else if (u < 13) {
+                if (8 * (u - 9) + px < kT3R * kT3C) dma16(z3b, tsrc[i] + cbb, __builtin_amdgcn_readfirstlane(tbase + (unsigned)(kT3Off + 1024 * (u - 9))));
+            } else if (u < kTapRuns) {
+                if (8 * (u - 13) + px < kT4R * kT4C) dma16(z4b, tsrc[i] + cbb, __builtin_amdgcn_readfirstlane(tbase + (unsigned)(kT4Off + 1024 * (u - 13))));
+            }
+        }
+    };
 
     // accumulators: D row = class 32 mt + (e & 3) + 8 (e >> 2) + 4 kg
     f32x16 acc[5];
@@ -175,40 +199,27 @@ __global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
 
-    // requested a chunk ahead: z1 (4), the x2 branch (2 x 4), W_p's pieces (8)
-    f32x4 q1[4], q2t[4], q2b[4], t3[3], b3[3], t4[2], b4[2];
+    // requested a chunk ahead into registers: z1 (4 vectors) and the chunk's scale / shift / bias (this thread's 4 channels)
+    const bool hasb = fbias != nullptr;
+    f32x4 q1[4], qs, qh, qb;
     {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) q1[i] = z, q2t[i] = z, q2b[i] = z;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) t3[i] = z, b3[i] = z;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) t4[i] = z, b4[i] = z;
+        for (int i = 0; i < 4; ++i) q1[i] = z;
+        qs = z, qh = z, qb = z;
     }
     auto request = [&](int kc) {
-        const unsigned cbb = (unsigned)(kc * kKC) * 4u;
+        const unsigned cbb = (unsigned)(kc * kKC) * 4u, tb = cbb + 16u * c4;
 #pragma unroll
         for (int p = 0; p < 4; ++p) pinned_load16(q1[p], z1b, o1 + (unsigned)p * (unsigned)E * 4u + cbb);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            pinned_load16(q2t[j], z2b, g2.row0 + g2.colo[j] + cbb);
-            pinned_load16(q2b[j], z2b, g2.row1 + g2.colo[j] + cbb);
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            pinned_load16(t3[j], z3b, g3.row0 + g3.colo[j] + cbb);
-            pinned_load16(b3[j], z3b, g3.row1 + g3.colo[j] + cbb);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            pinned_load16(t4[j], z4b, g4.row0 + g4.colo[j] + cbb);
-            pinned_load16(b4[j], z4b, g4.row1 + g4.colo[j] + cbb);
-        }
+        pinned_load16(qs, scale, tb);
+        pinned_load16(qh, shift, tb);
+        pinned_load16(qb, hasb ? fbias : shift, tb);      // always 7 requests: the counted wait below is exact (without a bias the values are unused)
     };
     request(0);
-    __syncthreads();                                     // tables visible
+    dma_taps(0);
     wait_loads();
+    __syncthreads();                                     // chunk 0's taps visible
 #ifdef SD_HEAD_TAIL_STAMPS
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
     const unsigned long long tstart = tlast;
@@ -216,25 +227,49 @@ __global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__
 
     const int nchunk = E / kKC;
     for (int kc = 0; kc < nchunk; ++kc) {
-        const int cb = kc * kKC + 4 * c4;
         // -- W_p chunk -> LDS by DMA (the barrier at the end of the previous iteration freed both tiles); in flight under the sum stage --
         {
-            const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ldsW);      // LDS byte address of the W region
+            const unsigned wbase = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)ldsW);
 #pragma unroll
             for (int i = 0; i < kWRunsPerWave; ++i)
-                if (wave + 4 * i < kWRuns) dma16(wplanes, wsrc[i] + (unsigned)(kc * kKC) * 2u, wbase + 1024u * (unsigned)(wave + 4 * i));
+                if (wave + 4 * i < wruns && 1024 * (wave + 4 * i) + 16 * lane < wbytes)      // (the last run is partial: its lanes beyond the region stay off)
+                    dma16(wplanes, wsrc[i] + (unsigned)(kc * kKC) * 2u, __builtin_amdgcn_readfirstlane(wbase + 1024u * (unsigned)(wave + 4 * i)));
         }
         SD_ST(0);                                        // W chunk DMA issued
-        // -- z1 + bias, then the branches in upsum_fwd_strip's order --
-        const f32x4 fb = *reinterpret_cast<const f32x4 *>(ldsB + cb);
+        // -- z1 + bias, then the branches in upsum_fwd_strip's order; the coarse taps come from LDS --
         float a[4][4];
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[p][i] = q1[p][i] + fb[i];
-        add_branch<2, 4>(a, q2t, q2b, g2.ly, g2.lx);
-        add_branch<4, 3>(a, t3, b3, g3.ly, g3.lx);
-        add_branch<8, 2>(a, t4, b4, g4.ly, g4.lx);
+            for (int i = 0; i < 4; ++i) a[p][i] = hasb ? q1[p][i] + qb[i] : q1[p][i];
+        {
+            f32x4 top[4], bot[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                top[j] = *reinterpret_cast<const f32x4 *>(ldsT + ta2 + 128 * j);
+                bot[j] = *reinterpret_cast<const f32x4 *>(ldsT + ta2 + 128 * (j + kT2C));
+            }
+            add_branch<2, 4>(a, top, bot, ly2, lx2);
+        }
+        {
+            f32x4 top[3], bot[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                top[j] = *reinterpret_cast<const f32x4 *>(ldsT + ta3 + 128 * j);
+                bot[j] = *reinterpret_cast<const f32x4 *>(ldsT + ta3 + 128 * (j + kT3C));
+            }
+            add_branch<4, 3>(a, top, bot, ly3, lx3);
+        }
+        {
+            f32x4 top[2], bot[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                top[j] = *reinterpret_cast<const f32x4 *>(ldsT + ta4 + 128 * j);
+                bot[j] = *reinterpret_cast<const f32x4 *>(ldsT + ta4 + 128 * (j + kT4C));
+            }
+            add_branch<8, 2>(a, top, bot, ly4, lx4);
+        }
+        const f32x4 sc = qs, sh = qh;
         // every register of this chunk's request has been consumed: the next chunk's goes out now
         __builtin_amdgcn_sched_barrier(0);
 #ifdef SD_HEAD_TAIL_STAMPS
@@ -245,7 +280,6 @@ __global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__
         __builtin_amdgcn_sched_barrier(0);
         SD_ST(2);                                        // requests issued
         // -- affine + ReLU, split, pixel tile --
-        const f32x4 sc = *reinterpret_cast<const f32x4 *>(ldsS + cb), sh = *reinterpret_cast<const f32x4 *>(ldsH + cb);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             float g[4];
@@ -261,21 +295,22 @@ __global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__
             *reinterpret_cast<uint2 *>(q + 2 * kPPlane) = __builtin_bit_cast(uint2, ll);
         }
         SD_ST(3);                                        // affine + split + LDS stores
-        asm volatile("s_waitcnt vmcnt(22)" ::: "memory");   // the W chunk has landed: it is older than the 22 requests of the next chunk, which stay in flight
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");    // the W chunk has landed: it is older than the 7 requests of the next chunk, which stay in flight
         SD_ST(4);                                        // wait for the W chunk
-        __syncthreads();
+        __syncthreads();                                 // pixel tile + W chunk visible; every thread has read this chunk's taps
         SD_ST(5);                                        // barrier 1
+        dma_taps(kc + 1 < nchunk ? kc + 1 : kc);         // the next chunk's taps: in flight under the matrix stage
         // -- matrix stage: A = W_p rows (classes), B = this wave's 32 pixels --
 #pragma unroll
         for (int s = 0; s < kKC / 16; ++s) {
-            const unsigned char *qb = ldsP + (32 * wave + col) * kPitch + 32 * s + 16 * kg;
-            const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(qb), bm = *reinterpret_cast<const bf16x8 *>(qb + kPPlane),
-                         bl = *reinterpret_cast<const bf16x8 *>(qb + 2 * kPPlane);
+            const unsigned char *qb_ = ldsP + (32 * wave + col) * kPitch + 32 * s + 16 * kg;
+            const bf16x8 bh = *reinterpret_cast<const bf16x8 *>(qb_), bm = *reinterpret_cast<const bf16x8 *>(qb_ + kPPlane),
+                         bl = *reinterpret_cast<const bf16x8 *>(qb_ + 2 * kPPlane);
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt) {
                 const unsigned char *qa = ldsW + (32 * mt + col) * kPitch + 32 * s + 16 * kg;
-                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(qa), am = *reinterpret_cast<const bf16x8 *>(qa + kWPlane),
-                             al = *reinterpret_cast<const bf16x8 *>(qa + 2 * kWPlane);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(qa), am = *reinterpret_cast<const bf16x8 *>(qa + wplane),
+                             al = *reinterpret_cast<const bf16x8 *>(qa + 2 * wplane);
                 f32x16 c = acc[mt];
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);      // small terms first (token_gemm.hip's order)
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
@@ -293,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void head_tail_x3(const float *__restrict__
         // the wait sits here, not at the loop top: whatever copies the compiler makes of the loop-carried request registers at the back edge read
         // arrived data (tools/asm_pending_audit.py)
         wait_loads();
-        __syncthreads();                                 // this chunk's fragment reads are done: the tiles may be overwritten
+        __syncthreads();                                 // fragment reads done, the next chunk's taps visible: the tiles may be overwritten
         SD_ST(7);                                        // wait for the next chunk's operands + barrier 2
     }
 #ifdef SD_HEAD_TAIL_STAMPS
@@ -345,7 +380,7 @@ int sd_head_tail_f32(const float *z1, const float *z2, const float *z3, const fl
          reinterpret_cast<uintptr_t>(pred_row_planes) | reinterpret_cast<uintptr_t>(logits)) & 15)
         return SD_E_ALIGN;
     const int tx = W / sd::kTW, tpi = tx * (H / sd::kTH);
-    const size_t ldsb = (size_t)3 * sd::kPPlane + (size_t)sd::kWRuns * 1024 + (size_t)12 * E;
+    const size_t ldsb = (size_t)3 * sd::kPPlane + (size_t)3 * classes * sd::kPitch + (size_t)sd::kTapBytes;     // 81312 B at 150 classes: two workgroups per CU
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sd::head_tail_x3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -65,12 +65,16 @@ __device__ __forceinline__ void split2(float x0, float x1, bf16x2 &h, bf16x2 &m,
 // explicit s_waitcnt of wait_loads(); tools/asm_pending_audit.py checks that nothing touches the destination registers in between
 // ("+v": the destination IS the loop-carried variable's register -- with "=v" the compiler defines a fresh value and copies it into the loop
 // variable right behind the request, i.e. before the data has arrived)
+// hazard (gfx9): a VALU instruction that WRITES an SGPR (the v_readlane that restores a spilled base pointer, a v_readfirstlane) followed by a
+// vector-memory instruction that READS it needs 5 wait states; hipcc inserts them for its own instructions, not in front of inline asm -- the load
+// then goes to a stale address (round 6: a memory fault in head_tail.hip as soon as a spilled pointer was involved).  Every asm load with a
+// scalar operand therefore carries its own wait states (tools/asm_sgpr_hazard_scan.py checks the built code).
 __device__ __forceinline__ void pinned_load16(f32x4 &v, const void *base, unsigned off) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(v) : "v"(off), "s"(base) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "+v"(v) : "v"(off), "s"(base) : "memory");
 }
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void pinned_load8(u32x2 &v, const void *base, unsigned off) {
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(v) : "v"(off), "s"(base) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "+v"(v) : "v"(off), "s"(base) : "memory");
 }
 __device__ __forceinline__ void wait_loads() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

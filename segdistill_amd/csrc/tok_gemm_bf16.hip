@@ -39,8 +39,12 @@ int g_force_variant = -1;           // A/B tunable (-1 = the dispatch below)
 
 // global -> LDS, 16 bytes per lane (align_tok.hip): M0 = wave-uniform LDS byte address of lane 0's 16 bytes, lane l lands at M0 + 16 l; the source is a
 // wave-uniform base (SGPR pair) + a per-lane unsigned byte offset.  From inline asm, so that the waits are the hand-counted ones below.
+// hazard (gfx9): a VALU instruction that WRITES an SGPR (the v_readlane that restores a spilled base pointer, a v_readfirstlane) followed by a
+// vector-memory instruction that READS it needs 5 wait states; hipcc inserts them for its own instructions, not in front of inline asm -- the load
+// then goes to a stale address (round 6: a memory fault in head_tail.hip as soon as a spilled pointer was involved).  Every asm load with a
+// scalar operand therefore carries its own wait states (tools/asm_sgpr_hazard_scan.py checks the built code).
 __device__ __forceinline__ void dma16(const void *base, unsigned lane_off, unsigned lds_byte) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base), "s"(lds_byte) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base), "s"(lds_byte) : "memory");
 }
 
 template <int N>

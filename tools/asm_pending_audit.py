@@ -87,7 +87,7 @@ def main():
     bad = 0
     with tempfile.TemporaryDirectory() as tmp:
         for f in files:
-            if 'asm volatile("global_load' not in open(f).read() and 'asm volatile("buffer_load' not in open(f).read():
+            if not re.search(r'asm volatile\("[^"]*(global_load|buffer_load)', open(f).read()):
                 continue
             s = os.path.join(tmp, os.path.basename(f) + '.s')
             subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'), '-S',
