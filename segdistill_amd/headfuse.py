@@ -97,6 +97,8 @@ def head_tail_supported(zs, sizes, classes):
     geometry (factors 2, 4, 8), no autograd, no autocast."""
     if not (_HEAD_TAIL and supported(zs, sizes) and zs[0].dtype == torch.float32 and not torch.is_grad_enabled() and not torch.is_autocast_enabled()):
         return False
+    if os.environ.get('SEGDISTILL_SPLIT_BF16', '1') != '1':
+        return False      # exact-f32 mode (bench.py's value_exact_f32): this kernel's product is split-bf16 arithmetic
     (H, W) = sizes[0]
     if [H // h for (h, w) in sizes[1:]] != [2, 4, 8]:
         return False

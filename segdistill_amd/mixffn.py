@@ -24,6 +24,8 @@ def usable(h, conv, fc2, hw):
         return False
     # fp32 storage without autocast, or bf16 activations under bf16 autocast (fc2 would then run as a bf16 product on the weight's bf16 rounding)
     amp = torch.is_autocast_enabled()
+    if h.dtype == torch.float32 and os.environ.get('SEGDISTILL_SPLIT_BF16', '1') != '1':
+        return False      # exact-f32 mode (bench.py's value_exact_f32): this kernel's fp32 product is split-bf16 arithmetic
     if not ((h.dtype == torch.float32 and not amp) or (h.dtype == torch.bfloat16 and amp and torch.get_autocast_dtype('cuda') == torch.bfloat16)):
         return False
     if conv.bias is None or fc2.bias is None or conv.weight.dtype != torch.float32 or fc2.weight.dtype != torch.float32:
