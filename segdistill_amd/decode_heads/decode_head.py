@@ -97,8 +97,10 @@ class BaseDecodeHead(nn.Module, metaclass=ABCMeta):
             loss = loss_pix.sum()
         else:
             loss = loss_pix
-        acc = hits.to(torch.float32) * (100.0 / seg_label.numel())
-        return {'loss_seg': crit.loss_weight * loss, 'acc_seg': acc}
+        acc = hits * (100.0 / seg_label.numel())          # int32 count times a Python float: ONE kernel, fp32 result
+        # loss_weight == 1 (every shipped config): no multiply -- with reduction='none' it was a pass over the [B, H, W] map each way, and its backward
+        # turned the broadcast gradient of the map's mean into a dense map the fused CE backward then had to read per class group
+        return {'loss_seg': loss if crit.loss_weight == 1.0 else crit.loss_weight * loss, 'acc_seg': acc}
 
     def losses(self, seg_logit, seg_label):
         fused = self._fused_losses(seg_logit, seg_label)

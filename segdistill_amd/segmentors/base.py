@@ -29,6 +29,7 @@ def _mean(value):
     if value.is_cuda and value.numel() >= 8192 and value.is_contiguous() and value.is_floating_point():
         for group in (1024, 512, 256):
             if value.numel() % group == 0:
+                # (sums, then ONE division: a mean's backward divides the EXPANDED gradient, i.e. materialises the dense map again)
                 return value.reshape(-1, group).sum(1).sum() / value.numel()
     return value.mean()
 
@@ -50,7 +51,10 @@ def parse_losses(losses, want_host_values=True, extra=None):
             log_vars[name] = sum(_mean(v) for v in value)
         else:
             raise TypeError(f'{name} is not a tensor or list of tensors')
-    loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+    terms = [v for k, v in log_vars.items() if 'loss' in k]
+    loss = terms[0] if terms else 0
+    for v in terms[1:]:      # (Python's sum() starts from the int 0: one more add kernel)
+        loss = loss + v
     if extra is not None:   # diagnostics computed from the per-key means (SDModule's `log_grad` angle): logged, never part of `loss`
         log_vars.update(extra(log_vars))
     log_vars['loss'] = loss
