@@ -66,6 +66,23 @@ def test_no_asm_load_reads_a_scalar_register_a_vector_instruction_just_wrote():
         assert f + ': 0 asm' in res.stdout, res.stdout
 
 
+def test_the_hazard_scan_flags_a_restored_pointer_in_front_of_an_asm_load(tmp_path):
+    """Positive control for tools/asm_sgpr_hazard_scan.py: the sequence that faulted in round 6 (v_readlane restoring a spilled base pointer, then an
+    inline-asm load on it) is reported; with five wait states in between it is not."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import asm_sgpr_hazard_scan as scan
+    bad = tmp_path / 'bad.s'
+    bad.write_text('_Zkernel:\n\tv_readlane_b32 s98, v240, 14\n\tv_readlane_b32 s99, v240, 15\n\t;;#ASMSTART\n'
+                   '\tglobal_load_dwordx4 v[134:137], v239, s[98:99]\n\t;;#ASMEND\n\ts_endpgm\n')
+    ok = tmp_path / 'ok.s'
+    ok.write_text('_Zkernel:\n\tv_readlane_b32 s98, v240, 14\n\tv_readlane_b32 s99, v240, 15\n\t;;#ASMSTART\n\ts_nop 4\n'
+                  '\tglobal_load_dwordx4 v[134:137], v239, s[98:99]\n\t;;#ASMEND\n\ts_endpgm\n')
+    found = scan.scan(str(bad))
+    assert found and all(98 in f[3] or 99 in f[3] for f in found)
+    assert scan.scan(str(ok)) == []
+
+
 def test_slab_budget_of_config_5_stays_under_its_operand_bytes():
     """tools/slab_budget.py (host-side plans only): with the default cap the bf16 B1 student's split-K weight gradients move fewer slab bytes than
     operand bytes per step; without it more than twice as many (the 2.9 GB / 1.4 GB finding of round 4)."""
